@@ -1,0 +1,222 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (imported from /root/reference, CPU,
+build container only) on the seeded inputs of tests/golden_inputs.py.  The fixtures are data only: inputs
+are regenerated from seeds by the tests, expected outputs are stored (full when small, strided sample +
+checksums when large).  Re-run:  python tools/make_goldens.py [--skip-full]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_import  # noqa: E402
+from morphablediffusion_amd import synthetic  # noqa: E402
+from morphablediffusion_amd.spec import UNetConfig, VolumeConfig, full_manifest, unet_manifest  # noqa: E402
+from tests import golden_inputs as gi  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, packs, extra=None):
+    flat = gi.flatten_packs(packs)
+    if extra:
+        flat.update(extra)
+    np.savez_compressed(os.path.join(OUT, name), **flat)
+    print("wrote", name, f"{os.path.getsize(os.path.join(OUT, name)) / 1024:.0f} KiB")
+
+
+def cfg_kwargs(cfg: UNetConfig):
+    return dict(volume_dims=list(cfg.volume_dims), image_size=cfg.image_size, in_channels=cfg.in_channels,
+                out_channels=cfg.out_channels, model_channels=cfg.model_channels,
+                attention_resolutions=list(cfg.attention_resolutions), num_res_blocks=cfg.num_res_blocks,
+                channel_mult=list(cfg.channel_mult), num_heads=cfg.num_heads, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=cfg.context_dim, use_checkpoint=False, legacy=False)
+
+
+def load_unet(ns, cfg):
+    m = ns.attention.DepthWiseAttention(**cfg_kwargs(cfg)).eval()
+    W = gi.unet_weights(cfg)
+    sd = {k[len("model.diffusion_model."):]: v for k, v in W.items()}
+    ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(ref_keys) == set(sd), (set(ref_keys) ^ set(sd))
+    for k in sd:
+        assert ref_keys[k] == tuple(sd[k].shape), (k, ref_keys[k], sd[k].shape)
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def gold_basic(ns):
+    packs = {}
+    for dim in (256, 320):
+        t = torch.tensor([1, 481, 981], dtype=torch.long)
+        packs[f"temb{dim}"] = gi.pack(ns.dutil.timestep_embedding(t, dim))
+    save("basic.npz", packs)
+
+
+def gold_unet_small(ns):
+    cfg = gi.SMALL_UNET
+    m = load_unet(ns, cfg)
+    x, t, ctx, sd = gi.unet_inputs(cfg, Bv=2)
+    packs = {}
+    with torch.no_grad():
+        packs["unet_out"] = gi.pack(m(x, t, ctx, source_dict=sd))
+        temb = ns.dutil.timestep_embedding(t, cfg.model_channels)
+        emb = m.time_embed(temb)
+        packs["emb"] = gi.pack(emb)
+        g = torch.Generator().manual_seed(5)
+        h64 = torch.randn(2, 64, 32, 32, generator=g)
+        h128 = torch.randn(2, 128, 16, 16, generator=g)
+        h256 = torch.randn(2, 256, 8, 8, generator=g)
+        packs["res_same"] = gi.pack(m.input_blocks[1][0](h64, emb))  # 64 -> 64
+        packs["res_skip"] = gi.pack(m.input_blocks[4][0](h64[:, :, ::2, ::2].contiguous(), emb))  # 64 -> 128 @16
+        packs["st32"] = gi.pack(m.input_blocks[1][1](h64, ctx))
+        packs["st16"] = gi.pack(m.input_blocks[4][1](h128, ctx))
+        packs["st8"] = gi.pack(m.input_blocks[7][1](h256, ctx))
+        packs["down"] = gi.pack(m.input_blocks[3][0](h64))
+        packs["up"] = gi.pack(m.output_blocks[8][2](h128))  # Upsample 128ch 16->32
+        packs["cond8"] = gi.pack(m.output_conditions[8](h64, context=sd[32]))
+        packs["cond3"] = gi.pack(m.output_conditions[3](h128, context=sd[16]))
+        packs["cond_mid"] = gi.pack(m.middle_conditions(h256[:, :, ::2, ::2].contiguous(), context=sd[4]))
+    save("unet_small.npz", packs)
+
+
+def gold_unet_full(ns):
+    cfg = gi.FULL_UNET
+    t0 = time.time()
+    m = load_unet(ns, cfg)
+    x, t, ctx, sd = gi.unet_inputs(cfg, Bv=2)
+    with torch.no_grad():
+        out = m(x, t, ctx, source_dict=sd)
+    print("full unet", time.time() - t0, "s")
+    save("unet_full.npz", {"unet_out": gi.pack(out)})
+
+
+def build_full_model(ns, ucfg, vcfg, N):
+    md = ns.md
+    model = md.SyncMultiviewDiffusion(
+        unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": cfg_kwargs(ucfg)},
+        scheduler_config=None, finetune_unet=False, projection=vcfg.projection, use_spatial_volume=False,
+        view_num=N, image_size=256, cfg_scale=2.0, output_num=8, batch_view_num=4, drop_conditions=False,
+        clip_image_encoder_path="", sample_type="ddim", sample_steps=50, target_elevation=0).eval()
+    model.spatial_volume.smpl_feature_extractor.num_views = N  # gotcha G3: hard-wired 16 in the reference
+    W = gi.full_weights(ucfg, vcfg)
+    ref_sd = model.state_dict()
+    hot = {k: tuple(v.shape) for k, v in ref_sd.items()
+           if k.startswith(("model.diffusion_model.", "spatial_volume.", "time_embed."))
+           and not k.endswith("num_batches_tracked")}
+    assert set(hot) == set(W), sorted(set(hot) ^ set(W))[:10]
+    for k in W:
+        assert hot[k] == tuple(W[k].shape), (k, hot[k], W[k].shape)
+    missing, unexpected = model.load_state_dict(W, strict=False)
+    assert not unexpected, unexpected
+    return model, hot
+
+
+def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, stages=False):
+    vcfg = VolumeConfig(num_views=N, projection=projection)
+    model, hot = build_full_model(ns, ucfg, vcfg, N)
+    batch = synthetic.make_batch(N, projection, nverts, mesh_seed=1)
+    x_T, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    sampler = model.sampler
+    step = int(sampler.ddim_timesteps[index])
+    ts = torch.full((1,), step, dtype=torch.long)
+    packs = {}
+    extra = {"index": index, "step": step, "N": N, "nverts_in": nverts, "bvn": bvn,
+             "with_noise": int(with_noise), "noise_seed": 99}
+    with torch.no_grad():
+        t0 = time.time()
+        torch.manual_seed(99)
+        out = sampler.denoise_apply(x_T, {"x": x_in, "elevation": batch["input_elevation"][:, 0]}, clip, ts, index,
+                                    2.0, batch_view_num=bvn, is_step0=not with_noise, batch=batch)
+        print(name, "denoise_apply", time.time() - t0, "s")
+        packs["x_prev"] = gi.pack(out)
+        if stages:
+            v_embed = model.get_viewpoint_embedding(batch)
+            t_embed = model.embed_time(ts)
+            packs["t_embed"] = gi.pack(t_embed)
+            packs["v_embed"] = gi.pack(v_embed)
+            sv = model.spatial_volume
+            f0 = sv.target_encoder(x_T[:, 0], t_embed, v_embed[:, 0])
+            packs["enc_view0"] = gi.pack(f0)
+            V = 32
+            lin = torch.linspace(-0.5, 0.5, V)
+            verts = torch.stack(torch.meshgrid(lin, lin, lin), -1).reshape(1, V ** 3, 3)[:, :, (2, 1, 0)]
+            verts = verts.view(1, V, V, V, 3).permute(0, 4, 1, 2, 3)
+            for vi in (0, N - 1):
+                c = ns.utils.get_warp_coordinates(verts, 32, 256, batch["target_K"][:, vi], batch["target_RT"][:, vi],
+                                                  projection=projection)
+                packs[f"warp_view{vi}"] = gi.pack(c)
+            spatial_volume = sv.construct_spatial_volume(x_T, t_embed, v_embed, batch)
+            packs["spatial_volume"] = gi.pack(spatial_volume)
+            # intermediate: per-view vertex features and fused features, via the same calls the reference makes
+            feats = []
+            for ni in range(N):
+                x_ = sv.target_encoder(x_T[:, ni], t_embed, v_embed[:, ni])
+                cs = ns.utils.get_warp_coordinates(verts, 32, 256, batch["target_K"][:, ni], batch["target_RT"][:, ni],
+                                                   projection=projection).view(1, V, V * V, 2)
+                u = torch.nn.functional.grid_sample(x_, cs, mode="bilinear", padding_mode="zeros", align_corners=True)
+                feats.append(u.view(1, -1, V, V, V))
+            feats = torch.stack(feats, 1).view(1, -1, V, V, V)
+            Nv = batch["vertices"].shape[1]
+            grid = (batch["vertices"].unsqueeze(2).unsqueeze(2) / 0.5).unsqueeze(1).repeat(1, N, 1, 1, 1, 1).reshape(N, Nv, 1, 1, 3)
+            vf = torch.nn.functional.grid_sample(feats.reshape(N, -1, V, V, V), grid, mode="bilinear", padding_mode="zeros",
+                                                 align_corners=True)[:, :, :, 0, 0].reshape(1, N, -1, Nv)
+            packs["vertex_feats"] = gi.pack(vf)
+            fused = sv.smpl_feature_extractor(vf).permute(0, 2, 1)
+            packs["fused"] = gi.pack(fused)
+            from spconv.pytorch.core import SparseConvTensor
+            coord = torch.cat([torch.zeros(Nv, 1, dtype=torch.int32), batch["coord"][0]], 1).int()
+            dense = sv.xyzc_net(SparseConvTensor(fused[0], coord, batch["out_sh"][0].tolist(), 1))
+            packs["sparse_dense"] = gi.pack(dense)
+            idx = torch.arange(0, min(2, N))[None]
+            fd, _ = sv.construct_view_frustum_volume(spatial_volume, t_embed, v_embed, idx, batch)
+            for k, v in fd.items():
+                packs[f"frustum_{k}"] = gi.pack(v)
+            # frustum geometry
+            poses = batch["target_RT"][0, :2]
+            Ks = batch["target_K"][0, :2]
+            camp = -(poses[:, :, :3].transpose(1, 2) @ poses[:, :, 3:])[:, :, 0]
+            dist = camp.norm(dim=-1).reshape(2, 1)
+            near = torch.ones(2, 1, 32, 32) * dist[..., None, None] - 0.86603
+            far = torch.ones(2, 1, 32, 32) * dist[..., None, None] + 0.86603
+            xyz, _ = ns.utils.create_target_volume(48, 32, 256, poses, Ks, near, far, projection)
+            packs["frustum_xyz"] = gi.pack(xyz)
+            extra["nverts"] = Nv
+    save(name, packs, extra)
+    return hot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    ns = ref_import.import_reference_full()
+    gold_basic(ns)
+    gold_unet_small(ns)
+    hot = gold_step(ns, "step_small_persp.npz", gi.SMALL_UNET, 4, "perspective", 25, True, 600, 2, stages=True)
+    gold_step(ns, "step_small_ortho.npz", gi.SMALL_UNET, 4, "orthographic", 0, False, 600, 4, stages=True)
+    if not args.skip_full:
+        gold_unet_full(ns)
+        hot = gold_step(ns, "step_full.npz", gi.FULL_UNET, 16, "perspective", 49, True, 5023, 8)
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump({k: list(v) for k, v in sorted(hot.items())}, f)
+    # DDIM tables from the reference sampler
+    model, _ = build_full_model(ns, gi.SMALL_UNET, VolumeConfig(num_views=4), 4)
+    s = model.sampler
+    np.savez_compressed(os.path.join(OUT, "ddim.npz"), timesteps=s.ddim_timesteps.astype(np.int64),
+                        alphas=s.ddim_alphas.numpy(), alphas_prev=s.ddim_alphas_prev.numpy(),
+                        sigmas=s.ddim_sigmas.numpy(), sqrt_one_minus_alphas=s.ddim_sqrt_one_minus_alphas.numpy())
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
