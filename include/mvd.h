@@ -1,0 +1,132 @@
+/* libmvd_hip.so -- C ABI of the MI355X-native multi-view denoiser (Morphable Diffusion hot path).
+ *
+ * The reference has no FFI: its plug-in surface is Python (YAML ``target:`` classes + method signatures,
+ * SURVEY.md section 8(b)).  This header is the boundary a binding for that surface talks to; each entry
+ * point names the reference interface it replaces.  Plain pointers and sizes only, no torch types.
+ * Device pointers are HIP device memory on the context's device; ``stream`` is a hipStream_t (NULL = the
+ * default stream).  Tensors at the boundary use the reference's own layouts (NCHW / NCDHW, fp32).
+ * Every function returns 0 on success, non-zero on failure; mvd_last_error() gives the text.
+ * A context is thread-compatible (one thread at a time per context).  No allocation happens on the step
+ * path: weights and the workspace are allocated at create / finalize / set_mesh time.
+ */
+#ifndef MVD_H
+#define MVD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvd_ctx mvd_ctx;
+
+/* kwargs of ldm.models.diffusion.attention.DepthWiseAttention (reference configs/facescape.yaml:28-42,
+ * ctor ldm/modules/diffusionmodules/openaimodel.py:444-727, ldm/models/diffusion/attention.py:87-115) */
+typedef struct {
+  int image_size;       /* latent resolution (32) */
+  int in_channels;      /* 8 */
+  int out_channels;     /* 4 */
+  int model_channels;   /* 320 */
+  int num_res_blocks;   /* 2 */
+  int channel_mult[4];  /* 1,2,4,4 */
+  int num_heads;        /* 8 */
+  int context_dim;      /* 768 */
+  int volume_dims[4];   /* 64,128,256,512 */
+  int attention_levels; /* bit i set: attention at downsample rate 2^i (attention_resolutions [4,2,1] -> 0x7) */
+} mvd_unet_config;
+
+/* SpatialVolumeNet ctor (ldm/models/diffusion/morphable_diffusion.py:152-180) */
+typedef struct {
+  int time_dim;             /* 256 */
+  int view_dim;             /* 4 */
+  int num_views;            /* N: SMPLFeatureExtractor.num_views (hard-coded 16 in the reference) */
+  int input_image_size;     /* 256 */
+  int frustum_volume_depth; /* 48 */
+  int spatial_volume_size;  /* 32 */
+  float spatial_volume_length; /* 0.5 */
+  float frustum_volume_length; /* 0.86603 */
+  int projection;           /* 0 perspective, 1 orthographic */
+  int frustum_dims[4];      /* 64,128,256,512 */
+  float voxel_size;         /* 0.005 */
+} mvd_volume_config;
+
+int mvd_create(const mvd_unet_config* ucfg, const mvd_volume_config* vcfg, int device, size_t workspace_bytes,
+               mvd_ctx** out);
+void mvd_destroy(mvd_ctx* ctx);
+const char* mvd_last_error(void);
+
+/* Replaces load_state_dict (reference generate_face.py:75-76): one call per state_dict entry, keyed by the
+ * reference's own names.  data is fp32, contiguous, reference layout; on_device
+ * selects device or host memory.  Unknown keys (VAE, CLIP, schedule buffers) are ignored and return 0. */
+int mvd_upload_weight(mvd_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim, int on_device);
+/* Packs/folds the uploaded tensors into their MFMA layouts; fails (listing the key) if one is missing. */
+int mvd_finalize_weights(mvd_ctx* ctx);
+
+/* DepthWiseAttention.forward(x, timesteps, context, source_dict) -- ldm/models/diffusion/attention.py:117-138.
+ * x [Bv,in_channels,s,s]; timesteps [Bv] int64; context [Bv,1,context_dim]; src{32,16,8,4}: the source_dict
+ * volumes [n_ctx,C_l,D_l,s_l,s_l] fp32 for the FIRST n_ctx samples, the remaining Bv-n_ctx samples are
+ * treated as all-zero volumes (the classifier-free-guidance half, morphable_diffusion.py:137-139);
+ * depth0 = D of the finest level (48); out [Bv,out_channels,s,s]. */
+int mvd_unet_forward(mvd_ctx* ctx, const float* x, const int64_t* timesteps, const float* context, int Bv, int n_ctx,
+                     const float* src0, const float* src1, const float* src2, const float* src3, int depth0, float* out,
+                     void* stream);
+
+/* SyncMultiviewDiffusion.embed_time -- morphable_diffusion.py:491-494. t [B] int64 -> out [B,time_dim] */
+int mvd_embed_time(mvd_ctx* ctx, const int64_t* t, int B, float* out, void* stream);
+
+/* Step-invariant per-sample metadata (batch dict, generate_face.py:227-241), HOST pointers:
+ * vertices [Nv,3] fp32 (+-0.5 cube frame), coord [Nv,3] int32 (z,y,x), out_sh [3] int32, bounds [2,3] fp32.
+ * Builds the sparse-convolution neighbour tables (replaces spconv's indice generation, morphable_diffusion.py:245-254). */
+int mvd_set_mesh(mvd_ctx* ctx, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+                 int Nv);
+/* target_K [N,4,4], target_RT [N,3,4] fp32 HOST pointers (batch['target_K'], batch['target_RT']) */
+int mvd_set_cameras(mvd_ctx* ctx, const float* K, const float* RT, int N);
+
+/* First half of SpatialVolumeNet.construct_spatial_volume (morphable_diffusion.py:203-231) for the views
+ * view_idx[0..n_local): x_noisy [n_local,4,s,s], t_embed [time_dim], v_embed [n_local,view_dim];
+ * fused_out [Nv,16] = this rank's share of conv0(mean over ALL num_views views); with add_bias != 0 the
+ * conv bias is included (exactly one rank adds it).  Summing fused_out over ranks gives the full tensor. */
+int mvd_vertex_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed,
+                        const int32_t* view_idx, int n_local, int add_bias, float* fused_out, void* stream);
+/* Second half (morphable_diffusion.py:232-257): sparse voxel CNN + lattice gather. fused [Nv,16] ->
+ * volume_out [64,V,V,V] (reference layout, may be NULL); the result is also kept in the context for
+ * mvd_frustum_volumes / mvd_denoise_views. */
+int mvd_volume_from_fused(mvd_ctx* ctx, const float* fused, float* volume_out, void* stream);
+
+/* SpatialVolumeNet.construct_view_frustum_volume (morphable_diffusion.py:265-320) for TN views of the
+ * volume held in the context.  out_l: [TN,C_l,D_l,s_l,s_l] fp32 (reference layout), any may be NULL. */
+int mvd_frustum_volumes(mvd_ctx* ctx, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
+                        float* out0, float* out1, float* out2, float* out3, void* stream);
+
+/* The per-view part of SyncDDIMSampler.denoise_apply (morphable_diffusion.py:721-738) for TN views, fully on
+ * the device without leaving the library's layouts: frustum volumes -> CFG-batched UNet
+ * (predict_with_unconditional_scale :132-149) -> DDIM update (:675-698).
+ * x_noisy [TN,4,s,s], x_input [4,s,s], clip [context_dim], noise [TN,4,s,s] or NULL (is_step0),
+ * coefficients from the DDIM tables; eps_out / x_prev [TN,4,s,s] (either may be NULL). */
+int mvd_denoise_views(mvd_ctx* ctx, const float* x_noisy, const float* x_input, const float* clip, int64_t timestep,
+                      const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
+                      const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
+                      float sigma, float* eps_out, float* x_prev, void* stream);
+
+/* ---- single-kernel hooks used by the parity tests (tests/test_gpu_ops.py) ---- */
+int mvd_op_conv(mvd_ctx* ctx, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
+                int Cout, int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
+                void* stream);
+int mvd_op_linear(mvd_ctx* ctx, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu,
+                  float* out, void* stream);
+int mvd_op_group_norm(mvd_ctx* ctx, const float* x_nchw, int B, int C, int HW, int groups, const float* gamma,
+                      const float* beta, float eps, int act, float* out_nchw, void* stream);
+int mvd_op_layer_norm(mvd_ctx* ctx, const float* x, int rows, int C, const float* gamma, const float* beta, float* out,
+                      void* stream);
+int mvd_op_attention(mvd_ctx* ctx, const float* q, const float* k, const float* v, int B, int T, int heads, int d,
+                     float* out, void* stream);
+int mvd_op_conv3d(mvd_ctx* ctx, const float* x_ncdhw, int B, int Cin, int D, int H, int W, const float* w,
+                  const float* bias, int Cout, int stride, int transposed, const float* resid, float* out, void* stream);
+/* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
+ * returns the mean kernel time in ms measured with HIP events on that stream */
+int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,425 @@
+// extern "C" surface of libmvd_hip.so (declared in include/mvd.h).
+#include <array>
+#include <string.h>
+
+#include <string>
+
+#include "engine.h"
+
+int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N);
+int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+                    int Nv);
+
+static thread_local std::string g_err;
+int mvd_fail(const char* msg) {
+  g_err = msg ? msg : "unknown error";
+  return -1;
+}
+const char* mvd_error_text() { return g_err.c_str(); }
+
+namespace {
+
+__global__ void f16_to_f32_kernel(const half_t* in, float* out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+// q,k [rows][C] fp32 -> qk fp16 [rows][2C];  v [rows][C] -> vt fp16 [C][rows]
+__global__ void pack_qkv_kernel(const float* q, const float* k, const float* v, int rows, int C, half_t* qk, half_t* vt) {
+  const long total = (long)rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i % C);
+    qk[(long)r * 2 * C + c] = (half_t)q[i];
+    qk[(long)r * 2 * C + C + c] = (half_t)k[i];
+    vt[(long)c * rows + r] = (half_t)v[i];
+  }
+}
+// UNetWrapper.predict_with_unconditional_scale input assembly (morphable_diffusion.py:133-146), channels-last:
+// rows [0,TN) = [x | x_input / 0.18215], rows [TN,2TN) = [x | 0]
+__global__ void build_cfg_input_kernel(const float* x_noisy, const float* x_input, int TN, int HW, int copies, float* out) {
+  const long total = (long)copies * TN * HW * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i & 7);
+    const long bp = i >> 3;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    const int v = b % TN, half = b / TN;
+    float val;
+    if (ch < 4) val = x_noisy[((long)v * 4 + ch) * HW + p];
+    else val = half == 0 ? x_input[(long)(ch - 4) * HW + p] / 0.18215f : 0.f;
+    out[i] = val;
+  }
+}
+__global__ void build_cfg_context_kernel(const float* clip, int TN, int dim, int copies, float* ctx, int64_t* t, int64_t step) {
+  const int total = copies * TN * dim;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / dim, j = i - b * dim;
+    ctx[i] = b < TN ? clip[j] : 0.f;
+    if (j == 0) t[b] = step;
+  }
+}
+__global__ void fill_pattern_f16_kernel(half_t* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (half_t)(((float)(h & 0xFFFF) / 32768.0f) - 1.0f);
+  }
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+inline int nblk(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+}  // namespace
+
+extern "C" {
+
+const char* mvd_last_error(void) { return g_err.c_str(); }
+
+int mvd_create(const mvd_unet_config* ucfg, const mvd_volume_config* vcfg, int device, size_t workspace_bytes,
+               mvd_ctx** out) {
+  if (!ucfg || !vcfg || !out) return mvd_fail("mvd_create: null argument");
+  HIP_CHECK_RET(hipSetDevice(device));
+  mvd_ctx* c = new mvd_ctx();
+  c->u = *ucfg;
+  c->v = *vcfg;
+  c->device = device;
+  if (workspace_bytes == 0) workspace_bytes = (size_t)8 << 30;
+  hipError_t e = hipMalloc((void**)&c->ws.base, workspace_bytes);
+  if (e != hipSuccess) {
+    delete c;
+    return mvd_fail("mvd_create: workspace allocation failed");
+  }
+  c->ws.size = workspace_bytes;
+  *out = c;
+  return 0;
+}
+
+void mvd_destroy(mvd_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& kv : c->raw) hipFree(kv.second.d);
+  for (void* p : c->owned) hipFree(p);
+  MeshTables& m = c->mesh;
+  hipFree(m.verts);
+  for (int i = 0; i < 3; ++i) hipFree(m.nbr_subm[i]);
+  for (int i = 0; i < 2; ++i) { hipFree(m.nbr_down[i]); hipFree(m.feat[i]); }
+  hipFree(m.grid2);
+  hipFree(c->cams);
+  hipFree(c->volume);
+  hipFree(c->ws.base);
+  delete c;
+}
+
+int mvd_upload_weight(mvd_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim, int on_device) {
+  if (!c || !name || !data) return mvd_fail("mvd_upload_weight: null argument");
+  if (c->finalized) return mvd_fail("mvd_upload_weight: weights already finalized");
+  const std::string k(name);
+  if (k.rfind("model.diffusion_model.", 0) != 0 && k.rfind("spatial_volume.", 0) != 0 && k.rfind("time_embed.", 0) != 0)
+    return 0;  // VAE / CLIP / schedule buffers: not on this path
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  RawTensor t;
+  t.numel = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    t.numel *= (size_t)shape[i];
+  }
+  HIP_CHECK_RET(hipMalloc((void**)&t.d, std::max<size_t>(t.numel, 1) * sizeof(float)));
+  HIP_CHECK_RET(hipMemcpy(t.d, data, t.numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  auto it = c->raw.find(k);
+  if (it != c->raw.end()) hipFree(it->second.d);
+  c->raw[k] = t;
+  return 0;
+}
+
+int mvd_finalize_weights(mvd_ctx* c) {
+  if (!c) return mvd_fail("null context");
+  if (c->finalized) return 0;
+  return engine_finalize(c);
+}
+
+int mvd_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds, int Nv) {
+  if (!c || !vertices || !coord || !out_sh || !bounds || Nv <= 0) return mvd_fail("mvd_set_mesh: bad argument");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_set_mesh(c, vertices, coord, out_sh, bounds, Nv);
+}
+
+int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
+  if (!c || !K || !RT || N <= 0) return mvd_fail("mvd_set_cameras: bad argument");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_set_cameras(c, K, RT, N);
+}
+
+int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  const size_t mark = c->ws.off;
+  const int td = c->v.time_dim;
+  float* e0 = ws_alloc<float>(c, (size_t)B * td);
+  float* e1 = ws_alloc<float>(c, (size_t)B * td);
+  WS_CHECK(e0 && e1);
+  RET_IF(launch_timestep_embedding(t, B, td, e0, S(stream)));
+  RET_IF(launch_small_linear(e0, td, B, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, e1, td, 0, S(stream)));
+  RET_IF(launch_small_linear(e1, td, B, td, c->step_te2.w, c->step_te2.bias, td, ACT_SILU, out, td, 0, S(stream)));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const float* context, int Bv, int n_ctx,
+                     const float* src0, const float* src1, const float* src2, const float* src3, int depth0, float* out,
+                     void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (n_ctx < 0 || n_ctx > Bv) return mvd_fail("mvd_unet_forward: n_ctx out of range");
+  hipStream_t s = S(stream);
+  const mvd_unet_config& u = c->u;
+  const size_t mark = c->ws.off;
+  const int HW = u.image_size * u.image_size;
+  const int cin = u.in_channels;
+  if (cin % 8) return mvd_fail("in_channels must be a multiple of 8");
+  float* xn = ws_alloc<float>(c, (size_t)Bv * HW * cin);
+  float* eps = ws_alloc<float>(c, (size_t)Bv * HW * u.out_channels);
+  WS_CHECK(xn && eps);
+  RET_IF(launch_nchw_to_nhwc(x, Bv, cin, HW, xn, cin, cin, s));
+  const float* srcs[4] = {src0, src1, src2, src3};
+  Ctx5 cl[4];
+  for (int l = 0; l < 4 && n_ctx > 0; ++l) {
+    if (!srcs[l]) return mvd_fail("mvd_unet_forward: missing source_dict level");
+    const int sl = u.image_size >> l, Dl = depth0 >> l, C = u.volume_dims[l];
+    float* t = ws_alloc<float>(c, (size_t)n_ctx * Dl * sl * sl * C);
+    WS_CHECK(t);
+    RET_IF(launch_nchw_to_nhwc(srcs[l], n_ctx, C, Dl * sl * sl, t, C, C, s));
+    cl[l].p = t;
+    cl[l].f32 = 1;
+  }
+  RET_IF(engine_unet(c, xn, cin, timesteps, context, Bv, n_ctx, depth0, cl, eps, s));
+  RET_IF(launch_nhwc_to_nchw(eps, u.out_channels, Bv, u.out_channels, HW, out, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
+                        const int32_t* view_idx, int n_local, int add_bias, float* fused_out, void* stream) {
+  if (!c) return mvd_fail("null context");
+  return engine_vertex_features(c, x_noisy, t_embed, v_embed, view_idx, n_local, add_bias, fused_out, S(stream));
+}
+
+int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  RET_IF(engine_volume_from_fused(c, fused, S(stream)));
+  if (volume_out) {
+    const int V = c->v.spatial_volume_size;
+    RET_IF(launch_nhwc_to_nchw(c->volume, 64, 1, 64, V * V * V, volume_out, S(stream)));
+  }
+  return 0;
+}
+
+int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
+                        float* out0, float* out1, float* out2, float* out3, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  const size_t mark = c->ws.off;
+  FrustumOut fo;
+  RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, S(stream)));
+  float* outs[4] = {out0, out1, out2, out3};
+  int D = c->v.frustum_volume_depth, Sz = c->v.input_image_size / 8;
+  for (int l = 0; l < 4; ++l) {
+    if (outs[l]) RET_IF(launch_nhwc_to_nchw(fo.lvl[l], c->v.frustum_dims[l], TN, c->v.frustum_dims[l], D * Sz * Sz, outs[l], S(stream)));
+    D = (D - 1) / 2 + 1;
+    Sz = (Sz - 1) / 2 + 1;
+  }
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, const float* clip, int64_t timestep,
+                      const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
+                      const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
+                      float sigma, float* eps_out, float* x_prev, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  hipStream_t s = S(stream);
+  const mvd_unet_config& u = c->u;
+  if (u.in_channels != 8 || u.out_channels != 4) return mvd_fail("denoise_views: expects the 8-in / 4-out latent UNet");
+  const size_t mark = c->ws.off;
+  const int HW = u.image_size * u.image_size;
+  const bool cfg = cfg_scale != 1.0f;
+  const int copies = cfg ? 2 : 1, Bv = copies * TN;
+  FrustumOut fo;
+  RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, s));
+  float* xin = ws_alloc<float>(c, (size_t)Bv * HW * 8);
+  float* ctx = ws_alloc<float>(c, (size_t)Bv * u.context_dim);
+  int64_t* tt = ws_alloc<int64_t>(c, (size_t)Bv);
+  float* eps = ws_alloc<float>(c, (size_t)Bv * HW * 4);
+  float* eps_nchw = ws_alloc<float>(c, (size_t)Bv * HW * 4);
+  WS_CHECK(xin && ctx && tt && eps && eps_nchw);
+  hipLaunchKernelGGL(build_cfg_input_kernel, dim3(nblk((size_t)Bv * HW * 8)), dim3(256), 0, s, x_noisy, x_input, TN, HW,
+                     copies, xin);
+  hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)Bv * u.context_dim)), dim3(256), 0, s, clip, TN,
+                     u.context_dim, copies, ctx, tt, timestep);
+  HIP_CHECK_RET(hipGetLastError());
+  Ctx5 cl[4];
+  for (int l = 0; l < 4; ++l) {
+    cl[l].p = fo.lvl[l];
+    cl[l].f32 = 1;
+  }
+  RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s));
+  RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));
+  const size_t n = (size_t)TN * 4 * HW;
+  RET_IF(launch_cfg_ddim(eps_nchw, cfg ? eps_nchw + n : nullptr, cfg_scale, x_noisy, noise, sqrt_one_minus_at, sqrt_at,
+                         sqrt_aprev, dir_coef, sigma, eps_out, x_prev, n, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ test hooks
+int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout,
+                int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
+                void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  const int cpad = (Cin + 7) / 8 * 8, taps = ksize * ksize;
+  const int Hv = H << upsample, Wv = W << upsample;
+  const int Ho = (Hv - 1) / stride + 1, Wo = (Wv - 1) / stride + 1;
+  float* xn = ws_alloc<float>(c, (size_t)B * H * W * cpad);
+  half_t* wp = ws_alloc<half_t>(c, (size_t)taps * Cout * cpad);
+  float* on = ws_alloc<float>(c, (size_t)B * Ho * Wo * Cout);
+  float* rn = resid_nchw ? ws_alloc<float>(c, (size_t)B * Ho * Wo * Cout) : nullptr;
+  WS_CHECK(xn && wp && on);
+  RET_IF(launch_nchw_to_nhwc(x_nchw, B, Cin, H * W, xn, cpad, cpad, s));
+  RET_IF(launch_pack_weight(w, Cout, cpad, taps, 0, 0, wp, s, Cin));
+  if (rn) RET_IF(launch_nchw_to_nhwc(resid_nchw, B, Cout, Ho * Wo, rn, Cout, Cout, s));
+  ConvW cw;
+  cw.w = wp; cw.bias = const_cast<float*>(bias); cw.N = Cout; cw.Cin = cpad; cw.taps = taps;
+  GemmArgs g;
+  g.a = xn; g.a_f32 = 1; g.lda = cpad; g.w = &cw; g.out = on; g.ldc = Cout; g.resid = rn; g.ldr = Cout;
+  g.use_bias = bias != nullptr; g.force_splitk = force_splitk;
+  RET_IF(run_conv2d(c, g, B, H, W, stride, upsample, s));
+  RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Ho * Wo, out_nchw, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int W, const float* w, const float* bias,
+                  int Cout, int stride, int transposed, const float* resid, float* out, void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  if (Cin % 8) return mvd_fail("op_conv3d: Cin must be a multiple of 8");
+  const int Do = transposed ? 2 * D : (D - 1) / stride + 1, Ho = transposed ? 2 * H : (H - 1) / stride + 1,
+            Wo = transposed ? 2 * W : (W - 1) / stride + 1;
+  float* xn = ws_alloc<float>(c, (size_t)B * D * H * W * Cin);
+  half_t* wp = ws_alloc<half_t>(c, (size_t)27 * Cout * Cin);
+  float* on = ws_alloc<float>(c, (size_t)B * Do * Ho * Wo * Cout);
+  WS_CHECK(xn && wp && on);
+  RET_IF(launch_nchw_to_nhwc(x, B, Cin, D * H * W, xn, Cin, Cin, s));
+  RET_IF(launch_pack_weight(w, Cout, Cin, 27, transposed, 0, wp, s, Cin));
+  if (resid) RET_IF(launch_nchw_to_nhwc(resid, B, Cout, Do * Ho * Wo, on, Cout, Cout, s));
+  ConvW cw;
+  cw.w = wp; cw.bias = const_cast<float*>(bias); cw.N = Cout; cw.Cin = Cin; cw.taps = 27;
+  GemmArgs g;
+  g.a = xn; g.a_f32 = 1; g.lda = Cin; g.w = &cw; g.out = on; g.ldc = Cout; g.use_bias = bias != nullptr;
+  if (resid) { g.resid = on; g.ldr = Cout; }
+  if (transposed) RET_IF(run_convT3d(c, g, B, D, H, W, s));
+  else RET_IF(run_conv3d(c, g, B, D, H, W, stride, s));
+  RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Do * Ho * Wo, out, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu, float* out,
+                  void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  if (K % 8) return mvd_fail("op_linear: K must be a multiple of 8");
+  half_t* wp = ws_alloc<half_t>(c, (size_t)N * K);
+  float* bp = ws_alloc<float>(c, (size_t)N);
+  WS_CHECK(wp && bp);
+  RET_IF(launch_pack_weight(w, N, K, 1, 0, geglu, wp, s, K));
+  if (bias) {
+    if (geglu) RET_IF(launch_permute_geglu_bias(bias, N, bp, s));
+    else HIP_CHECK_RET(hipMemcpyAsync(bp, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  }
+  ConvW cw;
+  cw.w = wp; cw.bias = bias ? bp : nullptr; cw.N = N; cw.Cin = K; cw.taps = 1;
+  GemmArgs g;
+  g.a = a; g.a_f32 = 1; g.lda = K; g.w = &cw; g.out = out; g.ldc = geglu ? N / 2 : N; g.geglu = geglu;
+  g.use_bias = bias != nullptr;
+  RET_IF(run_linear(c, g, 1, M, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int groups, const float* gamma,
+                      const float* beta, float eps, int act, float* out_nchw, void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  float* xn = ws_alloc<float>(c, (size_t)B * HW * C);
+  half_t* y = ws_alloc<half_t>(c, (size_t)B * HW * C);
+  float* yf = ws_alloc<float>(c, (size_t)B * HW * C);
+  WS_CHECK(xn && y && yf);
+  RET_IF(launch_nchw_to_nhwc(x_nchw, B, C, HW, xn, C, C, s));
+  NormW n;
+  n.g = const_cast<float*>(gamma); n.b = const_cast<float*>(beta); n.C = C;
+  RET_IF(run_group_norm(c, xn, C, B, HW, n, groups, eps, act, nullptr, y, C, s));
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)B * HW * C)), dim3(256), 0, s, y, yf, (size_t)B * HW * C);
+  RET_IF(launch_nhwc_to_nchw(yf, C, B, C, HW, out_nchw, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* gamma, const float* beta, float* out,
+                      void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  half_t* y = ws_alloc<half_t>(c, (size_t)rows * C);
+  WS_CHECK(y);
+  RET_IF(launch_layernorm(x, rows, C, gamma, beta, 1e-5f, y, s));
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, y, out, (size_t)rows * C);
+  HIP_CHECK_RET(hipGetLastError());
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v, int B, int T, int heads, int d, float* out,
+                     void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  const int C = heads * d, rows = B * T;
+  half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
+  half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* o = ws_alloc<half_t>(c, (size_t)rows * C);
+  WS_CHECK(qk && vt && o);
+  hipLaunchKernelGGL(pack_qkv_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, q, k, v, rows, C, qk, vt);
+  RET_IF(launch_attention(qk, 2 * C, vt, rows, o, C, B, T, heads, d, s));
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, o, out, (size_t)rows * C);
+  HIP_CHECK_RET(hipGetLastError());
+  c->ws.off = mark;
+  return 0;
+}
+
+int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  const size_t na = (size_t)B * H * W * C, nw = (size_t)9 * Cout * C;
+  half_t* a = ws_alloc<half_t>(c, na);
+  half_t* w = ws_alloc<half_t>(c, nw);
+  float* o = ws_alloc<float>(c, (size_t)B * H * W * Cout);
+  WS_CHECK(a && w && o);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(na)), dim3(256), 0, s, a, na, 17u);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(nw)), dim3(256), 0, s, w, nw, 91u);
+  ConvW cw;
+  cw.w = w; cw.N = Cout; cw.Cin = C; cw.taps = 9;
+  GemmArgs g;
+  g.a = a; g.lda = C; g.w = &cw; g.out = o; g.ldc = Cout; g.use_bias = false;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));  // warm-up
+  hipEvent_t e0, e1;
+  HIP_CHECK_RET(hipEventCreate(&e0));
+  HIP_CHECK_RET(hipEventCreate(&e1));
+  HIP_CHECK_RET(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  HIP_CHECK_RET(hipEventRecord(e1, s));
+  HIP_CHECK_RET(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_out = ms / (float)iters;
+  c->ws.off = mark;
+  return 0;
+}
+
+}  // extern "C"

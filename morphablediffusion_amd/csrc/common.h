@@ -1,0 +1,127 @@
+// Shared declarations for the gfx950 kernels and the host engine.  HIP only, wave64, no CUDA shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MVD_MAX_TAPS 27
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor:  out[row(m)][n] = epilogue( sum_{tap,c} A[in(m,tap)][c] * W[tap][n][c] )
+// A is a channels-last activation tensor [B, PZ, PY, PX, lda] (fp16 or fp32) gathered through a
+// tap table; W is fp16 [ntaps][N][Cin] (k-contiguous per output channel).
+// ------------------------------------------------------------------------------------------------
+struct IGemm {
+  const void* a;        // activation base (channel offset already applied)
+  int a_f32;            // 1: fp32 source (converted to fp16 while staging), 0: fp16 source
+  int lda;              // elements between consecutive pixels
+  int Cin;              // channels per tap (multiple of 8)
+  // logical output grid; M = B*Z*Y*X
+  int B, Z, Y, X;
+  // virtual input extent (after nearest upsample), strides, physical extent = virtual >> ups
+  int IZ, IY, IX;
+  int sz, sy, sx;
+  int ups;
+  int PZ, PY, PX;
+  int ntaps;
+  signed char dz[MVD_MAX_TAPS], dy[MVD_MAX_TAPS], dx[MVD_MAX_TAPS];
+  signed char wt[MVD_MAX_TAPS];  // weight slab used by loop tap i (identity except for transposed-conv parity classes)
+  // weights
+  const half_t* w;
+  int N;                // GEMM N (before GEGLU halving)
+  // output
+  void* out;
+  int out_f32;
+  int ldc;
+  int out_linear;       // 1: row offset = m*ldc ; 0: use the (OZ..oxo) mapping below
+  int OZ, OY, OX, ozm, ozo, oym, oyo, oxm, oxo;
+  // epilogue
+  const float* bias;    // [N] or null
+  const float* rowbias; // [B][rb_ld] or null (per-sample bias, e.g. timestep embedding)
+  int rb_ld;
+  const void* resid;    // same row mapping / ld as out, or null
+  int resid_f32;
+  int ldr;
+  int geglu;            // pairs 32-column blocks (x | gate): out cols = N/2
+  float alpha;          // scale on the accumulator before bias
+  // split-K
+  int splitk;
+  float* partial;       // [splitk][M][N] fp32 when splitk > 1
+};
+
+struct MvdStream {
+  hipStream_t s;
+};
+
+#define HIP_CHECK_RET(expr)                                        \
+  do {                                                             \
+    hipError_t _e = (expr);                                        \
+    if (_e != hipSuccess) return mvd_fail(hipGetErrorString(_e));  \
+  } while (0)
+
+int mvd_fail(const char* msg);  // records thread-local error text, returns -1
+const char* mvd_error_text();
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------------
+int launch_igemm(const IGemm& g, hipStream_t s);
+size_t igemm_partial_bytes(const IGemm& g);
+int igemm_pick_splitk(int M, int N, int ksteps);
+
+int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+                    float* partial, int* nslabs_out, hipStream_t s);
+int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+                    const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
+                    half_t* out, int ldo, hipStream_t s);
+int gn_max_slabs();
+int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
+                     half_t* out, hipStream_t s);
+int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
+                     int heads, int d, hipStream_t s);
+int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
+                      hipStream_t s);
+int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,
+                        int act_in, float* out, int ldo, int accumulate, hipStream_t s);
+int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipStream_t s);
+int launch_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, int ldo, int cpad, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, int ld, int B, int C, int HW, float* out, hipStream_t s);
+int launch_pack_weight(const float* src, int N, int Cin, int taps, int transposed, int geglu, half_t* dst,
+                       hipStream_t s, int cin_src = -1);
+int launch_permute_geglu_bias(const float* src, int N, float* dst, hipStream_t s);
+int launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
+int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n, hipStream_t s);
+int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
+                   hipStream_t s);
+int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s);
+int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s);
+int launch_cfg_ddim(const float* eps_c, const float* eps_u, float scale, const float* x, const float* noise,
+                    float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,
+                    float* eps_out, float* x_prev, size_t n, hipStream_t s);
+// conditioner
+struct ViewCam {
+  float P[12];     // 3x4 projection into the size x size feature map (rows of the 4x4 minus the last)
+  float Pinv[12];  // 3x4 inverse mapping (perspective: inv(P); orthographic: see engine)
+  float Kinv[9];   // orthographic only
+  float near_, far_;
+};
+int launch_vertex_gather(const float* feats, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
+                         float vol_len, int fsize, int persp, float* out, hipStream_t s);
+int launch_fuse_views(const float* vf, int n_views, int Nv, int total_views, const float* w, const float* b,
+                      float* out, int accumulate, hipStream_t s);
+int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w,
+                       const float* scale, const float* shift, float* out, hipStream_t s);
+int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
+                         const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s);
+int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V,
+                          float vol_len, int persp, half_t* out, hipStream_t s);
+int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s);

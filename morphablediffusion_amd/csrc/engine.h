@@ -1,0 +1,196 @@
+// Host-side engine: weight store, block plan, workspace, and the executors that turn one denoising step
+// into a fixed sequence of kernel launches on one HIP stream (no Python in the loop, no allocation).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mvd.h"
+#include "common.h"
+
+struct RawTensor {
+  float* d = nullptr;  // device fp32 copy in reference layout
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+};
+
+struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
+  half_t* w = nullptr;
+  float* bias = nullptr;
+  int N = 0, Cin = 0, taps = 1;
+};
+struct NormW {
+  float* g = nullptr;
+  float* b = nullptr;
+  int C = 0;
+};
+struct LinW {  // small per-sample linear: fp16 [N][K]
+  half_t* w = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0;
+};
+
+struct ResW {
+  NormW n1, n2;
+  ConvW c1, c2, skip;
+  bool has_skip = false;
+  int cin = 0, cout = 0, emb_off = 0;
+};
+struct STW {
+  NormW norm, ln1, ln3;
+  ConvW proj_in, qk, vt, attn_out, ff1, ff2, proj_out;
+  LinW a2v, a2o;
+  int C = 0, heads = 8;
+};
+struct CondW {
+  ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;
+  NormW gn_in, gn_ctx, gn_o1, gn_o2;
+  half_t* relu_beta = nullptr;  // [4*Cc] z row for an all-zero context (CFG uncond half)
+  int dim = 0, Cc = 0, I = 0;
+};
+struct UOp {
+  int kind = 0;  // 0 conv_in, 1 res, 2 st, 3 down, 4 up
+  int idx = 0;   // index into the per-kind weight vectors
+  int cin = 0, cout = 0;
+};
+enum { OP_CONV_IN = 0, OP_RES = 1, OP_ST = 2, OP_DOWN = 3, OP_UP = 4 };
+
+struct FrustumBlockW {
+  LinW t_conv, v_conv;
+  NormW gn;
+  ConvW conv;
+  int cin = 0, cout = 0, stride = 1;
+};
+struct SparseLayerW {
+  float* w = nullptr;      // [27][Cin][Cout] fp32
+  float* scale = nullptr;  // folded eval BatchNorm
+  float* shift = nullptr;
+  int cin = 0, cout = 0;
+  bool strided = false;
+};
+struct EncBlockW {
+  LinW t, v;
+  NormW n1, n2;
+  ConvW c1, c2;
+};
+
+struct Workspace {
+  char* base = nullptr;
+  size_t size = 0, off = 0, peak = 0;
+  void* alloc(size_t bytes) {
+    size_t o = (off + 255) & ~(size_t)255;
+    if (o + bytes > size) return nullptr;
+    off = o + bytes;
+    if (off > peak) peak = off;
+    return base + o;
+  }
+};
+
+struct MeshTables {
+  int Nv = 0;
+  float* verts = nullptr;  // device [Nv][3]
+  int n_sites[3] = {0, 0, 0};
+  int shape[3][3];           // (d,h,w) per level
+  int* nbr_subm[3] = {nullptr, nullptr, nullptr};
+  int* nbr_down[2] = {nullptr, nullptr};  // level l -> l+1, indexed by output site
+  int* grid2 = nullptr;                    // coarse index grid (level 2)
+  float min_xyz[3];
+  int out_sh[3];
+  float* feat[2] = {nullptr, nullptr};  // ping-pong feature buffers [max_sites][64]
+};
+
+struct mvd_ctx {
+  mvd_unet_config u;
+  mvd_volume_config v;
+  int device = 0;
+  bool finalized = false;
+  bool has_unet = false, has_cond = false, has_step = false;
+  std::map<std::string, RawTensor> raw;
+  std::vector<void*> owned;  // packed device allocations
+
+  // UNet
+  LinW te0, te2, emb_all;
+  int emb_total = 0;
+  std::vector<std::vector<UOp>> in_blocks, out_blocks;
+  std::vector<UOp> mid_block;
+  std::vector<ResW> res;
+  std::vector<STW> st;
+  std::vector<ConvW> convs;  // conv_in / down / up
+  std::vector<CondW> conds;  // [0] middle, [1+k] output_conditions.k
+  NormW out_norm;
+  ConvW out_conv;
+  // step embedding MLP of the Lightning module
+  LinW step_te0, step_te2;
+  // conditioner
+  ConvW enc_init, enc_final;
+  NormW enc_final_norm;
+  EncBlockW enc_blocks[3];
+  float* fuse_w = nullptr;
+  float* fuse_b = nullptr;
+  SparseLayerW sparse[9];
+  ConvW fr_conv0;
+  FrustumBlockW fr_blocks[6], fr_up[3];
+
+  Workspace ws;
+  MeshTables mesh;
+  ViewCam* cams = nullptr;  // device [n_cams]
+  int n_cams = 0;
+  float* volume = nullptr;  // device [V][V][V][64] fp32 (channels-last)
+};
+
+// engine_weights.hip
+int engine_finalize(mvd_ctx* c);
+// engine_unet.hip
+struct Ctx5 {  // channels-last context volume of one level for the first n_ctx samples
+  const void* p = nullptr;
+  int f32 = 1;
+};
+int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s);
+// engine_cond.hip
+int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
+                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s);
+int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s);
+struct FrustumOut {
+  float* lvl[4];  // channels-last fp32 [TN, D_l, s_l, s_l, C_l]
+};
+int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
+                   FrustumOut* out, hipStream_t s);
+
+// helpers shared by the executors
+struct GemmArgs {
+  const void* a = nullptr;
+  int a_f32 = 0, lda = 0;
+  const ConvW* w = nullptr;
+  void* out = nullptr;
+  int out_f32 = 1, ldc = 0;
+  const float* rowbias = nullptr;
+  int rb_ld = 0;
+  const void* resid = nullptr;
+  int resid_f32 = 1, ldr = 0;
+  int geglu = 0;
+  bool use_bias = true;
+  int force_splitk = 0;
+};
+// plain GEMM / 1x1 conv over `rows` rows grouped in `B` samples (rows % B == 0)
+int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s);
+// 3x3 conv (stride 1/2, optional nearest x2 upsample of the input) on [B,H,W,*] channels-last
+int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, int ups, hipStream_t s);
+// 3x3x3 conv stride 1/2 on [B,D,H,W,*]
+int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int stride, hipStream_t s);
+// ConvTranspose3d(k3,s2,p1,op1): 8 output-parity classes
+int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s);
+// GroupNorm(+act) -> fp16
+int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s);
+template <typename T>
+inline T* ws_alloc(mvd_ctx* c, size_t n) {
+  return (T*)c->ws.alloc(n * sizeof(T));
+}
+#define WS_CHECK(p) \
+  if (!(p)) return mvd_fail("workspace exhausted: create the context with a larger workspace_bytes")
+#define RET_IF(x)          \
+  do {                     \
+    int _r = (x);          \
+    if (_r) return _r;     \
+  } while (0)

@@ -1,0 +1,350 @@
+// Mesh conditioner + per-view frustum network executors (reference SpatialVolumeNet,
+// ldm/models/diffusion/morphable_diffusion.py:151-320; networks in ldm/models/diffusion/network.py).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <unordered_map>
+
+#include "engine.h"
+
+namespace {
+
+// ---- 4x4 helpers (host, double) -------------------------------------------------------------------
+bool inv4(const double* m, double* out) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = m[i * 4 + j];
+      a[i][j + 4] = i == j ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+    if (fabs(a[piv][col]) < 1e-300) return false;
+    if (piv != col)
+      for (int j = 0; j < 8; ++j) std::swap(a[piv][j], a[col][j]);
+    const double d = a[col][col];
+    for (int j = 0; j < 8; ++j) a[col][j] /= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double fct = a[r][col];
+        for (int j = 0; j < 8; ++j) a[r][j] -= fct * a[col][j];
+      }
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][j + 4];
+  return true;
+}
+
+void mul4(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
+
+inline long key3(int z, int y, int x) { return ((long)z << 40) | ((long)y << 20) | (long)x; }
+
+int upload_ints(const std::vector<int>& h, int** d) {
+  if (*d) hipFree(*d);
+  *d = nullptr;
+  HIP_CHECK_RET(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(int)));
+  if (!h.empty()) HIP_CHECK_RET(hipMemcpy(*d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------
+// mvd_set_cameras: construct_project_matrix (utils.py:46-69), the inverse used by create_target_volume
+// (utils.py:79-153) and near/far from the camera distance (morphable_diffusion.py:281-299), once per sample.
+int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
+  std::vector<ViewCam> cams(N);
+  const double ratio = (double)(c->v.input_image_size / 8) / (double)c->v.input_image_size;
+  for (int i = 0; i < N; ++i) {
+    const float* k = K + i * 16;
+    const float* rt = RT + i * 12;
+    double RT4[16], K4[16], P4[16], Pinv[16];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 4; ++b) RT4[a * 4 + b] = rt[a * 4 + b];
+    RT4[12] = RT4[13] = RT4[14] = 0;
+    RT4[15] = 1;
+    for (int a = 0; a < 16; ++a) K4[a] = k[a];
+    ViewCam& v = cams[i];
+    memset(&v, 0, sizeof(v));
+    if (c->v.projection == 0) {
+      double KS[16] = {0};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) KS[a * 4 + b] = K4[a * 4 + b] * (a < 2 ? ratio : 1.0);
+      KS[15] = 1;
+      mul4(KS, RT4, P4);  // rows 0..2 = diag(r,r,1) K3 [R|t]; row 3 = (0,0,0,1)
+      if (!inv4(P4, Pinv)) return mvd_fail("set_cameras: singular projection matrix");
+      for (int a = 0; a < 12; ++a) {
+        v.P[a] = (float)P4[a];
+        v.Pinv[a] = (float)Pinv[a];
+      }
+    } else {
+      double Kinv[16], RTinv[16];
+      mul4(K4, RT4, P4);
+      if (!inv4(K4, Kinv) || !inv4(RT4, RTinv)) return mvd_fail("set_cameras: singular K or RT");
+      for (int a = 0; a < 12; ++a) {
+        v.P[a] = (float)P4[a];
+        v.Pinv[a] = (float)RTinv[a];
+      }
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) v.Kinv[a * 3 + b] = (float)Kinv[a * 4 + b];
+    }
+    double pos[3];
+    for (int a = 0; a < 3; ++a) pos[a] = -(RT4[0 * 4 + a] * RT4[3] + RT4[1 * 4 + a] * RT4[7] + RT4[2 * 4 + a] * RT4[11]);
+    const double dist = sqrt(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+    v.near_ = (float)dist - c->v.frustum_volume_length;
+    v.far_ = (float)dist + c->v.frustum_volume_length;
+  }
+  if (c->cams) hipFree(c->cams);
+  HIP_CHECK_RET(hipMalloc((void**)&c->cams, N * sizeof(ViewCam)));
+  HIP_CHECK_RET(hipMemcpy(c->cams, cams.data(), N * sizeof(ViewCam), hipMemcpyHostToDevice));
+  c->n_cams = N;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// mvd_set_mesh: the "rulebook" spconv would build per call (SubMConv3d k3 / SparseConv3d k3 s2 p1), built
+// once per mesh on the host because coord/out_sh/bounds are step-invariant (SURVEY gotcha G15).
+int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+                    int Nv) {
+  MeshTables& m = c->mesh;
+  m.Nv = Nv;
+  if (m.verts) hipFree(m.verts);
+  HIP_CHECK_RET(hipMalloc((void**)&m.verts, (size_t)Nv * 3 * sizeof(float)));
+  HIP_CHECK_RET(hipMemcpy(m.verts, vertices, (size_t)Nv * 3 * sizeof(float), hipMemcpyHostToDevice));
+  for (int a = 0; a < 3; ++a) {
+    m.min_xyz[a] = bounds[a];
+    m.out_sh[a] = out_sh[a];
+  }
+  std::vector<std::array<int, 3>> sites(Nv);
+  for (int i = 0; i < Nv; ++i) sites[i] = {coord[i * 3], coord[i * 3 + 1], coord[i * 3 + 2]};
+  int shape[3] = {out_sh[0], out_sh[1], out_sh[2]};
+  int max_sites = Nv;
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    std::unordered_map<long, int> idx;
+    idx.reserve(sites.size() * 2);
+    for (int i = 0; i < (int)sites.size(); ++i) {
+      auto& s = sites[i];
+      if (s[0] < 0 || s[1] < 0 || s[2] < 0 || s[0] >= shape[0] || s[1] >= shape[1] || s[2] >= shape[2])
+        return mvd_fail("set_mesh: voxel coordinate outside out_sh");
+      if (!idx.emplace(key3(s[0], s[1], s[2]), i).second)
+        return mvd_fail("set_mesh: duplicate voxel coordinates (undefined in spconv; de-duplicate the mesh)");
+    }
+    m.n_sites[lvl] = (int)sites.size();
+    for (int a = 0; a < 3; ++a) m.shape[lvl][a] = shape[a];
+    std::vector<int> nbr(sites.size() * 27);
+    for (int i = 0; i < (int)sites.size(); ++i)
+      for (int k = 0; k < 27; ++k) {
+        const int z = sites[i][0] + k / 9 - 1, y = sites[i][1] + (k / 3) % 3 - 1, x = sites[i][2] + k % 3 - 1;
+        auto it = (z < 0 || y < 0 || x < 0) ? idx.end() : idx.find(key3(z, y, x));
+        nbr[(size_t)i * 27 + k] = it == idx.end() ? -1 : it->second;
+      }
+    RET_IF(upload_ints(nbr, &m.nbr_subm[lvl]));
+    if (lvl == 2) {
+      std::vector<int> grid((size_t)shape[0] * shape[1] * shape[2], -1);
+      for (int i = 0; i < (int)sites.size(); ++i)
+        grid[((size_t)sites[i][0] * shape[1] + sites[i][1]) * shape[2] + sites[i][2]] = i;
+      RET_IF(upload_ints(grid, &m.grid2));
+      break;
+    }
+    // strided conv to the next level: o = (i + 1 - k) / 2 when integral and in range
+    int oshape[3] = {(shape[0] - 1) / 2 + 1, (shape[1] - 1) / 2 + 1, (shape[2] - 1) / 2 + 1};
+    std::vector<long> keys;
+    for (auto& s : sites)
+      for (int k = 0; k < 27; ++k) {
+        const int nz = s[0] + 1 - k / 9, ny = s[1] + 1 - (k / 3) % 3, nx = s[2] + 1 - k % 3;
+        if ((nz & 1) || (ny & 1) || (nx & 1) || nz < 0 || ny < 0 || nx < 0) continue;
+        const int oz = nz / 2, oy = ny / 2, ox = nx / 2;
+        if (oz >= oshape[0] || oy >= oshape[1] || ox >= oshape[2]) continue;
+        keys.push_back(key3(oz, oy, ox));
+      }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<std::array<int, 3>> osites(keys.size());
+    std::vector<int> dn(keys.size() * 27);
+    for (size_t o = 0; o < keys.size(); ++o) {
+      const int oz = (int)(keys[o] >> 40), oy = (int)((keys[o] >> 20) & 0xFFFFF), ox = (int)(keys[o] & 0xFFFFF);
+      osites[o] = {oz, oy, ox};
+      for (int k = 0; k < 27; ++k) {
+        const int z = 2 * oz - 1 + k / 9, y = 2 * oy - 1 + (k / 3) % 3, x = 2 * ox - 1 + k % 3;
+        auto it = (z < 0 || y < 0 || x < 0) ? idx.end() : idx.find(key3(z, y, x));
+        dn[o * 27 + k] = it == idx.end() ? -1 : it->second;
+      }
+    }
+    RET_IF(upload_ints(dn, &m.nbr_down[lvl]));
+    sites.swap(osites);
+    for (int a = 0; a < 3; ++a) shape[a] = oshape[a];
+    max_sites = std::max(max_sites, (int)sites.size());
+  }
+  for (int b = 0; b < 2; ++b) {
+    if (m.feat[b]) hipFree(m.feat[b]);
+    HIP_CHECK_RET(hipMalloc((void**)&m.feat[b], (size_t)max_sites * 64 * sizeof(float)));
+  }
+  if (!c->volume) {
+    const int V = c->v.spatial_volume_size;
+    HIP_CHECK_RET(hipMalloc((void**)&c->volume, (size_t)V * V * V * 64 * sizeof(float)));
+  }
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// NoisyTargetViewEncoder (network.py:181-207) for n_local views + fused unprojection/vertex gather + this
+// rank's share of the view mean (morphable_diffusion.py:203-231).
+int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
+                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
+  const size_t mark = c->ws.off;
+  const int S = c->u.image_size, HW = S * S, rows = n_local * HW, td = c->v.time_dim, vd = c->v.view_dim;
+  float* x8 = ws_alloc<float>(c, (size_t)rows * 8);
+  float* h = ws_alloc<float>(c, (size_t)rows * 16);
+  float* h2 = ws_alloc<float>(c, (size_t)rows * 16);
+  float* r1 = ws_alloc<float>(c, (size_t)rows * 16);
+  half_t* a = ws_alloc<half_t>(c, (size_t)rows * 16);
+  float* pre = ws_alloc<float>(c, (size_t)n_local * 16);
+  float* tpart = ws_alloc<float>(c, 16);
+  float* feats = ws_alloc<float>(c, (size_t)rows * 16);
+  float* vf = ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
+  WS_CHECK(x8 && h && h2 && r1 && a && pre && tpart && feats && vf);
+  RET_IF(launch_nchw_to_nhwc(x_noisy, n_local, 4, HW, x8, 8, 8, s));
+  GemmArgs g;
+  g.a = x8; g.a_f32 = 1; g.lda = 8; g.w = &c->enc_init; g.out = h; g.ldc = 16;
+  RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
+  float* cur = h;
+  float* nxt = h2;
+  for (int i = 0; i < 3; ++i) {
+    const EncBlockW& e = c->enc_blocks[i];
+    // x + time_embed(t) + view_embed(v): the step embedding is shared by all views of the sample
+    for (int v = 0; v < n_local; ++v)
+      RET_IF(launch_small_linear(t_embed, td, 1, td, e.t.w, e.t.bias, 16, ACT_NONE, pre + v * 16, 16, 0, s));
+    RET_IF(launch_small_linear(v_embed, vd, n_local, vd, e.v.w, e.v.bias, 16, ACT_NONE, pre, 16, 1, s));
+    RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre, a, 16, s));
+    g = GemmArgs();
+    g.a = a; g.lda = 16; g.w = &e.c1; g.out = r1; g.ldc = 16;
+    RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
+    RET_IF(run_group_norm(c, r1, 16, n_local, HW, e.n2, 8, 1e-5f, ACT_SILU, nullptr, a, 16, s));
+    g = GemmArgs();
+    g.a = a; g.lda = 16; g.w = &e.c2; g.out = nxt; g.ldc = 16; g.resid = cur; g.ldr = 16;
+    RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
+    std::swap(cur, nxt);
+  }
+  RET_IF(run_group_norm(c, cur, 16, n_local, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, a, 16, s));
+  g = GemmArgs();
+  g.a = a; g.lda = 16; g.w = &c->enc_final; g.out = feats; g.ldc = 16;
+  RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
+  RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
+                              c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
+  RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
+                           0, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// SparseConvNet (network.py:74-96) + latent-code volume gather (morphable_diffusion.py:232-257)
+int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s) {
+  MeshTables& m = c->mesh;
+  if (!m.Nv) return mvd_fail("mvd_set_mesh must be called first");
+  const float* in = fused;
+  int lvl = 0, pp = 0;
+  for (int i = 0; i < 9; ++i) {
+    const SparseLayerW& L = c->sparse[i];
+    const int* nbr;
+    int n_out;
+    if (L.strided) {
+      nbr = m.nbr_down[lvl];
+      ++lvl;
+      n_out = m.n_sites[lvl];
+    } else {
+      nbr = m.nbr_subm[lvl];
+      n_out = m.n_sites[lvl];
+    }
+    float* out = m.feat[pp];
+    RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.scale, L.shift, out, s));
+    in = out;
+    pp ^= 1;
+  }
+  RET_IF(launch_latent_gather(in, m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh,
+                              c->v.voxel_size, c->v.spatial_volume_size, c->v.spatial_volume_length, c->volume, s));
+  return 0;
+}
+
+// construct_view_frustum_volume (morphable_diffusion.py:265-320): frustum gather + FrustumTV3DNet
+// (network.py:313-347).  Outputs stay channels-last fp32 in the workspace (caller owns the mark).
+int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
+                   FrustumOut* out, hipStream_t s) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->volume || !c->cams) return mvd_fail("volume / cameras not set");
+  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
+  const int* fd = c->v.frustum_dims;
+  int D[4], S[4];
+  for (int l = 0; l < 4; ++l) {
+    D[l] = l ? (D[l - 1] - 1) / 2 + 1 : D0;
+    S[l] = l ? (S[l - 1] - 1) / 2 + 1 : S0;
+  }
+  auto vox = [&](int l) { return (size_t)TN * D[l] * S[l] * S[l]; };
+  // outputs (persist for the caller)
+  float* x[4];
+  for (int l = 0; l < 4; ++l) {
+    x[l] = ws_alloc<float>(c, vox(l) * fd[l]);
+    WS_CHECK(x[l]);
+    out->lvl[l] = x[l];
+  }
+  const size_t mark = c->ws.off;
+  half_t* gath = ws_alloc<half_t>(c, vox(0) * 64);
+  float* tmp = ws_alloc<float>(c, vox(1) * fd[1]);  // largest intermediate (conv1 output == level-1 size)
+  half_t* a = ws_alloc<half_t>(c, vox(0) * fd[0]);
+  float* pre = ws_alloc<float>(c, (size_t)TN * 512);
+  float* up = ws_alloc<float>(c, vox(0) * fd[0]);
+  WS_CHECK(gath && tmp && a && pre && up);
+  RET_IF(launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
+                               c->v.spatial_volume_length, c->v.projection == 0, gath, s));
+  GemmArgs g;
+  g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = x[0]; g.ldc = fd[0];
+  RET_IF(run_conv3d(c, g, TN, D0, S0, S0, 1, s));
+  auto film = [&](const FrustumBlockW& b) -> int {
+    // x + t_conv(t) + v_conv(v) (network.py:294,308): per-(view, channel) constant folded into the norm
+    for (int v = 0; v < TN; ++v)
+      RET_IF(launch_small_linear(t_embed, td, 1, td, b.t_conv.w, b.t_conv.bias, b.cin, ACT_NONE, pre + (size_t)v * b.cin,
+                                 b.cin, 0, s));
+    RET_IF(launch_small_linear(v_embed, vd, TN, vd, b.v_conv.w, b.v_conv.bias, b.cin, ACT_NONE, pre, b.cin, 1, s));
+    return 0;
+  };
+  // down path: conv{1,3,5} stride 2, conv{2,4,6} stride 1
+  for (int l = 0; l < 3; ++l) {
+    const FrustumBlockW& b1 = c->fr_blocks[2 * l];
+    const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
+    RET_IF(film(b1));
+    RET_IF(run_group_norm(c, x[l], fd[l], TN, D[l] * S[l] * S[l], b1.gn, 8, 1e-5f, ACT_SILU, pre, a, fd[l], s));
+    g = GemmArgs();
+    g.a = a; g.lda = fd[l]; g.w = &b1.conv; g.out = tmp; g.ldc = fd[l + 1];
+    RET_IF(run_conv3d(c, g, TN, D[l], S[l], S[l], 2, s));
+    RET_IF(film(b2));
+    RET_IF(run_group_norm(c, tmp, fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], b2.gn, 8, 1e-5f, ACT_SILU, pre, a,
+                          fd[l + 1], s));
+    g = GemmArgs();
+    g.a = a; g.lda = fd[l + 1]; g.w = &b2.conv; g.out = x[l + 1]; g.ldc = fd[l + 1];
+    RET_IF(run_conv3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], 1, s));
+  }
+  // up path: x_l = up(x_{l+1}) + x_l  (in place on x_l through the residual epilogue)
+  for (int l = 2; l >= 0; --l) {
+    const FrustumBlockW& u = c->fr_up[2 - l];
+    RET_IF(film(u));
+    RET_IF(run_group_norm(c, x[l + 1], fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], u.gn, 8, 1e-5f, ACT_SILU, pre, a,
+                          fd[l + 1], s));
+    g = GemmArgs();
+    g.a = a; g.lda = fd[l + 1]; g.w = &u.conv; g.out = x[l]; g.ldc = fd[l]; g.resid = x[l]; g.ldr = fd[l];
+    RET_IF(run_convT3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], s));
+  }
+  c->ws.off = mark;
+  return 0;
+}

@@ -1,0 +1,484 @@
+// UNet executor: DepthWiseAttention.forward (reference ldm/models/diffusion/attention.py:117-138) as a fixed
+// launch sequence.  Data layout in HBM:
+//   * residual stream / anything read by a norm or a residual add: fp32, channels-last [B*H*W, C]
+//   * anything that is only ever an MFMA operand (norm outputs, q/k/v, attention output, GEGLU output,
+//     depth-attention z): fp16
+//   * skip connections are "concatenated by construction": the producer of each skip tensor writes into the
+//     channel slice of the buffer the matching output block will read (row stride = concatenated width).
+#include <string.h>
+
+#include "engine.h"
+
+namespace {
+
+void igemm_init(IGemm& g) {
+  memset(&g, 0, sizeof(g));
+  g.alpha = 1.0f;
+  g.sz = g.sy = g.sx = 1;
+  g.out_linear = 1;
+  g.Z = g.Y = g.X = g.B = 1;
+  g.IZ = g.IY = g.IX = 1;
+  g.PZ = g.PY = g.PX = 1;
+  for (int i = 0; i < MVD_MAX_TAPS; ++i) g.wt[i] = (signed char)i;
+}
+
+void igemm_fill(IGemm& g, const GemmArgs& ga) {
+  g.a = ga.a;
+  g.a_f32 = ga.a_f32;
+  g.lda = ga.lda;
+  g.Cin = ga.w->Cin;
+  g.w = ga.w->w;
+  g.N = ga.w->N;
+  g.out = ga.out;
+  g.out_f32 = ga.out_f32;
+  g.ldc = ga.ldc;
+  g.bias = ga.use_bias ? ga.w->bias : nullptr;
+  g.rowbias = ga.rowbias;
+  g.rb_ld = ga.rb_ld;
+  g.resid = ga.resid;
+  g.resid_f32 = ga.resid_f32;
+  g.ldr = ga.ldr;
+  g.geglu = ga.geglu;
+}
+
+int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
+  const int M = g.B * g.Z * g.Y * g.X;
+  const int ksteps = g.ntaps * cdiv(g.Cin, 64);
+  int sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps);
+  if (sk > ksteps) sk = ksteps;
+  const size_t mark = c->ws.off;
+  g.splitk = sk;
+  g.partial = nullptr;
+  if (sk > 1) {
+    g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
+    if (!g.partial) {  // not enough scratch: fall back to a single pass
+      g.splitk = 1;
+    }
+  }
+  const int r = launch_igemm(g, s);
+  c->ws.off = mark;  // stream-ordered reuse
+  return r;
+}
+
+}  // namespace
+
+int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s) {
+  IGemm g;
+  igemm_init(g);
+  igemm_fill(g, ga);
+  g.B = B;
+  g.X = rows / B;
+  g.IX = g.X;
+  g.PX = g.X;
+  g.ntaps = 1;
+  return igemm_go(c, g, ga.force_splitk, s);
+}
+
+int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, int ups, hipStream_t s) {
+  IGemm g;
+  igemm_init(g);
+  igemm_fill(g, ga);
+  g.B = B;
+  g.PY = H;
+  g.PX = W;
+  g.ups = ups;
+  g.IY = H << ups;
+  g.IX = W << ups;
+  g.sy = g.sx = stride;
+  g.Y = (g.IY - 1) / stride + 1;
+  g.X = (g.IX - 1) / stride + 1;
+  if (ga.w->taps == 9) {
+    g.ntaps = 9;
+    for (int t = 0; t < 9; ++t) {
+      g.dy[t] = (signed char)(t / 3 - 1);
+      g.dx[t] = (signed char)(t % 3 - 1);
+    }
+  } else if (ga.w->taps == 1) {
+    g.ntaps = 1;
+  } else {
+    return mvd_fail("run_conv2d: kernel must be 1x1 or 3x3");
+  }
+  return igemm_go(c, g, ga.force_splitk, s);
+}
+
+int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int stride, hipStream_t s) {
+  IGemm g;
+  igemm_init(g);
+  igemm_fill(g, ga);
+  g.B = B;
+  g.PZ = g.IZ = D;
+  g.PY = g.IY = H;
+  g.PX = g.IX = W;
+  g.sz = g.sy = g.sx = stride;
+  g.Z = (D - 1) / stride + 1;
+  g.Y = (H - 1) / stride + 1;
+  g.X = (W - 1) / stride + 1;
+  if (ga.w->taps == 27) {
+    g.ntaps = 27;
+    for (int t = 0; t < 27; ++t) {
+      g.dz[t] = (signed char)(t / 9 - 1);
+      g.dy[t] = (signed char)((t / 3) % 3 - 1);
+      g.dx[t] = (signed char)(t % 3 - 1);
+    }
+  } else if (ga.w->taps == 1) {
+    g.ntaps = 1;
+  } else {
+    return mvd_fail("run_conv3d: kernel must be 1 or 27 taps");
+  }
+  return igemm_go(c, g, ga.force_splitk, s);
+}
+
+// out[o] += in[i] * W[k] with o = 2 i - 1 + k  (ConvTranspose3d k3 s2 p1 op1).  For output parity p:
+// p = 0 -> k = 1, i = q ;  p = 1 -> (k = 0, i = q + 1), (k = 2, i = q)   where o = 2 q + p.
+int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s) {
+  if (ga.w->taps != 27) return mvd_fail("run_convT3d: expects a 3x3x3 kernel");
+  for (int par = 0; par < 8; ++par) {
+    const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+    IGemm g;
+    igemm_init(g);
+    igemm_fill(g, ga);
+    g.B = B;
+    g.Z = g.PZ = g.IZ = D;
+    g.Y = g.PY = g.IY = H;
+    g.X = g.PX = g.IX = W;
+    const int kz[2] = {pz ? 0 : 1, 2}, dzv[2] = {pz ? 1 : 0, 0}, nz = pz ? 2 : 1;
+    const int ky[2] = {py ? 0 : 1, 2}, dyv[2] = {py ? 1 : 0, 0}, ny = py ? 2 : 1;
+    const int kx[2] = {px ? 0 : 1, 2}, dxv[2] = {px ? 1 : 0, 0}, nx = px ? 2 : 1;
+    int t = 0;
+    for (int a = 0; a < nz; ++a)
+      for (int b = 0; b < ny; ++b)
+        for (int e = 0; e < nx; ++e) {
+          g.dz[t] = (signed char)dzv[a];
+          g.dy[t] = (signed char)dyv[b];
+          g.dx[t] = (signed char)dxv[e];
+          g.wt[t] = (signed char)((kz[a] * 3 + ky[b]) * 3 + kx[e]);
+          ++t;
+        }
+    g.ntaps = t;
+    g.out_linear = 0;
+    g.OZ = 2 * D;
+    g.OY = 2 * H;
+    g.OX = 2 * W;
+    g.ozm = g.oym = g.oxm = 2;
+    g.ozo = pz;
+    g.oyo = py;
+    g.oxo = px;
+    RET_IF(igemm_go(c, g, ga.force_splitk, s));
+  }
+  return 0;
+}
+
+int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s) {
+  const size_t mark = c->ws.off;
+  float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
+  WS_CHECK(partial);
+  int nslabs = 0;
+  RET_IF(launch_gn_stats(x, ld, B, rows_per_sample, n.C, groups, preadd, partial, &nslabs, s));
+  RET_IF(launch_gn_apply(x, ld, B, rows_per_sample, n.C, groups, preadd, partial, nslabs, n.g, n.b, eps, act, out, ldo, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+namespace {
+
+struct View {
+  float* p = nullptr;
+  int ld = 0, C = 0;
+};
+
+struct Fwd {
+  mvd_ctx* c;
+  hipStream_t s;
+  int Bv, n_ctx, depth0;
+  const float* emb_all;  // [Bv][emb_total]
+  const float* context;  // [Bv][context_dim]
+  const Ctx5* src;
+};
+
+// ResBlock._forward, openaimodel.py:256-276
+int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
+  mvd_ctx* c = f.c;
+  const size_t mark = c->ws.off;
+  const int rows = f.Bv * H * W;
+  half_t* a1 = ws_alloc<half_t>(c, (size_t)rows * r.cin);
+  float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
+  half_t* a2 = ws_alloc<half_t>(c, (size_t)rows * r.cout);
+  WS_CHECK(a1 && h1 && a2);
+  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin, f.s));
+  GemmArgs g1;
+  g1.a = a1; g1.lda = r.cin; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
+  g1.rowbias = f.emb_all + r.emb_off; g1.rb_ld = c->emb_total;
+  RET_IF(run_conv2d(c, g1, f.Bv, H, W, 1, 0, f.s));
+  RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout, f.s));
+  const float* resid = in.p;
+  int ldr = in.ld;
+  if (r.has_skip) {
+    float* sk = ws_alloc<float>(c, (size_t)rows * r.cout);
+    WS_CHECK(sk);
+    GemmArgs gs;
+    gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
+    RET_IF(run_linear(c, gs, f.Bv, rows, f.s));
+    resid = sk;
+    ldr = r.cout;
+  }
+  GemmArgs g2;
+  g2.a = a2; g2.lda = r.cout; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
+  RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// SpatialTransformer.forward modules/attention.py:325-336, BasicTransformerBlock._forward :265-269
+int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
+  mvd_ctx* c = f.c;
+  const size_t mark = c->ws.off;
+  const int C = t.C, T = H * W, rows = f.Bv * T;
+  half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C);
+  float* t0 = ws_alloc<float>(c, (size_t)rows * C);
+  half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
+  half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
+  float* v2a = ws_alloc<float>(c, (size_t)f.Bv * C);
+  float* v2 = ws_alloc<float>(c, (size_t)f.Bv * C);
+  float* t2 = ws_alloc<float>(c, (size_t)rows * C);
+  half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
+  float* t3 = ws_alloc<float>(c, (size_t)rows * C);
+  WS_CHECK(n0 && t0 && l1 && qk && vt && ao && v2a && v2 && t2 && gg && t3);
+  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C, f.s));
+  GemmArgs g;
+  g.a = n0; g.lda = C; g.w = &t.proj_in; g.out = t0; g.ldc = C;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
+  // q | k projection
+  g = GemmArgs();
+  g.a = l1; g.lda = C; g.w = &t.qk; g.out = qk; g.out_f32 = 0; g.ldc = 2 * C; g.use_bias = false;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  // V^T = W_v X^T : the weight matrix is the "activation" operand, the tokens are the "weights"
+  ConvW xw;
+  xw.w = l1; xw.N = rows; xw.Cin = C; xw.taps = 1;
+  g = GemmArgs();
+  g.a = t.vt.w; g.lda = C; g.w = &xw; g.out = vt; g.out_f32 = 0; g.ldc = rows; g.use_bias = false;
+  RET_IF(run_linear(c, g, 1, C, f.s));
+  RET_IF(launch_attention(qk, 2 * C, vt, rows, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
+  // attn2 with the single CLIP token: softmax over one key == 1 -> to_out(to_v(ctx)) broadcast over tokens
+  RET_IF(launch_small_linear(f.context, c->u.context_dim, f.Bv, c->u.context_dim, t.a2v.w, nullptr, C, ACT_NONE, v2a, C, 0, f.s));
+  RET_IF(launch_small_linear(v2a, C, f.Bv, C, t.a2o.w, t.a2o.bias, C, ACT_NONE, v2, C, 0, f.s));
+  g = GemmArgs();
+  g.a = ao; g.lda = C; g.w = &t.attn_out; g.out = t2; g.ldc = C; g.resid = t0; g.ldr = C; g.rowbias = v2; g.rb_ld = C;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l1, f.s));
+  g = GemmArgs();
+  g.a = l1; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  g = GemmArgs();
+  g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.ldc = C; g.resid = t2; g.ldr = C;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  g = GemmArgs();
+  g.a = t3; g.a_f32 = 1; g.lda = C; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// DepthTransformer._forward attention.py:78-84 with DepthAttention folded (see k_depth.hip)
+int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level) {
+  mvd_ctx* c = f.c;
+  const size_t mark = c->ws.off;
+  const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
+  const int crow = f.n_ctx * HW;
+  float* p = ws_alloc<float>(c, (size_t)rows * I);
+  half_t* pn = ws_alloc<half_t>(c, (size_t)rows * I);
+  half_t* z = ws_alloc<half_t>(c, (size_t)rows * 4 * Cc);
+  float* o = ws_alloc<float>(c, (size_t)rows * I);
+  float* o2 = ws_alloc<float>(c, (size_t)rows * I);
+  WS_CHECK(p && pn && z && o && o2);
+  GemmArgs g;
+  g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &d.proj_in; g.out = p; g.ldc = I;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, I, f.s));
+  if (f.n_ctx > 0) {
+    float* qk = ws_alloc<float>(c, (size_t)crow * 4 * Cc);
+    float* pc = ws_alloc<float>(c, (size_t)crow * D * Cc);
+    half_t* cn = ws_alloc<half_t>(c, (size_t)crow * D * Cc);
+    WS_CHECK(qk && pc && cn);
+    g = GemmArgs();
+    g.a = pn; g.lda = I; g.w = &d.wqk; g.out = qk; g.ldc = 4 * Cc; g.use_bias = false;
+    RET_IF(run_linear(c, g, f.n_ctx, crow, f.s));
+    g = GemmArgs();
+    g.a = f.src[level].p; g.a_f32 = f.src[level].f32; g.lda = Cc; g.w = &d.proj_ctx; g.out = pc; g.ldc = Cc; g.use_bias = false;
+    RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
+    RET_IF(run_group_norm(c, pc, Cc, f.n_ctx, D * HW, d.gn_ctx, 8, 1e-5f, ACT_RELU, nullptr, cn, Cc, f.s));
+    RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s));
+  }
+  if (f.Bv > f.n_ctx)  // all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every head
+    RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc, 4 * Cc, rows - crow, d.relu_beta, 4 * Cc, f.s));
+  g = GemmArgs();
+  g.a = z; g.lda = 4 * Cc; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
+  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, I, f.s));
+  g = GemmArgs();
+  g.a = pn; g.lda = I; g.w = &d.conv1; g.out = o2; g.ldc = I; g.use_bias = false;
+  RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
+  RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, I, f.s));
+  g = GemmArgs();
+  g.a = pn; g.lda = I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
+  RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
+  c->ws.off = mark;
+  return 0;
+}
+
+int do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W) {
+  mvd_ctx* c = f.c;
+  switch (op.kind) {
+    case OP_RES: return do_res(f, c->res[op.idx], in, out, H, W);
+    case OP_ST: return do_st(f, c->st[op.idx], in, out, H, W);
+    case OP_CONV_IN:
+    case OP_DOWN:
+    case OP_UP: {
+      GemmArgs g;
+      g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &c->convs[op.idx]; g.out = out.p; g.ldc = out.ld;
+      const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
+      RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
+      if (op.kind == OP_DOWN) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
+      if (op.kind == OP_UP) { H *= 2; W *= 2; }
+      return 0;
+    }
+  }
+  return mvd_fail("unknown op");
+}
+
+int out_res_of(const std::vector<UOp>& ops, int H) {
+  for (auto& o : ops) {
+    if (o.kind == OP_DOWN) H = (H - 1) / 2 + 1;
+    if (o.kind == OP_UP) H *= 2;
+  }
+  return H;
+}
+
+}  // namespace
+
+int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s) {
+  if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
+  const mvd_unet_config& u = c->u;
+  const int mc = u.model_channels, temb = 4 * mc;
+  const size_t mark0 = c->ws.off;
+  Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, src};
+  // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
+  float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
+  float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);
+  float* e2 = ws_alloc<float>(c, (size_t)Bv * temb);
+  float* ea = ws_alloc<float>(c, (size_t)Bv * c->emb_total);
+  WS_CHECK(e0 && e1 && e2 && ea);
+  RET_IF(launch_timestep_embedding(t, Bv, mc, e0, s));
+  RET_IF(launch_small_linear(e0, mc, Bv, mc, c->te0.w, c->te0.bias, temb, ACT_NONE, e1, temb, 0, s));
+  RET_IF(launch_small_linear(e1, temb, Bv, temb, c->te2.w, c->te2.bias, temb, ACT_SILU, e2, temb, 0, s));
+  RET_IF(launch_small_linear(e2, temb, Bv, temb, c->emb_all.w, c->emb_all.bias, c->emb_total, ACT_SILU, ea, c->emb_total, 0, s));
+  f.emb_all = ea;
+
+  // shapes of the concat buffers
+  const int nb = (int)c->in_blocks.size();
+  std::vector<int> in_ch(nb), in_res(nb);
+  {
+    int H = u.image_size;
+    for (int j = 0; j < nb; ++j) {
+      H = out_res_of(c->in_blocks[j], H);
+      in_ch[j] = c->in_blocks[j].back().cout;
+      in_res[j] = H;
+    }
+  }
+  std::vector<int> h_ch(nb + 1), cat_C(nb);
+  std::vector<float*> cat(nb);
+  h_ch[0] = in_ch[nb - 1];
+  for (int i = 0; i < nb; ++i) {
+    const int j = nb - 1 - i;
+    cat_C[i] = h_ch[i] + in_ch[j];
+    cat[i] = ws_alloc<float>(c, (size_t)Bv * in_res[j] * in_res[j] * cat_C[i]);
+    WS_CHECK(cat[i]);
+    h_ch[i + 1] = c->out_blocks[i].back().cout;
+  }
+  float* final_h = ws_alloc<float>(c, (size_t)Bv * u.image_size * u.image_size * mc);
+  WS_CHECK(final_h);
+
+  auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W) -> int {
+    const size_t mark = c->ws.off;
+    View cur = in;
+    const int nstage = (int)ops.size() + (cond ? 1 : 0);
+    for (int k = 0; k < nstage; ++k) {
+      const bool last = k == nstage - 1;
+      const bool is_cond = cond && k == (int)ops.size();
+      const int cout = is_cond ? cond->dim : ops[k].cout;
+      int Ho = H;
+      if (!is_cond) Ho = out_res_of({ops[k]}, H);
+      View o;
+      if (last) o = dst;
+      else {
+        o.p = ws_alloc<float>(c, (size_t)Bv * Ho * Ho * cout);
+        WS_CHECK(o.p);
+        o.ld = cout;
+      }
+      o.C = cout;
+      if (is_cond) {
+        int level = 0;
+        for (int r = u.image_size; r > H; r >>= 1) ++level;
+        RET_IF(do_cond(f, *cond, cur, o, H, W, level));
+      } else {
+        RET_IF(do_op(f, ops[k], cur, o, H, W));
+      }
+      cur = o;
+    }
+    c->ws.off = mark;
+    return 0;
+  };
+
+  int H = u.image_size, W = u.image_size;
+  View cur;
+  cur.p = const_cast<float*>(x_nhwc);
+  cur.ld = x_ld;
+  cur.C = u.in_channels;
+  for (int j = 0; j < nb; ++j) {
+    const int i = nb - 1 - j;
+    View dst;
+    dst.p = cat[i] + h_ch[i];
+    dst.ld = cat_C[i];
+    dst.C = in_ch[j];
+    RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
+    cur = dst;
+  }
+  {
+    View dst;
+    dst.p = cat[0];
+    dst.ld = cat_C[0];
+    RET_IF(run_chain(c->mid_block, &c->conds[0], cur, dst, H, W));
+  }
+  for (int i = 0; i < nb; ++i) {
+    View in;
+    in.p = cat[i];
+    in.ld = cat_C[i];
+    in.C = cat_C[i];
+    View dst;
+    if (i + 1 < nb) {
+      dst.p = cat[i + 1];
+      dst.ld = cat_C[i + 1];
+    } else {
+      dst.p = final_h;
+      dst.ld = mc;
+    }
+    const CondW* cond = i >= 3 ? &c->conds[1 + (i - 3)] : nullptr;  // attention.py:100
+    RET_IF(run_chain(c->out_blocks[i], cond, in, dst, H, W));
+  }
+  // out: GroupNorm32 + SiLU + zero-init conv (openaimodel.py:717-721)
+  {
+    const int rows = Bv * H * W;
+    half_t* a = ws_alloc<half_t>(c, (size_t)rows * mc);
+    WS_CHECK(a);
+    RET_IF(run_group_norm(c, final_h, mc, Bv, H * W, c->out_norm, 32, 1e-5f, ACT_SILU, nullptr, a, mc, s));
+    GemmArgs g;
+    g.a = a; g.lda = mc; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
+    RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));
+  }
+  c->ws.off = mark0;
+  return 0;
+}

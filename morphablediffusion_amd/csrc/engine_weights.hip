@@ -1,0 +1,386 @@
+// Weight store: turns the reference's state_dict (uploaded key by key, fp32, reference layouts) into the
+// packed / folded device layouts the kernels consume, and builds the UNet block plan from the config
+// exactly as the reference ctor does (openaimodel.py:535-720, attention.py:87-115).
+#include <math.h>
+#include <string.h>
+
+#include "engine.h"
+
+namespace {
+
+int dmalloc(mvd_ctx* c, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  HIP_CHECK_RET(hipMalloc(p, bytes));
+  c->owned.push_back(*p);
+  return 0;
+}
+
+int get_raw(mvd_ctx* c, const std::string& k, RawTensor** out) {
+  auto it = c->raw.find(k);
+  if (it == c->raw.end()) {
+    static thread_local std::string msg;
+    msg = "missing weight: " + k;
+    return mvd_fail(msg.c_str());
+  }
+  *out = &it->second;
+  return 0;
+}
+
+int copy_f32(mvd_ctx* c, const std::string& k, float** out, int* n = nullptr) {
+  RawTensor* r;
+  RET_IF(get_raw(c, k, &r));
+  RET_IF(dmalloc(c, (void**)out, r->numel * sizeof(float)));
+  HIP_CHECK_RET(hipMemcpy(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice));
+  if (n) *n = (int)r->numel;
+  return 0;
+}
+
+int load_norm(mvd_ctx* c, const std::string& p, NormW* n) {
+  RET_IF(copy_f32(c, p + ".weight", &n->g, &n->C));
+  RET_IF(copy_f32(c, p + ".bias", &n->b));
+  return 0;
+}
+
+// conv / linear weight -> fp16 [taps][N][Cin(+pad)]
+int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool transposed, bool geglu, ConvW* o,
+              int cin_pad = 0) {
+  RawTensor* r;
+  RET_IF(get_raw(c, wkey, &r));
+  if (r->shape.size() < 2) return mvd_fail("pack_conv: weight rank < 2");
+  int d0 = (int)r->shape[0], d1 = (int)r->shape[1];
+  int taps = 1;
+  for (size_t i = 2; i < r->shape.size(); ++i) taps *= (int)r->shape[i];
+  const int N = transposed ? d1 : d0, cin_src = transposed ? d0 : d1;
+  const int Cin = cin_pad > cin_src ? cin_pad : cin_src;
+  o->N = N;
+  o->Cin = Cin;
+  o->taps = taps;
+  RET_IF(dmalloc(c, (void**)&o->w, (size_t)taps * N * Cin * sizeof(half_t)));
+  RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, 0, cin_src));
+  if (!bkey.empty()) {
+    if (geglu) {
+      RawTensor* b;
+      RET_IF(get_raw(c, bkey, &b));
+      RET_IF(dmalloc(c, (void**)&o->bias, (size_t)N * sizeof(float)));
+      RET_IF(launch_permute_geglu_bias(b->d, N, o->bias, 0));
+    } else {
+      RET_IF(copy_f32(c, bkey, &o->bias));
+    }
+  }
+  return 0;
+}
+
+int pack_lin(mvd_ctx* c, const std::string& wkey, const std::string& bkey, LinW* o) {
+  RawTensor* r;
+  RET_IF(get_raw(c, wkey, &r));
+  o->N = (int)r->shape[0];
+  o->K = (int)(r->numel / r->shape[0]);
+  RET_IF(dmalloc(c, (void**)&o->w, r->numel * sizeof(half_t)));
+  RET_IF(launch_f32_to_f16(r->d, o->w, r->numel, 0));
+  if (!bkey.empty()) RET_IF(copy_f32(c, bkey, &o->bias));
+  return 0;
+}
+
+int build_res(mvd_ctx* c, const std::string& p, int cin, int cout, ResW* r) {
+  r->cin = cin;
+  r->cout = cout;
+  RET_IF(load_norm(c, p + ".in_layers.0", &r->n1));
+  RET_IF(pack_conv(c, p + ".in_layers.2.weight", p + ".in_layers.2.bias", false, false, &r->c1));
+  RET_IF(load_norm(c, p + ".out_layers.0", &r->n2));
+  RET_IF(pack_conv(c, p + ".out_layers.3.weight", p + ".out_layers.3.bias", false, false, &r->c2));
+  r->has_skip = c->raw.count(p + ".skip_connection.weight") > 0;
+  if (r->has_skip) RET_IF(pack_conv(c, p + ".skip_connection.weight", p + ".skip_connection.bias", false, false, &r->skip));
+  else if (cin != cout) return mvd_fail("ResBlock changes width but has no skip_connection weight");
+  return 0;
+}
+
+int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
+  s->C = C;
+  s->heads = c->u.num_heads;
+  const std::string t = p + ".transformer_blocks.0";
+  RET_IF(load_norm(c, p + ".norm", &s->norm));
+  RET_IF(pack_conv(c, p + ".proj_in.weight", p + ".proj_in.bias", false, false, &s->proj_in));
+  RET_IF(pack_conv(c, p + ".proj_out.weight", p + ".proj_out.bias", false, false, &s->proj_out));
+  RET_IF(load_norm(c, t + ".norm1", &s->ln1));
+  RET_IF(load_norm(c, t + ".norm3", &s->ln3));
+  RawTensor *q, *k;
+  RET_IF(get_raw(c, t + ".attn1.to_q.weight", &q));
+  RET_IF(get_raw(c, t + ".attn1.to_k.weight", &k));
+  s->qk.N = 2 * C;
+  s->qk.Cin = C;
+  s->qk.taps = 1;
+  RET_IF(dmalloc(c, (void**)&s->qk.w, (size_t)2 * C * C * sizeof(half_t)));
+  RET_IF(launch_f32_to_f16(q->d, s->qk.w, (size_t)C * C, 0));
+  RET_IF(launch_f32_to_f16(k->d, s->qk.w + (size_t)C * C, (size_t)C * C, 0));
+  RET_IF(pack_conv(c, t + ".attn1.to_v.weight", "", false, false, &s->vt));
+  RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
+  RET_IF(pack_lin(c, t + ".attn2.to_v.weight", "", &s->a2v));
+  RET_IF(pack_lin(c, t + ".attn2.to_out.0.weight", t + ".attn2.to_out.0.bias", &s->a2o));
+  RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
+  RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
+  return 0;
+}
+
+int build_cond(mvd_ctx* c, const std::string& p, int dim, int Cc, CondW* d) {
+  const int heads = 4, hd = Cc / 2, I = 2 * Cc;
+  d->dim = dim;
+  d->Cc = Cc;
+  d->I = I;
+  RET_IF(pack_conv(c, p + ".proj_in.0.weight", p + ".proj_in.0.bias", false, false, &d->proj_in));
+  RET_IF(load_norm(c, p + ".proj_in.1", &d->gn_in));
+  RET_IF(pack_conv(c, p + ".proj_context.0.weight", "", false, false, &d->proj_ctx));
+  RET_IF(load_norm(c, p + ".proj_context.1", &d->gn_ctx));
+  RawTensor *wq, *wk, *wv, *wo;
+  RET_IF(get_raw(c, p + ".depth_attn.to_q.weight", &wq));
+  RET_IF(get_raw(c, p + ".depth_attn.to_k.weight", &wk));
+  RET_IF(get_raw(c, p + ".depth_attn.to_v.weight", &wv));
+  RET_IF(get_raw(c, p + ".depth_attn.to_out.weight", &wo));
+  d->wqk.N = heads * Cc;
+  d->wqk.Cin = I;
+  d->wqk.taps = 1;
+  RET_IF(dmalloc(c, (void**)&d->wqk.w, (size_t)heads * Cc * I * sizeof(half_t)));
+  RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, Cc, I, 1.0f / sqrtf((float)hd), d->wqk.w, 0));
+  d->wov.N = I;
+  d->wov.Cin = heads * Cc;
+  d->wov.taps = 1;
+  RET_IF(dmalloc(c, (void**)&d->wov.w, (size_t)heads * Cc * I * sizeof(half_t)));
+  RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, Cc, I, d->wov.w, 0));
+  RET_IF(load_norm(c, p + ".proj_out.0", &d->gn_o1));
+  RET_IF(pack_conv(c, p + ".proj_out.2.weight", "", false, false, &d->conv1));
+  RET_IF(load_norm(c, p + ".proj_out.3", &d->gn_o2));
+  RET_IF(pack_conv(c, p + ".proj_out.5.weight", "", false, false, &d->conv2));
+  RET_IF(dmalloc(c, (void**)&d->relu_beta, (size_t)heads * Cc * sizeof(half_t)));
+  RET_IF(launch_relu_beta_tile(d->gn_ctx.b, Cc, heads, d->relu_beta, 0));
+  return 0;
+}
+
+int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk, int slot, bool strided, SparseLayerW* L) {
+  RawTensor *w, *g, *b, *rm, *rv;
+  const std::string wk = p + blk + "." + std::to_string(slot) + ".weight";
+  const std::string bn = p + blk + "." + std::to_string(slot + 1);
+  RET_IF(get_raw(c, wk, &w));
+  RET_IF(get_raw(c, bn + ".weight", &g));
+  RET_IF(get_raw(c, bn + ".bias", &b));
+  RET_IF(get_raw(c, bn + ".running_mean", &rm));
+  RET_IF(get_raw(c, bn + ".running_var", &rv));
+  const int cout = (int)w->shape[0], cin = (int)w->shape[1];
+  L->cin = cin;
+  L->cout = cout;
+  L->strided = strided;
+  std::vector<float> hw(w->numel), pk(w->numel), hg(cout), hb(cout), hm(cout), hv(cout), sc(cout), sh(cout);
+  HIP_CHECK_RET(hipMemcpy(hw.data(), w->d, w->numel * 4, hipMemcpyDeviceToHost));
+  HIP_CHECK_RET(hipMemcpy(hg.data(), g->d, cout * 4, hipMemcpyDeviceToHost));
+  HIP_CHECK_RET(hipMemcpy(hb.data(), b->d, cout * 4, hipMemcpyDeviceToHost));
+  HIP_CHECK_RET(hipMemcpy(hm.data(), rm->d, cout * 4, hipMemcpyDeviceToHost));
+  HIP_CHECK_RET(hipMemcpy(hv.data(), rv->d, cout * 4, hipMemcpyDeviceToHost));
+  // dense-emulation layout [cout][cin][kd][kh][kw] -> [27][cin][cout]
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int k = 0; k < 27; ++k) pk[((size_t)k * cin + ci) * cout + co] = hw[((size_t)co * cin + ci) * 27 + k];
+  for (int co = 0; co < cout; ++co) {  // eval BatchNorm1d(eps 1e-3), network.py:105
+    sc[co] = hg[co] / sqrtf(hv[co] + 1e-3f);
+    sh[co] = hb[co] - hm[co] * sc[co];
+  }
+  RET_IF(dmalloc(c, (void**)&L->w, pk.size() * 4));
+  RET_IF(dmalloc(c, (void**)&L->scale, cout * 4));
+  RET_IF(dmalloc(c, (void**)&L->shift, cout * 4));
+  HIP_CHECK_RET(hipMemcpy(L->w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+  HIP_CHECK_RET(hipMemcpy(L->scale, sc.data(), cout * 4, hipMemcpyHostToDevice));
+  HIP_CHECK_RET(hipMemcpy(L->shift, sh.data(), cout * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int build_frustum_block(mvd_ctx* c, const std::string& p, const char* norm_name, bool transposed, int stride,
+                        FrustumBlockW* f) {
+  RET_IF(pack_lin(c, p + "t_conv.weight", p + "t_conv.bias", &f->t_conv));
+  RET_IF(pack_lin(c, p + "v_conv.weight", p + "v_conv.bias", &f->v_conv));
+  RET_IF(load_norm(c, p + norm_name, &f->gn));
+  RET_IF(pack_conv(c, p + "conv.weight", p + "conv.bias", transposed, false, &f->conv));
+  f->cin = f->conv.Cin;
+  f->cout = f->conv.N;
+  f->stride = stride;
+  return 0;
+}
+
+}  // namespace
+
+int engine_finalize(mvd_ctx* c) {
+  const std::string U = "model.diffusion_model.";
+  const mvd_unet_config& u = c->u;
+  const int mc = u.model_channels;
+  const int temb = 4 * mc;
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  // sections are optional: a stand-alone UNet (YAML unet_config.target) uploads only its own keys
+  const bool has_unet = c->raw.count(U + "time_embed.0.weight") > 0;
+  const bool has_cond = c->raw.count("spatial_volume.target_encoder.init_conv.weight") > 0;
+  const bool has_step = c->raw.count("time_embed.0.weight") > 0;
+  if (!has_unet && !has_cond) return mvd_fail("finalize: no UNet and no spatial_volume weights were uploaded");
+  // ---------------- UNet plan (openaimodel.py:535-720) ----------------
+  auto build_unet = [&]() -> int {
+  RET_IF(pack_lin(c, U + "time_embed.0.weight", U + "time_embed.0.bias", &c->te0));
+  RET_IF(pack_lin(c, U + "time_embed.2.weight", U + "time_embed.2.bias", &c->te2));
+  struct EmbPiece {
+    std::string key;
+    int cout;
+  };
+  std::vector<EmbPiece> emb_pieces;
+  auto add_res = [&](const std::string& name, int cin, int cout, std::vector<UOp>& ops) -> int {
+    ResW r;
+    RET_IF(build_res(c, U + name, cin, cout, &r));
+    r.emb_off = c->emb_total;
+    c->emb_total += cout;
+    emb_pieces.push_back({U + name + ".emb_layers.1", cout});
+    c->res.push_back(r);
+    ops.push_back({OP_RES, (int)c->res.size() - 1, cin, cout});
+    return 0;
+  };
+  auto add_st = [&](const std::string& name, int C, std::vector<UOp>& ops) -> int {
+    STW s;
+    RET_IF(build_st(c, U + name, C, &s));
+    c->st.push_back(s);
+    ops.push_back({OP_ST, (int)c->st.size() - 1, C, C});
+    return 0;
+  };
+  auto add_conv = [&](const std::string& wkey, int kind, int cin, int cout, std::vector<UOp>& ops) -> int {
+    ConvW w;
+    RET_IF(pack_conv(c, U + wkey + ".weight", U + wkey + ".bias", false, false, &w));
+    c->convs.push_back(w);
+    ops.push_back({kind, (int)c->convs.size() - 1, cin, cout});
+    return 0;
+  };
+  {
+    std::vector<UOp> ops;
+    RET_IF(add_conv("input_blocks.0.0", OP_CONV_IN, u.in_channels, mc, ops));
+    c->in_blocks.push_back(ops);
+  }
+  std::vector<int> chans{mc};
+  int ch = mc, ds = 1, bi = 1;
+  for (int level = 0; level < 4; ++level) {
+    const int mult = u.channel_mult[level];
+    for (int nr = 0; nr < u.num_res_blocks; ++nr) {
+      std::vector<UOp> ops;
+      const std::string b = "input_blocks." + std::to_string(bi);
+      RET_IF(add_res(b + ".0", ch, mult * mc, ops));
+      ch = mult * mc;
+      if (u.attention_levels & ds) RET_IF(add_st(b + ".1", ch, ops));
+      c->in_blocks.push_back(ops);
+      chans.push_back(ch);
+      ++bi;
+    }
+    if (level != 3) {
+      std::vector<UOp> ops;
+      RET_IF(add_conv("input_blocks." + std::to_string(bi) + ".0.op", OP_DOWN, ch, ch, ops));
+      c->in_blocks.push_back(ops);
+      chans.push_back(ch);
+      ++bi;
+      ds *= 2;
+    }
+  }
+  RET_IF(add_res("middle_block.0", ch, ch, c->mid_block));
+  RET_IF(add_st("middle_block.1", ch, c->mid_block));
+  RET_IF(add_res("middle_block.2", ch, ch, c->mid_block));
+  bi = 0;
+  for (int level = 3; level >= 0; --level) {
+    const int mult = u.channel_mult[level];
+    for (int i = 0; i <= u.num_res_blocks; ++i) {
+      const int ich = chans.back();
+      chans.pop_back();
+      std::vector<UOp> ops;
+      const std::string b = "output_blocks." + std::to_string(bi);
+      RET_IF(add_res(b + ".0", ch + ich, mc * mult, ops));
+      ch = mc * mult;
+      int j = 1;
+      if (u.attention_levels & ds) {
+        RET_IF(add_st(b + "." + std::to_string(j), ch, ops));
+        ++j;
+      }
+      if (level && i == u.num_res_blocks) {
+        RET_IF(add_conv(b + "." + std::to_string(j) + ".conv", OP_UP, ch, ch, ops));
+        ds /= 2;
+      }
+      c->out_blocks.push_back(ops);
+      ++bi;
+    }
+  }
+  RET_IF(load_norm(c, U + "out.0", &c->out_norm));
+  RET_IF(pack_conv(c, U + "out.2.weight", U + "out.2.bias", false, false, &c->out_conv));
+  // all ResBlock emb projections as ONE [emb_total][temb] linear (openaimodel.py:219-225)
+  c->emb_all.N = c->emb_total;
+  c->emb_all.K = temb;
+  RET_IF(dmalloc(c, (void**)&c->emb_all.w, (size_t)c->emb_total * temb * sizeof(half_t)));
+  RET_IF(dmalloc(c, (void**)&c->emb_all.bias, (size_t)c->emb_total * sizeof(float)));
+  {
+    int off = 0;
+    for (auto& pz : emb_pieces) {
+      RawTensor *w, *b;
+      RET_IF(get_raw(c, pz.key + ".weight", &w));
+      RET_IF(get_raw(c, pz.key + ".bias", &b));
+      RET_IF(launch_f32_to_f16(w->d, c->emb_all.w + (size_t)off * temb, w->numel, 0));
+      HIP_CHECK_RET(hipMemcpy(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      off += pz.cout;
+    }
+  }
+  // conditioning blocks (attention.py:97-115)
+  {
+    const int c2 = mc * u.channel_mult[2], c1 = mc * u.channel_mult[1], c0 = mc * u.channel_mult[0];
+    const int* d = u.volume_dims;
+    const int dims[10] = {c2, c2, c2, c2, c1, c1, c1, c0, c0, c0};
+    const int ccs[10] = {d[3], d[2], d[2], d[1], d[1], d[1], d[0], d[0], d[0], d[0]};
+    c->conds.resize(10);
+    RET_IF(build_cond(c, U + "middle_conditions", dims[0], ccs[0], &c->conds[0]));
+    for (int k = 0; k < 9; ++k)
+      RET_IF(build_cond(c, U + "output_conditions." + std::to_string(k), dims[k + 1], ccs[k + 1], &c->conds[k + 1]));
+  }
+  return 0;
+  };
+  if (has_unet) RET_IF(build_unet());
+  c->has_unet = has_unet;
+  // ---------------- Lightning-module step embedding (morphable_diffusion.py:452-458) ----------------
+  if (has_step) {
+    RET_IF(pack_lin(c, "time_embed.0.weight", "time_embed.0.bias", &c->step_te0));
+    RET_IF(pack_lin(c, "time_embed.2.weight", "time_embed.2.bias", &c->step_te2));
+  }
+  c->has_step = has_step;
+  c->has_cond = has_cond;
+  // ---------------- mesh conditioner ----------------
+  auto build_cond = [&]() -> int {
+  const std::string S = "spatial_volume.";
+  RET_IF(pack_conv(c, S + "target_encoder.init_conv.weight", S + "target_encoder.init_conv.bias", false, false,
+                   &c->enc_init, 8));
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = S + "target_encoder.out_conv" + std::to_string(i) + ".";
+    EncBlockW& e = c->enc_blocks[i];
+    RET_IF(pack_lin(c, p + "time_embed.weight", p + "time_embed.bias", &e.t));
+    RET_IF(pack_lin(c, p + "view_embed.weight", p + "view_embed.bias", &e.v));
+    RET_IF(load_norm(c, p + "conv.0", &e.n1));
+    RET_IF(pack_conv(c, p + "conv.2.weight", p + "conv.2.bias", false, false, &e.c1));
+    RET_IF(load_norm(c, p + "conv.3", &e.n2));
+    RET_IF(pack_conv(c, p + "conv.5.weight", p + "conv.5.bias", false, false, &e.c2));
+  }
+  RET_IF(load_norm(c, S + "target_encoder.final_out.0", &c->enc_final_norm));
+  RET_IF(pack_conv(c, S + "target_encoder.final_out.2.weight", S + "target_encoder.final_out.2.bias", false, false,
+                   &c->enc_final));
+  RET_IF(copy_f32(c, S + "smpl_feature_extractor.conv0.weight", &c->fuse_w));
+  RET_IF(copy_f32(c, S + "smpl_feature_extractor.conv0.bias", &c->fuse_b));
+  {
+    const char* blk[9] = {"conv0", "conv0", "down0", "conv1", "conv1", "down1", "conv2", "conv2", "conv2"};
+    const int slot[9] = {0, 3, 0, 0, 3, 0, 0, 3, 6};
+    for (int i = 0; i < 9; ++i)
+      RET_IF(build_sparse_layer(c, S + "xyzc_net.", blk[i], slot[i], blk[i][0] == 'd', &c->sparse[i]));
+  }
+  const std::string F = S + "frustum_volume_feats.";
+  RET_IF(pack_conv(c, F + "conv0.weight", F + "conv0.bias", false, false, &c->fr_conv0));
+  for (int i = 0; i < 6; ++i)
+    RET_IF(build_frustum_block(c, F + "conv" + std::to_string(i + 1) + ".", "bn", false, (i % 2 == 0) ? 2 : 1,
+                               &c->fr_blocks[i]));
+  for (int i = 0; i < 3; ++i)
+    RET_IF(build_frustum_block(c, F + "up" + std::to_string(i) + ".", "norm", true, 2, &c->fr_up[i]));
+  return 0;
+  };
+  if (has_cond) RET_IF(build_cond());
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  for (auto& kv : c->raw) hipFree(kv.second.d);
+  c->raw.clear();
+  c->finalized = true;
+  return 0;
+}

@@ -1,0 +1,171 @@
+// Spatial self-attention (per view, 8 heads, T = h*w tokens <= 1024) as a flash-style kernel on the matrix
+// cores.  Both products are computed TRANSPOSED so that everything that belongs to one query lives in one
+// lane:
+//     S^T = K Q^T        (A = K rows from LDS, B = Q fragment held in registers)
+//     O^T = V^T P^T      (A = V^T rows from LDS, B = P^T straight from the S^T accumulators)
+// In the 32x32 accumulator layout lane l owns query column q = l&31 and 16 key rows
+// {(r&3) + 8(r>>2) + 4(l>>5)}; the softmax max/sum over keys is therefore 16 in-lane ops plus ONE
+// cross-half exchange, and the running rescale of O^T is lane-local.  The fp16 P^T fragment that feeds
+// the second MFMA is exactly the accumulator register order, provided V^T is read with the same key
+// permutation (two 8-byte LDS reads per fragment instead of one 16-byte read) -- no shuffles, no LDS
+// round trip for P.  V arrives already transposed ([head*d + dv][token]) because the V projection is
+// issued as the swapped GEMM  V^T = W_v X^T.
+#include "common.h"
+
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
+                                                   const half_t* __restrict__ vt, int ldvt,
+                                                   half_t* __restrict__ out, int ldo, int T, int heads, float scale) {
+  constexpr int KS = (D + 15) / 16;        // k-steps of the QK^T product
+  constexpr int DK = KS * 16;
+  constexpr int DVF = (D + 31) / 32;       // 32-row fragments of O^T
+  constexpr int DVP = DVF * 32;
+  constexpr int KLD = DK + 8;              // halfs per K row in LDS
+  constexpr int VLD = 64 + 8;              // halfs per V^T row in LDS
+  __shared__ __attribute__((aligned(16))) half_t sK[64 * KLD];
+  __shared__ __attribute__((aligned(16))) half_t sV[DVP * VLD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, lq = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = heads * D;
+  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
+  const long tok0 = (long)b * T;
+
+  // Q fragment (B operand): lane (q, hh) holds d = ks*16 + hh*8 .. +8
+  h8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = ks * 16 + hh * 8;
+    if (q_row < T && d0 < D) qf[ks] = *(const h8*)(qk + (tok0 + q_row) * ldqk + head * D + d0);
+    else qf[ks] = (h8)(half_t)0;
+  }
+
+  f32x16 o[DVF];
+#pragma unroll
+  for (int f = 0; f < DVF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    __syncthreads();
+    // K tile: 64 keys x DK halfs
+    for (int idx = tid; idx < 64 * (DK / 8); idx += 256) {
+      const int key = idx / (DK / 8), ch = idx - key * (DK / 8);
+      h8 v = (h8)(half_t)0;
+      if (k0 + key < T && ch * 8 < D) v = *(const h8*)(qk + (tok0 + k0 + key) * ldqk + C + head * D + ch * 8);
+      *(h8*)(sK + key * KLD + ch * 8) = v;
+    }
+    // V^T tile: DVP rows x 64 keys
+    for (int idx = tid; idx < DVP * 8; idx += 256) {
+      const int dv = idx >> 3, ch = idx & 7;
+      h8 v = (h8)(half_t)0;
+      if (dv < D && k0 + ch * 8 < T) v = *(const h8*)(vt + (long)(head * D + dv) * ldvt + tok0 + k0 + ch * 8);
+      *(h8*)(sV + dv * VLD + ch * 8) = v;
+    }
+    __syncthreads();
+
+    f32x16 s[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+      }
+    }
+    // online softmax over the key axis (rows of S^T)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float v = key < T ? s[f][r] * scale : -INFINITY;
+        s[f][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[f][r] - m_new);
+        s[f][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int f = 0; f < DVF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+    // O^T += V^T P^T : 4 k-steps of 16 keys
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      h8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (half_t)s[kk >> 1][8 * (kk & 1) + j];
+#pragma unroll
+      for (int f = 0; f < DVF; ++f) {
+        const half_t* vrow = sV + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
+        const h4 v0 = *(const h4*)(vrow);
+        const h4 v1 = *(const h4*)(vrow + 8);
+        h8 va;
+        va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
+        va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
+        o[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[f], 0, 0, 0);
+      }
+    }
+  }
+
+  if (q_row < T) {
+    const float inv = 1.0f / l_run;
+    half_t* orow = out + (tok0 + q_row) * ldo + head * D;
+#pragma unroll
+    for (int f = 0; f < DVF; ++f)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int dv = f * 32 + 8 * rg + 4 * hh;
+        if (dv < D) {
+          h4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (half_t)(o[f][rg * 4 + j] * inv);
+          *(h4*)(orow + dv) = v;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
+                     int heads, int d, hipStream_t s) {
+  if (T % 8 || ldqk % 8 || ldvt % 8 || ldo % 4 || d % 8) return mvd_fail("attention: alignment (T, ld, d multiples of 8)");
+  dim3 grid(cdiv(T, 128), heads, B);
+  const float scale = 1.0f / sqrtf((float)d);
+#define MVD_ATTN(DD) \
+  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, vt, ldvt, out, ldo, T, heads, scale); break;
+  switch (d) {
+    MVD_ATTN(8)
+    MVD_ATTN(16)
+    MVD_ATTN(32)
+    MVD_ATTN(40)
+    MVD_ATTN(64)
+    MVD_ATTN(80)
+    MVD_ATTN(160)
+    default: return mvd_fail("attention: unsupported head dim");
+  }
+#undef MVD_ATTN
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,254 @@
+// Mesh-conditioner gathers (all HBM/L2-bound scatter-gather, no GEMM shape):
+//   vertex_gather   fused  project lattice -> bilinear 2-D sample -> trilinear gather at mesh vertices
+//                   (morphable_diffusion.py:211-229): the 32^3 x 16N unprojection volume is never built
+//   fuse_views      mean over views + 16x16 k=1 conv (network.py:41-72)
+//   sparse_conv     submanifold / strided sparse 3x3x3 conv through a host-built neighbour table,
+//                   eval BatchNorm + ReLU folded (network.py:74-161)
+//   latent_gather   trilinear sample of the sparse CNN output at the 32^3 lattice (:232-257)
+//   frustum_gather  trilinear sample of the fused volume along each target view's frustum (:302-315)
+#include "common.h"
+
+namespace {
+
+// torch.linspace(a, b, n)[i] in fp32 (symmetric evaluation, as ATen does)
+__device__ __forceinline__ float linspace_at(float a, float b, int n, int i) {
+  const float step = (b - a) / (float)(n - 1);
+  return i < n / 2 ? a + step * (float)i : b - step * (float)(n - 1 - i);
+}
+
+__global__ __launch_bounds__(256) void vertex_gather_kernel(const float* __restrict__ feats, const ViewCam* __restrict__ cams,
+                                                            const int* __restrict__ view_idx, int n_views, const float* __restrict__ verts, int Nv, int V,
+                                                            float vol_len, int S, int persp, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_views * Nv) return;
+  const int view = idx / Nv, vi = idx - view * Nv;
+  const ViewCam cam = cams[view_idx[view]];
+  float pos[3], fr[3];
+  int lo[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float g = verts[vi * 3 + a] / vol_len;
+    pos[a] = (g + 1.0f) * 0.5f * (float)(V - 1);
+    const float f = floorf(pos[a]);
+    lo[a] = (int)f;
+    fr[a] = pos[a] - f;
+  }
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  const float* fv = feats + (long)view * S * S * 16;
+  for (int corner = 0; corner < 8; ++corner) {
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+    const int ix = lo[0] + bx, iy = lo[1] + by, iz = lo[2] + bz;
+    if (ix < 0 || ix > V - 1 || iy < 0 || iy > V - 1 || iz < 0 || iz > V - 1) continue;
+    const float w3 = (bx ? fr[0] : 1.f - fr[0]) * (by ? fr[1] : 1.f - fr[1]) * (bz ? fr[2] : 1.f - fr[2]);
+    const float X = linspace_at(-vol_len, vol_len, V, ix), Y = linspace_at(-vol_len, vol_len, V, iy),
+                Z = linspace_at(-vol_len, vol_len, V, iz);
+    const float u = cam.P[0] * X + cam.P[1] * Y + cam.P[2] * Z + cam.P[3];
+    const float v = cam.P[4] * X + cam.P[5] * Y + cam.P[6] * Z + cam.P[7];
+    float px, py;
+    if (persp) {
+      float w = cam.P[8] * X + cam.P[9] * Y + cam.P[10] * Z + cam.P[11];
+      w = w < 1e-4f ? 1e-4f : w;
+      const float hs = (float)(S - 1) * 0.5f;
+      px = ((u / w) / hs - 1.0f + 1.0f) * 0.5f * (float)(S - 1);
+      py = ((v / w) / hs - 1.0f + 1.0f) * 0.5f * (float)(S - 1);
+    } else {
+      px = (u + 1.0f) * 0.5f * (float)(S - 1);
+      py = (v + 1.0f) * 0.5f * (float)(S - 1);
+    }
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float tx = px - fx0, ty = py - fy0;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
+      if (xx < 0 || xx > S - 1 || yy < 0 || yy > S - 1) continue;
+      const float w2 = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * w3;
+      const float4* f4 = (const float4*)(fv + ((long)yy * S + xx) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 f = f4[q];
+        acc[q * 4 + 0] += w2 * f.x;
+        acc[q * 4 + 1] += w2 * f.y;
+        acc[q * 4 + 2] += w2 * f.z;
+        acc[q * 4 + 3] += w2 * f.w;
+      }
+    }
+  }
+  float4* o4 = (float4*)(out + (long)idx * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o4[q] = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+}
+
+// out[v][co] (+)= (1/total_views) * sum_view sum_ci w[co][ci] * vf[view][v][ci]  (+ bias)
+__global__ void fuse_views_kernel(const float* __restrict__ vf, int n_views, int Nv, int total_views,
+                                  const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+                                  int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Nv * 16) return;
+  const int v = idx >> 4, co = idx & 15;
+  float acc = 0.f;
+  for (int view = 0; view < n_views; ++view) {
+    const float* f = vf + ((long)view * Nv + v) * 16;
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci) acc += w[co * 16 + ci] * f[ci];
+  }
+  acc /= (float)total_views;
+  if (b) acc += b[co];
+  out[idx] = accumulate ? out[idx] + acc : acc;
+}
+
+// in [n_in][Cin], nbr [n_out][27] (-1 = inactive), w [27][Cin][Cout]; out = relu(conv*scale + shift)
+__global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
+                                                          int n_out, int Cin, int Cout, const float* __restrict__ w,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out) {
+  const int per_block = 256 / Cout;
+  const int site = blockIdx.x * per_block + threadIdx.x / Cout;
+  const int co = threadIdx.x % Cout;
+  if (threadIdx.x >= per_block * Cout || site >= n_out) return;
+  float acc = 0.f;
+  for (int k = 0; k < 27; ++k) {
+    const int nb = nbr[(long)site * 27 + k];
+    if (nb < 0) continue;
+    const float* f = in + (long)nb * Cin;
+    const float* wk = w + (long)k * Cin * Cout + co;
+    for (int c = 0; c < Cin; ++c) acc += f[c] * wk[(long)c * Cout];
+  }
+  out[(long)site * Cout + co] = fmaxf(acc * scale[co] + shift[co], 0.f);
+}
+
+// out [V][V][V][C] (z,y,x,c) fp32
+__global__ void latent_gather_kernel(const float* __restrict__ feats, const int* __restrict__ grid, int gd, int gh, int gw,
+                                     float minx, float miny, float minz, float shx, float shy, float shz, float voxel, int V,
+                                     float vol_len, int C, float* __restrict__ out) {
+  const long total = (long)V * V * V * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int pt = (int)(idx / C);
+    const int ix = pt % V, iy = (pt / V) % V, iz = pt / (V * V);
+    const float X = linspace_at(-vol_len, vol_len, V, ix), Y = linspace_at(-vol_len, vol_len, V, iy),
+                Z = linspace_at(-vol_len, vol_len, V, iz);
+    const float gx = (X - minx) / voxel / shx * 2.f - 1.f;
+    const float gy = (Y - miny) / voxel / shy * 2.f - 1.f;
+    const float gz = (Z - minz) / voxel / shz * 2.f - 1.f;
+    const float px = (gx + 1.f) * 0.5f * (float)(gw - 1), py = (gy + 1.f) * 0.5f * (float)(gh - 1),
+                pz = (gz + 1.f) * 0.5f * (float)(gd - 1);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float tx = px - fx, ty = py - fy, tz = pz - fz;
+    float acc = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+      const int xx = x0 + bx, yy = y0 + by, zz = z0 + bz;
+      if (xx < 0 || xx > gw - 1 || yy < 0 || yy > gh - 1 || zz < 0 || zz > gd - 1) continue;
+      const int row = grid[((long)zz * gh + yy) * gw + xx];
+      if (row < 0) continue;
+      const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
+      acc += wgt * feats[(long)row * C + c];
+    }
+    out[idx] = acc;
+  }
+}
+
+// vol [V][V][V][C] fp32 -> out [TN][D][S][S][C] fp16 ; 16 threads per point, C/16 channels each (C = 64 -> 4)
+__global__ __launch_bounds__(256) void frustum_gather_kernel(const float* __restrict__ vol, const ViewCam* __restrict__ cams,
+                                                             const int* __restrict__ view_idx, int TN, int D, int S, int V,
+                                                             float vol_len, int persp, half_t* __restrict__ out) {
+  constexpr int C = 64;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pt = gid >> 4;
+  const int cq = (int)(gid & 15) * 4;
+  const long npts = (long)TN * D * S * S;
+  if (pt >= npts) return;
+  const int x = (int)(pt % S), y = (int)((pt / S) % S), d = (int)((pt / ((long)S * S)) % D), tv = (int)(pt / ((long)S * S * D));
+  const ViewCam cam = cams[view_idx[tv]];
+  const float depth = linspace_at(0.f, 1.f, D, d) * (cam.far_ - cam.near_) + cam.near_;
+  float wx, wy, wz;
+  if (persp) {
+    const float a = (float)x * depth, b = (float)y * depth, c = depth;
+    wx = cam.Pinv[0] * a + cam.Pinv[1] * b + cam.Pinv[2] * c + cam.Pinv[3];
+    wy = cam.Pinv[4] * a + cam.Pinv[5] * b + cam.Pinv[6] * c + cam.Pinv[7];
+    wz = cam.Pinv[8] * a + cam.Pinv[9] * b + cam.Pinv[10] * c + cam.Pinv[11];
+  } else {
+    const float gx = 2.f * (float)x / (float)(S - 1) - 1.f, gy = 2.f * (float)y / (float)(S - 1) - 1.f;
+    const float a = cam.Kinv[0] * gx + cam.Kinv[1] * gy + cam.Kinv[2];
+    const float b = cam.Kinv[3] * gx + cam.Kinv[4] * gy + cam.Kinv[5];
+    const float c = depth;
+    wx = cam.Pinv[0] * a + cam.Pinv[1] * b + cam.Pinv[2] * c + cam.Pinv[3];
+    wy = cam.Pinv[4] * a + cam.Pinv[5] * b + cam.Pinv[6] * c + cam.Pinv[7];
+    wz = cam.Pinv[8] * a + cam.Pinv[9] * b + cam.Pinv[10] * c + cam.Pinv[11];
+  }
+  const float px = (wx / vol_len + 1.f) * 0.5f * (float)(V - 1), py = (wy / vol_len + 1.f) * 0.5f * (float)(V - 1),
+              pz = (wz / vol_len + 1.f) * 0.5f * (float)(V - 1);
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const float tx = px - fx, ty = py - fy, tz = pz - fz;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+    const int xx = x0 + bx, yy = y0 + by, zz = z0 + bz;
+    if (xx < 0 || xx > V - 1 || yy < 0 || yy > V - 1 || zz < 0 || zz > V - 1) continue;
+    const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
+    const float4 f = *(const float4*)(vol + (((long)zz * V + yy) * V + xx) * C + cq);
+    acc.x += wgt * f.x;
+    acc.y += wgt * f.y;
+    acc.z += wgt * f.z;
+    acc.w += wgt * f.w;
+  }
+  h4 o;
+  o[0] = (half_t)acc.x; o[1] = (half_t)acc.y; o[2] = (half_t)acc.z; o[3] = (half_t)acc.w;
+  *(h4*)(out + pt * C + cq) = o;
+}
+
+}  // namespace
+
+int launch_vertex_gather(const float* feats, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
+                         float vol_len, int fsize, int persp, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(vertex_gather_kernel, dim3(cdiv(n_views * Nv, 256)), dim3(256), 0, s, feats, cams, view_idx, n_views, verts,
+                     Nv, V, vol_len, fsize, persp, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_fuse_views(const float* vf, int n_views, int Nv, int total_views, const float* w, const float* b, float* out,
+                      int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(fuse_views_kernel, dim3(cdiv(Nv * 16, 256)), dim3(256), 0, s, vf, n_views, Nv, total_views, w, b,
+                     out, accumulate);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w, const float* scale,
+                       const float* shift, float* out, hipStream_t s) {
+  if (Cout > 256 || n_out <= 0) return n_out <= 0 ? 0 : mvd_fail("sparse_conv: Cout > 256");
+  const int per_block = 256 / Cout;
+  hipLaunchKernelGGL(sparse_conv_kernel, dim3(cdiv(n_out, per_block)), dim3(256), 0, s, in, nbr, n_out, Cin, Cout, w,
+                     scale, shift, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
+                         const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s) {
+  // min_xyz / out_sh are HOST pointers (step-invariant mesh metadata); out_sh is (d,h,w) = (z,y,x)
+  const int C = 64;
+  size_t total = (size_t)V * V * V * C;
+  int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(latent_gather_kernel, dim3(blocks), dim3(256), 0, s, feats, grid, gd, gh, gw, min_xyz[0], min_xyz[1],
+                     min_xyz[2], (float)out_sh[2], (float)out_sh[1], (float)out_sh[0], voxel, V, vol_len, C, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V,
+                          float vol_len, int persp, half_t* out, hipStream_t s) {
+  const long threads = (long)TN * D * S * S * 16;
+  hipLaunchKernelGGL(frustum_gather_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, vol, cams, view_idx, TN,
+                     D, S, V, vol_len, persp, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

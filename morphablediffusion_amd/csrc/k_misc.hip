@@ -1,0 +1,286 @@
+// Small HBM-/latency-bound helpers: per-sample linears (timestep MLPs, FiLM projections), sinusoidal
+// embedding, layout changes at the NCHW boundary, weight packing/folding, CFG + DDIM update.
+#include "common.h"
+
+namespace {
+
+// out[r][n] (+)= sum_k act(a[r][k]) * w[n][k] + bias[n];  rows <= a few dozen (one per sample / view).
+// One wave per output column, lanes split K, 8 rows per pass.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ a, int lda, int rows, int K,
+                                                           const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                           int N, int act_in, float* __restrict__ out, int ldo,
+                                                           int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const half_t* wr = w + (long)n * K;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = (float)wr[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (r0 + j < rows) {
+          float v = a[(long)(r0 + j) * lda + k];
+          if (act_in == ACT_SILU) v = v / (1.0f + __expf(-v));
+          acc[j] += v * wv;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (r0 + j < rows) {
+          float v = acc[j] + (bias ? bias[n] : 0.f);
+          float* o = out + (long)(r0 + j) * ldo + n;
+          *o = accumulate ? (*o + v) : v;
+        }
+      }
+    }
+  }
+}
+
+// ldm/modules/diffusionmodules/util.py:151-171
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int dim, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx - b * dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    const int i = j < half ? j : j - half;
+    const float f = expf(-9.210340371976184f * (float)i / (float)half);
+    const float arg = (float)t[b] * f;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[idx] = v;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, int HW, float* __restrict__ out, int ldo,
+                                    int cpad) {
+  const long total = (long)B * HW * cpad;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpad);
+    const long bp = idx / cpad;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    out[bp * ldo + c] = c < C ? in[((long)b * C + c) * HW + p] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld, int B, int C, int HW, float* __restrict__ out) {
+  const long total = (long)B * C * HW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % HW);
+    const long bc = idx / HW;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    out[idx] = in[((long)b * HW + p) * ld + c];
+  }
+}
+
+// dst fp16 [taps][N][Cin]; src fp32 [N][Cin][taps] (conv / linear) or [Cin][N][taps] (ConvTranspose).
+// geglu: rows are re-ordered into alternating 32-row blocks (value | gate) so the GEMM epilogue can pair
+// fragment 0 with fragment 1 of a wave.
+// cin_src < Cin zero-pads the channel axis (e.g. the 4-channel latent conv padded to 8).
+__global__ void pack_weight_kernel(const float* __restrict__ src, int N, int Cin, int taps, int transposed, int geglu,
+                                   int cin_src, half_t* __restrict__ dst) {
+  const long total = (long)taps * N * Cin;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cin);
+    const long tn = idx / Cin;
+    const int nd = (int)(tn % N), t = (int)(tn / N);
+    int n = nd;
+    if (geglu) {
+      const int j = nd >> 6, wi = nd & 63;
+      n = wi < 32 ? 32 * j + wi : N / 2 + 32 * j + (wi - 32);
+    }
+    if (c >= cin_src) {
+      dst[idx] = (half_t)0;
+      continue;
+    }
+    const long s = transposed ? ((long)c * N + n) * taps + t : ((long)n * cin_src + c) * taps + t;
+    dst[idx] = (half_t)src[s];
+  }
+}
+
+__global__ void permute_geglu_bias_kernel(const float* __restrict__ src, int N, float* __restrict__ dst) {
+  const int nd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nd >= N) return;
+  const int j = nd >> 6, wi = nd & 63;
+  dst[nd] = src[wi < 32 ? 32 * j + wi : N / 2 + 32 * j + (wi - 32)];
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (half_t)in[i];
+}
+
+__global__ void fill_rows_f16_kernel(half_t* __restrict__ out, int ld, int rows, const half_t* __restrict__ vec, int n) {
+  const long total = (long)rows * n;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % n);
+    out[(idx / n) * ld + c] = vec[c];
+  }
+}
+
+// W_qk[hn*Cc + j][i] = scale * sum_c Wk[hn*hd + c][j] * Wq[hn*hd + c][i]
+__global__ void fold_qk_kernel(const float* __restrict__ wq, const float* __restrict__ wk, int heads, int hd, int Cc,
+                               int I, float scale, half_t* __restrict__ out) {
+  const long total = (long)heads * Cc * I;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % I);
+    const int row = (int)(idx / I);
+    const int hn = row / Cc, j = row - hn * Cc;
+    double acc = 0.0;
+    for (int c = 0; c < hd; ++c) acc += (double)wk[(long)(hn * hd + c) * Cc + j] * (double)wq[(long)(hn * hd + c) * I + i];
+    out[idx] = (half_t)(float)(acc * scale);
+  }
+}
+
+// W_ov[i][hn*Cc + j] = sum_c Wo[i][hn*hd + c] * Wv[hn*hd + c][j]
+__global__ void fold_ov_kernel(const float* __restrict__ wo, const float* __restrict__ wv, int heads, int hd, int Cc,
+                               int I, half_t* __restrict__ out) {
+  const long total = (long)I * heads * Cc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % (heads * Cc));
+    const int i = (int)(idx / (heads * Cc));
+    const int hn = col / Cc, j = col - hn * Cc;
+    double acc = 0.0;
+    for (int c = 0; c < hd; ++c) acc += (double)wo[(long)i * I + hn * hd + c] * (double)wv[(long)(hn * hd + c) * Cc + j];
+    out[idx] = (half_t)(float)acc;
+  }
+}
+
+__global__ void relu_beta_tile_kernel(const float* __restrict__ beta, int Cc, int heads, half_t* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= heads * Cc) return;
+  out[idx] = (half_t)fmaxf(beta[idx % Cc], 0.f);
+}
+
+// UNetWrapper.predict_with_unconditional_scale (morphable_diffusion.py:148) + denoise_apply_impl (:692-697)
+__global__ void cfg_ddim_kernel(const float* __restrict__ ec, const float* __restrict__ eu, float scale,
+                                const float* __restrict__ x, const float* __restrict__ noise, float s1m, float sqrt_at,
+                                float sqrt_aprev, float dir_coef, float sigma, float* __restrict__ eps_out,
+                                float* __restrict__ x_prev, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float e = ec[i];
+    if (eu) e = eu[i] + scale * (e - eu[i]);
+    if (eps_out) eps_out[i] = e;
+    if (x_prev) {
+      const float pred_x0 = (x[i] - s1m * e) / sqrt_at;
+      float xp = sqrt_aprev * pred_x0 + dir_coef * e;
+      if (noise) xp += sigma * noise[i];
+      x_prev[i] = xp;
+    }
+  }
+}
+
+__global__ void add_rows_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = a[i] + (b ? b[i] : 0.f);
+}
+
+inline int grid_for(size_t n, int block = 256, int cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,
+                        int act_in, float* out, int ldo, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a, lda, rows, K, w, bias, N, act_in, out,
+                     ldo, accumulate);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(B * dim, 256)), dim3(256), 0, s, t, B, dim, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, int ldo, int cpad, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * HW * cpad)), dim3(256), 0, s, in, B, C, HW, out,
+                     ldo, cpad);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_nhwc_to_nchw(const float* in, int ld, int B, int C, int HW, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * HW * C)), dim3(256), 0, s, in, ld, B, C, HW, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_weight(const float* src, int N, int Cin, int taps, int transposed, int geglu, half_t* dst,
+                       hipStream_t s, int cin_src) {
+  if (cin_src <= 0) cin_src = Cin;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)N * Cin * taps)), dim3(256), 0, s, src, N, Cin, taps,
+                     transposed, geglu, cin_src, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_permute_geglu_bias(const float* src, int N, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(permute_geglu_bias_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, src, N, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_rows_f16_kernel, dim3(grid_for((size_t)rows * n)), dim3(256), 0, s, out, ld, rows, vec, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(fold_qk_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wq, wk, heads, hd, Cc, I,
+                     scale, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(fold_ov_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wo, wv, heads, hd, Cc, I,
+                     out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(relu_beta_tile_kernel, dim3(cdiv(heads * Cc, 256)), dim3(256), 0, s, beta, Cc, heads, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_cfg_ddim(const float* eps_c, const float* eps_u, float scale, const float* x, const float* noise,
+                    float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,
+                    float* eps_out, float* x_prev, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n)), dim3(256), 0, s, eps_c, eps_u, scale, x, noise,
+                     sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma, eps_out, x_prev, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, a, b, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,243 @@
+"""Thin object wrapper over the C ABI: owns one mvd_ctx on one GPU, hands torch device tensors to the
+library by pointer (PyTorch is used for device memory and streams only)."""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+from .spec import UNetConfig, VolumeConfig
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0):
+        if not torch.cuda.is_available():
+            raise L.MvdError("no MI355X visible: the denoiser has no CPU path")
+        self.lib = L.load()
+        ucfg.validate()
+        self.ucfg, self.vcfg = ucfg, vcfg
+        self.device = torch.device(device)
+        uc = L.UNetConfigC()
+        uc.image_size, uc.in_channels, uc.out_channels = ucfg.image_size, ucfg.in_channels, ucfg.out_channels
+        uc.model_channels, uc.num_res_blocks = ucfg.model_channels, ucfg.num_res_blocks
+        for i in range(4):
+            uc.channel_mult[i] = ucfg.channel_mult[i]
+            uc.volume_dims[i] = ucfg.volume_dims[i]
+        uc.num_heads, uc.context_dim = ucfg.num_heads, ucfg.context_dim
+        uc.attention_levels = sum(int(r) for r in ucfg.attention_resolutions)
+        vc = L.VolumeConfigC()
+        vc.time_dim, vc.view_dim, vc.num_views = vcfg.time_dim, vcfg.view_dim, vcfg.num_views
+        vc.input_image_size, vc.frustum_volume_depth = vcfg.input_image_size, vcfg.frustum_volume_depth
+        vc.spatial_volume_size = vcfg.spatial_volume_size
+        vc.spatial_volume_length, vc.frustum_volume_length = vcfg.spatial_volume_length, vcfg.frustum_volume_length
+        if vcfg.projection not in ("perspective", "orthographic"):
+            raise NotImplementedError(vcfg.projection)  # utils.py:41,66
+        vc.projection = 0 if vcfg.projection == "perspective" else 1
+        for i in range(4):
+            vc.frustum_dims[i] = vcfg.frustum_dims[i]
+        vc.voxel_size = vcfg.voxel_size
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.mvd_create(C.byref(uc), C.byref(vc), self.device.index or 0,
+                                        C.c_size_t(int(workspace_gb * (1 << 30))), C.byref(self._ctx)))
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.mvd_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing."""
+        for k, v in sd.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            t = v.detach().to(dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            on_dev = 1 if t.is_cuda else 0
+            L.check(self.lib.mvd_upload_weight(self._ctx, k.encode(), L.ptr(t), shape, t.dim(), on_dev))
+        L.check(self.lib.mvd_finalize_weights(self._ctx))
+
+    # ---- stages --------------------------------------------------------------------------------
+    def unet_forward(self, x, timesteps, context, source_dict, n_ctx: Optional[int] = None):
+        """DepthWiseAttention.forward (attention.py:117-138). source_dict {res: [n_ctx,C,D,res,res]}."""
+        dev = self.device
+        Bv = x.shape[0]
+        s = self.ucfg.image_size
+        if context.dim() != 3 or context.shape[1] != 1:
+            raise NotImplementedError("cross-attention context must be a single token [B,1,768] "
+                                      "(morphable_diffusion.py:512)")
+        x = _f32(x, dev)
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        ctx = _f32(context, dev)
+        srcs = []
+        for lvl in range(4):
+            r = s >> lvl
+            if r not in source_dict:
+                raise KeyError(r)
+            srcs.append(_f32(source_dict[r], dev))
+        if n_ctx is None:
+            n_ctx = srcs[0].shape[0]
+        depth0 = srcs[0].shape[2]
+        out = torch.empty(Bv, self.ucfg.out_channels, s, s, device=dev, dtype=torch.float32)
+        L.check(self.lib.mvd_unet_forward(self._ctx, L.ptr(x), L.ptr(t), L.ptr(ctx), Bv, n_ctx, L.ptr(srcs[0]),
+                                          L.ptr(srcs[1]), L.ptr(srcs[2]), L.ptr(srcs[3]), depth0, L.ptr(out), _stream()))
+        return out
+
+    def embed_time(self, t):
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(t.shape[0], self.vcfg.time_dim, device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_embed_time(self._ctx, L.ptr(t), t.shape[0], L.ptr(out), _stream()))
+        return out
+
+    def set_mesh(self, vertices, coord, out_sh, bounds):
+        """Per-sample, step-invariant mesh metadata (hoists the .tolist() sync of morphable_diffusion.py:251-252)."""
+        v = vertices.detach().cpu().float().contiguous()
+        c = coord.detach().cpu().to(torch.int32).contiguous()
+        o = out_sh.detach().cpu().to(torch.int32).contiguous()
+        b = bounds.detach().cpu().float().contiguous()
+        self.num_vertices = v.shape[0]
+        L.check(self.lib.mvd_set_mesh(self._ctx, L.ptr(v), L.ptr(c), L.ptr(o), L.ptr(b), v.shape[0]))
+
+    def set_cameras(self, K, RT):
+        K = K.detach().cpu().float().contiguous()
+        RT = RT.detach().cpu().float().contiguous()
+        if K.shape[-2:] != (4, 4):
+            raise ValueError("target_K must be [N,4,4] (morphable_diffusion.py:296)")
+        L.check(self.lib.mvd_set_cameras(self._ctx, L.ptr(K), L.ptr(RT), K.shape[0]))
+
+    def vertex_features(self, x_noisy, t_embed, v_embed, view_idx, add_bias=True):
+        dev = self.device
+        x = _f32(x_noisy, dev)
+        te, ve = _f32(t_embed, dev), _f32(v_embed, dev)
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        out = torch.empty(self.num_vertices, 16, device=dev, dtype=torch.float32)
+        L.check(self.lib.mvd_vertex_features(self._ctx, L.ptr(x), L.ptr(te), L.ptr(ve), L.ptr(vi), x.shape[0],
+                                             1 if add_bias else 0, L.ptr(out), _stream()))
+        return out
+
+    def volume_from_fused(self, fused, want_output=True):
+        V = self.vcfg.spatial_volume_size
+        out = torch.empty(64, V, V, V, device=self.device, dtype=torch.float32) if want_output else None
+        L.check(self.lib.mvd_volume_from_fused(self._ctx, L.ptr(_f32(fused, self.device)), L.ptr(out), _stream()))
+        return out
+
+    def frustum_volumes(self, t_embed, v_embed, view_idx):
+        dev = self.device
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        TN = vi.shape[0]
+        D, S = self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size
+        outs = {}
+        ptrs = []
+        for lvl in range(4):
+            o = torch.empty(TN, self.vcfg.frustum_dims[lvl], D >> lvl, S >> lvl, S >> lvl, device=dev, dtype=torch.float32)
+            outs[S >> lvl] = o
+            ptrs.append(L.ptr(o))
+        L.check(self.lib.mvd_frustum_volumes(self._ctx, L.ptr(_f32(t_embed, dev)), L.ptr(_f32(v_embed, dev)), L.ptr(vi), TN,
+                                             *ptrs, _stream()))
+        return outs
+
+    def denoise_views(self, x_noisy, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg_scale, noise, coef,
+                      want_eps=False):
+        """coef = (sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma) python floats."""
+        dev = self.device
+        x = _f32(x_noisy, dev)
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        TN = vi.shape[0]
+        x_prev = torch.empty_like(x)
+        eps = torch.empty_like(x) if want_eps else None
+        nz = None if noise is None else _f32(noise, dev)
+        L.check(self.lib.mvd_denoise_views(
+            self._ctx, L.ptr(x), L.ptr(_f32(x_input, dev)), L.ptr(_f32(clip, dev)), C.c_int64(int(timestep)),
+            L.ptr(_f32(t_embed, dev)), L.ptr(_f32(v_embed, dev)), L.ptr(vi), TN, C.c_float(cfg_scale), L.ptr(nz),
+            C.c_float(coef[0]), C.c_float(coef[1]), C.c_float(coef[2]), C.c_float(coef[3]), C.c_float(coef[4]),
+            L.ptr(eps), L.ptr(x_prev), _stream()))
+        return (x_prev, eps) if want_eps else x_prev
+
+    # ---- single-kernel hooks (parity tests) -------------------------------------------------------
+    def op_conv(self, x, w, bias=None, stride=1, upsample=0, resid=None, force_splitk=0):
+        dev = self.device
+        x, w = _f32(x, dev), _f32(w, dev)
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[2]
+        Ho, Wo = ((H << upsample) - 1) // stride + 1, ((W << upsample) - 1) // stride + 1
+        out = torch.empty(B, Cout, Ho, Wo, device=dev)
+        b = None if bias is None else _f32(bias, dev)
+        r = None if resid is None else _f32(resid, dev)
+        L.check(self.lib.mvd_op_conv(self._ctx, L.ptr(x), B, Cin, H, W, L.ptr(w), L.ptr(b), Cout, k, stride, upsample,
+                                     L.ptr(r), L.ptr(out), force_splitk, _stream()))
+        return out
+
+    def op_conv3d(self, x, w, bias=None, stride=1, transposed=False, resid=None):
+        dev = self.device
+        x, w = _f32(x, dev), _f32(w, dev)
+        B, Cin, D, H, W = x.shape
+        Cout = w.shape[1] if transposed else w.shape[0]
+        if transposed:
+            od = (2 * D, 2 * H, 2 * W)
+        else:
+            od = ((D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
+        out = torch.empty(B, Cout, *od, device=dev)
+        b = None if bias is None else _f32(bias, dev)
+        r = None if resid is None else _f32(resid, dev)
+        L.check(self.lib.mvd_op_conv3d(self._ctx, L.ptr(x), B, Cin, D, H, W, L.ptr(w), L.ptr(b), Cout, stride,
+                                       1 if transposed else 0, L.ptr(r), L.ptr(out), _stream()))
+        return out
+
+    def op_linear(self, a, w, bias=None, geglu=False):
+        dev = self.device
+        a, w = _f32(a, dev), _f32(w, dev)
+        M, K = a.shape
+        N = w.shape[0]
+        out = torch.empty(M, N // 2 if geglu else N, device=dev)
+        b = None if bias is None else _f32(bias, dev)
+        L.check(self.lib.mvd_op_linear(self._ctx, L.ptr(a), M, K, L.ptr(w), L.ptr(b), N, 1 if geglu else 0, L.ptr(out),
+                                       _stream()))
+        return out
+
+    def op_group_norm(self, x, groups, gamma, beta, eps, act=0):
+        dev = self.device
+        x = _f32(x, dev)
+        B, Cc = x.shape[:2]
+        HW = x[0, 0].numel()
+        out = torch.empty_like(x)
+        L.check(self.lib.mvd_op_group_norm(self._ctx, L.ptr(x), B, Cc, HW, groups, L.ptr(_f32(gamma, dev)),
+                                           L.ptr(_f32(beta, dev)), C.c_float(eps), act, L.ptr(out), _stream()))
+        return out
+
+    def op_layer_norm(self, x, gamma, beta):
+        dev = self.device
+        x = _f32(x, dev)
+        out = torch.empty_like(x)
+        L.check(self.lib.mvd_op_layer_norm(self._ctx, L.ptr(x), x.shape[0], x.shape[1], L.ptr(_f32(gamma, dev)),
+                                           L.ptr(_f32(beta, dev)), L.ptr(out), _stream()))
+        return out
+
+    def op_attention(self, q, k, v, heads):
+        dev = self.device
+        q, k, v = _f32(q, dev), _f32(k, dev), _f32(v, dev)
+        B, T, Cc = q.shape
+        out = torch.empty_like(q)
+        L.check(self.lib.mvd_op_attention(self._ctx, L.ptr(q), L.ptr(k), L.ptr(v), B, T, heads, Cc // heads, L.ptr(out),
+                                          _stream()))
+        return out
+
+    def bench_conv(self, B, Cc, H, W, Cout, iters=20):
+        ms = C.c_float(0)
+        L.check(self.lib.mvd_bench_conv(self._ctx, B, Cc, H, W, Cout, iters, C.byref(ms), _stream()))
+        return ms.value

@@ -1,0 +1,72 @@
+"""ctypes binding of libmvd_hip.so (C ABI in include/mvd.h).
+
+The HIP library is the product path: there is NO CPU / PyTorch fallback.  If the shared object is missing
+(or fails to load) every entry point raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvd_hip.so")
+
+SYMBOLS = [
+    "mvd_create", "mvd_destroy", "mvd_last_error", "mvd_upload_weight", "mvd_finalize_weights", "mvd_unet_forward",
+    "mvd_embed_time", "mvd_set_mesh", "mvd_set_cameras", "mvd_vertex_features", "mvd_volume_from_fused",
+    "mvd_frustum_volumes", "mvd_denoise_views", "mvd_op_conv", "mvd_op_linear", "mvd_op_group_norm",
+    "mvd_op_layer_norm", "mvd_op_attention", "mvd_op_conv3d", "mvd_bench_conv",
+]
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+                ("model_channels", C.c_int), ("num_res_blocks", C.c_int), ("channel_mult", C.c_int * 4),
+                ("num_heads", C.c_int), ("context_dim", C.c_int), ("volume_dims", C.c_int * 4),
+                ("attention_levels", C.c_int)]
+
+
+class VolumeConfigC(C.Structure):
+    _fields_ = [("time_dim", C.c_int), ("view_dim", C.c_int), ("num_views", C.c_int), ("input_image_size", C.c_int),
+                ("frustum_volume_depth", C.c_int), ("spatial_volume_size", C.c_int),
+                ("spatial_volume_length", C.c_float), ("frustum_volume_length", C.c_float), ("projection", C.c_int),
+                ("frustum_dims", C.c_int * 4), ("voxel_size", C.c_float)]
+
+
+class MvdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libmvd_hip.so; raises MvdError if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvdError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mvd_last_error.restype = C.c_char_p
+    lib.mvd_destroy.restype = None
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise MvdError(f"libmvd_hip.so does not export {name}")
+    for name in SYMBOLS:
+        if name not in ("mvd_last_error", "mvd_destroy"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MvdError(load().mvd_last_error().decode())
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "tensor must be contiguous at the C boundary"
+    return C.c_void_p(t.data_ptr())

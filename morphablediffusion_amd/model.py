@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference's plug-in surface for the denoising hot path.
+
+Same class names, constructor kwargs, method names, argument meaning, batch-dict schema and state_dict keys
+as the reference (ldm/models/diffusion/morphable_diffusion.py, ldm/models/diffusion/attention.py), so a
+caller written against the reference (generate_face.py:227-243) runs unchanged; all arithmetic of the
+denoising step executes in libmvd_hip.so.  The frozen VAE / CLIP encoders are host plumbing that stays in
+PyTorch (north_star) and are injected by the caller (``first_stage_model`` / ``clip_image_encoder``).
+"""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+from .schedule import DDIMSchedule
+from .spec import UNetConfig, VolumeConfig
+
+
+def _unet_cfg(kw) -> UNetConfig:
+    known = UNetConfig.__dataclass_fields__.keys()
+    extra = {k: v for k, v in kw.items() if k not in known}
+    for k in extra:
+        if k not in ("dropout", "conv_resample", "dims", "num_classes", "use_fp16", "num_head_channels",
+                     "num_heads_upsample", "use_scale_shift_norm", "resblock_updown", "use_new_attention_order",
+                     "n_embed", "disable_self_attentions", "num_attention_blocks"):
+            raise TypeError(f"unexpected UNet argument {k!r}")
+    args = {k: (tuple(v) if isinstance(v, (list, tuple)) or type(v).__name__ == "ListConfig" else v)
+            for k, v in kw.items() if k in known}
+    return UNetConfig(**args)
+
+
+def instantiate_from_config(config):
+    """ldm/util.py:217-232: ``target`` strings that name the reference's classes resolve to this module."""
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    name = config["target"].rsplit(".", 1)[1]
+    table = {"DepthWiseAttention": DepthWiseAttention, "SyncMultiviewDiffusion": SyncMultiviewDiffusion}
+    if name not in table:
+        raise NotImplementedError(config["target"])
+    return table[name](**config.get("params", dict()))
+
+
+class DepthWiseAttention(nn.Module):
+    """Drop-in for ldm.models.diffusion.attention.DepthWiseAttention (YAML unet_config.target,
+    configs/facescape.yaml:26-42).  forward(x, timesteps, context, source_dict) -> [Bv,4,h,w]."""
+
+    def __init__(self, volume_dims=(5, 16, 32, 64), *args, **kwargs):
+        super().__init__()
+        if args:
+            raise TypeError("pass UNet arguments by keyword, as the reference config does")
+        self.cfg = _unet_cfg(dict(kwargs, volume_dims=tuple(volume_dims)))
+        self.cfg.validate()
+        self._engine: Optional[Engine] = None
+        self._owns_engine = False
+
+    def bind(self, engine: Engine):
+        self._engine = engine
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Standalone use: keys as in the reference UNet's own state_dict (no ``model.diffusion_model.`` prefix)."""
+        if self._engine is None:
+            self._engine = Engine(self.cfg, VolumeConfig())
+            self._owns_engine = True
+        self._engine.load_state_dict({"model.diffusion_model." + k: v for k, v in state_dict.items()})
+        return [], []
+
+    def forward(self, x, timesteps=None, context=None, source_dict=None, **kwargs):
+        if self._engine is None:
+            raise RuntimeError("DepthWiseAttention has no weights: call load_state_dict first")
+        return self._engine.unet_forward(x, timesteps, context, source_dict)
+
+    def get_trainable_parameters(self):
+        return []  # inference engine: the conditioning blocks are not trainable here (training is a next-row item)
+
+
+class UNetWrapper(nn.Module):
+    """morphable_diffusion.py:67-149 (inference paths)."""
+
+    def __init__(self, diff_model_config, drop_conditions=False, drop_scheme="default", use_zero_123=True):
+        super().__init__()
+        if drop_scheme != "default":
+            raise NotImplementedError  # morphable_diffusion.py:92
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.drop_conditions = drop_conditions
+        self.use_zero_123 = use_zero_123
+
+    def get_trainable_parameters(self):
+        return self.diffusion_model.get_trainable_parameters()
+
+    def forward(self, x, t, clip_embed, volume_feats, x_concat, is_train=False):
+        if is_train:
+            raise NotImplementedError("training step is out of scope of the inference engine")
+        xc = x_concat * 1.0
+        if self.use_zero_123:
+            xc[:, :4] = xc[:, :4] / 0.18215
+        return self.diffusion_model(torch.cat([x, xc], 1), t, clip_embed, source_dict=volume_feats)
+
+    def predict_with_unconditional_scale(self, x, t, clip_embed, volume_feats, x_concat, unconditional_scale):
+        x_ = torch.cat([x] * 2, 0)
+        t_ = torch.cat([t] * 2, 0)
+        clip_ = torch.cat([clip_embed, torch.zeros_like(clip_embed)], 0)
+        xc = torch.cat([x_concat, torch.zeros_like(x_concat)], 0)
+        if self.use_zero_123:
+            xc[:, :4] = xc[:, :4] / 0.18215
+        eng = self.diffusion_model._engine
+        # the unconditional half has all-zero volumes (morphable_diffusion.py:137-139): pass only the cond half
+        s, s_uc = eng.unet_forward(torch.cat([x_, xc], 1), t_, clip_, volume_feats, n_ctx=x.shape[0]).chunk(2)
+        return s_uc + unconditional_scale * (s - s_uc)
+
+
+class SpatialVolumeNet(nn.Module):
+    """morphable_diffusion.py:151-320, use_spatial_volume=False (both shipped configs)."""
+
+    def __init__(self, time_dim, view_dim, view_num, input_image_size=256, frustum_volume_depth=48,
+                 spatial_volume_size=32, spatial_volume_length=0.5, frustum_volume_length=0.86603,
+                 projection="perspective", use_spatial_volume=False):
+        super().__init__()
+        if use_spatial_volume:
+            raise NotImplementedError("use_spatial_volume=True (SpatialTime3DNet) is not used by any shipped config")
+        self.cfg = VolumeConfig(time_dim=time_dim, view_dim=view_dim, num_views=view_num,
+                                input_image_size=input_image_size, frustum_volume_depth=frustum_volume_depth,
+                                spatial_volume_size=spatial_volume_size, spatial_volume_length=spatial_volume_length,
+                                frustum_volume_length=frustum_volume_length, projection=projection)
+        self.frustum_volume_size = input_image_size // 8
+        self.frustum_volume_depth = frustum_volume_depth
+        self.spatial_volume_size = spatial_volume_size
+        self._engine: Optional[Engine] = None
+        self._mesh_key = None
+
+    def bind(self, engine: Engine):
+        self._engine = engine
+
+    def _set_sample(self, batch, bi):
+        key = (id(batch.get("vertices")), bi)
+        if key != self._mesh_key:
+            self._engine.set_mesh(batch["vertices"][bi], batch["coord"][bi], batch["out_sh"][bi], batch["bounds"][bi])
+            self._engine.set_cameras(batch["target_K"][bi], batch["target_RT"][bi])
+            self._mesh_key = key
+
+    def construct_spatial_volume(self, x, t_embed, v_embed, batch):
+        B, N = x.shape[:2]
+        vols = []
+        for bi in range(B):
+            self._set_sample(batch, bi)
+            fused = self._engine.vertex_features(x[bi], t_embed[bi], v_embed[bi], torch.arange(N))
+            vols.append(self._engine.volume_from_fused(fused))
+        return torch.stack(vols)
+
+    def construct_view_frustum_volume(self, spatial_volume, t_embed, v_embed, target_indices, batch):
+        """Uses the volume held by the engine from the last construct_spatial_volume of the same sample."""
+        B, TN = target_indices.shape
+        if B != 1:
+            raise NotImplementedError("frustum volumes are built one sample at a time")
+        self._set_sample(batch, 0)
+        idx = target_indices[0]
+        out = self._engine.frustum_volumes(t_embed[0], v_embed[0][idx.to(v_embed.device)], idx)
+        return out, None
+
+
+class SyncMultiviewDiffusion(nn.Module):
+    """morphable_diffusion.py:322-646, inference surface (sample / prepare / embed_time / ...)."""
+
+    def __init__(self, unet_config, scheduler_config=None, finetune_unet=False, finetune_projection=True,
+                 projection="perspective", use_spatial_volume=False, view_num=16, image_size=256, cfg_scale=3.0,
+                 output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
+                 clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
+                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0):
+        super().__init__()
+        self.view_num = view_num
+        self.viewpoint_dim = 4
+        self.output_num = output_num
+        self.image_size = image_size
+        self.batch_view_num = batch_view_num
+        self.cfg_scale = cfg_scale
+        self.target_elevation = target_elevation
+        self.time_embed_dim = 256
+        self.first_stage_scale_factor = 0.18215
+        self.first_stage_model = first_stage_model
+        self.clip_image_encoder = clip_image_encoder
+        self.num_timesteps = 1000
+        self.model = UNetWrapper(unet_config, drop_conditions=drop_conditions, drop_scheme=drop_scheme)
+        self.spatial_volume = SpatialVolumeNet(self.time_embed_dim, self.viewpoint_dim, view_num,
+                                               input_image_size=image_size, projection=projection,
+                                               use_spatial_volume=use_spatial_volume)
+        self.engine = Engine(self.model.diffusion_model.cfg, self.spatial_volume.cfg, device=device,
+                             workspace_gb=workspace_gb)
+        self.model.diffusion_model.bind(self.engine)
+        self.spatial_volume.bind(self.engine)
+        self._device = torch.device(device)
+        if sample_type != "ddim":
+            raise NotImplementedError  # morphable_diffusion.py:359
+        self.sampler = SyncDDIMSampler(self, sample_steps, "uniform", 1.0, latent_size=image_size // 8)
+
+    @property
+    def device(self):
+        return self._device
+
+    def load_state_dict(self, state_dict, strict=False):
+        self.engine.load_state_dict(state_dict)
+        return [], []
+
+    def get_viewpoint_embedding(self, batch):
+        d_e = torch.deg2rad(batch["target_elevation"]) - torch.deg2rad(batch["input_elevation"])
+        d_a = torch.deg2rad(batch["target_azimuth"]) - torch.deg2rad(batch["input_azimuth"])
+        return torch.stack([d_e, torch.sin(d_a), torch.cos(d_a), torch.zeros_like(d_a)], -1)
+
+    def embed_time(self, t):
+        return self.engine.embed_time(t)
+
+    def encode_first_stage(self, x, sample=True):
+        if self.first_stage_model is None:
+            raise RuntimeError("no first_stage_model injected (the frozen VAE stays in PyTorch)")
+        with torch.no_grad():
+            posterior = self.first_stage_model.encode(x)
+            z = posterior.sample() if sample else posterior.mode()
+            return z.detach() * self.first_stage_scale_factor
+
+    def decode_first_stage(self, z):
+        if self.first_stage_model is None:
+            raise RuntimeError("no first_stage_model injected (the frozen VAE stays in PyTorch)")
+        with torch.no_grad():
+            return self.first_stage_model.decode(z / self.first_stage_scale_factor)
+
+    def prepare(self, batch):
+        """morphable_diffusion.py:473-489.  The reference also VAE-encodes the 16 target images and then
+        discards them at inference (:475-479,568); that dead work is skipped."""
+        image_input = batch["input_image"].permute(0, 3, 1, 2)
+        x_input = self.encode_first_stage(image_input)
+        input_info = {"image": image_input, "elevation": batch["input_elevation"][:, 0], "x": x_input}
+        with torch.no_grad():
+            clip_embed = self.clip_image_encoder.encode(image_input)
+        return None, clip_embed, input_info
+
+    def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):
+        B, _, H, W = x_input.shape
+        TN = target_index.shape[1]
+        vf, _ = self.spatial_volume.construct_view_frustum_volume(spatial_volume, t_embed, v_embed, target_index, batch)
+        clip_ = clip_embed.unsqueeze(1).repeat(1, TN, 1, 1).view(B * TN, 1, 768)
+        x_ = x_input.unsqueeze(1).repeat(1, TN, 1, 1, 1).view(B * TN, 4, H, W)
+        return clip_, vf, x_
+
+    def sample(self, sampler, batch, cfg_scale, batch_view_num, return_inter_results=False, inter_interval=50,
+               inter_view_interval=2):
+        _, clip_embed, input_info = self.prepare(batch)
+        x_sample, inter = sampler.sample(input_info, clip_embed, unconditional_scale=cfg_scale,
+                                         log_every_t=inter_interval, batch_view_num=batch_view_num, batch=batch)
+        N = x_sample.shape[1]
+        x_sample = torch.stack([self.decode_first_stage(x_sample[:, ni]) for ni in range(N)], 1)
+        if return_inter_results:
+            inter = torch.stack(inter["x_inter"], 2)
+            T = inter.shape[2]
+            res = [torch.stack([self.decode_first_stage(inter[:, ni, ti]) for ti in range(T)], 1)
+                   for ni in range(0, N, inter_view_interval)]
+            return x_sample, torch.stack(res, 1)
+        return x_sample
+
+
+class SyncDDIMSampler:
+    """morphable_diffusion.py:648-776.  With torch.distributed initialised and ``shard_views=True`` the N views
+    are partitioned over the ranks (contiguous slices); the only per-step exchange is one all-reduce of the
+    [Nv,16] fused vertex features."""
+
+    def __init__(self, model, ddim_num_steps, ddim_discretize="uniform", ddim_eta=1.0, latent_size=32,
+                 shard_views=False):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.latent_size = latent_size
+        self.schedule = DDIMSchedule(ddim_num_steps, ddim_eta, self.ddpm_num_timesteps)
+        if ddim_discretize != "uniform":
+            raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discretize}"')
+        self.ddim_timesteps = self.schedule.ddim_timesteps
+        self.ddim_alphas, self.ddim_alphas_prev = self.schedule.ddim_alphas, self.schedule.ddim_alphas_prev
+        self.ddim_sigmas = self.schedule.ddim_sigmas
+        self.ddim_sqrt_one_minus_alphas = self.schedule.ddim_sqrt_one_minus_alphas
+        self.eta = ddim_eta
+        self.shard_views = shard_views
+
+    # -- distributed helpers -------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if self.shard_views and dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def view_range(self, N):
+        rank, world = self._world()
+        if N % world:
+            raise ValueError(f"{N} views do not shard evenly over {world} ranks")
+        per = N // world
+        return rank * per, (rank + 1) * per
+
+    def denoise_apply(self, x_target_noisy, input_info, clip_embed, time_steps, index, unconditional_scale,
+                      batch_view_num=1, is_step0=False, batch=None, noise=None):
+        """One multi-view denoising step.  x_target_noisy [B,N_local,4,H,W] holds this rank's views
+        (all N when not sharded).  ``noise``: optional explicit N(0,1) draw [B,N_local,4,H,W]; default is a
+        fresh torch.randn_like as in the reference (:695-697)."""
+        import torch.distributed as dist
+        m = self.model
+        eng = m.engine
+        x_input = input_info["x"]
+        B, NL, C, H, W = x_target_noisy.shape
+        N = m.view_num
+        rank, world = self._world()
+        lo = rank * NL if world > 1 else 0
+        if world == 1 and NL != N:
+            raise ValueError("x_target_noisy must hold all views when the sampler is not sharded")
+        v_embed = m.get_viewpoint_embedding(batch).to(x_target_noisy.device)
+        t_embed = m.embed_time(time_steps)
+        coef = self.schedule.coefficients(index)
+        if noise is None and not is_step0:
+            noise = torch.randn_like(x_target_noisy)
+        out = torch.empty_like(x_target_noisy)
+        local_idx = torch.arange(lo, lo + NL)
+        for bi in range(B):
+            m.spatial_volume._set_sample(batch, bi)
+            fused = eng.vertex_features(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx,
+                                        add_bias=(rank == 0))
+            if world > 1:
+                dist.all_reduce(fused)  # RCCL over xGMI: Nv*16 fp32, latency-bound
+            eng.volume_from_fused(fused, want_output=False)
+            for ni in range(0, NL, batch_view_num):
+                sl = slice(ni, min(NL, ni + batch_view_num))
+                idx = local_idx[sl]
+                out[bi, sl] = eng.denoise_views(
+                    x_target_noisy[bi, sl], x_input[bi], clip_embed[bi].reshape(-1), int(time_steps[bi]), t_embed[bi],
+                    v_embed[bi, idx], idx, float(unconditional_scale),
+                    None if is_step0 else noise[bi, sl], coef)
+        return out
+
+    def sample(self, input_info, clip_embed, unconditional_scale=1.0, log_every_t=50, batch_view_num=1, batch=None,
+               generator=None):
+        """Returns (x [B,N,4,h,w], {'x_inter': [...]}) like the reference; with view sharding every rank
+        returns the gathered full tensor."""
+        import torch.distributed as dist
+        print(f"unconditional scale {unconditional_scale:.1f}")
+        C, H, W = 4, self.latent_size, self.latent_size
+        B = clip_embed.shape[0]
+        N = self.model.view_num
+        device = self.model.device
+        rank, world = self._world()
+        lo, hi = self.view_range(N)
+        # full-size draws on every rank (same generator state) then slice: matches the single-GPU RNG stream
+        x_full = torch.randn([B, N, C, H, W], device=device, generator=generator)
+        x = x_full[:, lo:hi].contiguous()
+        intermediates = {"x_inter": []}
+        time_range = np.flip(self.ddim_timesteps)
+        total_steps = self.ddim_timesteps.shape[0]
+        with torch.no_grad():
+            for i, step in enumerate(time_range):
+                index = total_steps - i - 1
+                time_steps = torch.full((B,), int(step), device=device, dtype=torch.long)
+                noise = None
+                if index != 0:
+                    noise = torch.randn([B, N, C, H, W], device=device, generator=generator)[:, lo:hi].contiguous()
+                x = self.denoise_apply(x, input_info, clip_embed, time_steps, index, unconditional_scale,
+                                       batch_view_num=batch_view_num, is_step0=index == 0, batch=batch, noise=noise)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    intermediates["x_inter"].append(self._gather(x, world))
+        return self._gather(x, world), intermediates
+
+    def _gather(self, x, world):
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous())
+        return torch.cat(parts, 1)
