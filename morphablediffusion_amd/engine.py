@@ -134,7 +134,8 @@ class Engine:
     def volume_from_fused(self, fused, want_output=True):
         V = self.vcfg.spatial_volume_size
         out = torch.empty(64, V, V, V, device=self.device, dtype=torch.float32) if want_output else None
-        L.check(self.lib.mvd_volume_from_fused(self._ctx, L.ptr(_f32(fused, self.device)), L.ptr(out), _stream()))
+        f = _f32(fused, self.device)
+        L.check(self.lib.mvd_volume_from_fused(self._ctx, L.ptr(f), L.ptr(out), _stream()))
         return out
 
     def frustum_volumes(self, t_embed, v_embed, view_idx):
@@ -148,8 +149,8 @@ class Engine:
             o = torch.empty(TN, self.vcfg.frustum_dims[lvl], D >> lvl, S >> lvl, S >> lvl, device=dev, dtype=torch.float32)
             outs[S >> lvl] = o
             ptrs.append(L.ptr(o))
-        L.check(self.lib.mvd_frustum_volumes(self._ctx, L.ptr(_f32(t_embed, dev)), L.ptr(_f32(v_embed, dev)), L.ptr(vi), TN,
-                                             *ptrs, _stream()))
+        te, ve = _f32(t_embed, dev), _f32(v_embed, dev)
+        L.check(self.lib.mvd_frustum_volumes(self._ctx, L.ptr(te), L.ptr(ve), L.ptr(vi), TN, *ptrs, _stream()))
         return outs
 
     def denoise_views(self, x_noisy, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg_scale, noise, coef,
@@ -162,9 +163,10 @@ class Engine:
         x_prev = torch.empty_like(x)
         eps = torch.empty_like(x) if want_eps else None
         nz = None if noise is None else _f32(noise, dev)
+        xi, cl, te, ve = _f32(x_input, dev), _f32(clip, dev), _f32(t_embed, dev), _f32(v_embed, dev)
         L.check(self.lib.mvd_denoise_views(
-            self._ctx, L.ptr(x), L.ptr(_f32(x_input, dev)), L.ptr(_f32(clip, dev)), C.c_int64(int(timestep)),
-            L.ptr(_f32(t_embed, dev)), L.ptr(_f32(v_embed, dev)), L.ptr(vi), TN, C.c_float(cfg_scale), L.ptr(nz),
+            self._ctx, L.ptr(x), L.ptr(xi), L.ptr(cl), C.c_int64(int(timestep)),
+            L.ptr(te), L.ptr(ve), L.ptr(vi), TN, C.c_float(cfg_scale), L.ptr(nz),
             C.c_float(coef[0]), C.c_float(coef[1]), C.c_float(coef[2]), C.c_float(coef[3]), C.c_float(coef[4]),
             L.ptr(eps), L.ptr(x_prev), _stream()))
         return (x_prev, eps) if want_eps else x_prev
@@ -216,16 +218,18 @@ class Engine:
         B, Cc = x.shape[:2]
         HW = x[0, 0].numel()
         out = torch.empty_like(x)
-        L.check(self.lib.mvd_op_group_norm(self._ctx, L.ptr(x), B, Cc, HW, groups, L.ptr(_f32(gamma, dev)),
-                                           L.ptr(_f32(beta, dev)), C.c_float(eps), act, L.ptr(out), _stream()))
+        g, b = _f32(gamma, dev), _f32(beta, dev)  # keep alive across the call
+        L.check(self.lib.mvd_op_group_norm(self._ctx, L.ptr(x), B, Cc, HW, groups, L.ptr(g), L.ptr(b), C.c_float(eps),
+                                           act, L.ptr(out), _stream()))
         return out
 
     def op_layer_norm(self, x, gamma, beta):
         dev = self.device
         x = _f32(x, dev)
         out = torch.empty_like(x)
-        L.check(self.lib.mvd_op_layer_norm(self._ctx, L.ptr(x), x.shape[0], x.shape[1], L.ptr(_f32(gamma, dev)),
-                                           L.ptr(_f32(beta, dev)), L.ptr(out), _stream()))
+        g, b = _f32(gamma, dev), _f32(beta, dev)  # keep alive across the call
+        L.check(self.lib.mvd_op_layer_norm(self._ctx, L.ptr(x), x.shape[0], x.shape[1], L.ptr(g), L.ptr(b), L.ptr(out),
+                                           _stream()))
         return out
 
     def op_attention(self, q, k, v, heads):

@@ -32,7 +32,9 @@ def seeded_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
     for s in shape:
         n *= s
     fan_in = n // shape[0]
-    return (torch.rand(shape, generator=g) * 2.0 - 1.0) * (3.0 / fan_in) ** 0.5
+    # U(-1/sqrt(fan_in), 1/sqrt(fan_in)): the distribution of the reference's own default initialisation
+    # (nn.Conv*/nn.Linear: kaiming_uniform_(a=sqrt(5)) -> bound = 1/sqrt(fan_in))
+    return (torch.rand(shape, generator=g) * 2.0 - 1.0) * (1.0 / fan_in) ** 0.5
 
 
 def seeded_state_dict(manifest: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:

@@ -16,7 +16,7 @@ def pack(t, limit=65536, target=16384):
     flat = t.flatten()
     if flat.numel() <= limit:
         return {"full": flat.numpy(), "shape": list(t.shape)}
-    stride = max(1, flat.numel() // target)
+    stride = max(1, flat.numel() // target) | 1  # odd: never aliases with the power-of-two tensor extents
     return {"sample": flat[::stride].numpy(), "stride": stride, "shape": list(t.shape),
             "sum": float(flat.double().sum()), "abssum": float(flat.double().abs().sum())}
 

@@ -19,8 +19,12 @@ REL_L2, MAX_N = 1e-3, 5e-3
 
 
 def compare(got, g, key, rel=REL_L2, mx=MAX_N):
-    a, b, _ = gi.unpack_compare(got.detach().float().cpu(), g, key)
+    a, b, sums = gi.unpack_compare(got.detach().float().cpu(), g, key)
     assert torch.isfinite(a).all(), f"{key}: non-finite"
+    assert b.abs().max() > 0, f"{key}: golden sample is all zero (vacuous)"
+    if sums is not None:  # whole-tensor checksums of the strided goldens
+        s_, ws, a_, wa = sums
+        assert abs(a_ - wa) <= 2e-3 * wa and abs(s_ - ws) <= 2e-3 * wa, f"{key}: checksum {s_},{a_} vs {ws},{wa}"
     rl2 = ((a - b).norm() / (b.norm() + 1e-20)).item()
     mxe = ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
     print(f"[parity] {key}: relL2={rl2:.2e} maxnorm={mxe:.2e}")
@@ -128,5 +132,7 @@ def test_step_full_width_n16_vs_golden():
     out2 = m.sampler.denoise_apply(x_T, {"x": x_in}, clip, ts, index, 2.0, batch_view_num=16, batch=batch, noise=noise)
     d = ((out - out2).norm() / out.norm()).item()
     print(f"[property] batch_view_num 8 vs 16: relL2={d:.2e}")
-    assert d <= 2e-4
+    # not bit-identical: the split-K factor depends on the batch, fp32 summation order changes, and a 1e-7
+    # perturbation occasionally flips an fp16 operand rounding downstream
+    assert d <= 5e-4
     m.engine.close()
