@@ -53,6 +53,7 @@ struct IGemm {
   int ldr;
   int geglu;            // pairs 32-column blocks (x | gate): out cols = N/2
   float alpha;          // scale on the accumulator before bias
+  int act;              // ACT_SILU applied last (non-GEGLU path)
   // split-K
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1

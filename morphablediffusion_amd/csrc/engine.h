@@ -169,6 +169,7 @@ struct GemmArgs {
   const void* resid = nullptr;
   int resid_f32 = 1, ldr = 0;
   int geglu = 0;
+  int act = 0;
   bool use_bias = true;
   int force_splitk = 0;
 };

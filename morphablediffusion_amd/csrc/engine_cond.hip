@@ -225,8 +225,7 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   for (int i = 0; i < 3; ++i) {
     const EncBlockW& e = c->enc_blocks[i];
     // x + time_embed(t) + view_embed(v): the step embedding is shared by all views of the sample
-    for (int v = 0; v < n_local; ++v)
-      RET_IF(launch_small_linear(t_embed, td, 1, td, e.t.w, e.t.bias, 16, ACT_NONE, pre + v * 16, 16, 0, s));
+    RET_IF(launch_small_linear(t_embed, td, -n_local, td, e.t.w, e.t.bias, 16, ACT_NONE, pre, 16, 0, s));
     RET_IF(launch_small_linear(v_embed, vd, n_local, vd, e.v.w, e.v.bias, 16, ACT_NONE, pre, 16, 1, s));
     RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre, a, 16, s));
     g = GemmArgs();
@@ -313,9 +312,7 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   RET_IF(run_conv3d(c, g, TN, D0, S0, S0, 1, s));
   auto film = [&](const FrustumBlockW& b) -> int {
     // x + t_conv(t) + v_conv(v) (network.py:294,308): per-(view, channel) constant folded into the norm
-    for (int v = 0; v < TN; ++v)
-      RET_IF(launch_small_linear(t_embed, td, 1, td, b.t_conv.w, b.t_conv.bias, b.cin, ACT_NONE, pre + (size_t)v * b.cin,
-                                 b.cin, 0, s));
+    RET_IF(launch_small_linear(t_embed, td, -TN, td, b.t_conv.w, b.t_conv.bias, b.cin, ACT_NONE, pre, b.cin, 0, s));
     RET_IF(launch_small_linear(v_embed, vd, TN, vd, b.v_conv.w, b.v_conv.bias, b.cin, ACT_NONE, pre, b.cin, 1, s));
     return 0;
   };

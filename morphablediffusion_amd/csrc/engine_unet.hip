@@ -39,6 +39,7 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.resid_f32 = ga.resid_f32;
   g.ldr = ga.ldr;
   g.geglu = ga.geglu;
+  g.act = ga.act;
 }
 
 int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
@@ -373,9 +374,21 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   float* ea = ws_alloc<float>(c, (size_t)Bv * c->emb_total);
   WS_CHECK(e0 && e1 && e2 && ea);
   RET_IF(launch_timestep_embedding(t, Bv, mc, e0, s));
-  RET_IF(launch_small_linear(e0, mc, Bv, mc, c->te0.w, c->te0.bias, temb, ACT_NONE, e1, temb, 0, s));
-  RET_IF(launch_small_linear(e1, temb, Bv, temb, c->te2.w, c->te2.bias, temb, ACT_SILU, e2, temb, 0, s));
-  RET_IF(launch_small_linear(e2, temb, Bv, temb, c->emb_all.w, c->emb_all.bias, c->emb_total, ACT_SILU, ea, c->emb_total, 0, s));
+  {  // time_embed MLP and every ResBlock's emb projection as three weight-streaming GEMMs (M = Bv rows)
+    ConvW w0, w2, wa;
+    w0.w = c->te0.w; w0.bias = c->te0.bias; w0.N = temb; w0.Cin = mc;
+    w2.w = c->te2.w; w2.bias = c->te2.bias; w2.N = temb; w2.Cin = temb;
+    wa.w = c->emb_all.w; wa.bias = c->emb_all.bias; wa.N = c->emb_total; wa.Cin = temb;
+    GemmArgs g;
+    g.a = e0; g.a_f32 = 1; g.lda = mc; g.w = &w0; g.out = e1; g.ldc = temb; g.act = ACT_SILU;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    g = GemmArgs();
+    g.a = e1; g.a_f32 = 1; g.lda = temb; g.w = &w2; g.out = e2; g.ldc = temb; g.act = ACT_SILU;  // emb is only used as silu(emb)
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    g = GemmArgs();
+    g.a = e2; g.a_f32 = 1; g.lda = temb; g.w = &wa; g.out = ea; g.ldc = c->emb_total;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+  }
   f.emb_all = ea;
 
   // shapes of the concat buffers

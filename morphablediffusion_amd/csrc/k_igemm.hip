@@ -55,6 +55,7 @@ __device__ __forceinline__ void epilogue_store(const IGemm& g, int m, long orow,
       if (g.resid_f32) v += ((const float*)g.resid)[orow * g.ldr + n];
       else v += (float)((const half_t*)g.resid)[orow * g.ldr + n];
     }
+    if (g.act == ACT_SILU) v = v / (1.0f + __expf(-v));
   }
   if (g.out_f32) ((float*)g.out)[orow * g.ldc + ncol] = v;
   else ((half_t*)g.out)[orow * g.ldc + ncol] = (half_t)v;
@@ -113,20 +114,34 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   h8 ra16[A_F32 ? 1 : 4];
   h8 rb[4];
 
-  auto load_tiles = [&](int ks) {
-    const int tap = ks / cpt;
-    const int c = (ks - tap * cpt) * BK + chunk * 8;
-    const bool cok = c < g.Cin;
+  // Per-tap gather state: element offsets of the 4 A rows / 4 W rows this thread stages (-1 = zero fill).
+  // Recomputed only when the tap changes; inside a tap the k-steps just advance the channel offset.
+  long a_off[4], b_off[4];
+  int ld_tap = kbeg / cpt, ld_cc = kbeg - ld_tap * cpt;
+  auto set_tap = [&](int tap) {
     const int dz = g.dz[tap], dy = g.dy[tap], dx = g.dx[tap];
     const int wslab = g.wt[tap];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
-      const bool ok = cok && ab[i] >= 0 && iz >= 0 && iz < g.IZ && iy >= 0 && iy < g.IY && ix >= 0 && ix < g.IX;
+      const bool ok = ab[i] >= 0 && iz >= 0 && iz < g.IZ && iy >= 0 && iy < g.IY && ix >= 0 && ix < g.IX;
       const long pix = ((long)(ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups);
+      a_off[i] = ok ? pix * g.lda + chunk * 8 : -1;
+      const int n = n0 + r0 + 32 * i;
+      b_off[i] = n < N ? ((long)wslab * N + n) * g.Cin + chunk * 8 : -1;
+    }
+  };
+  if (kbeg < kend) set_tap(ld_tap);
+
+  auto load_tiles = [&]() {
+    const int cb = ld_cc * BK;
+    const bool cok = cb + chunk * 8 < g.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = cok && a_off[i] >= 0;
       if constexpr (A_F32) {
         if (ok) {
-          const float4* p = (const float4*)((const float*)g.a + pix * g.lda + c);
+          const float4* p = (const float4*)((const float*)g.a + a_off[i] + cb);
           ra32[i][0] = p[0];
           ra32[i][1] = p[1];
         } else {
@@ -134,15 +149,20 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
           ra32[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       } else {
-        if (ok) ra16[i] = *(const h8*)((const half_t*)g.a + pix * g.lda + c);
+        if (ok) ra16[i] = *(const h8*)((const half_t*)g.a + a_off[i] + cb);
         else ra16[i] = (h8)(half_t)0;
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = n0 + r0 + 32 * i;
-      if (cok && n < N) rb[i] = *(const h8*)(g.w + ((long)wslab * N + n) * g.Cin + c);
+      if (cok && b_off[i] >= 0) rb[i] = *(const h8*)(g.w + b_off[i] + cb);
       else rb[i] = (h8)(half_t)0;
+    }
+    // advance to the next k-step
+    if (++ld_cc == cpt) {
+      ld_cc = 0;
+      ++ld_tap;
+      if (ld_tap < g.ntaps) set_tap(ld_tap);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -172,14 +192,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kbeg < kend) {
-    load_tiles(kbeg);
+    load_tiles();
     store_tiles(0);
   }
   __syncthreads();
   int cur = 0;
   for (int ks = kbeg; ks < kend; ++ks) {
     const bool more = ks + 1 < kend;
-    if (more) load_tiles(ks + 1);
+    if (more) load_tiles();
     const char* sA = smem + cur * 32768;
     const char* sB = sA + 16384;
 #pragma unroll

@@ -14,20 +14,54 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const half_t* wr = w + (long)n * K;
-  for (int r0 = 0; r0 < rows; r0 += 8) {
+  // rows < 0: the single input row is broadcast to -rows output rows (FiLM: one step embedding, many views)
+  const int out_rows = rows < 0 ? -rows : rows;
+  const int in_rows = rows < 0 ? 1 : rows;
+  for (int r0 = 0; r0 < in_rows; r0 += 8) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int k = lane; k < K; k += 64) {
-      const float wv = (float)wr[k];
+    if ((K & 7) == 0 && (lda & 3) == 0) {
+      for (int k = lane * 8; k < K; k += 512) {
+        const h8 wv = *(const h8*)(wr + k);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (r0 + j < rows) {
-          float v = a[(long)(r0 + j) * lda + k];
-          if (act_in == ACT_SILU) v = v / (1.0f + __expf(-v));
-          acc[j] += v * wv;
+        for (int j = 0; j < 8; ++j) {
+          if (r0 + j < in_rows) {
+            const float4 a0 = *(const float4*)(a + (long)(r0 + j) * lda + k);
+            const float4 a1 = *(const float4*)(a + (long)(r0 + j) * lda + k + 4);
+            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = v[e];
+              if (act_in == ACT_SILU) x = x / (1.0f + __expf(-x));
+              acc[j] += x * (float)wv[e];
+            }
+          }
         }
       }
+    } else {
+      for (int k = lane; k < K; k += 64) {
+        const float wv = (float)wr[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (r0 + j < in_rows) {
+            float v = a[(long)(r0 + j) * lda + k];
+            if (act_in == ACT_SILU) v = v / (1.0f + __expf(-v));
+            acc[j] += v * wv;
+          }
+        }
+      }
+    }
+    if (rows < 0) {
+      float v = acc[0];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      v += bias ? bias[n] : 0.f;
+      for (int r = lane; r < out_rows; r += 64) {
+        float* o = out + (long)r * ldo + n;
+        *o = accumulate ? (*o + v) : v;
+      }
+      return;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -1,57 +1,89 @@
 // GroupNorm (two kernels: coalesced slab statistics -> normalise + activation + fp16 cast) and LayerNorm.
 // Both are HBM-bound: one fp32 read for the statistics, one fp32 read + one fp16 write for the apply.
 // The fp16 output exists only as an MFMA operand of the following implicit GEMM.
+//
+// Thread mapping (both GN kernels): a thread owns fixed channel quads (float4) and walks rows, so a wave
+// always reads a contiguous run of channels (16 B per lane) and no per-element index arithmetic or
+// division is needed; narrow tensors (C/4 < 256) put several rows in flight per block.
 #include "common.h"
 
 namespace {
 
 constexpr int GN_MAX_SLABS = 64;
-constexpr int GN_CPT = 10;  // channels per thread: supports C <= 2560 with 256 threads
+constexpr int GN_MAXC = 2560;
+constexpr int GN_NQ = 3;  // channel quads per thread when C/4 > 256 (C <= 3072)
 
-// grid (nslabs, B). Thread t owns channels t, t+256, ...; rows of the slab are walked sequentially so every
-// wave-level load is a contiguous run of channels (coalesced).  Per-slab (sum, sumsq) per group are
-// written to partial[b][slab][g][2]; the apply kernel combines the slabs in fp64.
+struct GnMap {
+  int Q, lanes_q, row_par, nq;
+  bool active;
+  int q0, rsub;
+};
+
+__device__ __forceinline__ GnMap gn_map(int C, int t) {
+  GnMap m;
+  m.Q = C >> 2;
+  if (m.Q <= 256) {
+    m.lanes_q = m.Q;
+    m.row_par = 256 / m.Q;
+    m.nq = 1;
+  } else {
+    m.lanes_q = 256;
+    m.row_par = 1;
+    m.nq = (m.Q + 255) >> 8;
+  }
+  m.active = t < m.lanes_q * m.row_par;
+  m.q0 = t % m.lanes_q;
+  m.rsub = t / m.lanes_q;
+  return m;
+}
+
+// grid (nslabs, B): per-slab (sum, sumsq) per group -> partial[b][slab][g][2]; combined in fp64 by the apply.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ld, int rows_per_sample, int C,
                                                        int G, const float* __restrict__ preadd, int rows_per_slab,
                                                        float* __restrict__ partial) {
-  __shared__ float s_sum[GN_CPT * 256];
-  __shared__ float s_sq[GN_CPT * 256];
+  __shared__ float s_sum[GN_MAXC];
+  __shared__ float s_sq[GN_MAXC];
   const int b = blockIdx.y, slab = blockIdx.x, t = threadIdx.x;
   const int r_beg = slab * rows_per_slab;
   const int r_end = min(rows_per_sample, r_beg + rows_per_slab);
-  // narrow tensors (C < 256, C | 256): several rows in flight per block so all 256 threads load
-  const int row_par = (C < 256 && (256 % C) == 0) ? 256 / C : 1;
-  const int lanes_c = C < 256 ? C : 256;
-  const bool active = t < lanes_c * row_par;
-  const int c0 = t % lanes_c, rsub = t / lanes_c;
-  float sum[GN_CPT], sq[GN_CPT], pa[GN_CPT];
+  const GnMap m = gn_map(C, t);
+  float sum[GN_NQ][4], sq[GN_NQ][4], pa[GN_NQ][4];
 #pragma unroll
-  for (int i = 0; i < GN_CPT; ++i) {
-    sum[i] = 0.f;
-    sq[i] = 0.f;
-    const int c = c0 + 256 * i;
-    pa[i] = (preadd && c < C) ? preadd[(long)b * C + c] : 0.f;
-  }
+  for (int i = 0; i < GN_NQ; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sum[i][e] = 0.f;
+      sq[i][e] = 0.f;
+      const int c = (m.q0 + 256 * i) * 4 + e;
+      pa[i][e] = (preadd && i < m.nq && c < C) ? preadd[(long)b * C + c] : 0.f;
+    }
   const float* xb = x + (long)b * rows_per_sample * ld;
-  if (active) {
-    for (int r = r_beg + rsub; r < r_end; r += row_par) {
+  if (m.active) {
+    for (int r = r_beg + m.rsub; r < r_end; r += m.row_par) {
       const float* xr = xb + (long)r * ld;
 #pragma unroll
-      for (int i = 0; i < GN_CPT; ++i) {
-        const int c = c0 + 256 * i;
-        if (c < C) {
-          const float v = xr[c] + pa[i];
-          sum[i] += v;
-          sq[i] += v * v;
+      for (int i = 0; i < GN_NQ; ++i) {
+        const int q = m.q0 + 256 * i;
+        if (i < m.nq && q < m.Q) {
+          const float4 v = *(const float4*)(xr + q * 4);
+          const float vv[4] = {v.x + pa[i][0], v.y + pa[i][1], v.z + pa[i][2], v.w + pa[i][3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sum[i][e] += vv[e];
+            sq[i][e] += vv[e] * vv[e];
+          }
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < GN_CPT; ++i) {
-      const int c = c0 + 256 * i;
-      if (c < C) {
-        s_sum[rsub * C + c] = sum[i];
-        s_sq[rsub * C + c] = sq[i];
+    for (int i = 0; i < GN_NQ; ++i) {
+      const int q = m.q0 + 256 * i;
+      if (i < m.nq && q < m.Q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s_sum[m.rsub * C + q * 4 + e] = sum[i][e];
+          s_sq[m.rsub * C + q * 4 + e] = sq[i][e];
+        }
       }
     }
   }
@@ -59,7 +91,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   if (t < G) {
     const int cpg = C / G;
     float a = 0.f, q = 0.f;
-    for (int rs = 0; rs < row_par; ++rs)
+    for (int rs = 0; rs < m.row_par; ++rs)
       for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
         a += s_sum[rs * C + c];
         q += s_sq[rs * C + c];
@@ -76,13 +108,14 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// grid (blocks_per_sample, B); each thread handles 4 consecutive channels of one row per iteration.
+// grid (blocks_per_sample, B).  y = act(x * scale[c] + shift[c]) with scale/shift precomputed in LDS.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ld, int rows_per_sample, int C,
                                                        int G, const float* __restrict__ preadd,
                                                        const float* __restrict__ partial, int nslabs,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int act, half_t* __restrict__ out, int ldo) {
   __shared__ float s_mean[32], s_rstd[32];
+  __shared__ float s_scale[GN_MAXC], s_shift[GN_MAXC];
   const int b = blockIdx.y, t = threadIdx.x;
   if (t < G) {
     double a = 0.0, q = 0.0;
@@ -100,26 +133,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
   __syncthreads();
   const int cpg = C / G;
-  const int c4 = C >> 2;
-  const long total = (long)rows_per_sample * c4;
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = s_rstd[g] * gamma[c];
+    const float pa = preadd ? preadd[(long)b * C + c] : 0.f;
+    s_scale[c] = sc;
+    s_shift[c] = beta[c] + (pa - s_mean[g]) * sc;
+  }
+  __syncthreads();
+  const GnMap m = gn_map(C, t);
+  if (!m.active) return;
+  const int rows_per_block = (rows_per_sample + gridDim.x - 1) / gridDim.x;
+  const int r_beg = blockIdx.x * rows_per_block;
+  const int r_end = min(rows_per_sample, r_beg + rows_per_block);
   const float* xb = x + (long)b * rows_per_sample * ld;
   half_t* ob = out + (long)b * rows_per_sample * ldo;
-  for (long idx = (long)blockIdx.x * 256 + t; idx < total; idx += (long)gridDim.x * 256) {
-    const int r = (int)(idx / c4);
-    const int c = (int)(idx - (long)r * c4) * 4;
-    const float4 v = *(const float4*)(xb + (long)r * ld + c);
-    float vv[4] = {v.x, v.y, v.z, v.w};
-    h4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cc = c + j;
-      const int g = cc / cpg;
-      float u = vv[j];
-      if (preadd) u += preadd[(long)b * C + cc];
-      u = (u - s_mean[g]) * s_rstd[g] * gamma[cc] + beta[cc];
-      o[j] = (half_t)act_apply(u, act);
+  for (int i = 0; i < GN_NQ; ++i) {
+    const int q = m.q0 + 256 * i;
+    if (i >= m.nq || q >= m.Q) continue;
+    const float4 sc = *(const float4*)(s_scale + q * 4);
+    const float4 sh = *(const float4*)(s_shift + q * 4);
+    for (int r = r_beg + m.rsub; r < r_end; r += m.row_par) {
+      const float4 v = *(const float4*)(xb + (long)r * ld + q * 4);
+      h4 o;
+      o[0] = (half_t)act_apply(v.x * sc.x + sh.x, act);
+      o[1] = (half_t)act_apply(v.y * sc.y + sh.y, act);
+      o[2] = (half_t)act_apply(v.z * sc.z + sh.z, act);
+      o[3] = (half_t)act_apply(v.w * sc.w + sh.w, act);
+      *(h4*)(ob + (long)r * ldo + q * 4) = o;
     }
-    *(h4*)(ob + (long)r * ldo + c) = o;
   }
 }
 
@@ -167,10 +210,12 @@ int gn_max_slabs() { return GN_MAX_SLABS; }
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
                     float* partial, int* nslabs_out, hipStream_t s) {
-  if (C > GN_CPT * 256 || G > 32 || C % G) return mvd_fail("gn_stats: unsupported channel/group count");
+  if (C > GN_MAXC || G > 32 || C % G || C % 4 || ld % 4) return mvd_fail("gn_stats: unsupported channel/group count");
   int nslabs = rows_per_sample / 16;
   if (nslabs < 1) nslabs = 1;
   if (nslabs > GN_MAX_SLABS) nslabs = GN_MAX_SLABS;
+  // keep the whole chip busy when the batch is small, without shrinking slabs below a few rows per thread row
+  while (nslabs * B < 256 && nslabs * 2 <= GN_MAX_SLABS && rows_per_sample / (nslabs * 2) >= 4) nslabs *= 2;
   const int rps = cdiv(rows_per_sample, nslabs);
   nslabs = cdiv(rows_per_sample, rps);
   *nslabs_out = nslabs;
@@ -183,10 +228,11 @@ int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, i
 int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s) {
-  if (C % 4 || ld % 4 || ldo % 4) return mvd_fail("gn_apply: channel counts must be multiples of 4");
-  long total = (long)rows_per_sample * (C / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 512) blocks = 512;
+  if (C > GN_MAXC || C % 4 || ld % 4 || ldo % 4) return mvd_fail("gn_apply: channel counts must be multiples of 4");
+  int blocks = rows_per_sample / 8;
+  if (blocks < 1) blocks = 1;
+  const int cap = B >= 16 ? 64 : (B >= 4 ? 128 : 512);
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, partial,
                      nslabs, gamma, beta, eps, act, out, ldo);
   HIP_CHECK_RET(hipGetLastError());
