@@ -33,8 +33,9 @@ struct IGemm {
   int ups;
   int PZ, PY, PX;
   int ntaps;
-  signed char dz[MVD_MAX_TAPS], dy[MVD_MAX_TAPS], dx[MVD_MAX_TAPS];
-  signed char wt[MVD_MAX_TAPS];  // weight slab used by loop tap i (identity except for transposed-conv parity classes)
+  // per loop tap: (dz+1) | (dy+1)<<2 | (dx+1)<<4 | weight_slab<<8.  The weight slab is the tap's index in
+  // the packed weights (identity except for the transposed-conv parity classes).
+  int tap[MVD_MAX_TAPS];
   // weights
   const half_t* w;
   int N;                // GEMM N (before GEGLU halving)
@@ -73,6 +74,7 @@ int mvd_fail(const char* msg);  // records thread-local error text, returns -1
 const char* mvd_error_text();
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int igemm_tap(int dz, int dy, int dx, int slab) { return (dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4) | (slab << 8); }
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------------
 int launch_igemm(const IGemm& g, hipStream_t s);

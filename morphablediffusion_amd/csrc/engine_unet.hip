@@ -19,7 +19,7 @@ void igemm_init(IGemm& g) {
   g.Z = g.Y = g.X = g.B = 1;
   g.IZ = g.IY = g.IX = 1;
   g.PZ = g.PY = g.PX = 1;
-  for (int i = 0; i < MVD_MAX_TAPS; ++i) g.wt[i] = (signed char)i;
+  for (int i = 0; i < MVD_MAX_TAPS; ++i) g.tap[i] = igemm_tap(0, 0, 0, i);
 }
 
 void igemm_fill(IGemm& g, const GemmArgs& ga) {
@@ -90,10 +90,7 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
   g.X = (g.IX - 1) / stride + 1;
   if (ga.w->taps == 9) {
     g.ntaps = 9;
-    for (int t = 0; t < 9; ++t) {
-      g.dy[t] = (signed char)(t / 3 - 1);
-      g.dx[t] = (signed char)(t % 3 - 1);
-    }
+    for (int t = 0; t < 9; ++t) g.tap[t] = igemm_tap(0, t / 3 - 1, t % 3 - 1, t);
   } else if (ga.w->taps == 1) {
     g.ntaps = 1;
   } else {
@@ -116,11 +113,7 @@ int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int s
   g.X = (W - 1) / stride + 1;
   if (ga.w->taps == 27) {
     g.ntaps = 27;
-    for (int t = 0; t < 27; ++t) {
-      g.dz[t] = (signed char)(t / 9 - 1);
-      g.dy[t] = (signed char)((t / 3) % 3 - 1);
-      g.dx[t] = (signed char)(t % 3 - 1);
-    }
+    for (int t = 0; t < 27; ++t) g.tap[t] = igemm_tap(t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1, t);
   } else if (ga.w->taps == 1) {
     g.ntaps = 1;
   } else {
@@ -149,10 +142,7 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
     for (int a = 0; a < nz; ++a)
       for (int b = 0; b < ny; ++b)
         for (int e = 0; e < nx; ++e) {
-          g.dz[t] = (signed char)dzv[a];
-          g.dy[t] = (signed char)dyv[b];
-          g.dx[t] = (signed char)dxv[e];
-          g.wt[t] = (signed char)((kz[a] * 3 + ky[b]) * 3 + kx[e]);
+          g.tap[t] = igemm_tap(dzv[a], dyv[b], dxv[e], (kz[a] * 3 + ky[b]) * 3 + kx[e]);
           ++t;
         }
     g.ntaps = t;

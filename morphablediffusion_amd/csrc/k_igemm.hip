@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -110,59 +111,65 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     }
   }
 
-  float4 ra32[A_F32 ? 4 : 1][2];
-  h8 ra16[A_F32 ? 1 : 4];
-  h8 rb[4];
-
-  // Per-tap gather state: element offsets of the 4 A rows / 4 W rows this thread stages (-1 = zero fill).
-  // Recomputed only when the tap changes; inside a tap the k-steps just advance the channel offset.
-  long a_off[4], b_off[4];
-  int ld_tap = kbeg / cpt, ld_cc = kbeg - ld_tap * cpt;
+  // Branch-free staging through buffer loads: a row that must be zero-filled (spatial padding, M/N/K
+  // tails) gets the offset 0xFFFFFFFF, which the buffer unit range-checks against num_records and returns
+  // as zeros -- no divergent control flow around the loads, so all 8-12 loads of a k-step are issued
+  // back to back and stay in flight behind the MFMAs of the previous k-step.
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  constexpr int ESZ = A_F32 ? 4 : 2;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
+  i32x4 ra[A_F32 ? 8 : 4];
+  i32x4 rb[4];
+  unsigned a_off[4], b_off[4];  // byte offsets of this thread's 4 A rows / 4 W rows for the current tap
+  int ld_tap = kbeg / cpt, ld_cc = kbeg - ld_tap * cpt, set_for = -1;
   auto set_tap = [&](int tap) {
-    const int dz = g.dz[tap], dy = g.dy[tap], dx = g.dx[tap];
-    const int wslab = g.wt[tap];
+    // one packed dword per tap, fetched with a scalar load (the tap index is wave-uniform)
+    const int ti = g.tap[__builtin_amdgcn_readfirstlane(tap)];
+    const int dz = (ti & 3) - 1, dy = ((ti >> 2) & 3) - 1, dx = ((ti >> 4) & 3) - 1;
+    const int wslab = ti >> 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
       const bool ok = ab[i] >= 0 && iz >= 0 && iz < g.IZ && iy >= 0 && iy < g.IY && ix >= 0 && ix < g.IX;
-      const long pix = ((long)(ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups);
-      a_off[i] = ok ? pix * g.lda + chunk * 8 : -1;
+      const unsigned pix = (unsigned)(((ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups));
+      // invalid rows are forced to 0xFFFFFFFF with a bit mask (no select -> no divergent branch)
+      a_off[i] = ((pix * (unsigned)g.lda + chunk * 8) * ESZ) | (0u - (unsigned)(!ok));
       const int n = n0 + r0 + 32 * i;
-      b_off[i] = n < N ? ((long)wslab * N + n) * g.Cin + chunk * 8 : -1;
+      b_off[i] = ((((unsigned)wslab * N + n) * (unsigned)g.Cin + chunk * 8) * 2) | (0u - (unsigned)(n >= N));
     }
   };
-  if (kbeg < kend) set_tap(ld_tap);
 
   auto load_tiles = [&]() {
+    // (re)derive the gather offsets BEFORE issuing this k-step's loads: nothing is in flight here, so the
+    // scalar-load wait of set_tap cannot drain a tile load
+    if (ld_tap != set_for) {
+      set_tap(ld_tap);
+      set_for = ld_tap;
+    }
     const int cb = ld_cc * BK;
-    const bool cok = cb + chunk * 8 < g.Cin;
+    const unsigned kmask = 0u - (unsigned)(cb + chunk * 8 >= g.Cin);  // K tail of narrow layers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = cok && a_off[i] >= 0;
+      // a_off == 0xFFFFFFFF stays out of range after the add only through the mask below
+      const unsigned inval = kmask | (0u - (unsigned)(a_off[i] == OOB));
+      const unsigned oa = (a_off[i] + cb * ESZ) | inval;
       if constexpr (A_F32) {
-        if (ok) {
-          const float4* p = (const float4*)((const float*)g.a + a_off[i] + cb);
-          ra32[i][0] = p[0];
-          ra32[i][1] = p[1];
-        } else {
-          ra32[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-          ra32[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        ra[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, oa, 0, 0);
+        ra[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (a_off[i] + cb * ESZ + 16) | inval, 0, 0);
       } else {
-        if (ok) ra16[i] = *(const h8*)((const half_t*)g.a + a_off[i] + cb);
-        else ra16[i] = (h8)(half_t)0;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, oa, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (cok && b_off[i] >= 0) rb[i] = *(const h8*)(g.w + b_off[i] + cb);
-      else rb[i] = (h8)(half_t)0;
+      const unsigned ob = (b_off[i] + cb * 2) | kmask | (0u - (unsigned)(b_off[i] == OOB));
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, ob, 0, 0);
     }
     // advance to the next k-step
     if (++ld_cc == cpt) {
       ld_cc = 0;
       ++ld_tap;
-      if (ld_tap < g.ntaps) set_tap(ld_tap);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -171,15 +178,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 32 * i;
-      h8 v;
       if constexpr (A_F32) {
-        v[0] = (half_t)ra32[i][0].x; v[1] = (half_t)ra32[i][0].y; v[2] = (half_t)ra32[i][0].z; v[3] = (half_t)ra32[i][0].w;
-        v[4] = (half_t)ra32[i][1].x; v[5] = (half_t)ra32[i][1].y; v[6] = (half_t)ra32[i][1].z; v[7] = (half_t)ra32[i][1].w;
+        const f32x4 lo = __builtin_bit_cast(f32x4, ra[2 * i]), hi = __builtin_bit_cast(f32x4, ra[2 * i + 1]);
+        h8 v;
+        v[0] = (half_t)lo[0]; v[1] = (half_t)lo[1]; v[2] = (half_t)lo[2]; v[3] = (half_t)lo[3];
+        v[4] = (half_t)hi[0]; v[5] = (half_t)hi[1]; v[6] = (half_t)hi[2]; v[7] = (half_t)hi[3];
+        *(h8*)(sA + swz(row, chunk)) = v;
       } else {
-        v = ra16[i];
+        *(i32x4*)(sA + swz(row, chunk)) = ra[i];
       }
-      *(h8*)(sA + swz(row, chunk)) = v;
-      *(h8*)(sB + swz(row, chunk)) = rb[i];
+      *(i32x4*)(sB + swz(row, chunk)) = rb[i];
     }
   };
 
@@ -297,6 +305,11 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
   if (g.ntaps < 1 || g.ntaps > MVD_MAX_TAPS) return mvd_fail("igemm: bad tap count");
   if (g.geglu && (g.N % 64)) return mvd_fail("igemm: GEGLU needs N % 64 == 0");
   if (g.splitk > 1 && !g.partial) return mvd_fail("igemm: split-K without a partial buffer");
+  {  // 32-bit buffer offsets
+    const long a_bytes = (long)g.B * g.PZ * g.PY * g.PX * g.lda * (g.a_f32 ? 4 : 2);
+    const long w_bytes = (long)MVD_MAX_TAPS * g.N * g.Cin * 2;
+    if (a_bytes >= 0xFFFFFF00L || w_bytes >= 0xFFFFFF00L) return mvd_fail("igemm: operand exceeds 4 GiB buffer addressing");
+  }
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
