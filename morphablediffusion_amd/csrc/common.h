@@ -56,6 +56,7 @@ struct IGemm {
   float alpha;          // scale on the accumulator before bias
   int act;              // ACT_SILU applied last (non-GEGLU path)
   // split-K
+  int bn;               // column-tile width (64 / 128 / 160); 0 = pick from N
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1
 };
@@ -78,8 +79,8 @@ static inline int igemm_tap(int dz, int dy, int dx, int slab) { return (dz + 1) 
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------------
 int launch_igemm(const IGemm& g, hipStream_t s);
-size_t igemm_partial_bytes(const IGemm& g);
-int igemm_pick_splitk(int M, int N, int ksteps);
+int igemm_pick_bn(int N, int geglu);
+int igemm_pick_splitk(int M, int N, int ksteps, int bn);
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
                     float* partial, int* nslabs_out, hipStream_t s);

@@ -45,7 +45,8 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
 int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
   const int ksteps = g.ntaps * cdiv(g.Cin, 64);
-  int sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps);
+  g.bn = igemm_pick_bn(g.N, g.geglu);
+  int sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
   if (sk > ksteps) sk = ksteps;
   const size_t mark = c->ws.off;
   g.splitk = sk;

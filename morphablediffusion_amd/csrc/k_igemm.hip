@@ -3,23 +3,26 @@
 //
 //   out[row(m)][n] = epilogue( sum_{tap} sum_{c} A[in(m,tap)][c] * W[tap][n][c] )
 //
-// * 128x128x64 tile, 256 threads = 4 waves in a 2x2 grid, each wave a 64x64 sub-tile = 2x2 fragments of
-//   v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate).
-// * A (channels-last activations, fp32 or fp16 in HBM) is gathered per tap with zero fill at the borders,
-//   converted to fp16 while it is staged; W is fp16 [tap][N][Cin].  Both land in LDS as [row][64 halfs]
-//   with the 16-byte chunk index XORed by (row>>1)&7, which makes the 16-lane groups of ds_read_b128
-//   conflict-free for the fragment reads (row = lane&31, chunk = 2*kk + lane>>5).
-// * register-staged double buffering: the global loads of k-step s+1 are in flight while the MFMAs of
-//   k-step s run; one barrier per k-step.
-// * fused epilogue: alpha, bias[n], per-sample bias[b][n] (timestep embedding), residual, GEGLU pairing,
-//   fp16 or fp32 store with an arbitrary row mapping (concat-by-construction, transposed-conv parity
-//   scatter).  split-K writes fp32 partials and a second kernel applies the same epilogue.
+// * 128 x BN x 64 tile, 256 threads = 4 waves, v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate).
+//   Three column widths so that the layer widths of this model tile without waste:
+//     BN=128: waves 2x2, 64x64 each (2x2 fragments)      -- N = 640/1280/1920/2560, GEGLU
+//     BN=160: waves 4x1, 32x160 each (1x5 fragments)     -- N = 320/960 (level-32 convs: exactly 2 tiles)
+//     BN= 64: waves 4x1, 32x64 each (1x2 fragments)      -- N <= 64 (frustum / context / encoder layers)
+// * A (channels-last activations, fp32 or fp16 in HBM) is gathered per tap through buffer loads whose
+//   out-of-range offsets (spatial padding, M/N/K tails) return zeros in hardware: no divergent control
+//   flow around the loads, all loads of a k-step are issued back to back and stay in flight behind the
+//   MFMAs of the previous k-step (register-staged double buffering, one barrier per k-step).
+// * LDS layout [row][64 halfs] with the 16-byte chunk index XORed by (row>>1)&7: the 16-lane groups of
+//   ds_read_b128 are conflict-free for the fragment reads (row = lane&31, chunk = 2*kk + lane>>5).
+// * fused epilogue: alpha, bias[n], per-sample bias[b][n] (timestep embedding), residual, SiLU, GEGLU
+//   pairing, fp16 or fp32 store with an arbitrary row mapping (concat-by-construction, transposed-conv
+//   parity scatter).  split-K writes fp32 partials and a second kernel applies the same epilogue.
 // * blockIdx is remapped so that consecutive logical tiles (which share A rows) run on the same XCD.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int BM = 128, BK = 64, NT = 256;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -62,11 +65,15 @@ __device__ __forceinline__ void epilogue_store(const IGemm& g, int m, long orow,
   else ((half_t*)g.out)[orow * g.ldc + ncol] = (half_t)v;
 }
 
-template <bool A_F32>
+template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave sub-tile
+  constexpr int FM = WM / 32, FN = WN / 32;             // 32x32 fragments per wave
+  constexpr int NB = BN / 32;                           // W rows staged per thread
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int M = g.B * g.Z * g.Y * g.X;
   const int N = g.N;
   const int tiles_n = (N + BN - 1) / BN;
@@ -111,17 +118,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     }
   }
 
-  // Branch-free staging through buffer loads: a row that must be zero-filled (spatial padding, M/N/K
-  // tails) gets the offset 0xFFFFFFFF, which the buffer unit range-checks against num_records and returns
-  // as zeros -- no divergent control flow around the loads, so all 8-12 loads of a k-step are issued
-  // back to back and stay in flight behind the MFMAs of the previous k-step.
   constexpr unsigned OOB = 0xFFFFFFFFu;
   constexpr int ESZ = A_F32 ? 4 : 2;
   const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
   const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
   i32x4 ra[A_F32 ? 8 : 4];
-  i32x4 rb[4];
-  unsigned a_off[4], b_off[4];  // byte offsets of this thread's 4 A rows / 4 W rows for the current tap
+  i32x4 rb[NB];
+  unsigned a_off[4], b_off[NB];  // byte offsets of this thread's A rows / W rows for the current tap
   int ld_tap = kbeg / cpt, ld_cc = kbeg - ld_tap * cpt, set_for = -1;
   auto set_tap = [&](int tap) {
     // one packed dword per tap, fetched with a scalar load (the tap index is wave-uniform)
@@ -135,6 +138,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       const unsigned pix = (unsigned)(((ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups));
       // invalid rows are forced to 0xFFFFFFFF with a bit mask (no select -> no divergent branch)
       a_off[i] = ((pix * (unsigned)g.lda + chunk * 8) * ESZ) | (0u - (unsigned)(!ok));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
       const int n = n0 + r0 + 32 * i;
       b_off[i] = ((((unsigned)wslab * N + n) * (unsigned)g.Cin + chunk * 8) * 2) | (0u - (unsigned)(n >= N));
     }
@@ -151,7 +157,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     const unsigned kmask = 0u - (unsigned)(cb + chunk * 8 >= g.Cin);  // K tail of narrow layers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // a_off == 0xFFFFFFFF stays out of range after the add only through the mask below
       const unsigned inval = kmask | (0u - (unsigned)(a_off[i] == OOB));
       const unsigned oa = (a_off[i] + cb * ESZ) | inval;
       if constexpr (A_F32) {
@@ -162,19 +167,18 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const unsigned ob = (b_off[i] + cb * 2) | kmask | (0u - (unsigned)(b_off[i] == OOB));
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, ob, 0, 0);
     }
-    // advance to the next k-step
     if (++ld_cc == cpt) {
       ld_cc = 0;
       ++ld_tap;
     }
   };
   auto store_tiles = [&](int buf) {
-    char* sA = smem + buf * 32768;
-    char* sB = sA + 16384;
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 32 * i;
@@ -187,15 +191,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       } else {
         *(i32x4*)(sA + swz(row, chunk)) = ra[i];
       }
-      *(i32x4*)(sB + swz(row, chunk)) = rb[i];
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *(i32x4*)(sB + swz(r0 + 32 * i, chunk)) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -208,21 +213,20 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   for (int ks = kbeg; ks < kend; ++ks) {
     const bool more = ks + 1 < kend;
     if (more) load_tiles();
-    const char* sA = smem + cur * 32768;
-    const char* sB = sA + 16384;
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = kk * 2 + (lane >> 5);
-      h8 af[2], bf[2];
+      h8 af[FM], bf[FN];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        af[f] = *(const h8*)(sA + swz(wm * 64 + f * 32 + (lane & 31), ch));
-        bf[f] = *(const h8*)(sB + swz(wn * 64 + f * 32 + (lane & 31), ch));
-      }
+      for (int f = 0; f < FM; ++f) af[f] = *(const h8*)(sA + swz(wm * WM + f * 32 + (lane & 31), ch));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int f = 0; f < FN; ++f) bf[f] = *(const h8*)(sB + swz(wn * WN + f * 32 + (lane & 31), ch));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -230,17 +234,17 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   }
 
   // ---- epilogue ----
-  const int ncol0 = n0 + wn * 64 + (lane & 31);
+  const int ncol0 = n0 + wn * WN + (lane & 31);
   if (g.splitk > 1) {
     float* part = g.partial + (long)blockIdx.y * M * N;
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+    for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm * WM + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= M) continue;
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
+        for (int fn = 0; fn < FN; ++fn) {
           const int n = ncol0 + fn * 32;
           if (n < N) part[(long)m * N + n] = acc[fm][fn][r];
         }
@@ -248,20 +252,22 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     return;
   }
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
+  for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = m0 + wm * WM + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m >= M) continue;
       const long orow = out_row(g, m);
-      if (g.geglu) {
-        if (ncol0 + 32 < N) epilogue_store(g, m, orow, ncol0, acc[fm][0][r], acc[fm][1][r]);
-      } else {
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-          const int n = ncol0 + fn * 32;
-          if (n < N) epilogue_store(g, m, orow, n, acc[fm][fn][r], 0.f);
+      if constexpr (FN == 2 && WN == 64) {
+        if (g.geglu) {
+          if (ncol0 + 32 < N) epilogue_store(g, m, orow, ncol0, acc[fm][0][r], acc[fm][1][r]);
+          continue;
         }
+      }
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = ncol0 + fn * 32;
+        if (n < N) epilogue_store(g, m, orow, n, acc[fm][fn][r], 0.f);
       }
     }
 }
@@ -282,20 +288,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
   }
 }
 
+template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
+int launch_variant(const IGemm& g, int M, hipStream_t s) {
+  constexpr int LDS = 2 * (BM * 128 + BN * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<A_F32, BN, WAVES_M, WAVES_N>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(M, BM) * cdiv(g.N, BN), g.splitk > 1 ? g.splitk : 1);
+  hipLaunchKernelGGL((igemm_kernel<A_F32, BN, WAVES_M, WAVES_N>), grid, dim3(NT), LDS, s, g);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
-int igemm_pick_splitk(int M, int N, int ksteps) {
-  const int tiles = cdiv(M, BM) * cdiv(N, BN);
+// column-tile width that wastes the fewest MFMA columns for this N (GEGLU needs the 64-column wave tile)
+int igemm_pick_bn(int N, int geglu) {
+  if (geglu) return 128;
+  if (N <= 64) return 64;
+  const int w128 = cdiv(N, 128) * 128, w160 = cdiv(N, 160) * 160;
+  return w160 < w128 ? 160 : 128;
+}
+
+int igemm_pick_splitk(int M, int N, int ksteps, int bn) {
+  const int tiles = cdiv(M, BM) * cdiv(N, bn);
   if (tiles >= 192 || ksteps < 8) return 1;
   int sk = cdiv(512, tiles);
   if (sk > ksteps / 4) sk = ksteps / 4;
   if (sk > 16) sk = 16;
   return sk < 1 ? 1 : sk;
-}
-
-size_t igemm_partial_bytes(const IGemm& g) {
-  if (g.splitk <= 1) return 0;
-  return (size_t)g.splitk * g.B * g.Z * g.Y * g.X * g.N * sizeof(float);
 }
 
 int launch_igemm(const IGemm& g, hipStream_t s) {
@@ -310,16 +334,12 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
     const long w_bytes = (long)MVD_MAX_TAPS * g.N * g.Cin * 2;
     if (a_bytes >= 0xFFFFFF00L || w_bytes >= 0xFFFFFF00L) return mvd_fail("igemm: operand exceeds 4 GiB buffer addressing");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    attr_set = true;
-  }
-  dim3 grid(cdiv(M, BM) * cdiv(g.N, BN), g.splitk > 1 ? g.splitk : 1);
-  if (g.a_f32) hipLaunchKernelGGL(igemm_kernel<true>, grid, dim3(NT), 65536, s, g);
-  else hipLaunchKernelGGL(igemm_kernel<false>, grid, dim3(NT), 65536, s, g);
-  HIP_CHECK_RET(hipGetLastError());
+  const int bn = g.bn ? g.bn : igemm_pick_bn(g.N, g.geglu);
+  int r;
+  if (bn == 160) r = g.a_f32 ? launch_variant<true, 160, 4, 1>(g, M, s) : launch_variant<false, 160, 4, 1>(g, M, s);
+  else if (bn == 64) r = g.a_f32 ? launch_variant<true, 64, 4, 1>(g, M, s) : launch_variant<false, 64, 4, 1>(g, M, s);
+  else r = g.a_f32 ? launch_variant<true, 128, 2, 2>(g, M, s) : launch_variant<false, 128, 2, 2>(g, M, s);
+  if (r) return r;
   if (g.splitk > 1) {
     long total = (long)M * g.N;
     int blocks = (int)((total + 255) / 256);
