@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-view-num", type=int, default=0, help="views per UNet pass (0 = all local views)")
+    ap.add_argument("--simulate-gpus", type=int, default=0,
+                    help="timing aid: run ONE rank's share of a G-way view sharding on one GPU (no collective); "
+                         "reported as a per-rank step time, never as the headline value")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -91,6 +94,8 @@ def main():
     model.load_state_dict(W)
     sampler = model.sampler
     sampler.shard_views = world > 1
+    if args.simulate_gpus and world == 1:
+        sampler.simulate_world = args.simulate_gpus
     lo, hi = sampler.view_range(N_VIEWS)
     nl = hi - lo
     bvn = args.batch_view_num or nl
@@ -150,7 +155,10 @@ def main():
                                    f"{conv_ms * 1e3:.1f} us/launch (HIP events on the launch stream)"},
             "step_tflops": 433.9e9 * N_VIEWS / (dt / args.steps) / 1e12,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.simulate_gpus:
+            out["metric"] = f"SIMULATED per-rank step rate of a {args.simulate_gpus}-way view sharding (one rank, no collective)"
+            out["n_gpus"] = 1
+        if not args.no_cpu_baseline and world == 1 and not args.simulate_gpus:
             out["cpu_baseline"] = cpu_baseline(W, ucfg)
         print(json.dumps(out))
     if world > 1:

@@ -1,5 +1,6 @@
 // extern "C" surface of libmvd_hip.so (declared in include/mvd.h).
 #include <array>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -81,6 +82,7 @@ int mvd_create(const mvd_unet_config* ucfg, const mvd_volume_config* vcfg, int d
   c->u = *ucfg;
   c->v = *vcfg;
   c->device = device;
+  c->use_halo = getenv("MVD_NO_HALO") == nullptr;
   if (workspace_bytes == 0) workspace_bytes = (size_t)8 << 30;
   hipError_t e = hipMalloc((void**)&c->ws.base, workspace_bytes);
   if (e != hipSuccess) {
@@ -288,6 +290,13 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
   GemmArgs g;
   g.a = xn; g.a_f32 = 1; g.lda = cpad; g.w = &cw; g.out = on; g.ldc = Cout; g.resid = rn; g.ldr = Cout;
   g.use_bias = bias != nullptr; g.force_splitk = force_splitk;
+  if (cpad % 64 == 0) {  // exercise the fp16-source paths (incl. the LDS-halo 3x3 kernel) the UNet uses
+    half_t* xh = ws_alloc<half_t>(c, (size_t)B * H * W * cpad);
+    WS_CHECK(xh);
+    RET_IF(launch_f32_to_f16(xn, xh, (size_t)B * H * W * cpad, s));
+    g.a = xh;
+    g.a_f32 = 0;
+  }
   RET_IF(run_conv2d(c, g, B, H, W, stride, upsample, s));
   RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Ho * Wo, out_nchw, s));
   c->ws.off = mark;

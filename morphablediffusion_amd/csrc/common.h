@@ -80,6 +80,10 @@ static inline int igemm_tap(int dz, int dy, int dx, int slab) { return (dz + 1) 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------------
 int launch_igemm(const IGemm& g, hipStream_t s);
 int igemm_pick_bn(int N, int geglu);
+int launch_splitk_reduce(const IGemm& g, hipStream_t s);
+bool conv3_halo_eligible(const IGemm& g);
+int conv3_halo_tiles(const IGemm& g, int bn);
+int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,

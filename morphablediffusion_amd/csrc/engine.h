@@ -40,7 +40,7 @@ struct STW {
   NormW norm, ln1, ln3;
   ConvW proj_in, qk, vt, attn_out, ff1, ff2, proj_out;
   LinW a2v, a2o;
-  int C = 0, heads = 8;
+  int C = 0, heads = 8, a2_off = 0;
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;
@@ -105,12 +105,15 @@ struct mvd_ctx {
   int device = 0;
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
+  bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
 
   // UNet
   LinW te0, te2, emb_all;
   int emb_total = 0;
+  ConvW a2v_all;  // attn2.to_v of every SpatialTransformer stacked: [a2_total][context_dim]
+  int a2_total = 0;
   std::vector<std::vector<UOp>> in_blocks, out_blocks;
   std::vector<UOp> mid_block;
   std::vector<ResW> res;

@@ -44,20 +44,35 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
 
 int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
-  const int ksteps = g.ntaps * cdiv(g.Cin, 64);
   g.bn = igemm_pick_bn(g.N, g.geglu);
-  int sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
-  if (sk > ksteps) sk = ksteps;
+  if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
+  const bool halo = c->use_halo && conv3_halo_eligible(g);
+  int sk;
+  if (halo) {  // LDS-halo 3x3 kernel: split over 64-channel chunks until the chip is full
+    if (g.bn == 64) g.bn = 128;
+    const int tiles = conv3_halo_tiles(g, g.bn), ncc = g.Cin / 64;
+    sk = force_splitk > 0 ? force_splitk : (tiles >= 200 ? 1 : cdiv(256, tiles));
+    if (sk > ncc) sk = ncc;
+    if (sk > 8) sk = 8;
+  } else {
+    const int ksteps = g.ntaps * cdiv(g.Cin, 64);
+    sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
+    if (sk > ksteps) sk = ksteps;
+  }
   const size_t mark = c->ws.off;
   g.splitk = sk;
   g.partial = nullptr;
   if (sk > 1) {
     g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
-    if (!g.partial) {  // not enough scratch: fall back to a single pass
-      g.splitk = 1;
-    }
+    if (!g.partial) g.splitk = 1;  // not enough scratch: single pass
   }
-  const int r = launch_igemm(g, s);
+  int r;
+  if (halo) {
+    r = launch_conv3_halo(g, s);
+    if (!r && g.splitk > 1) r = launch_splitk_reduce(g, s);
+  } else {
+    r = launch_igemm(g, s);
+  }
   c->ws.off = mark;  // stream-ordered reuse
   return r;
 }

@@ -234,9 +234,13 @@ int engine_finalize(mvd_ctx* c) {
     ops.push_back({OP_RES, (int)c->res.size() - 1, cin, cout});
     return 0;
   };
+  std::vector<std::string> a2v_keys;
   auto add_st = [&](const std::string& name, int C, std::vector<UOp>& ops) -> int {
     STW s;
     RET_IF(build_st(c, U + name, C, &s));
+    s.a2_off = c->a2_total;
+    c->a2_total += C;
+    a2v_keys.push_back(U + name + ".transformer_blocks.0.attn2.to_v.weight");
     c->st.push_back(s);
     ops.push_back({OP_ST, (int)c->st.size() - 1, C, C});
     return 0;
@@ -318,6 +322,20 @@ int engine_finalize(mvd_ctx* c) {
       RET_IF(launch_f32_to_f16(w->d, c->emb_all.w + (size_t)off * temb, w->numel, 0));
       HIP_CHECK_RET(hipMemcpy(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice));
       off += pz.cout;
+    }
+  }
+  // attn2.to_v of all SpatialTransformers as one [a2_total][context_dim] matrix (the CLIP token is shared)
+  c->a2v_all.N = c->a2_total;
+  c->a2v_all.Cin = u.context_dim;
+  c->a2v_all.taps = 1;
+  RET_IF(dmalloc(c, (void**)&c->a2v_all.w, (size_t)c->a2_total * u.context_dim * sizeof(half_t)));
+  {
+    size_t off = 0;
+    for (auto& k : a2v_keys) {
+      RawTensor* w;
+      RET_IF(get_raw(c, k, &w));
+      RET_IF(launch_f32_to_f16(w->d, c->a2v_all.w + off, w->numel, 0));
+      off += w->numel;
     }
   }
   // conditioning blocks (attention.py:97-115)

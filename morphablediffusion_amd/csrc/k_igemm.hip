@@ -19,6 +19,7 @@
 //   parity scatter).  split-K writes fp32 partials and a second kernel applies the same epilogue.
 // * blockIdx is remapped so that consecutive logical tiles (which share A rows) run on the same XCD.
 #include "common.h"
+#include "igemm_epilogue.h"
 
 namespace {
 
@@ -26,44 +27,6 @@ constexpr int BM = 128, BK = 64, NT = 256;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-
-__device__ __forceinline__ long out_row(const IGemm& g, int m) {
-  if (g.out_linear) return m;
-  int x = m % g.X;
-  int t = m / g.X;
-  int y = t % g.Y;
-  t /= g.Y;
-  int z = t % g.Z;
-  int b = t / g.Z;
-  return ((long)(b * g.OZ + z * g.ozm + g.ozo) * g.OY + (y * g.oym + g.oyo)) * g.OX + (x * g.oxm + g.oxo);
-}
-
-// v: accumulator for column n (and `gate` for column n+32 when geglu)
-__device__ __forceinline__ void epilogue_store(const IGemm& g, int m, long orow, int n, float v, float gate) {
-  v *= g.alpha;
-  if (g.bias) v += g.bias[n];
-  int ncol = n;
-  if (g.geglu) {
-    gate *= g.alpha;
-    if (g.bias) gate += g.bias[n + 32];
-    v = v * gelu_erf(gate);
-    ncol = (n >> 6) * 32 + (n & 31);
-  } else {
-    if (g.rowbias) {
-      int b = m / (g.Z * g.Y * g.X);
-      v += g.rowbias[(long)b * g.rb_ld + n];
-    }
-    if (g.resid) {
-      if (g.resid_f32) v += ((const float*)g.resid)[orow * g.ldr + n];
-      else v += (float)((const half_t*)g.resid)[orow * g.ldr + n];
-    }
-    if (g.act == ACT_SILU) v = v / (1.0f + __expf(-v));
-  }
-  if (g.out_f32) ((float*)g.out)[orow * g.ldc + ncol] = v;
-  else ((half_t*)g.out)[orow * g.ldc + ncol] = (half_t)v;
-}
 
 template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
@@ -215,18 +178,25 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     if (more) load_tiles();
     const char* sA = smem + cur * STAGE;
     const char* sB = sA + A_BYTES;
+    // fragment reads are software-pipelined one kk ahead of the MFMAs (two fragment register sets), so the
+    // LDS latency of kk+1 hides behind the FM*FN MFMAs of kk instead of being exposed before every kk
+    h8 af[2][FM], bf[2][FN];
+    auto read_frags = [&](int kk, h8 (&a)[FM], h8 (&b)[FN]) {
+      const int ch = kk * 2 + (lane >> 5);
+#pragma unroll
+      for (int f = 0; f < FM; ++f) a[f] = *(const h8*)(sA + swz(wm * WM + f * 32 + (lane & 31), ch));
+#pragma unroll
+      for (int f = 0; f < FN; ++f) b[f] = *(const h8*)(sB + swz(wn * WN + f * 32 + (lane & 31), ch));
+    };
+    read_frags(0, af[0], bf[0]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int ch = kk * 2 + (lane >> 5);
-      h8 af[FM], bf[FN];
-#pragma unroll
-      for (int f = 0; f < FM; ++f) af[f] = *(const h8*)(sA + swz(wm * WM + f * 32 + (lane & 31), ch));
-#pragma unroll
-      for (int f = 0; f < FN; ++f) bf[f] = *(const h8*)(sB + swz(wn * WN + f * 32 + (lane & 31), ch));
+      if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -260,14 +230,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       const long orow = out_row(g, m);
       if constexpr (FN == 2 && WN == 64) {
         if (g.geglu) {
-          if (ncol0 + 32 < N) epilogue_store(g, m, orow, ncol0, acc[fm][0][r], acc[fm][1][r]);
+          if (ncol0 + 32 < N) igemm_epilogue_store(g, m, orow, ncol0, acc[fm][0][r], acc[fm][1][r]);
           continue;
         }
       }
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) {
         const int n = ncol0 + fn * 32;
-        if (n < N) epilogue_store(g, m, orow, n, acc[fm][fn][r], 0.f);
+        if (n < N) igemm_epilogue_store(g, m, orow, n, acc[fm][fn][r], 0.f);
       }
     }
 }
@@ -284,7 +254,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
       v += g.partial[(long)s * total + idx];
       if (g.geglu) gate += g.partial[(long)s * total + idx + 32];
     }
-    epilogue_store(g, m, out_row(g, m), n, v, gate);
+    igemm_epilogue_store(g, m, out_row(g, m), n, v, gate);
   }
 }
 
@@ -304,6 +274,15 @@ int launch_variant(const IGemm& g, int M, hipStream_t s) {
 }
 
 }  // namespace
+
+int launch_splitk_reduce(const IGemm& g, hipStream_t s) {
+  const long total = (long)g.B * g.Z * g.Y * g.X * g.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 // column-tile width that wastes the fewest MFMA columns for this N (GEGLU needs the 64-column wave tile)
 int igemm_pick_bn(int N, int geglu) {
@@ -340,12 +319,6 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
   else if (bn == 64) r = g.a_f32 ? launch_variant<true, 64, 4, 1>(g, M, s) : launch_variant<false, 64, 4, 1>(g, M, s);
   else r = g.a_f32 ? launch_variant<true, 128, 2, 2>(g, M, s) : launch_variant<false, 128, 2, 2>(g, M, s);
   if (r) return r;
-  if (g.splitk > 1) {
-    long total = (long)M * g.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
-    HIP_CHECK_RET(hipGetLastError());
-  }
+  if (g.splitk > 1) return launch_splitk_reduce(g, s);
   return 0;
 }

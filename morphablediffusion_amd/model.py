@@ -275,10 +275,13 @@ class SyncDDIMSampler:
         self.ddim_sqrt_one_minus_alphas = self.schedule.ddim_sqrt_one_minus_alphas
         self.eta = ddim_eta
         self.shard_views = shard_views
+        self.simulate_world = 0  # timing aid (bench.py --simulate-gpus): run ONE rank's share without a process group
 
     # -- distributed helpers -------------------------------------------------------------------------
     def _world(self):
         import torch.distributed as dist
+        if self.simulate_world:
+            return 0, self.simulate_world
         if self.shard_views and dist.is_available() and dist.is_initialized():
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
@@ -316,7 +319,7 @@ class SyncDDIMSampler:
             m.spatial_volume._set_sample(batch, bi)
             fused = eng.vertex_features(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx,
                                         add_bias=(rank == 0))
-            if world > 1:
+            if world > 1 and not self.simulate_world:
                 dist.all_reduce(fused)  # RCCL over xGMI: Nv*16 fp32, latency-bound
             eng.volume_from_fused(fused, want_output=False)
             for ni in range(0, NL, batch_view_num):

@@ -66,6 +66,13 @@ def test_linear_geglu(eng):
     dict(B=1, Cin=320, H=32, W=32, Cout=4, k=3, stride=1, up=0, res=False, sk=0),
     dict(B=2, Cin=256, H=4, W=4, Cout=256, k=3, stride=1, up=0, res=True, sk=3),
     dict(B=1, Cin=64, H=7, W=5, Cout=40, k=3, stride=2, up=0, res=False, sk=0),
+    # LDS-halo 3x3 kernel: 16x16 blocks (32x32 and 16x16 images), 8x8 images (4 per tile), both column widths,
+    # partial last tile, split over channel chunks
+    dict(B=3, Cin=128, H=32, W=32, Cout=320, k=3, stride=1, up=0, res=True, sk=0),
+    dict(B=5, Cin=192, H=16, W=16, Cout=128, k=3, stride=1, up=0, res=False, sk=0),
+    dict(B=7, Cin=128, H=8, W=8, Cout=192, k=3, stride=1, up=0, res=True, sk=0),
+    dict(B=2, Cin=256, H=16, W=16, Cout=320, k=3, stride=1, up=0, res=True, sk=2),
+    dict(B=6, Cin=320, H=8, W=8, Cout=64, k=3, stride=1, up=0, res=False, sk=5),
 ])
 def test_conv2d(eng, cfg):
     x = rnd(cfg["B"], cfg["Cin"], cfg["H"], cfg["W"])
