@@ -40,3 +40,73 @@ __device__ __forceinline__ void igemm_epilogue_store(const IGemm& g, int m, long
   else ((half_t*)g.out)[orow * g.ldc + ncol] = (half_t)v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Vectorised tile epilogue.  In the MFMA C layout a lane owns ONE column and 16 rows of a 32x32 fragment, so
+// a direct store is 16 x 4-byte writes per fragment per lane (issue-bound, 128-byte segments).  Instead each
+// wave transposes the fragment through a private LDS scratch ([32][36] floats) and every lane then owns
+// 4 x (one row, 4 consecutive columns): bias / per-sample bias / residual are 16-byte loads and the result is
+// one 16-byte (fp32) or 8-byte (fp16) store, 8 lanes covering 128 contiguous bytes of an output row.
+// Requires N % 4 == 0, ldc % 4 == 0, ldr % 4 == 0 and no GEGLU (checked once per launch: igemm_fast_epi).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EPI_LD = 36;                          // floats per scratch row (16-byte aligned, conflict-light)
+constexpr int EPI_WAVE_BYTES = 32 * EPI_LD * 4;     // 4608 B per wave
+
+__device__ __forceinline__ bool igemm_fast_epi(const IGemm& g) {
+  return !g.geglu && (g.N & 3) == 0 && (g.ldc & 3) == 0 && (!g.resid || (g.ldr & 3) == 0) &&
+         (!g.rowbias || (g.rb_ld & 3) == 0);
+}
+
+// rows4[i] / orow4[i]: GEMM row index m and output row of fragment row (lane>>3) + 8 i  (m < 0: skip)
+__device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16& acc, float* scratch, int lane,
+                                                    const int (&rows4)[4], const long (&orow4)[4], int n_base,
+                                                    float* partial) {
+  // C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own writes are visible to its own reads
+  const int cq = (lane & 7) * 4;
+  const int n = n_base + cq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int fr = (lane >> 3) + 8 * i;
+    const int m = rows4[i];
+    if (m < 0 || n >= g.N) continue;
+    float4 v = *(const float4*)(scratch + fr * EPI_LD + cq);
+    if (partial) {
+      *(float4*)(partial + (long)m * g.N + n) = v;
+      continue;
+    }
+    v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+    if (g.bias) {
+      const float4 b = *(const float4*)(g.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (g.rowbias) {
+      const int bs = m / (g.Z * g.Y * g.X);
+      const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    const long o = orow4[i];
+    if (g.resid) {
+      if (g.resid_f32) {
+        const float4 q = *(const float4*)((const float*)g.resid + o * g.ldr + n);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      } else {
+        const h4 q = *(const h4*)((const half_t*)g.resid + o * g.ldr + n);
+        v.x += (float)q[0]; v.y += (float)q[1]; v.z += (float)q[2]; v.w += (float)q[3];
+      }
+    }
+    if (g.act == ACT_SILU) {
+      v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
+      v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
+    }
+    if (g.out_f32) {
+      *(float4*)((float*)g.out + o * g.ldc + n) = v;
+    } else {
+      h4 hv;
+      hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+      *(h4*)((half_t*)g.out + o * g.ldc + n) = hv;
+    }
+  }
+}

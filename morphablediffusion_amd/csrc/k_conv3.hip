@@ -15,6 +15,8 @@
 // branch-free.  LDS rows are 128 B (64 halfs) with the 16-byte chunk XOR-swizzled by (row>>1)&7.
 // The epilogue (bias / per-sample bias / residual / SiLU, fp16 or fp32 store, split-K partials) is the
 // implicit GEMM's.
+#include <stdlib.h>
+
 #include "common.h"
 #include "igemm_epilogue.h"
 
@@ -164,9 +166,13 @@ __global__ __launch_bounds__(NT3, 2) void conv3_halo_kernel(const IGemm g) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+      // pin the order: the LDS reads of kk+1 are in flight while the MFMAs of kk run (without this the
+      // scheduler sinks every ds_read next to its MFMA to save registers and exposes the LDS latency)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_w((s + 1) & 1);
     if (tap == 8 && cc + 1 < cc_end) store_halo(hbuf ^ 1);
@@ -178,6 +184,25 @@ __global__ __launch_bounds__(NT3, 2) void conv3_halo_kernel(const IGemm g) {
 
   // ---- epilogue: C layout row = (r&3) + 8(r>>2) + 4(lane>>5) inside the wave's 32 pixels ----
   const int M = g.B * H * W;
+  if (igemm_fast_epi(g)) {
+    float* scratch = (float*)(smem + wave * EPI_WAVE_BYTES);
+    float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
+    int rows4[4];
+    long orow4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = wave * 32 + (lane >> 3) + 8 * i;
+      const int j = pp / (IW * IH), rr = pp - j * (IW * IH);
+      const int gb = tm * NI + j;
+      const int b = gb / bpi, rem = gb - b * bpi;
+      const int y = (rem / bx_per) * IH + rr / IW, x = (rem % bx_per) * IW + rr % IW;
+      rows4[i] = b < g.B ? (b * H + y) * W + x : -1;
+      orow4[i] = rows4[i];
+    }
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+    return;
+  }
   const int ncol0 = n0 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -203,6 +228,262 @@ __global__ __launch_bounds__(NT3, 2) void conv3_halo_kernel(const IGemm g) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: the halo and the weight tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB = 8
+// swizzled rows per wave-instruction), no VGPR staging and no ds_write.  Weights run through a WST-stage ring
+// so TWO steps of weight loads are in flight behind every MFMA block; completion is counted by hand
+// (s_waitcnt vmcnt(N) + raw s_barrier), because only the issuing wave's vmcnt orders an LDS-DMA.
+// Wave w issues 8-row groups w, w+8, ...; waves may differ by one instruction per tile, so the waits use the
+// minimum per-wave count (a wave with one more instruction merely waits for its oldest prefetch too).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <int BN, int IW, int IH, int DBG = 0>
+__global__ __launch_bounds__(NT3, 2) void conv3_dma_kernel(const IGemm g) {
+#if defined(__HIP_DEVICE_COMPILE__)  // LDS-DMA builtins exist only in the gfx950 device pass; the host pass needs just the stub
+  constexpr int NI = BMP / (IW * IH);
+  constexpr int HW_ = IW + 2, HH = IH + 2, HPB = HW_ * HH, HP = NI * HPB;
+  constexpr int HG = (HP + 7) / 8;             // halo groups of 8 rows (one DMA instruction each)
+  constexpr int WGR = BN / 8;                  // weight groups per stage
+  constexpr int NH = (HG + 7) / 8, NH_MIN = HG / 8;
+  constexpr int NW = (WGR + 7) / 8, NW_MIN = WGR / 8;
+  constexpr int WST = 3;
+  constexpr int FN = BN / 32;
+  constexpr int HALO_BYTES = HG * 1024, W_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sHalo = smem;                       // [2][HG*8 rows][128 B]
+  char* sW = smem + 2 * HALO_BYTES;         // [WST][BN][128 B]
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = g.Y, W = g.X, N = g.N, Cin = g.Cin;
+  const int bx_per = W / IW, by_per = H / IH, bpi = bx_per * by_per;
+  const int nblocks = g.B * bpi;
+  const int tiles_m = (nblocks + NI - 1) / NI, tiles_n = (N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int n0 = tn * BN;
+  const int ncc = Cin / 64;
+  int cc_beg = 0, cc_end = ncc;
+  if (g.splitk > 1) {
+    const int per = (ncc + g.splitk - 1) / g.splitk;
+    cc_beg = blockIdx.y * per;
+    cc_end = min(ncc, cc_beg + per);
+  }
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
+
+  // per-lane source offsets: LDS position (row, pos = lane&7) receives source chunk pos ^ ((row>>1)&7)
+  unsigned h_off[NH], w_off[NW];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int hp = (wave + 8 * i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((hp >> 1) & 7);
+    const int j = hp / HPB, hr = hp - j * HPB;
+    const int hy = hr / HW_, hx = hr - hy * HW_;
+    const int gb = tm * NI + j;
+    const int b = gb / bpi, rem = gb - b * bpi;
+    const int y = (rem / bx_per) * IH + hy - 1, x = (rem % bx_per) * IW + hx - 1;
+    const bool ok = hp < HP && b < g.B && y >= 0 && y < H && x >= 0 && x < W;
+    const unsigned pix = (unsigned)((b * H + y) * W + x);
+    h_off[i] = ((pix * (unsigned)g.lda + chunk * 8) * 2) | (0u - (unsigned)(!ok));
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int r = (wave + 8 * i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    const int n = n0 + r;
+    const bool ok = r < BN && n < N;
+    w_off[i] = (((unsigned)n * (unsigned)Cin + chunk * 8) * 2) | (0u - (unsigned)(!ok));
+  }
+  const unsigned tap_stride = (unsigned)N * (unsigned)Cin * 2;
+
+  auto dma_halo = [&](int cc, int buf) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int grp = wave + 8 * i;
+      if (grp < HG) {
+        const unsigned inval = 0u - (unsigned)(h_off[i] == 0xFFFFFFFFu);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sHalo + buf * HALO_BYTES + grp * 1024), 16,
+                                                 (h_off[i] + cc * 128) | inval, 0, 0, 0);
+      }
+    }
+  };
+  auto dma_w = [&](int tap, int cc, int stage) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int grp = wave + 8 * i;
+      if (grp < WGR) {
+        const unsigned inval = 0u - (unsigned)(w_off[i] == 0xFFFFFFFFu);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + stage * W_BYTES + grp * 1024), 16,
+                                                 (w_off[i] + tap * tap_stride + cc * 128) | inval, 0, 0, 0);
+      }
+    }
+  };
+
+  const int p = (tid >> 6) * 32 + (lane & 31);
+  const int pj = p / (IW * IH), pr = p - pj * (IW * IH);
+  const int centre = pj * HPB + (pr / IW + 1) * HW_ + (pr % IW) + 1;
+
+  f32x16 acc[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nsteps = (cc_end - cc_beg) * 9;
+  if (nsteps > 0) {
+    dma_halo(cc_beg, 0);
+    dma_w(0, cc_beg, 0);
+    if (nsteps > 1) {
+      dma_w(1, cc_beg, 1);
+      wait_vm<NW_MIN>();
+    } else {
+      wait_vm<0>();
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  int cc = cc_beg, tap = 0, hbuf = 0, stage = 0;
+  h8 af[2], bf[2][FN];
+  for (int s = 0; s < (DBG == 4 ? 0 : nsteps); ++s) {
+    // prefetch: weights two steps ahead into the ring slot that was read at step s-1; halo one chunk ahead
+    const bool pf_w = s + 2 < nsteps;
+    const bool pf_h = tap == 0 && cc + 1 < cc_end;
+    if (DBG == 0 && pf_h) dma_halo(cc + 1, hbuf ^ 1);
+    if (DBG == 0 && pf_w) {
+      int t2 = tap + 2, c2 = cc;
+      if (t2 >= 9) { t2 -= 9; c2 += 1; }
+      int st2 = stage + 2;
+      if (st2 >= WST) st2 -= WST;
+      dma_w(t2, c2, st2);
+    }
+    const char* hb = sHalo + hbuf * HALO_BYTES;
+    const char* wb = sW + stage * W_BYTES;
+    const int hrow = centre + (tap / 3 - 1) * HW_ + (tap % 3 - 1);
+    auto read_frags = [&](int kk, h8& a, h8 (&b)[FN]) {
+      const int ch = kk * 2 + (lane >> 5);
+      a = *(const h8*)(hb + swz3(hrow, ch));
+#pragma unroll
+      for (int f = 0; f < FN; ++f) b[f] = *(const h8*)(wb + swz3(f * 32 + (lane & 31), ch));
+    };
+    if (DBG < 3 || s == 0) read_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3 && (DBG < 3 || s == 0)) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+      // pin the order: the LDS reads of kk+1 are in flight while the MFMAs of kk run (without this the
+      // scheduler sinks every ds_read next to its MFMA to save registers and exposes the LDS latency)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // everything issued BEFORE this step (W(s+1), earlier halos) must have landed; only this step's own
+    // prefetches may stay in flight across the barrier
+    if (pf_w) {
+      if (pf_h) wait_vm<NW_MIN + NH_MIN>();
+      else wait_vm<NW_MIN>();
+    } else {
+      wait_vm<0>();
+    }
+    if (DBG < 2) __builtin_amdgcn_s_barrier();
+    if (++tap == 9) {
+      tap = 0;
+      ++cc;
+      hbuf ^= 1;
+    }
+    if (++stage == WST) stage = 0;
+  }
+
+  const int M = g.B * H * W;
+  if (igemm_fast_epi(g)) {
+    float* scratch = (float*)(smem + (tid >> 6) * EPI_WAVE_BYTES);
+    float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
+    int rows4[4];
+    long orow4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = (tid >> 6) * 32 + (lane >> 3) + 8 * i;
+      const int j = pp / (IW * IH), rr = pp - j * (IW * IH);
+      const int gb = tm * NI + j;
+      const int b = gb / bpi, rem = gb - b * bpi;
+      const int y = (rem / bx_per) * IH + rr / IW, x = (rem % bx_per) * IW + rr % IW;
+      rows4[i] = b < g.B ? (b * H + y) * W + x : -1;
+      orow4[i] = rows4[i];
+    }
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+    return;
+  }
+  const int ncol0 = n0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int pp = (tid >> 6) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int j = pp / (IW * IH), rr = pp - j * (IW * IH);
+    const int gb = tm * NI + j;
+    const int b = gb / bpi, rem = gb - b * bpi;
+    if (b >= g.B) continue;
+    const int y = (rem / bx_per) * IH + rr / IW, x = (rem % bx_per) * IW + rr % IW;
+    const int m = (b * H + y) * W + x;
+    if (g.splitk > 1) {
+      float* part = g.partial + (long)blockIdx.y * M * N;
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = ncol0 + fn * 32;
+        if (n < N) part[(long)m * N + n] = acc[fn][r];
+      }
+    } else {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = ncol0 + fn * 32;
+        if (n < N) igemm_epilogue_store(g, m, m, n, acc[fn][r], 0.f);
+      }
+    }
+  }
+#endif
+}
+
+template <int BN, int IW, int IH>
+int launch_c3_dma(const IGemm& g, hipStream_t s) {
+  constexpr int NI = BMP / (IW * IH);
+  constexpr int HP = NI * (IW + 2) * (IH + 2);
+  constexpr int LDS = 2 * ((HP + 7) / 8) * 1024 + 3 * BN * 128;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int nblocks = g.B * (g.Y / IH) * (g.X / IW);
+  dim3 grid(cdiv(nblocks, NI) * cdiv(g.N, BN), g.splitk > 1 ? g.splitk : 1);
+  static const int dbg = getenv("MVD_DBG") ? atoi(getenv("MVD_DBG")) : 0;  // timing ablations only (wrong results)
+  if (dbg == 1) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((conv3_dma_kernel<BN, IW, IH, 1>), grid, dim3(NT3), LDS, s, g);
+  } else if (dbg == 2) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((conv3_dma_kernel<BN, IW, IH, 2>), grid, dim3(NT3), LDS, s, g);
+  } else if (dbg == 4) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((conv3_dma_kernel<BN, IW, IH, 4>), grid, dim3(NT3), LDS, s, g);
+  } else if (dbg == 3) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((conv3_dma_kernel<BN, IW, IH, 3>), grid, dim3(NT3), LDS, s, g);
+  } else
+    hipLaunchKernelGGL((conv3_dma_kernel<BN, IW, IH>), grid, dim3(NT3), LDS, s, g);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }
 
 template <int BN, int IW, int IH>
@@ -245,6 +526,11 @@ int launch_conv3_halo(const IGemm& g, hipStream_t s) {
   const bool big = g.X % 16 == 0;
   const int bn = g.bn == 160 ? 160 : 128;
   if (g.splitk > 1 && !g.partial) return mvd_fail("conv3_halo: split-K without a partial buffer");
+  static const bool use_dma = getenv("MVD_NO_DMA") == nullptr;
+  if (use_dma) {
+    if (big) return bn == 160 ? launch_c3_dma<160, 16, 16>(g, s) : launch_c3_dma<128, 16, 16>(g, s);
+    return bn == 160 ? launch_c3_dma<160, 8, 8>(g, s) : launch_c3_dma<128, 8, 8>(g, s);
+  }
   if (big) return bn == 160 ? launch_c3<160, 16, 16>(g, s) : launch_c3<128, 16, 16>(g, s);
   return bn == 160 ? launch_c3<160, 8, 8>(g, s) : launch_c3<128, 8, 8>(g, s);
 }

@@ -192,11 +192,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads of kk+1 ahead of the MFMAs of kk
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -204,6 +206,26 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   }
 
   // ---- epilogue ----
+  if (igemm_fast_epi(g)) {
+    // all tile reads are done (the loop ends on a barrier): reuse the LDS as per-wave transpose scratch
+    float* scratch = (float*)(smem + wave * EPI_WAVE_BYTES);
+    float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      int rows4[4];
+      long orow4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * WM + fm * 32 + (lane >> 3) + 8 * i;
+        rows4[i] = m < M ? m : -1;
+        orow4[i] = m < M ? out_row(g, m) : 0;
+      }
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+        epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part);
+    }
+    return;
+  }
   const int ncol0 = n0 + wn * WN + (lane & 31);
   if (g.splitk > 1) {
     float* part = g.partial + (long)blockIdx.y * M * N;
