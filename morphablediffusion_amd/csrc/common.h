@@ -86,9 +86,9 @@ int conv3_halo_tiles(const IGemm& g, int bn);
 int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
 
-int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     float* partial, int* nslabs_out, hipStream_t s);
-int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s);
 int gn_max_slabs();

@@ -133,6 +133,9 @@ struct mvd_ctx {
   SparseLayerW sparse[9];
   ConvW fr_conv0;
   FrustumBlockW fr_blocks[6], fr_up[3];
+  // FiLM projections (t_conv / v_conv, time_embed / view_embed) of all blocks stacked: one launch each per step
+  LinW film_t, film_v, enc_t, enc_v;
+  int film_total = 0, film_off[9] = {0};
 
   Workspace ws;
   MeshTables mesh;
@@ -186,7 +189,7 @@ int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int s
 int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s);
 // GroupNorm(+act) -> fp16
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s);
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0);
 template <typename T>
 inline T* ws_alloc(mvd_ctx* c, size_t n) {
   return (T*)c->ws.alloc(n * sizeof(T));

@@ -211,7 +211,7 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   float* h2 = ws_alloc<float>(c, (size_t)rows * 16);
   float* r1 = ws_alloc<float>(c, (size_t)rows * 16);
   half_t* a = ws_alloc<half_t>(c, (size_t)rows * 16);
-  float* pre = ws_alloc<float>(c, (size_t)n_local * 16);
+  float* pre = ws_alloc<float>(c, (size_t)n_local * 48);
   float* tpart = ws_alloc<float>(c, 16);
   float* feats = ws_alloc<float>(c, (size_t)rows * 16);
   float* vf = ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
@@ -222,12 +222,13 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
   float* cur = h;
   float* nxt = h2;
+  // x + time_embed(t) + view_embed(v) of all three blocks in two launches (the step embedding is shared by
+  // all views of the sample): pre[v][16*i + c]
+  RET_IF(launch_small_linear(t_embed, td, -n_local, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre, 48, 0, s));
+  RET_IF(launch_small_linear(v_embed, vd, n_local, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre, 48, 1, s));
   for (int i = 0; i < 3; ++i) {
     const EncBlockW& e = c->enc_blocks[i];
-    // x + time_embed(t) + view_embed(v): the step embedding is shared by all views of the sample
-    RET_IF(launch_small_linear(t_embed, td, -n_local, td, e.t.w, e.t.bias, 16, ACT_NONE, pre, 16, 0, s));
-    RET_IF(launch_small_linear(v_embed, vd, n_local, vd, e.v.w, e.v.bias, 16, ACT_NONE, pre, 16, 1, s));
-    RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre, a, 16, s));
+    RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre + 16 * i, a, 16, s, 48));
     g = GemmArgs();
     g.a = a; g.lda = 16; g.w = &e.c1; g.out = r1; g.ldc = 16;
     RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
@@ -302,7 +303,7 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   half_t* gath = ws_alloc<half_t>(c, vox(0) * 64);
   float* tmp = ws_alloc<float>(c, vox(1) * fd[1]);  // largest intermediate (conv1 output == level-1 size)
   half_t* a = ws_alloc<half_t>(c, vox(0) * fd[0]);
-  float* pre = ws_alloc<float>(c, (size_t)TN * 512);
+  float* pre = ws_alloc<float>(c, (size_t)TN * c->film_total);
   float* up = ws_alloc<float>(c, vox(0) * fd[0]);
   WS_CHECK(gath && tmp && a && pre && up);
   RET_IF(launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
@@ -310,24 +311,22 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   GemmArgs g;
   g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = x[0]; g.ldc = fd[0];
   RET_IF(run_conv3d(c, g, TN, D0, S0, S0, 1, s));
-  auto film = [&](const FrustumBlockW& b) -> int {
-    // x + t_conv(t) + v_conv(v) (network.py:294,308): per-(view, channel) constant folded into the norm
-    RET_IF(launch_small_linear(t_embed, td, -TN, td, b.t_conv.w, b.t_conv.bias, b.cin, ACT_NONE, pre, b.cin, 0, s));
-    RET_IF(launch_small_linear(v_embed, vd, TN, vd, b.v_conv.w, b.v_conv.bias, b.cin, ACT_NONE, pre, b.cin, 1, s));
-    return 0;
-  };
+  // x + t_conv(t) + v_conv(v) (network.py:294,308) of all nine blocks in two launches: a per-(view, channel)
+  // constant that the GroupNorm kernels fold in (pre[v][film_off[i] + c])
+  const int FT = c->film_total;
+  RET_IF(launch_small_linear(t_embed, td, -TN, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre, FT, 0, s));
+  RET_IF(launch_small_linear(v_embed, vd, TN, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre, FT, 1, s));
   // down path: conv{1,3,5} stride 2, conv{2,4,6} stride 1
   for (int l = 0; l < 3; ++l) {
     const FrustumBlockW& b1 = c->fr_blocks[2 * l];
     const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
-    RET_IF(film(b1));
-    RET_IF(run_group_norm(c, x[l], fd[l], TN, D[l] * S[l] * S[l], b1.gn, 8, 1e-5f, ACT_SILU, pre, a, fd[l], s));
+    RET_IF(run_group_norm(c, x[l], fd[l], TN, D[l] * S[l] * S[l], b1.gn, 8, 1e-5f, ACT_SILU, pre + c->film_off[2 * l], a,
+                          fd[l], s, FT));
     g = GemmArgs();
     g.a = a; g.lda = fd[l]; g.w = &b1.conv; g.out = tmp; g.ldc = fd[l + 1];
     RET_IF(run_conv3d(c, g, TN, D[l], S[l], S[l], 2, s));
-    RET_IF(film(b2));
-    RET_IF(run_group_norm(c, tmp, fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], b2.gn, 8, 1e-5f, ACT_SILU, pre, a,
-                          fd[l + 1], s));
+    RET_IF(run_group_norm(c, tmp, fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], b2.gn, 8, 1e-5f, ACT_SILU,
+                          pre + c->film_off[2 * l + 1], a, fd[l + 1], s, FT));
     g = GemmArgs();
     g.a = a; g.lda = fd[l + 1]; g.w = &b2.conv; g.out = x[l + 1]; g.ldc = fd[l + 1];
     RET_IF(run_conv3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], 1, s));
@@ -335,9 +334,8 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   // up path: x_l = up(x_{l+1}) + x_l  (in place on x_l through the residual epilogue)
   for (int l = 2; l >= 0; --l) {
     const FrustumBlockW& u = c->fr_up[2 - l];
-    RET_IF(film(u));
-    RET_IF(run_group_norm(c, x[l + 1], fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], u.gn, 8, 1e-5f, ACT_SILU, pre, a,
-                          fd[l + 1], s));
+    RET_IF(run_group_norm(c, x[l + 1], fd[l + 1], TN, D[l + 1] * S[l + 1] * S[l + 1], u.gn, 8, 1e-5f, ACT_SILU,
+                          pre + c->film_off[6 + (2 - l)], a, fd[l + 1], s, FT));
     g = GemmArgs();
     g.a = a; g.lda = fd[l + 1]; g.w = &u.conv; g.out = x[l]; g.ldc = fd[l]; g.resid = x[l]; g.ldr = fd[l];
     RET_IF(run_convT3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], s));

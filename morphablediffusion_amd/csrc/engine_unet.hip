@@ -176,13 +176,14 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 }
 
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s) {
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld) {
   const size_t mark = c->ws.off;
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
   int nslabs = 0;
-  RET_IF(launch_gn_stats(x, ld, B, rows_per_sample, n.C, groups, preadd, partial, &nslabs, s));
-  RET_IF(launch_gn_apply(x, ld, B, rows_per_sample, n.C, groups, preadd, partial, nslabs, n.g, n.b, eps, act, out, ldo, s));
+  RET_IF(launch_gn_stats(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, &nslabs, s));
+  RET_IF(launch_gn_apply(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, nslabs, n.g, n.b, eps, act, out,
+                         ldo, s));
   c->ws.off = mark;
   return 0;
 }

@@ -393,6 +393,44 @@ int engine_finalize(mvd_ctx* c) {
                                &c->fr_blocks[i]));
   for (int i = 0; i < 3; ++i)
     RET_IF(build_frustum_block(c, F + "up" + std::to_string(i) + ".", "norm", true, 2, &c->fr_up[i]));
+  {  // stack the per-block FiLM projections: [sum cin][time_dim] and [sum cin][view_dim]
+    auto stack = [&](const std::vector<std::string>& prefixes, const char* wn, LinW* out, int K) -> int {
+      int total = 0;
+      std::vector<RawTensor*> ws, bs;
+      for (auto& p : prefixes) {
+        RawTensor *wt, *bt;
+        RET_IF(get_raw(c, p + wn + ".weight", &wt));
+        RET_IF(get_raw(c, p + wn + ".bias", &bt));
+        ws.push_back(wt);
+        bs.push_back(bt);
+        total += (int)wt->shape[0];
+      }
+      out->N = total;
+      out->K = K;
+      RET_IF(dmalloc(c, (void**)&out->w, (size_t)total * K * sizeof(half_t)));
+      RET_IF(dmalloc(c, (void**)&out->bias, (size_t)total * sizeof(float)));
+      size_t off = 0;
+      for (size_t i = 0; i < ws.size(); ++i) {
+        RET_IF(launch_f32_to_f16(ws[i]->d, out->w + off * K, ws[i]->numel, 0));
+        HIP_CHECK_RET(hipMemcpy(out->bias + off, bs[i]->d, bs[i]->numel * sizeof(float), hipMemcpyDeviceToDevice));
+        off += ws[i]->shape[0];
+      }
+      return 0;
+    };
+    std::vector<std::string> fp, ep;
+    int off = 0;
+    for (int i = 0; i < 9; ++i) {
+      fp.push_back(i < 6 ? F + "conv" + std::to_string(i + 1) + "." : F + "up" + std::to_string(i - 6) + ".");
+      c->film_off[i] = off;
+      off += i < 6 ? c->fr_blocks[i].cin : c->fr_up[i - 6].cin;
+    }
+    c->film_total = off;
+    RET_IF(stack(fp, "t_conv", &c->film_t, c->v.time_dim));
+    RET_IF(stack(fp, "v_conv", &c->film_v, c->v.view_dim));
+    for (int i = 0; i < 3; ++i) ep.push_back(S + "target_encoder.out_conv" + std::to_string(i) + ".");
+    RET_IF(stack(ep, "time_embed", &c->enc_t, c->v.time_dim));
+    RET_IF(stack(ep, "view_embed", &c->enc_v, c->v.view_dim));
+  }
   return 0;
   };
   if (has_cond) RET_IF(build_cond());

@@ -57,6 +57,40 @@ __device__ __forceinline__ bool igemm_fast_epi(const IGemm& g) {
          (!g.rowbias || (g.rb_ld & 3) == 0);
 }
 
+// bias / per-sample bias / residual / SiLU / store for 4 consecutive columns n..n+3 of GEMM row m
+__device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int n, float4 v) {
+    v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+    if (g.bias) {
+      const float4 b = *(const float4*)(g.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (g.rowbias) {
+      const int bs = m / (g.Z * g.Y * g.X);
+      const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (g.resid) {
+      if (g.resid_f32) {
+        const float4 q = *(const float4*)((const float*)g.resid + o * g.ldr + n);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      } else {
+        const h4 q = *(const h4*)((const half_t*)g.resid + o * g.ldr + n);
+        v.x += (float)q[0]; v.y += (float)q[1]; v.z += (float)q[2]; v.w += (float)q[3];
+      }
+    }
+    if (g.act == ACT_SILU) {
+      v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
+      v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
+    }
+    if (g.out_f32) {
+      *(float4*)((float*)g.out + o * g.ldc + n) = v;
+    } else {
+      h4 hv;
+      hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+      *(h4*)((half_t*)g.out + o * g.ldc + n) = hv;
+    }
+}
+
 // rows4[i] / orow4[i]: GEMM row index m and output row of fragment row (lane>>3) + 8 i  (m < 0: skip)
 __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16& acc, float* scratch, int lane,
                                                     const int (&rows4)[4], const long (&orow4)[4], int n_base,
@@ -77,36 +111,46 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
       *(float4*)(partial + (long)m * g.N + n) = v;
       continue;
     }
-    v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+    epilogue_vec4(g, m, orow4[i], n, v);
+  }
+}
+
+// GEGLU variant: fragment 0 holds 32 value columns, fragment 1 the matching 32 gate columns (weights are packed
+// in alternating 32-row blocks).  out[.., (n>>6)*32 + (n&31)] = (x + b_x) * gelu_erf(gate + b_g), 4 columns per lane.
+__device__ __forceinline__ void epilogue_geglu_frag_store(const IGemm& g, const f32x16& ax, const f32x16& ag, float* sx,
+                                                          float* sg, int lane, const int (&rows4)[4],
+                                                          const long (&orow4)[4], int n_base) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31);
+    sx[o] = ax[r];
+    sg[o] = ag[r];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cq = (lane & 7) * 4;
+  const int n = n_base + cq;  // value column; gate column = n + 32
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int fr = (lane >> 3) + 8 * i;
+    if (rows4[i] < 0 || n + 32 >= g.N) continue;
+    float4 x = *(const float4*)(sx + fr * EPI_LD + cq);
+    float4 q = *(const float4*)(sg + fr * EPI_LD + cq);
+    x.x *= g.alpha; x.y *= g.alpha; x.z *= g.alpha; x.w *= g.alpha;
+    q.x *= g.alpha; q.y *= g.alpha; q.z *= g.alpha; q.w *= g.alpha;
     if (g.bias) {
-      const float4 b = *(const float4*)(g.bias + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      const float4 bx = *(const float4*)(g.bias + n), bg = *(const float4*)(g.bias + n + 32);
+      x.x += bx.x; x.y += bx.y; x.z += bx.z; x.w += bx.w;
+      q.x += bg.x; q.y += bg.y; q.z += bg.z; q.w += bg.w;
     }
-    if (g.rowbias) {
-      const int bs = m / (g.Z * g.Y * g.X);
-      const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    const long o = orow4[i];
-    if (g.resid) {
-      if (g.resid_f32) {
-        const float4 q = *(const float4*)((const float*)g.resid + o * g.ldr + n);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-      } else {
-        const h4 q = *(const h4*)((const half_t*)g.resid + o * g.ldr + n);
-        v.x += (float)q[0]; v.y += (float)q[1]; v.z += (float)q[2]; v.w += (float)q[3];
-      }
-    }
-    if (g.act == ACT_SILU) {
-      v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
-      v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
-    }
+    float4 v;
+    v.x = x.x * gelu_erf(q.x); v.y = x.y * gelu_erf(q.y); v.z = x.z * gelu_erf(q.z); v.w = x.w * gelu_erf(q.w);
+    const int ncol = (n >> 6) * 32 + (n & 31);
     if (g.out_f32) {
-      *(float4*)((float*)g.out + o * g.ldc + n) = v;
+      *(float4*)((float*)g.out + orow4[i] * g.ldc + ncol) = v;
     } else {
       h4 hv;
       hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
-      *(h4*)((half_t*)g.out + o * g.ldc + n) = hv;
+      *(h4*)((half_t*)g.out + orow4[i] * g.ldc + ncol) = hv;
     }
   }
 }

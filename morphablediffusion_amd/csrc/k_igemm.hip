@@ -226,6 +226,25 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     }
     return;
   }
+  if constexpr (FN == 2 && WN == 64) {
+    if (g.geglu && g.splitk <= 1 && (N & 63) == 0 && (g.ldc & 3) == 0) {  // vectorised GEGLU (FF1 of every block)
+      float* sx = (float*)(smem + wave * 2 * EPI_WAVE_BYTES);
+      float* sg = sx + EPI_WAVE_BYTES / 4;
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        int rows4[4];
+        long orow4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wm * WM + fm * 32 + (lane >> 3) + 8 * i;
+          rows4[i] = m < M ? m : -1;
+          orow4[i] = m < M ? out_row(g, m) : 0;
+        }
+        epilogue_geglu_frag_store(g, acc[fm][0], acc[fm][1], sx, sg, lane, rows4, orow4, n0 + wn * WN);
+      }
+      return;
+    }
+  }
   const int ncol0 = n0 + wn * WN + (lane & 31);
   if (g.splitk > 1) {
     float* part = g.partial + (long)blockIdx.y * M * N;
@@ -268,6 +287,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
   const int M = g.B * g.Z * g.Y * g.X;
   const int N = g.N;
   const long total = (long)M * N;
+  if (igemm_fast_epi(g)) {  // 16-byte path: 4 consecutive columns per thread
+    const long total4 = total >> 2;
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+      const long idx = i4 << 2;
+      const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < g.splitk; ++s) {
+        const float4 q = *(const float4*)(g.partial + (long)s * total + idx);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      epilogue_vec4(g, m, out_row(g, m), n, v);
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
     if (g.geglu && (n & 32)) continue;
@@ -299,8 +332,9 @@ int launch_variant(const IGemm& g, int M, hipStream_t s) {
 
 int launch_splitk_reduce(const IGemm& g, hipStream_t s) {
   const long total = (long)g.B * g.Z * g.Y * g.X * g.N;
-  int blocks = (int)((total + 255) / 256);
+  int blocks = (int)((total / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

@@ -39,7 +39,7 @@ __device__ __forceinline__ GnMap gn_map(int C, int t) {
 
 // grid (nslabs, B): per-slab (sum, sumsq) per group -> partial[b][slab][g][2]; combined in fp64 by the apply.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ld, int rows_per_sample, int C,
-                                                       int G, const float* __restrict__ preadd, int rows_per_slab,
+                                                       int G, const float* __restrict__ preadd, int pld, int rows_per_slab,
                                                        float* __restrict__ partial) {
   __shared__ float s_sum[GN_MAXC];
   __shared__ float s_sq[GN_MAXC];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
       sum[i][e] = 0.f;
       sq[i][e] = 0.f;
       const int c = (m.q0 + 256 * i) * 4 + e;
-      pa[i][e] = (preadd && i < m.nq && c < C) ? preadd[(long)b * C + c] : 0.f;
+      pa[i][e] = (preadd && i < m.nq && c < C) ? preadd[(long)b * pld + c] : 0.f;
     }
   const float* xb = x + (long)b * rows_per_sample * ld;
   if (m.active) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 // grid (blocks_per_sample, B).  y = act(x * scale[c] + shift[c]) with scale/shift precomputed in LDS.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ld, int rows_per_sample, int C,
-                                                       int G, const float* __restrict__ preadd,
+                                                       int G, const float* __restrict__ preadd, int pld,
                                                        const float* __restrict__ partial, int nslabs,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int act, half_t* __restrict__ out, int ldo) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   for (int c = t; c < C; c += 256) {
     const int g = c / cpg;
     const float sc = s_rstd[g] * gamma[c];
-    const float pa = preadd ? preadd[(long)b * C + c] : 0.f;
+    const float pa = preadd ? preadd[(long)b * pld + c] : 0.f;
     s_scale[c] = sc;
     s_shift[c] = beta[c] + (pa - s_mean[g]) * sc;
   }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 int gn_max_slabs() { return GN_MAX_SLABS; }
 
-int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     float* partial, int* nslabs_out, hipStream_t s) {
   if (C > GN_MAXC || G > 32 || C % G || C % 4 || ld % 4) return mvd_fail("gn_stats: unsupported channel/group count");
   int nslabs = rows_per_sample / 16;
@@ -219,13 +219,13 @@ int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, i
   const int rps = cdiv(rows_per_sample, nslabs);
   nslabs = cdiv(rows_per_sample, rps);
   *nslabs_out = nslabs;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nslabs, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, rps,
-                     partial);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nslabs, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, pld ? pld : C,
+                     rps, partial);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd,
+int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s) {
   if (C > GN_MAXC || C % 4 || ld % 4 || ldo % 4) return mvd_fail("gn_apply: channel counts must be multiples of 4");
@@ -233,8 +233,8 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
   if (blocks < 1) blocks = 1;
   const int cap = B >= 16 ? 64 : (B >= 4 ? 128 : 512);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, partial,
-                     nslabs, gamma, beta, eps, act, out, ldo);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, pld ? pld : C,
+                     partial, nslabs, gamma, beta, eps, act, out, ldo);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
