@@ -39,7 +39,6 @@ struct ResW {
 struct STW {
   NormW norm, ln1, ln3;
   ConvW proj_in, qk, vt, attn_out, ff1, ff2, proj_out;
-  LinW a2v, a2o;
   int C = 0, heads = 8, a2_off = 0;
 };
 struct CondW {
@@ -112,7 +111,7 @@ struct mvd_ctx {
   // UNet
   LinW te0, te2, emb_all;
   int emb_total = 0;
-  ConvW a2v_all;  // attn2.to_v of every SpatialTransformer stacked: [a2_total][context_dim]
+  ConvW a2_all;  // folded attn2 (W_o W_v, b_o) of every SpatialTransformer stacked: [a2_total][context_dim]
   int a2_total = 0;
   std::vector<std::vector<UOp>> in_blocks, out_blocks;
   std::vector<UOp> mid_block;

@@ -66,12 +66,30 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
     if (!g.partial) g.splitk = 1;  // not enough scratch: single pass
   }
+  static const bool timing = getenv("MVD_LAYER_TIMING") != nullptr;  // debugging aid: per-GEMM time on stderr
+  static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (timing) {
+    if (!ev0) {
+      hipEventCreate(&ev0);
+      hipEventCreate(&ev1);
+    }
+    hipEventRecord(ev0, s);
+  }
   int r;
   if (halo) {
     r = launch_conv3_halo(g, s);
     if (!r && g.splitk > 1) r = launch_splitk_reduce(g, s);
   } else {
     r = launch_igemm(g, s);
+  }
+  if (timing) {
+    hipEventRecord(ev1, s);
+    hipEventSynchronize(ev1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    const double fl = 2.0 * M * g.N * g.Cin * g.ntaps;
+    fprintf(stderr, "[gemm] M=%d N=%d Cin=%d taps=%d f32=%d halo=%d bn=%d sk=%d geglu=%d  %.1f us  %.0f TF\n", M, g.N, g.Cin,
+            g.ntaps, g.a_f32, (int)halo, g.bn, g.splitk, g.geglu, ms * 1e3, fl / (ms * 1e-3) * 1e-12);
   }
   c->ws.off = mark;  // stream-ordered reuse
   return r;
@@ -201,6 +219,7 @@ struct Fwd {
   int Bv, n_ctx, depth0;
   const float* emb_all;  // [Bv][emb_total]
   const float* context;  // [Bv][context_dim]
+  const float* a2_all;   // [Bv][a2_total] folded attn2 output per SpatialTransformer
   const Ctx5* src;
 };
 
@@ -248,12 +267,10 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
   half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
-  float* v2a = ws_alloc<float>(c, (size_t)f.Bv * C);
-  float* v2 = ws_alloc<float>(c, (size_t)f.Bv * C);
   float* t2 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
   float* t3 = ws_alloc<float>(c, (size_t)rows * C);
-  WS_CHECK(n0 && t0 && l1 && qk && vt && ao && v2a && v2 && t2 && gg && t3);
+  WS_CHECK(n0 && t0 && l1 && qk && vt && ao && t2 && gg && t3);
   RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C, f.s));
   GemmArgs g;
   g.a = n0; g.lda = C; g.w = &t.proj_in; g.out = t0; g.ldc = C;
@@ -270,11 +287,11 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   g.a = t.vt.w; g.lda = C; g.w = &xw; g.out = vt; g.out_f32 = 0; g.ldc = rows; g.use_bias = false;
   RET_IF(run_linear(c, g, 1, C, f.s));
   RET_IF(launch_attention(qk, 2 * C, vt, rows, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
-  // attn2 with the single CLIP token: softmax over one key == 1 -> to_out(to_v(ctx)) broadcast over tokens
-  RET_IF(launch_small_linear(f.context, c->u.context_dim, f.Bv, c->u.context_dim, t.a2v.w, nullptr, C, ACT_NONE, v2a, C, 0, f.s));
-  RET_IF(launch_small_linear(v2a, C, f.Bv, C, t.a2o.w, t.a2o.bias, C, ACT_NONE, v2, C, 0, f.s));
+  // attn2 (single CLIP token -> per-sample constant, precomputed for all blocks in engine_unet) rides on the
+  // attn1 output projection as a per-sample bias
   g = GemmArgs();
-  g.a = ao; g.lda = C; g.w = &t.attn_out; g.out = t2; g.ldc = C; g.resid = t0; g.ldr = C; g.rowbias = v2; g.rb_ld = C;
+  g.a = ao; g.lda = C; g.w = &t.attn_out; g.out = t2; g.ldc = C; g.resid = t0; g.ldr = C;
+  g.rowbias = f.a2_all + t.a2_off; g.rb_ld = c->a2_total;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l1, f.s));
   g = GemmArgs();
@@ -373,7 +390,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels, temb = 4 * mc;
   const size_t mark0 = c->ws.off;
-  Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, src};
+  Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src};
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
   float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
   float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);
@@ -397,6 +414,14 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     RET_IF(run_linear(c, g, Bv, Bv, s));
   }
   f.emb_all = ea;
+  {
+    float* a2 = ws_alloc<float>(c, (size_t)Bv * c->a2_total);
+    WS_CHECK(a2);
+    GemmArgs g;
+    g.a = context; g.a_f32 = 1; g.lda = u.context_dim; g.w = &c->a2_all; g.out = a2; g.ldc = c->a2_total;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    f.a2_all = a2;
+  }
 
   // shapes of the concat buffers
   const int nb = (int)c->in_blocks.size();

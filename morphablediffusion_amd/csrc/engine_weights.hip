@@ -114,8 +114,6 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(launch_f32_to_f16(k->d, s->qk.w + (size_t)C * C, (size_t)C * C, 0));
   RET_IF(pack_conv(c, t + ".attn1.to_v.weight", "", false, false, &s->vt));
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
-  RET_IF(pack_lin(c, t + ".attn2.to_v.weight", "", &s->a2v));
-  RET_IF(pack_lin(c, t + ".attn2.to_out.0.weight", t + ".attn2.to_out.0.bias", &s->a2o));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
   return 0;
@@ -240,7 +238,7 @@ int engine_finalize(mvd_ctx* c) {
     RET_IF(build_st(c, U + name, C, &s));
     s.a2_off = c->a2_total;
     c->a2_total += C;
-    a2v_keys.push_back(U + name + ".transformer_blocks.0.attn2.to_v.weight");
+    a2v_keys.push_back(U + name + ".transformer_blocks.0.attn2");
     c->st.push_back(s);
     ops.push_back({OP_ST, (int)c->st.size() - 1, C, C});
     return 0;
@@ -324,18 +322,24 @@ int engine_finalize(mvd_ctx* c) {
       off += pz.cout;
     }
   }
-  // attn2.to_v of all SpatialTransformers as one [a2_total][context_dim] matrix (the CLIP token is shared)
-  c->a2v_all.N = c->a2_total;
-  c->a2v_all.Cin = u.context_dim;
-  c->a2v_all.taps = 1;
-  RET_IF(dmalloc(c, (void**)&c->a2v_all.w, (size_t)c->a2_total * u.context_dim * sizeof(half_t)));
+  // attn2 sees one CLIP token, so softmax == 1 and the block reduces to to_out(to_v(ctx)): fold W_o W_v per
+  // SpatialTransformer and stack them into one [a2_total][context_dim] matrix (one GEMM per UNet forward)
+  c->a2_all.N = c->a2_total;
+  c->a2_all.Cin = u.context_dim;
+  c->a2_all.taps = 1;
+  RET_IF(dmalloc(c, (void**)&c->a2_all.w, (size_t)c->a2_total * u.context_dim * sizeof(half_t)));
+  RET_IF(dmalloc(c, (void**)&c->a2_all.bias, (size_t)c->a2_total * sizeof(float)));
   {
     size_t off = 0;
     for (auto& k : a2v_keys) {
-      RawTensor* w;
-      RET_IF(get_raw(c, k, &w));
-      RET_IF(launch_f32_to_f16(w->d, c->a2v_all.w + off, w->numel, 0));
-      off += w->numel;
+      RawTensor *wv, *wo, *bo;
+      RET_IF(get_raw(c, k + ".to_v.weight", &wv));
+      RET_IF(get_raw(c, k + ".to_out.0.weight", &wo));
+      RET_IF(get_raw(c, k + ".to_out.0.bias", &bo));
+      const int C = (int)bo->numel;
+      RET_IF(launch_fold_ov(wo->d, wv->d, 1, C, u.context_dim, C, c->a2_all.w + off * u.context_dim, 0));
+      HIP_CHECK_RET(hipMemcpy(c->a2_all.bias + off, bo->d, C * sizeof(float), hipMemcpyDeviceToDevice));
+      off += C;
     }
   }
   // conditioning blocks (attention.py:97-115)

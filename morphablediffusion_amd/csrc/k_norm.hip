@@ -12,6 +12,7 @@ namespace {
 constexpr int GN_MAX_SLABS = 64;
 constexpr int GN_MAXC = 2560;
 constexpr int GN_NQ = 3;  // channel quads per thread when C/4 > 256 (C <= 3072)
+constexpr int GN_UNROLL = 4;
 
 struct GnMap {
   int Q, lanes_q, row_par, nq;
@@ -59,18 +60,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
   const float* xb = x + (long)b * rows_per_sample * ld;
   if (m.active) {
-    for (int r = r_beg + m.rsub; r < r_end; r += m.row_par) {
-      const float* xr = xb + (long)r * ld;
+    // GN_UNROLL independent 16-byte loads per thread and iteration (rows past the slab are clamped and masked)
+    for (int r = r_beg + m.rsub; r < r_end; r += GN_UNROLL * m.row_par) {
 #pragma unroll
       for (int i = 0; i < GN_NQ; ++i) {
         const int q = m.q0 + 256 * i;
         if (i < m.nq && q < m.Q) {
-          const float4 v = *(const float4*)(xr + q * 4);
-          const float vv[4] = {v.x + pa[i][0], v.y + pa[i][1], v.z + pa[i][2], v.w + pa[i][3]};
+          float4 v[GN_UNROLL];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            sum[i][e] += vv[e];
-            sq[i][e] += vv[e] * vv[e];
+          for (int u = 0; u < GN_UNROLL; ++u) {
+            const int ru = min(r + u * m.row_par, r_end - 1);
+            v[u] = *(const float4*)(xb + (long)ru * ld + q * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < GN_UNROLL; ++u) {
+            const float w = (r + u * m.row_par < r_end) ? 1.f : 0.f;
+            const float vv[4] = {v[u].x + pa[i][0], v[u].y + pa[i][1], v[u].z + pa[i][2], v[u].w + pa[i][3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sum[i][e] += w * vv[e];
+              sq[i][e] += w * vv[e] * vv[e];
+            }
           }
         }
       }
@@ -116,13 +126,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        float eps, int act, half_t* __restrict__ out, int ldo) {
   __shared__ float s_mean[32], s_rstd[32];
   __shared__ float s_scale[GN_MAXC], s_shift[GN_MAXC];
+  __shared__ double s_pa[256], s_pq[256];
   const int b = blockIdx.y, t = threadIdx.x;
+  // slab partials -> (mean, rstd) per group: 256/G threads per group, fp64 combine
+  const int parts = 256 / G;
+  {
+    const int gi = t % G, p = t / G;
+    double a = 0.0, q = 0.0;
+    if (p < parts)
+      for (int s = p; s < nslabs; s += parts) {
+        const float2 v = *(const float2*)(partial + (((long)b * nslabs + s) * G + gi) * 2);
+        a += (double)v.x;
+        q += (double)v.y;
+      }
+    s_pa[t] = a;
+    s_pq[t] = q;
+  }
+  // this thread's channels: issue the parameter loads before waiting on the reduction
+  constexpr int CPT = GN_MAXC / 256;
+  float ga[CPT], be[CPT], pa[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = t + 256 * i;
+    const bool ok = c < C;
+    ga[i] = ok ? gamma[c] : 0.f;
+    be[i] = ok ? beta[c] : 0.f;
+    pa[i] = (ok && preadd) ? preadd[(long)b * pld + c] : 0.f;
+  }
+  __syncthreads();
   if (t < G) {
     double a = 0.0, q = 0.0;
-    for (int s = 0; s < nslabs; ++s) {
-      const float* p = partial + (((long)b * nslabs + s) * G + t) * 2;
-      a += (double)p[0];
-      q += (double)p[1];
+    for (int p = 0; p < parts; ++p) {
+      a += s_pa[p * G + t];
+      q += s_pq[p * G + t];
     }
     const double n = (double)rows_per_sample * (double)(C / G);
     const double mean = a / n;
@@ -133,12 +169,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
   __syncthreads();
   const int cpg = C / G;
-  for (int c = t; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = s_rstd[g] * gamma[c];
-    const float pa = preadd ? preadd[(long)b * pld + c] : 0.f;
-    s_scale[c] = sc;
-    s_shift[c] = beta[c] + (pa - s_mean[g]) * sc;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = t + 256 * i;
+    if (c < C) {
+      const int gq = c / cpg;
+      const float sc = s_rstd[gq] * ga[i];
+      s_scale[c] = sc;
+      s_shift[c] = be[i] + (pa[i] - s_mean[gq]) * sc;
+    }
   }
   __syncthreads();
   const GnMap m = gn_map(C, t);
@@ -154,14 +193,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (i >= m.nq || q >= m.Q) continue;
     const float4 sc = *(const float4*)(s_scale + q * 4);
     const float4 sh = *(const float4*)(s_shift + q * 4);
-    for (int r = r_beg + m.rsub; r < r_end; r += m.row_par) {
-      const float4 v = *(const float4*)(xb + (long)r * ld + q * 4);
-      h4 o;
-      o[0] = (half_t)act_apply(v.x * sc.x + sh.x, act);
-      o[1] = (half_t)act_apply(v.y * sc.y + sh.y, act);
-      o[2] = (half_t)act_apply(v.z * sc.z + sh.z, act);
-      o[3] = (half_t)act_apply(v.w * sc.w + sh.w, act);
-      *(h4*)(ob + (long)r * ldo + q * 4) = o;
+    for (int r = r_beg + m.rsub; r < r_end; r += GN_UNROLL * m.row_par) {
+      float4 v[GN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const int ru = min(r + u * m.row_par, r_end - 1);
+        v[u] = *(const float4*)(xb + (long)ru * ld + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const int ru = r + u * m.row_par;
+        if (ru >= r_end) break;
+        h4 o;
+        o[0] = (half_t)act_apply(v[u].x * sc.x + sh.x, act);
+        o[1] = (half_t)act_apply(v[u].y * sc.y + sh.y, act);
+        o[2] = (half_t)act_apply(v[u].z * sc.z + sh.z, act);
+        o[3] = (half_t)act_apply(v[u].w * sc.w + sh.w, act);
+        *(h4*)(ob + (long)ru * ldo + q * 4) = o;
+      }
     }
   }
 }
