@@ -112,8 +112,11 @@ int mvd_denoise_views(mvd_ctx* ctx, const float* x_noisy, const float* x_input, 
 int mvd_op_conv(mvd_ctx* ctx, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
                 int Cout, int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
                 void* stream);
+/* a_half != 0: A is rounded to fp16 in HBM first (the layout of operand-only activations) and, for M >= 512,
+ * the dense LDS-DMA GEMM runs; resid [M][N] (or null) is added in the epilogue; force_splitk > 0 fixes the
+ * split-K factor */
 int mvd_op_linear(mvd_ctx* ctx, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu,
-                  float* out, void* stream);
+                  const float* resid, int a_half, int force_splitk, float* out, void* stream);
 int mvd_op_group_norm(mvd_ctx* ctx, const float* x_nchw, int B, int C, int HW, int groups, const float* gamma,
                       const float* beta, float eps, int act, float* out_nchw, void* stream);
 int mvd_op_layer_norm(mvd_ctx* ctx, const float* x, int rows, int C, const float* gamma, const float* beta, float* out,

@@ -329,8 +329,8 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
   return 0;
 }
 
-int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu, float* out,
-                  void* stream) {
+int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu,
+                  const float* resid, int a_half, int force_splitk, float* out, void* stream) {
   hipStream_t s = S(stream);
   const size_t mark = c->ws.off;
   if (K % 8) return mvd_fail("op_linear: K must be a multiple of 8");
@@ -347,6 +347,16 @@ int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, cons
   GemmArgs g;
   g.a = a; g.a_f32 = 1; g.lda = K; g.w = &cw; g.out = out; g.ldc = geglu ? N / 2 : N; g.geglu = geglu;
   g.use_bias = bias != nullptr;
+  g.force_splitk = force_splitk;
+  if (resid) {
+    g.resid = resid; g.resid_f32 = 1; g.ldr = N;
+  }
+  if (a_half) {
+    half_t* ah = ws_alloc<half_t>(c, (size_t)M * K);
+    WS_CHECK(ah);
+    RET_IF(launch_f32_to_f16(a, ah, (size_t)M * K, s));
+    g.a = ah; g.a_f32 = 0;
+  }
   RET_IF(run_linear(c, g, 1, M, s));
   c->ws.off = mark;
   return 0;

@@ -56,6 +56,7 @@ struct IGemm {
   float alpha;          // scale on the accumulator before bias
   int act;              // ACT_SILU applied last (non-GEGLU path)
   // split-K
+  int nch;              // dense GEMM kernel: column tiles walked by one workgroup
   int bn;               // column-tile width (64 / 128 / 160); 0 = pick from N
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1
@@ -85,6 +86,9 @@ bool conv3_halo_eligible(const IGemm& g);
 int conv3_halo_tiles(const IGemm& g, int bn);
 int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
+bool gemm_dma_eligible(const IGemm& g);
+void gemm_dma_plan(int M, int N, int Cin, int bn, int geglu, int* nch_out, int* splitk_out);
+int launch_gemm_dma(const IGemm& g, hipStream_t s);
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     float* partial, int* nslabs_out, hipStream_t s);

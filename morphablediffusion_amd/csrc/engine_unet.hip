@@ -47,6 +47,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   g.bn = igemm_pick_bn(g.N, g.geglu);
   if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
   const bool halo = c->use_halo && conv3_halo_eligible(g);
+  static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
+  const bool dense = use_dense && !halo && M >= 512 && gemm_dma_eligible(g);
   int sk;
   if (halo) {  // LDS-halo 3x3 kernel: split over 64-channel chunks until the chip is full
     if (g.bn == 64) g.bn = 128;
@@ -54,6 +56,13 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     sk = force_splitk > 0 ? force_splitk : (tiles >= 200 ? 1 : cdiv(256, tiles));
     if (sk > ncc) sk = ncc;
     if (sk > 8) sk = 8;
+  } else if (dense) {
+    if (g.bn == 64) g.bn = 128;
+    int nch = 1, sk2 = 1;
+    gemm_dma_plan(M, g.N, g.Cin, g.bn, g.geglu, &nch, &sk2);
+    sk = g.geglu ? 1 : (force_splitk > 0 ? force_splitk : sk2);
+    if (sk > cdiv(g.Cin, 64)) sk = cdiv(g.Cin, 64);
+    g.nch = sk > 1 ? 1 : nch;
   } else {
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
@@ -79,6 +88,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   if (halo) {
     r = launch_conv3_halo(g, s);
     if (!r && g.splitk > 1) r = launch_splitk_reduce(g, s);
+  } else if (dense) {
+    r = launch_gemm_dma(g, s);
   } else {
     r = launch_igemm(g, s);
   }
@@ -89,7 +100,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     hipEventElapsedTime(&ms, ev0, ev1);
     const double fl = 2.0 * M * g.N * g.Cin * g.ntaps;
     fprintf(stderr, "[gemm] M=%d N=%d Cin=%d taps=%d f32=%d halo=%d bn=%d sk=%d geglu=%d  %.1f us  %.0f TF\n", M, g.N, g.Cin,
-            g.ntaps, g.a_f32, (int)halo, g.bn, g.splitk, g.geglu, ms * 1e3, fl / (ms * 1e-3) * 1e-12);
+            g.ntaps, g.a_f32, halo ? 1 : (dense ? 2 : 0), g.bn, g.splitk, g.geglu, ms * 1e3, fl / (ms * 1e-3) * 1e-12);
   }
   c->ws.off = mark;  // stream-ordered reuse
   return r;
@@ -269,7 +280,7 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t2 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
-  float* t3 = ws_alloc<float>(c, (size_t)rows * C);
+  half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C);  // x + ff(x): only ever the proj_out operand -> fp16
   WS_CHECK(n0 && t0 && l1 && qk && vt && ao && t2 && gg && t3);
   RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C, f.s));
   GemmArgs g;
@@ -298,10 +309,10 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   g.a = l1; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
-  g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.ldc = C; g.resid = t2; g.ldr = C;
+  g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C; g.resid = t2; g.ldr = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
-  g.a = t3; g.a_f32 = 1; g.lda = C; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
+  g.a = t3; g.lda = C; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   c->ws.off = mark;
   return 0;

@@ -115,6 +115,30 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
   }
 }
 
+// transposed store of an already-final fragment (no bias / residual): columns ncol_base + [0, 32) of g.out, < ncols
+__device__ __forceinline__ void epilogue_frag_store_raw(const IGemm& g, const f32x16& v, float* scratch, int lane,
+                                                        const int (&rows4)[4], const long (&orow4)[4], int ncol_base,
+                                                        int ncols) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = v[r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cq = (lane & 7) * 4;
+  const int n = ncol_base + cq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int fr = (lane >> 3) + 8 * i;
+    if (rows4[i] < 0 || n >= ncols) continue;
+    const float4 x = *(const float4*)(scratch + fr * EPI_LD + cq);
+    if (g.out_f32) {
+      *(float4*)((float*)g.out + orow4[i] * g.ldc + n) = x;
+    } else {
+      h4 hv;
+      hv[0] = (half_t)x.x; hv[1] = (half_t)x.y; hv[2] = (half_t)x.z; hv[3] = (half_t)x.w;
+      *(h4*)((half_t*)g.out + orow4[i] * g.ldc + n) = hv;
+    }
+  }
+}
+
 // GEGLU variant: fragment 0 holds 32 value columns, fragment 1 the matching 32 gate columns (weights are packed
 // in alternating 32-row blocks).  out[.., (n>>6)*32 + (n&31)] = (x + b_x) * gelu_erf(gate + b_g), 4 columns per lane.
 __device__ __forceinline__ void epilogue_geglu_frag_store(const IGemm& g, const f32x16& ax, const f32x16& ag, float* sx,

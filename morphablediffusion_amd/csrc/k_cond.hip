@@ -100,23 +100,47 @@ __global__ void fuse_views_kernel(const float* __restrict__ vf, int n_views, int
 }
 
 // in [n_in][Cin], nbr [n_out][27] (-1 = inactive), w [27][Cin][Cout]; out = relu(conv*scale + shift)
+// One site per block: thread = (tap group p, output channel co); the 27 taps are dealt round-robin to the
+// 256/Cout groups and combined through LDS, so a thread's dependent chain is <= 7 taps x Cin/8 vector steps
+// instead of 27 x Cin scalar ones (the layer is latency-, not throughput-bound: <= 64 channels, ~10^3-10^4 sites).
 __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
                                                           int n_out, int Cin, int Cout, const float* __restrict__ w,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           float* __restrict__ out) {
-  const int per_block = 256 / Cout;
-  const int site = blockIdx.x * per_block + threadIdx.x / Cout;
-  const int co = threadIdx.x % Cout;
-  if (threadIdx.x >= per_block * Cout || site >= n_out) return;
+  __shared__ int s_nb[27];
+  __shared__ float s_red[256];
+  const int site = blockIdx.x, t = threadIdx.x;
+  if (t < 27) s_nb[t] = nbr[(long)site * 27 + t];
+  __syncthreads();
+  const int co = t % Cout, p = t / Cout, P = 256 / Cout;
   float acc = 0.f;
-  for (int k = 0; k < 27; ++k) {
-    const int nb = nbr[(long)site * 27 + k];
-    if (nb < 0) continue;
-    const float* f = in + (long)nb * Cin;
-    const float* wk = w + (long)k * Cin * Cout + co;
-    for (int c = 0; c < Cin; ++c) acc += f[c] * wk[(long)c * Cout];
+  if (p < P) {
+    for (int k = p; k < 27; k += P) {
+      const int nb = s_nb[k];
+      if (nb < 0) continue;
+      const float* f = in + (long)nb * Cin;
+      const float* wk = w + (long)k * Cin * Cout + co;
+      if ((Cin & 7) == 0) {
+        for (int c = 0; c < Cin; c += 8) {
+          const float4 f0 = *(const float4*)(f + c), f1 = *(const float4*)(f + c + 4);
+          float wv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wv[e] = wk[(long)(c + e) * Cout];
+          acc += f0.x * wv[0] + f0.y * wv[1] + f0.z * wv[2] + f0.w * wv[3];
+          acc += f1.x * wv[4] + f1.y * wv[5] + f1.z * wv[6] + f1.w * wv[7];
+        }
+      } else {
+        for (int c = 0; c < Cin; ++c) acc += f[c] * wk[(long)c * Cout];
+      }
+    }
   }
-  out[(long)site * Cout + co] = fmaxf(acc * scale[co] + shift[co], 0.f);
+  s_red[t] = acc;
+  __syncthreads();
+  if (t < Cout) {
+    float v = 0.f;
+    for (int q = 0; q < P; ++q) v += s_red[q * Cout + t];
+    out[(long)site * Cout + t] = fmaxf(v * scale[t] + shift[t], 0.f);
+  }
 }
 
 // out [V][V][V][C] (z,y,x,c) fp32
@@ -225,8 +249,7 @@ int launch_fuse_views(const float* vf, int n_views, int Nv, int total_views, con
 int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w, const float* scale,
                        const float* shift, float* out, hipStream_t s) {
   if (Cout > 256 || n_out <= 0) return n_out <= 0 ? 0 : mvd_fail("sparse_conv: Cout > 256");
-  const int per_block = 256 / Cout;
-  hipLaunchKernelGGL(sparse_conv_kernel, dim3(cdiv(n_out, per_block)), dim3(256), 0, s, in, nbr, n_out, Cin, Cout, w,
+  hipLaunchKernelGGL(sparse_conv_kernel, dim3(n_out), dim3(256), 0, s, in, nbr, n_out, Cin, Cout, w,
                      scale, shift, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

@@ -1,0 +1,292 @@
+// Dense GEMM for the Linear / 1x1-conv layers (fp16 A [M][lda], fp16 W [N][K], fp32 accumulate):
+//
+//   out[row(m)][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// These layers have short reductions (K = 320 ... 5120, i.e. 5 ... 80 k-steps of 64) and wide outputs, so what
+// limits them is not MFMA issue but (a) how far ahead of the MFMAs the operand loads are issued and (b) the
+// pipeline fill/drain paid per tile.  This kernel therefore
+//   * moves both operands HBM/L2 -> LDS with buffer_load ... lds (no VGPR staging, no ds_write) through a
+//     3-stage ring: the loads of TWO k-steps (96-104 KiB per CU) are in flight behind every MFMA block;
+//   * uses a 256 x BN tile (8 waves, wave w owns rows [32w, 32w+32) x BN columns): 11.7 B of operand traffic
+//     per kFLOP instead of 15.6 for the 128 x 128 tile;
+//   * lets one workgroup walk `nch` consecutive column tiles of the same 256 rows: the ring never drains at a
+//     tile boundary (the first two k-steps of the next tile are already landing while the epilogue of the
+//     previous one runs), and the A rows are re-read from L2;
+//   * zero-fills M / N / K tails in hardware (out-of-range buffer offsets), epilogue as in the implicit GEMM
+//     (bias, per-sample bias, residual, SiLU, GEGLU pairing, fp16/fp32 store, split-K partials).
+// LDS rows are 128 B (64 halfs) with the 16-byte chunk XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128.
+#include "common.h"
+#include "igemm_epilogue.h"
+
+namespace {
+
+constexpr int GBM = 256, GNT = 512, GST = 3;
+
+__device__ __forceinline__ int swzg(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmg() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int FN = BN / 32;
+  constexpr int A_BYTES = GBM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int WGR = BN / 8;                       // 8-row weight groups per stage (one DMA instruction each)
+  constexpr int NA = GBM / 64;                      // A instructions per wave and stage (4)
+  constexpr int NW = (WGR + 7) / 8, NW_MIN = WGR / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = g.B * g.Z * g.Y * g.X, N = g.N, Cin = g.Cin;
+  const int tiles_m = (M + GBM - 1) / GBM, tiles_n = (N + BN - 1) / BN;
+  const int nch = g.nch > 0 ? g.nch : 1;
+  const int groups_n = (tiles_n + nch - 1) / nch;
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective remap: consecutive workgroups (same rows, next column group) share an L2
+    const int nwg = tiles_m * groups_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = bid / groups_n, gn = bid - tm * groups_n;
+  const int m0 = tm * GBM;
+  const int tn_beg = gn * nch, tn_end = min(tiles_n, tn_beg + nch);
+
+  const int ksteps_all = (Cin + 63) / 64;
+  int kbeg = 0, kend = ksteps_all;
+  if (g.splitk > 1) {
+    const int per = (ksteps_all + g.splitk - 1) / g.splitk;
+    kbeg = blockIdx.y * per;
+    kend = min(ksteps_all, kbeg + per);
+  }
+  const int ksteps = kend - kbeg;
+  const int nsteps = ksteps > 0 ? ksteps * (tn_end - tn_beg) : 0;
+
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
+
+  // per-lane source offsets: LDS position (row, pos = lane&7) receives source chunk pos ^ ((row>>1)&7)
+  unsigned a_off[NA], w_off[NW];
+  int a_ch[NA], w_ch[NW], w_row[NW];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    a_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    a_off[i] = (((unsigned)m * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(m >= M));
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    w_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
+    w_row[i] = row;
+    w_off[i] = ((unsigned)row * (unsigned)Cin + w_ch[i] * 8) * 2;
+  }
+
+  // step index -> (column tile, k-step); the ring treats the whole walk as one stream
+  auto dma_step = [&](int tn, int ks, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sW = sA + A_BYTES;
+    const int kb = ks * 64;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const unsigned inval = (0u - (unsigned)(a_off[i] == 0xFFFFFFFFu)) | (0u - (unsigned)(kb + a_ch[i] * 8 >= Cin));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sA + (wave + 8 * i) * 1024), 16, (a_off[i] + kb * 2) | inval, 0,
+                                               0, 0);
+    }
+    const int n0 = tn * BN;
+    const unsigned wbase = (unsigned)n0 * (unsigned)Cin * 2 + kb * 2;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int grp = wave + 8 * i;
+      if (grp < WGR) {
+        const unsigned inval = (0u - (unsigned)(n0 + w_row[i] >= N)) | (0u - (unsigned)(kb + w_ch[i] * 8 >= Cin));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + grp * 1024), 16, (w_off[i] + wbase) | inval, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // prologue: steps 0 and 1 in flight, step 0 landed
+  int p_tn = tn_beg, p_ks = kbeg;  // (tile, k) of the next step to prefetch
+  auto advance = [&](int& tn, int& ks) {
+    if (++ks == kend) {
+      ks = kbeg;
+      ++tn;
+    }
+  };
+  if (nsteps > 0) {
+    dma_step(p_tn, p_ks, 0);
+    advance(p_tn, p_ks);
+    if (nsteps > 1) {
+      dma_step(p_tn, p_ks, 1);
+      advance(p_tn, p_ks);
+      wait_vmg<NA + NW_MIN>();
+    } else {
+      wait_vmg<0>();
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+
+  int tn = tn_beg, ks = kbeg, stage = 0;
+  h8 af[2], bf[2][FN];
+  for (int s = 0; s < nsteps; ++s) {
+    const bool pf = s + 2 < nsteps;
+    if (pf) {  // into the ring slot that was read at step s-1 (all waves passed the barrier that ended it)
+      int st2 = stage + 2;
+      if (st2 >= GST) st2 -= GST;
+      dma_step(p_tn, p_ks, st2);
+      advance(p_tn, p_ks);
+    }
+    const char* sA = smem + stage * STAGE;
+    const char* sW = sA + A_BYTES;
+    auto read_frags = [&](int kk, h8& a, h8 (&b)[FN]) {
+      const int ch = kk * 2 + (lane >> 5);
+      a = *(const h8*)(sA + swzg(wave * 32 + (lane & 31), ch));
+#pragma unroll
+      for (int f = 0; f < FN; ++f) b[f] = *(const h8*)(sW + swzg(f * 32 + (lane & 31), ch));
+    };
+    read_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // LDS reads of kk+1 stay in flight behind the MFMAs of kk
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // step s+1 must have landed before anyone reads it; only this step's own prefetch may stay in flight
+    if (pf) wait_vmg<NA + NW_MIN>();
+    else wait_vmg<0>();
+    __builtin_amdgcn_s_barrier();
+
+    const bool tile_done = ks + 1 == kend;
+    if (tile_done) {
+      // ---- epilogue of column tile tn; scratch = the ring slot just consumed (free until the next prefetch) ----
+      const int n0 = tn * BN;
+      float* scratch = (float*)(smem + stage * STAGE + wave * EPI_WAVE_BYTES);
+      int rows4[4];
+      long orow4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wave * 32 + (lane >> 3) + 8 * i;
+        rows4[i] = m < M ? m : -1;
+        orow4[i] = m < M ? out_row(g, m) : 0;
+      }
+      if (g.geglu) {
+        if constexpr (FN % 2 == 0) {
+          // value / gate fragments share the C layout: pair them in registers, then one transposed store
+          const int col = lane & 31;
+#pragma unroll
+          for (int p = 0; p < FN / 2; ++p) {
+            const int nx = n0 + p * 64 + col;
+            const bool okc = nx + 32 < N;
+            const float bx = (g.bias && okc) ? g.bias[nx] : 0.f, bg = (g.bias && okc) ? g.bias[nx + 32] : 0.f;
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              v[r] = (acc[2 * p][r] * g.alpha + bx) * gelu_erf(acc[2 * p + 1][r] * g.alpha + bg);
+            epilogue_frag_store_raw(g, v, scratch, lane, rows4, orow4, (n0 >> 1) + p * 32, N >> 1);
+          }
+        }
+      } else {
+        float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      if (s + 1 < nsteps) __builtin_amdgcn_s_barrier();  // scratch is the next prefetch target
+    }
+    advance(tn, ks);
+    if (++stage == GST) stage = 0;
+  }
+#endif
+}
+
+template <int BN>
+int launch_gd(const IGemm& g, int M, hipStream_t s) {
+  constexpr int LDS = GST * (GBM * 128 + BN * 128);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int nch = g.nch > 0 ? g.nch : 1;
+  dim3 grid(cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch), g.splitk > 1 ? g.splitk : 1);
+  hipLaunchKernelGGL((gemm_dma_kernel<BN>), grid, dim3(GNT), LDS, s, g);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// eligibility: plain row-major fp16 A (no taps / stride / upsample), 16-byte aligned rows, vectorisable epilogue
+bool gemm_dma_eligible(const IGemm& g) {
+  if (g.a_f32 || g.ntaps != 1 || g.sz != 1 || g.sy != 1 || g.sx != 1 || g.ups) return false;
+  if (g.IZ != g.Z || g.IY != g.Y || g.IX != g.X) return false;
+  if ((g.tap[0] & 0x3F) != (igemm_tap(0, 0, 0, 0) & 0x3F)) return false;  // the single tap must be the centre one
+  if ((g.lda & 7) || (g.Cin & 7) || ((uintptr_t)g.a & 15) || ((uintptr_t)g.w & 15)) return false;
+  if ((g.N & 3) || (g.ldc & 3)) return false;
+  if (g.geglu) return (g.N & 63) == 0;
+  if (g.resid && (g.ldr & 3)) return false;
+  if (g.rowbias && (g.rb_ld & 3)) return false;
+  return true;
+}
+
+// Tile walk: `nch` column tiles per workgroup, or split-K when the tile count cannot fill the chip.
+// Cost model in k-steps: waves * (steps per workgroup + ~4 for fill and epilogue).
+void gemm_dma_plan(int M, int N, int Cin, int bn, int geglu, int* nch_out, int* splitk_out) {
+  const int tiles_m = cdiv(M, GBM), tiles_n = cdiv(N, bn), ksteps = cdiv(Cin, 64);
+  const int CUS = 256;
+  int best_nch = 1, best_sk = 1;
+  long best = -1;
+  for (int nch = 1; nch <= tiles_n; ++nch) {
+    const int blocks = tiles_m * cdiv(tiles_n, nch);
+    const long cost = (long)cdiv(blocks, CUS) * (nch * ksteps + 4 + 2 * nch);
+    if (best < 0 || cost < best) {
+      best = cost;
+      best_nch = nch;
+    }
+  }
+  if (!geglu && tiles_m * tiles_n < CUS) {
+    for (int sk = 2; sk <= 16 && sk * 2 <= ksteps; ++sk) {
+      const int blocks = tiles_m * tiles_n * sk;
+      const long cost = (long)cdiv(blocks, CUS) * (cdiv(ksteps, sk) + 6) + 3;  // + the reduce pass
+      if (cost < best) {
+        best = cost;
+        best_nch = 1;
+        best_sk = sk;
+      }
+    }
+  }
+  *nch_out = best_nch;
+  *splitk_out = best_sk;
+}
+
+int launch_gemm_dma(const IGemm& g_in, hipStream_t s) {
+  IGemm g = g_in;
+  g.w += (size_t)(g.tap[0] >> 8) * g.N * g.Cin;  // weight slab of the tap (transposed-conv parity class 0)
+  const int M = g.B * g.Z * g.Y * g.X;
+  if (M <= 0 || g.N <= 0) return 0;
+  if (g.splitk > 1 && !g.partial) return mvd_fail("gemm_dma: split-K without a partial buffer");
+  if ((long)M * g.lda * 2 >= 0xFFFFFF00L || (long)g.N * g.Cin * 2 >= 0xFFFFFF00L)
+    return mvd_fail("gemm_dma: operand exceeds 4 GiB buffer addressing");
+  const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : launch_gd<128>(g, M, s);
+  if (r) return r;
+  if (g.splitk > 1) return launch_splitk_reduce(g, s);
+  return 0;
+}

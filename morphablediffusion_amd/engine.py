@@ -201,15 +201,16 @@ class Engine:
                                        1 if transposed else 0, L.ptr(r), L.ptr(out), _stream()))
         return out
 
-    def op_linear(self, a, w, bias=None, geglu=False):
+    def op_linear(self, a, w, bias=None, geglu=False, resid=None, a_half=False, force_splitk=0):
         dev = self.device
         a, w = _f32(a, dev), _f32(w, dev)
         M, K = a.shape
         N = w.shape[0]
         out = torch.empty(M, N // 2 if geglu else N, device=dev)
         b = None if bias is None else _f32(bias, dev)
-        L.check(self.lib.mvd_op_linear(self._ctx, L.ptr(a), M, K, L.ptr(w), L.ptr(b), N, 1 if geglu else 0, L.ptr(out),
-                                       _stream()))
+        r = None if resid is None else _f32(resid, dev)
+        L.check(self.lib.mvd_op_linear(self._ctx, L.ptr(a), M, K, L.ptr(w), L.ptr(b), N, 1 if geglu else 0, L.ptr(r),
+                                       1 if a_half else 0, int(force_splitk), L.ptr(out), _stream()))
         return out
 
     def op_group_norm(self, x, groups, gamma, beta, eps, act=0):

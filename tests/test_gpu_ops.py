@@ -48,6 +48,32 @@ def test_linear_asymmetric_identity(eng):
     close(eng.op_linear(torch.eye(K), w), w.t().contiguous(), "linear identity", rel=1e-6, mx=1e-6)
 
 
+# dense LDS-DMA GEMM (fp16 A in HBM, M >= 512): M / N / K tails, both column widths, multi-tile walks, split-K,
+# residual, GEGLU
+@pytest.mark.parametrize("M,K,N,res,sk,geglu", [
+    (1024, 64, 384, False, 0, False), (700, 328, 200, True, 0, False), (4096, 320, 320, True, 0, False),
+    (2048, 1280, 1280, False, 0, False), (2048, 1280, 640, True, 3, False), (513, 72, 964, False, 0, False),
+    (8192, 320, 2560, False, 0, True), (1000, 128, 512, False, 0, True), (16384, 64, 2048, True, 0, False),
+])
+def test_linear_dense(eng, M, K, N, res, sk, geglu):
+    a, w, b = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
+    want = F.linear(a, w, b)
+    if geglu:
+        x, gate = want.chunk(2, -1)
+        want = x * F.gelu(gate)
+    r = rnd(*want.shape, seed=5) if res else None
+    if r is not None:
+        want = want + r
+    got = eng.op_linear(a, w, b, geglu=geglu, resid=r, a_half=True, force_splitk=sk)
+    close(got, want, f"dense linear {M}x{K}x{N} res={res} sk={sk} geglu={geglu}")
+
+
+def test_linear_dense_identity(eng):
+    K = 512
+    w = torch.arange(K * K, dtype=torch.float32).reshape(K, K) % 251 / 64.0
+    close(eng.op_linear(torch.eye(K), w, a_half=True), w.t().contiguous(), "dense linear identity", rel=1e-6, mx=1e-6)
+
+
 def test_linear_geglu(eng):
     M, K, N = 200, 64, 512
     a, w, b = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
