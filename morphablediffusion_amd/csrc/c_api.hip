@@ -322,6 +322,13 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
   GemmArgs g;
   g.a = xn; g.a_f32 = 1; g.lda = Cin; g.w = &cw; g.out = on; g.ldc = Cout; g.use_bias = bias != nullptr;
   if (resid) { g.resid = on; g.ldr = Cout; }
+  if (Cin % 64 == 0) {  // fp16-source path (LDS-DMA implicit GEMM), as in the frustum network's inner layers
+    half_t* xh = ws_alloc<half_t>(c, (size_t)B * D * H * W * Cin);
+    WS_CHECK(xh);
+    RET_IF(launch_f32_to_f16(xn, xh, (size_t)B * D * H * W * Cin, s));
+    g.a = xh;
+    g.a_f32 = 0;
+  }
   if (transposed) RET_IF(run_convT3d(c, g, B, D, H, W, s));
   else RET_IF(run_conv3d(c, g, B, D, H, W, stride, s));
   RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Do * Ho * Wo, out, s));

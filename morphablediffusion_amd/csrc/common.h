@@ -87,7 +87,7 @@ int conv3_halo_tiles(const IGemm& g, int bn);
 int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
 bool gemm_dma_eligible(const IGemm& g);
-void gemm_dma_plan(int M, int N, int Cin, int bn, int geglu, int* nch_out, int* splitk_out);
+void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, int* splitk_out);
 int launch_gemm_dma(const IGemm& g, hipStream_t s);
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,

@@ -48,20 +48,39 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
   const bool halo = c->use_halo && conv3_halo_eligible(g);
   static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
-  const bool dense = use_dense && !halo && M >= 512 && gemm_dma_eligible(g);
+  // one 256-row workgroup per CU: wins for the Linear layers and wherever weights stream (small M, long K);
+  // the big shallow 3-D convs keep the 128-row gather kernel (finer tiles, 2 workgroups per CU)
+  const bool dense = use_dense && !halo && M >= 512 && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
   int sk;
-  if (halo) {  // LDS-halo 3x3 kernel: split over 64-channel chunks until the chip is full
-    if (g.bn == 64) g.bn = 128;
-    const int tiles = conv3_halo_tiles(g, g.bn), ncc = g.Cin / 64;
-    sk = force_splitk > 0 ? force_splitk : (tiles >= 200 ? 1 : cdiv(256, tiles));
-    if (sk > ncc) sk = ncc;
-    if (sk > 8) sk = 8;
+  if (halo) {
+    // LDS-halo 3x3 kernel, one workgroup per CU: pick the column width and the split over 64-channel chunks that
+    // minimise  rounds * (steps * step_cost + fill) + reduce pass  (microseconds, fitted to conv_bench3 sweeps)
+    const int ncc = g.Cin / 64;
+    double best = 1e30;
+    int best_bn = 128, best_sk = 1;
+    for (int bn = 128; bn <= 160; bn += 32) {
+      const int tiles = conv3_halo_tiles(g, bn);
+      for (int s2 = 1; s2 <= 8 && s2 <= ncc; ++s2) {
+        const int rounds = cdiv(tiles * s2, 256), steps = cdiv(ncc, s2) * 9;
+        double t = rounds * (steps * (bn == 160 ? 1.3 : 1.0) + 8.0);
+        if (s2 > 1) t += 3.0 + (s2 + 1) * (double)M * g.N * 4.0 / 3.5e6;
+        if (t < best) {
+          best = t;
+          best_bn = bn;
+          best_sk = s2;
+        }
+      }
+    }
+    g.bn = best_bn;
+    sk = force_splitk > 0 ? (force_splitk < ncc ? force_splitk : ncc) : best_sk;
+    if (getenv("MVD_HALO_BN")) g.bn = atoi(getenv("MVD_HALO_BN"));  // tuning experiments only
+    if (getenv("MVD_HALO_SK")) sk = atoi(getenv("MVD_HALO_SK"));
   } else if (dense) {
-    if (g.bn == 64) g.bn = 128;
     int nch = 1, sk2 = 1;
-    gemm_dma_plan(M, g.N, g.Cin, g.bn, g.geglu, &nch, &sk2);
+    const int ksteps = g.ntaps * cdiv(g.Cin, 64);
+    gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
     sk = g.geglu ? 1 : (force_splitk > 0 ? force_splitk : sk2);
-    if (sk > cdiv(g.Cin, 64)) sk = cdiv(g.Cin, 64);
+    if (sk > ksteps) sk = ksteps;
     g.nch = sk > 1 ? 1 : nch;
   } else {
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);

@@ -1,7 +1,10 @@
-// Dense GEMM for the Linear / 1x1-conv layers (fp16 A [M][lda], fp16 W [N][K], fp32 accumulate):
+// LDS-DMA implicit GEMM for every layer whose activation operand is fp16 in HBM: Linear / 1x1 layers and the
+// convolutions the halo kernel does not take (strided, upsampled, 3-D, 4x4 images):
 //
-//   out[row(m)][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//   out[row(m)][n] = epilogue( sum_{tap} sum_k A[in(m,tap)][k] * W[tap][n][k] )
 //
+// A rows are gathered per tap (the per-lane source offsets are recomputed when the tap changes; padding and
+// tails are out-of-range buffer offsets -> zeros).
 // These layers have short reductions (K = 320 ... 5120, i.e. 5 ... 80 k-steps of 64) and wide outputs, so what
 // limits them is not MFMA issue but (a) how far ahead of the MFMAs the operand loads are issued and (b) the
 // pipeline fill/drain paid per tile.  This kernel therefore
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   const int m0 = tm * GBM;
   const int tn_beg = gn * nch, tn_end = min(tiles_n, tn_beg + nch);
 
-  const int ksteps_all = (Cin + 63) / 64;
+  const int ksteps_all = g.ntaps * ((Cin + 63) / 64);
   int kbeg = 0, kend = ksteps_all;
   if (g.splitk > 1) {
     const int per = (ksteps_all + g.splitk - 1) / g.splitk;
@@ -72,12 +75,25 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   // per-lane source offsets: LDS position (row, pos = lane&7) receives source chunk pos ^ ((row>>1)&7)
   unsigned a_off[NA], w_off[NW];
   int a_ch[NA], w_ch[NW], w_row[NW];
+  int ab[NA], az[NA], ay[NA], ax[NA];  // output pixel of each A row, pre-multiplied by the stride
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = (wave + 8 * i) * 8 + (lane >> 3);
     a_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
-    a_off[i] = (((unsigned)m * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(m >= M));
+    if (m < M) {
+      const int x = m % g.X;
+      int t = m / g.X;
+      const int y = t % g.Y;
+      t /= g.Y;
+      ab[i] = t / g.Z;
+      az[i] = (t % g.Z) * g.sz;
+      ay[i] = y * g.sy;
+      ax[i] = x * g.sx;
+    } else {
+      ab[i] = -1;
+      az[i] = ay[i] = ax[i] = 0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
@@ -86,12 +102,32 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     w_row[i] = row;
     w_off[i] = ((unsigned)row * (unsigned)Cin + w_ch[i] * 8) * 2;
   }
+  const int cpt = (Cin + 63) / 64;  // k-steps per tap
+  unsigned w_slab = 0;              // byte offset of the current tap's weight slab
+  auto set_tap = [&](int tap) {
+    const int ti = g.tap[__builtin_amdgcn_readfirstlane(tap)];  // one packed dword per tap, scalar load
+    const int dz = (ti & 3) - 1, dy = ((ti >> 2) & 3) - 1, dx = ((ti >> 4) & 3) - 1;
+    w_slab = (unsigned)(ti >> 8) * (unsigned)N * (unsigned)Cin * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
+      const bool ok = ab[i] >= 0 && iz >= 0 && iz < g.IZ && iy >= 0 && iy < g.IY && ix >= 0 && ix < g.IX;
+      const unsigned pix = (unsigned)(((ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups));
+      a_off[i] = ((pix * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(!ok));
+    }
+  };
 
-  // step index -> (column tile, k-step); the ring treats the whole walk as one stream
+  // step stream: (column tile, k) with k = tap * cpt + cc; the ring treats the whole walk as one stream
+  int set_for = -1;
   auto dma_step = [&](int tn, int ks, int stage) {
     char* sA = smem + stage * STAGE;
     char* sW = sA + A_BYTES;
-    const int kb = ks * 64;
+    const int tap = ks / cpt, cc = ks - tap * cpt;
+    if (tap != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
+      set_tap(tap);
+      set_for = tap;
+    }
+    const int kb = cc * 64;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const unsigned inval = (0u - (unsigned)(a_off[i] == 0xFFFFFFFFu)) | (0u - (unsigned)(kb + a_ch[i] * 8 >= Cin));
@@ -99,7 +135,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
                                                0, 0);
     }
     const int n0 = tn * BN;
-    const unsigned wbase = (unsigned)n0 * (unsigned)Cin * 2 + kb * 2;
+    const unsigned wbase = w_slab + (unsigned)n0 * (unsigned)Cin * 2 + kb * 2;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int grp = wave + 8 * i;
@@ -234,11 +270,9 @@ int launch_gd(const IGemm& g, int M, hipStream_t s) {
 
 }  // namespace
 
-// eligibility: plain row-major fp16 A (no taps / stride / upsample), 16-byte aligned rows, vectorisable epilogue
+// eligibility: fp16 activations with 16-byte aligned rows and a vectorisable epilogue
 bool gemm_dma_eligible(const IGemm& g) {
-  if (g.a_f32 || g.ntaps != 1 || g.sz != 1 || g.sy != 1 || g.sx != 1 || g.ups) return false;
-  if (g.IZ != g.Z || g.IY != g.Y || g.IX != g.X) return false;
-  if ((g.tap[0] & 0x3F) != (igemm_tap(0, 0, 0, 0) & 0x3F)) return false;  // the single tap must be the centre one
+  if (g.a_f32) return false;
   if ((g.lda & 7) || (g.Cin & 7) || ((uintptr_t)g.a & 15) || ((uintptr_t)g.w & 15)) return false;
   if ((g.N & 3) || (g.ldc & 3)) return false;
   if (g.geglu) return (g.N & 63) == 0;
@@ -249,8 +283,8 @@ bool gemm_dma_eligible(const IGemm& g) {
 
 // Tile walk: `nch` column tiles per workgroup, or split-K when the tile count cannot fill the chip.
 // Cost model in k-steps: waves * (steps per workgroup + ~4 for fill and epilogue).
-void gemm_dma_plan(int M, int N, int Cin, int bn, int geglu, int* nch_out, int* splitk_out) {
-  const int tiles_m = cdiv(M, GBM), tiles_n = cdiv(N, bn), ksteps = cdiv(Cin, 64);
+void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, int* splitk_out) {
+  const int tiles_m = cdiv(M, GBM), tiles_n = cdiv(N, bn);
   const int CUS = 256;
   int best_nch = 1, best_sk = 1;
   long best = -1;
@@ -277,15 +311,13 @@ void gemm_dma_plan(int M, int N, int Cin, int bn, int geglu, int* nch_out, int* 
   *splitk_out = best_sk;
 }
 
-int launch_gemm_dma(const IGemm& g_in, hipStream_t s) {
-  IGemm g = g_in;
-  g.w += (size_t)(g.tap[0] >> 8) * g.N * g.Cin;  // weight slab of the tap (transposed-conv parity class 0)
+int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
   if (M <= 0 || g.N <= 0) return 0;
   if (g.splitk > 1 && !g.partial) return mvd_fail("gemm_dma: split-K without a partial buffer");
-  if ((long)M * g.lda * 2 >= 0xFFFFFF00L || (long)g.N * g.Cin * 2 >= 0xFFFFFF00L)
+  if ((long)g.B * g.PZ * g.PY * g.PX * g.lda * 2 >= 0xFFFFFF00L || (long)MVD_MAX_TAPS * g.N * g.Cin * 2 >= 0xFFFFFF00L)
     return mvd_fail("gemm_dma: operand exceeds 4 GiB buffer addressing");
-  const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : launch_gd<128>(g, M, s);
+  const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
   if (r) return r;
   if (g.splitk > 1) return launch_splitk_reduce(g, s);
   return 0;

@@ -99,6 +99,13 @@ def test_linear_geglu(eng):
     dict(B=7, Cin=128, H=8, W=8, Cout=192, k=3, stride=1, up=0, res=True, sk=0),
     dict(B=2, Cin=256, H=16, W=16, Cout=320, k=3, stride=1, up=0, res=True, sk=2),
     dict(B=6, Cin=320, H=8, W=8, Cout=64, k=3, stride=1, up=0, res=False, sk=5),
+    # LDS-DMA implicit GEMM with tap gather (fp16 source, M >= 512): stride 2, fused nearest upsample, 4x4 images
+    # with split-K, ragged image, 1x1 into a wide layer
+    dict(B=4, Cin=64, H=32, W=32, Cout=96, k=3, stride=2, up=0, res=False, sk=0),
+    dict(B=2, Cin=128, H=16, W=16, Cout=320, k=3, stride=1, up=1, res=True, sk=0),
+    dict(B=32, Cin=256, H=4, W=4, Cout=192, k=3, stride=1, up=0, res=True, sk=0),
+    dict(B=20, Cin=64, H=7, W=5, Cout=40, k=3, stride=1, up=0, res=False, sk=4),
+    dict(B=3, Cin=192, H=16, W=16, Cout=644, k=1, stride=1, up=0, res=True, sk=0),
 ])
 def test_conv2d(eng, cfg):
     x = rnd(cfg["B"], cfg["Cin"], cfg["H"], cfg["W"])
@@ -113,9 +120,10 @@ def test_conv2d(eng, cfg):
     close(got, want, f"conv2d {cfg}")
 
 
+@pytest.mark.parametrize("Cin", [32, 64])  # 32: fp32-source gather kernel, 64: fp16-source LDS-DMA kernel
 @pytest.mark.parametrize("stride,transposed,res", [(1, False, False), (2, False, False), (1, True, True), (1, True, False)])
-def test_conv3d(eng, stride, transposed, res):
-    B, Cin, D, H, W, Cout = 2, 64, 6, 8, 8, 32
+def test_conv3d(eng, stride, transposed, res, Cin):
+    B, D, H, W, Cout = 2, 6, 8, 8, 32
     x = rnd(B, Cin, D, H, W)
     b = rnd(Cout, seed=4)
     if transposed:
