@@ -128,6 +128,9 @@ int mvd_op_conv3d(mvd_ctx* ctx, const float* x_ncdhw, int B, int Cin, int D, int
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);
+/* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,
+ * 4 = GEGLU epilogue */
+int mvd_bench_linear(mvd_ctx* ctx, int M, int K, int N, int flags, int iters, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -448,4 +448,41 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
   return 0;
 }
 
+int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, float* ms_out, void* stream) {
+  hipStream_t s = S(stream);
+  const size_t mark = c->ws.off;
+  const size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
+  half_t* a = ws_alloc<half_t>(c, na);
+  half_t* w = ws_alloc<half_t>(c, nw);
+  float* o = ws_alloc<float>(c, no);
+  float* r = ws_alloc<float>(c, no);
+  WS_CHECK(a && w && o && r);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(na)), dim3(256), 0, s, a, na, 17u);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(nw)), dim3(256), 0, s, w, nw, 91u);
+  HIP_CHECK_RET(hipMemsetAsync(r, 0, no * sizeof(float), s));
+  ConvW cw;
+  cw.w = w; cw.N = N; cw.Cin = K; cw.taps = 1;
+  GemmArgs g;
+  g.a = a; g.lda = K; g.w = &cw; g.out = o; g.use_bias = false;
+  g.geglu = (flags & 4) ? 1 : 0;
+  g.ldc = g.geglu ? N / 2 : N;
+  g.out_f32 = (flags & 2) ? 0 : 1;
+  if (flags & 1) { g.resid = r; g.resid_f32 = 1; g.ldr = N; }
+  RET_IF(run_linear(c, g, 1, M, s));  // warm-up
+  hipEvent_t e0, e1;
+  HIP_CHECK_RET(hipEventCreate(&e0));
+  HIP_CHECK_RET(hipEventCreate(&e1));
+  HIP_CHECK_RET(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) RET_IF(run_linear(c, g, 1, M, s));
+  HIP_CHECK_RET(hipEventRecord(e1, s));
+  HIP_CHECK_RET(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_out = ms / (float)iters;
+  c->ws.off = mark;
+  return 0;
+}
+
 }  // extern "C"

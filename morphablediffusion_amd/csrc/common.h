@@ -96,6 +96,9 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s);
 int gn_max_slabs();
+bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo);
+int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
+                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s);
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                      half_t* out, hipStream_t s);
 int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,

@@ -215,6 +215,86 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// ---- single-pass form for per-(sample, group) slices that fit in the registers of one workgroup -----------------
+// grid = B * G workgroups; workgroup (b, g) owns the rows x (C/G) slice of its group: every thread issues all of its
+// (<= MAXE) 8-byte loads up front, the slice stays in registers, mean and the centred second moment are two block
+// reductions, and the normalised fp16 slice is written straight back.  x is read from HBM once (the two-pass form
+// reads it twice and needs two launches).  Logical workgroup ids are laid out so the groups of one sample share an XCD.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();  // s_red may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += s_red[i];
+  return t;
+}
+
+template <int NT, int MAXE>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
+                                                      const float* __restrict__ preadd, int pld,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int act, half_t* __restrict__ out, int ldo) {
+  __shared__ float s_red[NT / 64];
+  const int t = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, slot = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int b = wg / G, g = wg - b * G;
+  const int cpg = C / G, h = cpg >> 1, n2 = rows * h;
+  const float inv_h = 1.0f / (float)h;
+  const float* xb = x + (long)b * rows * ld + g * cpg;
+  half_t* ob = out + (long)b * rows * ldo + g * cpg;
+  const float* pre = preadd ? preadd + (long)b * pld + g * cpg : nullptr;
+  float2 v[MAXE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = t + i * NT;
+    v[i] = make_float2(0.f, 0.f);
+    if (e < n2) {
+      const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
+      v[i] = *(const float2*)(xb + (long)row * ld + 2 * j);
+      if (pre) {
+        v[i].x += pre[2 * j];
+        v[i].y += pre[2 * j + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) s += v[i].x + v[i].y;
+  const float n = (float)rows * (float)cpg;
+  const float mean = block_sum<NT>(s, s_red) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = t + i * NT;
+    if (e < n2) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean;
+      q += dx * dx + dy * dy;
+    }
+  }
+  const float rstd = rsqrtf(block_sum<NT>(q, s_red) / n + eps);
+  const float* gm = gamma + g * cpg;
+  const float* bt = beta + g * cpg;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = t + i * NT;
+    if (e < n2) {
+      const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
+      h2 o;
+      o[0] = (half_t)act_apply((v[i].x - mean) * rstd * gm[2 * j] + bt[2 * j], act);
+      o[1] = (half_t)act_apply((v[i].y - mean) * rstd * gm[2 * j + 1] + bt[2 * j + 1], act);
+      *(h2*)(ob + (long)row * ldo + 2 * j) = o;
+    }
+  }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -284,6 +364,30 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, pld ? pld : C,
                      partial, nslabs, gamma, beta, eps, act, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// rows * C/G <= 32768 elements per (sample, group), even channels per group, 8-byte aligned slices
+bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo) {
+  if (C % G) return false;
+  const int cpg = C / G;
+  return (cpg % 2) == 0 && (ld % 2) == 0 && (ldo % 2) == 0 && (pld % 2) == 0 && (long)rows * cpg <= 32768 && rows < (1 << 22);
+}
+
+int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
+                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s) {
+  const int n2 = rows * (C / G) / 2;
+  const dim3 grid(B * G);
+  if (n2 <= 256 * 4)
+    hipLaunchKernelGGL((gn_group_kernel<256, 4>), grid, dim3(256), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act,
+                       out, ldo);
+  else if (n2 <= 1024 * 4)
+    hipLaunchKernelGGL((gn_group_kernel<1024, 4>), grid, dim3(1024), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act,
+                       out, ldo);
+  else
+    hipLaunchKernelGGL((gn_group_kernel<1024, 16>), grid, dim3(1024), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps,
+                       act, out, ldo);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
