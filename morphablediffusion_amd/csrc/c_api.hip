@@ -297,7 +297,16 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
     g.a = xh;
     g.a_f32 = 0;
   }
-  RET_IF(run_conv2d(c, g, B, H, W, stride, upsample, s));
+  if (upsample && taps == 9 && stride == 1 && cpad == Cin && B * H * W >= 2048) {
+    // the UNet's path for large upsample convs: four parity-folded 2x2 convs (fp32 source, as in the decoder)
+    cw.w_up = ws_alloc<half_t>(c, (size_t)16 * Cout * Cin);
+    WS_CHECK(cw.w_up);
+    RET_IF(launch_pack_upconv_weight(w, Cout, Cin, cw.w_up, s));
+    g.a = xn; g.a_f32 = 1;
+    RET_IF(run_upconv2d(c, g, B, H, W, s));
+  } else {
+    RET_IF(run_conv2d(c, g, B, H, W, stride, upsample, s));
+  }
   RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Ho * Wo, out_nchw, s));
   c->ws.off = mark;
   return 0;

@@ -114,6 +114,8 @@ int launch_pack_weight(const float* src, int N, int Cin, int taps, int transpose
                        hipStream_t s, int cin_src = -1);
 int launch_permute_geglu_bias(const float* src, int N, float* dst, hipStream_t s);
 int launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
+int launch_rows_f32_to_f16(const float* in, int lda, long rows, int C, half_t* out, hipStream_t s);
+int launch_pack_upconv_weight(const float* src, int N, int Cin, half_t* dst, hipStream_t s);
 int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n, hipStream_t s);
 int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
                    hipStream_t s);

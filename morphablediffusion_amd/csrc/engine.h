@@ -16,6 +16,7 @@ struct RawTensor {
 
 struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
   half_t* w = nullptr;
+  half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
   float* bias = nullptr;
   int N = 0, Cin = 0, taps = 1;
 };
@@ -182,6 +183,8 @@ struct GemmArgs {
 int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s);
 // 3x3 conv (stride 1/2, optional nearest x2 upsample of the input) on [B,H,W,*] channels-last
 int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, int ups, hipStream_t s);
+// nearest x2 upsample + 3x3 conv as four parity-folded 2x2 convs on the [B,H,W] input (needs ConvW::w_up)
+int run_upconv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, hipStream_t s);
 // 3x3x3 conv stride 1/2 on [B,D,H,W,*]
 int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int stride, hipStream_t s);
 // ConvTranspose3d(k3,s2,p1,op1): 8 output-parity classes

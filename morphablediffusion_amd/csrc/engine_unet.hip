@@ -163,6 +163,48 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
   return igemm_go(c, g, ga.force_splitk, s);
 }
 
+int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStream_t s) {
+  if (!ga_in.w->w_up) return mvd_fail("run_upconv2d: weights were not folded");
+  const size_t mark = c->ws.off;
+  GemmArgs ga = ga_in;
+  ConvW cw = *ga_in.w;
+  cw.w = cw.w_up;
+  cw.taps = 16;
+  ga.w = &cw;
+  if (ga.a_f32) {  // operand copy: the LDS-DMA kernel streams fp16
+    half_t* ah = ws_alloc<half_t>(c, (size_t)B * H * W * cw.Cin);
+    WS_CHECK(ah);
+    RET_IF(launch_rows_f32_to_f16((const float*)ga.a, ga.lda, (long)B * H * W, cw.Cin, ah, s));
+    ga.a = ah;
+    ga.a_f32 = 0;
+    ga.lda = cw.Cin;
+  }
+  for (int par = 0; par < 4; ++par) {
+    const int py = par >> 1, px = par & 1;
+    IGemm g;
+    igemm_init(g);
+    igemm_fill(g, ga);
+    g.B = B;
+    g.Y = g.PY = g.IY = H;
+    g.X = g.PX = g.IX = W;
+    g.ntaps = 4;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        g.tap[a * 2 + b] = igemm_tap(0, py == 0 ? a - 1 : a, px == 0 ? b - 1 : b, par * 4 + a * 2 + b);
+    g.out_linear = 0;
+    g.OZ = 1;
+    g.OY = 2 * H;
+    g.OX = 2 * W;
+    g.ozm = 1;
+    g.oym = g.oxm = 2;
+    g.oyo = py;
+    g.oxo = px;
+    RET_IF(igemm_go(c, g, ga.force_splitk, s));
+  }
+  c->ws.off = mark;
+  return 0;
+}
+
 int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int stride, hipStream_t s) {
   IGemm g;
   igemm_init(g);
@@ -399,7 +441,9 @@ int do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W) {
       GemmArgs g;
       g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &c->convs[op.idx]; g.out = out.p; g.ldc = out.ld;
       const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
-      RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
+      // weight-streaming regime (few pixels): the 9-tap form moves 9 slabs instead of 16
+      if (ups && c->convs[op.idx].w_up && f.Bv * H * W >= 2048) RET_IF(run_upconv2d(c, g, f.Bv, H, W, f.s));
+      else RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
       if (op.kind == OP_DOWN) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
       if (op.kind == OP_UP) { H *= 2; W *= 2; }
       return 0;

@@ -246,6 +246,12 @@ int engine_finalize(mvd_ctx* c) {
   auto add_conv = [&](const std::string& wkey, int kind, int cin, int cout, std::vector<UOp>& ops) -> int {
     ConvW w;
     RET_IF(pack_conv(c, U + wkey + ".weight", U + wkey + ".bias", false, false, &w));
+    if (kind == OP_UP && w.taps == 9) {
+      RawTensor* r;
+      RET_IF(get_raw(c, U + wkey + ".weight", &r));
+      RET_IF(dmalloc(c, (void**)&w.w_up, (size_t)16 * w.N * w.Cin * sizeof(half_t)));
+      RET_IF(launch_pack_upconv_weight(r->d, w.N, w.Cin, w.w_up, 0));
+    }
     c->convs.push_back(w);
     ops.push_back({kind, (int)c->convs.size() - 1, cin, cout});
     return 0;

@@ -155,6 +155,42 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restri
     out[i] = (half_t)in[i];
 }
 
+// channels-last rows with stride lda -> dense fp16 rows (C % 4 == 0): operand copy for the LDS-DMA kernels
+__global__ void rows_f32_to_f16_kernel(const float* __restrict__ in, int lda, long rows, int C, half_t* __restrict__ out) {
+  const int q = C >> 2;
+  const long total = rows * q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const float4 v = *(const float4*)(in + r * lda + c);
+    h4 o;
+    o[0] = (half_t)v.x; o[1] = (half_t)v.y; o[2] = (half_t)v.z; o[3] = (half_t)v.w;
+    *(h4*)(out + r * C + c) = o;
+  }
+}
+
+// 3x3 conv applied to a nearest-x2 upsampled image == four 2x2 convs on the original image, one per output parity
+// (py, px): rows {2y-1, 2y, 2y+1} of the upsampled image are input rows {y-1, y, y} (py = 0) or {y, y, y+1} (py = 1),
+// so the taps that land on the same input pixel are summed once here (fp32) instead of multiplied separately:
+// 16 instead of 36 tap-GEMMs per four output pixels.  src [N][Cin][3][3] -> dst [(py*2+px)*4 + a*2 + b][N][Cin].
+__global__ void pack_upconv_weight_kernel(const float* __restrict__ src, int N, int Cin, half_t* __restrict__ dst) {
+  const long total = (long)16 * N * Cin;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cin);
+    const int n = (int)((idx / Cin) % N);
+    const int slab = (int)(idx / ((long)Cin * N));
+    const int b = slab & 1, a = (slab >> 1) & 1, px = (slab >> 2) & 1, py = slab >> 3;
+    // kernel rows / cols folded onto input offset a (resp. b) for this parity
+    const int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    const float* w = src + ((long)n * Cin + c) * 9;
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += w[ky * 3 + kx];
+    dst[idx] = (half_t)acc;
+  }
+}
+
 __global__ void fill_rows_f16_kernel(half_t* __restrict__ out, int ld, int rows, const half_t* __restrict__ vec, int n) {
   const long total = (long)rows * n;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -273,6 +309,19 @@ int launch_permute_geglu_bias(const float* src, int N, float* dst, hipStream_t s
 
 int launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_rows_f32_to_f16(const float* in, int lda, long rows, int C, half_t* out, hipStream_t s) {
+  if ((C & 3) || (lda & 3)) return mvd_fail("rows_f32_to_f16: C and lda must be multiples of 4");
+  hipLaunchKernelGGL(rows_f32_to_f16_kernel, dim3(grid_for((size_t)rows * C / 4)), dim3(256), 0, s, in, lda, rows, C, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_upconv_weight(const float* src, int N, int Cin, half_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(pack_upconv_weight_kernel, dim3(grid_for((size_t)16 * N * Cin)), dim3(256), 0, s, src, N, Cin, dst);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -106,6 +106,9 @@ def test_linear_geglu(eng):
     dict(B=32, Cin=256, H=4, W=4, Cout=192, k=3, stride=1, up=0, res=True, sk=0),
     dict(B=20, Cin=64, H=7, W=5, Cout=40, k=3, stride=1, up=0, res=False, sk=4),
     dict(B=3, Cin=192, H=16, W=16, Cout=644, k=1, stride=1, up=0, res=True, sk=0),
+    # parity-folded upsample conv (B*H*W >= 2048): even / odd edges, ragged width, residual, split-K
+    dict(B=2, Cin=64, H=32, W=32, Cout=96, k=3, stride=1, up=1, res=True, sk=0),
+    dict(B=12, Cin=128, H=16, W=12, Cout=72, k=3, stride=1, up=1, res=False, sk=2),
 ])
 def test_conv2d(eng, cfg):
     x = rnd(cfg["B"], cfg["Cin"], cfg["H"], cfg["W"])
