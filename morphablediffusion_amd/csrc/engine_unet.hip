@@ -48,9 +48,10 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
   const bool halo = c->use_halo && conv3_halo_eligible(g);
   static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
+  static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 512;
   // one 256-row workgroup per CU: wins for the Linear layers and wherever weights stream (small M, long K);
   // the big shallow 3-D convs keep the 128-row gather kernel (finer tiles, 2 workgroups per CU)
-  const bool dense = use_dense && !halo && M >= 512 && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
+  const bool dense = use_dense && !halo && M >= dense_min_m && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
   int sk;
   if (halo) {
     // LDS-halo 3x3 kernel, one workgroup per CU: pick the column width and the split over 64-channel chunks that

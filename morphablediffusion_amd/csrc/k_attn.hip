@@ -50,23 +50,46 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk
     for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int k0 = 0; k0 < T; k0 += 64) {
-    __syncthreads();
-    // K tile: 64 keys x DK halfs
-    for (int idx = tid; idx < 64 * (DK / 8); idx += 256) {
+  // K / V^T tiles are register-staged one tile ahead: the global loads of tile i+1 are in flight behind the
+  // MFMAs and the softmax of tile i
+  constexpr int KSLOTS = (64 * (DK / 8) + 255) / 256, VSLOTS = (DVP * 8 + 255) / 256;
+  h8 kreg[KSLOTS], vreg[VSLOTS];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KSLOTS; ++i) {
+      const int idx = tid + i * 256;
       const int key = idx / (DK / 8), ch = idx - key * (DK / 8);
-      h8 v = (h8)(half_t)0;
-      if (k0 + key < T && ch * 8 < D) v = *(const h8*)(qk + (tok0 + k0 + key) * ldqk + C + head * D + ch * 8);
-      *(h8*)(sK + key * KLD + ch * 8) = v;
+      kreg[i] = (h8)(half_t)0;
+      if (idx < 64 * (DK / 8) && k0 + key < T && ch * 8 < D)
+        kreg[i] = *(const h8*)(qk + (tok0 + k0 + key) * ldqk + C + head * D + ch * 8);
     }
-    // V^T tile: DVP rows x 64 keys
-    for (int idx = tid; idx < DVP * 8; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < VSLOTS; ++i) {
+      const int idx = tid + i * 256;
       const int dv = idx >> 3, ch = idx & 7;
-      h8 v = (h8)(half_t)0;
-      if (dv < D && k0 + ch * 8 < T) v = *(const h8*)(vt + (long)(head * D + dv) * ldvt + tok0 + k0 + ch * 8);
-      *(h8*)(sV + dv * VLD + ch * 8) = v;
+      vreg[i] = (h8)(half_t)0;
+      if (idx < DVP * 8 && dv < D && k0 + ch * 8 < T) vreg[i] = *(const h8*)(vt + (long)(head * D + dv) * ldvt + tok0 + k0 + ch * 8);
     }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < KSLOTS; ++i) {
+      const int idx = tid + i * 256;
+      const int key = idx / (DK / 8), ch = idx - key * (DK / 8);
+      if (idx < 64 * (DK / 8)) *(h8*)(sK + key * KLD + ch * 8) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VSLOTS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < DVP * 8) *(h8*)(sV + (idx >> 3) * VLD + (idx & 7) * 8) = vreg[i];
+    }
+  };
+  load_tiles(0);
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    __syncthreads();  // every wave is done reading the previous tile
+    store_tiles();
     __syncthreads();
+    if (k0 + 64 < T) load_tiles(k0 + 64);
 
     f32x16 s[2];
 #pragma unroll
@@ -92,13 +115,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // scores carry log2(e): exp(x) == exp2(x log2 e)
     float psum = 0.f;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __expf(s[f][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(s[f][r] - m_new);
         s[f][r] = p;
         psum += p;
       }
@@ -152,7 +175,7 @@ int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, hal
                      int heads, int d, hipStream_t s) {
   if (T % 8 || ldqk % 8 || ldvt % 8 || ldo % 4 || d % 8) return mvd_fail("attention: alignment (T, ld, d multiples of 8)");
   dim3 grid(cdiv(T, 128), heads, B);
-  const float scale = 1.0f / sqrtf((float)d);
+  const float scale = 1.4426950408889634f / sqrtf((float)d);  // softmax scale * log2(e): the kernel uses exp2
 #define MVD_ATTN(DD) \
   case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, vt, ldvt, out, ldo, T, heads, scale); break;
   switch (d) {
