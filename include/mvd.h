@@ -128,6 +128,11 @@ int mvd_op_conv3d(mvd_ctx* ctx, const float* x_ncdhw, int B, int Cin, int D, int
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);
+/* in-situ timing of the dominant kernel: while enabled, every launch of conv3_dma_kernel<160,16,16> (the level-32
+ * 3x3 convs of the UNet) is bracketed by HIP events on its launch stream; read returns the summed kernel time, the
+ * summed algorithmic FLOPs and the launch count since the last enable (it synchronises on the recorded events) */
+int mvd_probe_enable(mvd_ctx* ctx, int on);
+int mvd_probe_read(mvd_ctx* ctx, double* total_ms, double* total_flops, int* launches);
 /* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,
  * 4 = GEGLU epilogue */
 int mvd_bench_linear(mvd_ctx* ctx, int M, int K, int N, int flags, int iters, float* ms_out, void* stream);

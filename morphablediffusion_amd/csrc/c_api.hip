@@ -108,6 +108,7 @@ void mvd_destroy(mvd_ctx* c) {
   hipFree(c->cams);
   hipFree(c->volume);
   hipFree(c->ws.base);
+  for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
   delete c;
 }
 
@@ -454,6 +455,31 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
   hipEventDestroy(e1);
   *ms_out = ms / (float)iters;
   c->ws.off = mark;
+  return 0;
+}
+
+int mvd_probe_enable(mvd_ctx* c, int on) {
+  if (!c) return mvd_fail("mvd_probe_enable: null context");
+  c->probe_on = on != 0;
+  if (on) {
+    c->probe_used = 0;
+    c->probe_flops = 0.0;
+  }
+  return 0;
+}
+
+int mvd_probe_read(mvd_ctx* c, double* total_ms, double* total_flops, int* launches) {
+  if (!c || !total_ms || !total_flops || !launches) return mvd_fail("mvd_probe_read: null argument");
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
+    HIP_CHECK_RET(hipEventSynchronize(c->probe_ev[i + 1]));
+    float t = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&t, c->probe_ev[i], c->probe_ev[i + 1]));
+    ms += t;
+  }
+  *total_ms = ms;
+  *total_flops = c->probe_flops;
+  *launches = (int)(c->probe_used / 2);
   return 0;
 }
 

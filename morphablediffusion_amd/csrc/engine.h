@@ -106,6 +106,11 @@ struct mvd_ctx {
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
+  // in-situ timing of the dominant kernel (conv3_dma_kernel<160,16,16>): HIP events around each of its launches
+  bool probe_on = false;
+  std::vector<hipEvent_t> probe_ev;   // pool, two events per probed launch
+  size_t probe_used = 0;
+  double probe_flops = 0.0;
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
 

@@ -106,7 +106,24 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   }
   int r;
   if (halo) {
+    // measurement probe: only the <160,16,16> instantiation without split-K (the level-32 convs)
+    const bool probe = c->probe_on && g.bn == 160 && g.X % 16 == 0 && g.splitk <= 1;
+    if (probe) {
+      if (c->probe_used + 2 > c->probe_ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+          hipEvent_t ev;
+          if (hipEventCreate(&ev) != hipSuccess) return mvd_fail("probe: hipEventCreate failed");
+          c->probe_ev.push_back(ev);
+        }
+      }
+      hipEventRecord(c->probe_ev[c->probe_used], s);
+    }
     r = launch_conv3_halo(g, s);
+    if (probe) {
+      hipEventRecord(c->probe_ev[c->probe_used + 1], s);
+      c->probe_used += 2;
+      c->probe_flops += 2.0 * M * g.N * g.Cin * 9.0;
+    }
     if (!r && g.splitk > 1) r = launch_splitk_reduce(g, s);
   } else if (dense) {
     r = launch_gemm_dma(g, s);

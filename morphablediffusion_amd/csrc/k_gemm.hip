@@ -25,7 +25,7 @@ namespace {
 
 constexpr int GBM = 256, GNT = 512, GST = 3;
 
-__device__ __forceinline__ int swzg(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+[[maybe_unused]] __device__ __forceinline__ int swzg(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmg() {

@@ -252,3 +252,12 @@ class Engine:
         flags = (1 if resid else 0) | (2 if out_half else 0) | (4 if geglu else 0)
         L.check(self.lib.mvd_bench_linear(self._ctx, M, K, N, flags, iters, C.byref(ms), _stream()))
         return ms.value
+
+    def probe_enable(self, on=True):
+        L.check(self.lib.mvd_probe_enable(self._ctx, 1 if on else 0))
+
+    def probe_read(self):
+        """(total kernel ms, total algorithmic FLOPs, launches) of conv3_dma_kernel<160,16,16> since probe_enable."""
+        ms, fl, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        L.check(self.lib.mvd_probe_read(self._ctx, C.byref(ms), C.byref(fl), C.byref(n)))
+        return ms.value, fl.value, n.value
