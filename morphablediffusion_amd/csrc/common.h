@@ -57,6 +57,12 @@ struct IGemm {
   int act;              // ACT_SILU applied last (non-GEGLU path)
   // split-K
   int nch;              // dense GEMM kernel: column tiles walked by one workgroup
+  // parity-batched launch (LDS-DMA kernel only): blockIdx.z picks one of npar tap tables / output offsets, so the
+  // 8 parity classes of a transposed conv (or the 4 of a folded upsample conv) are ONE launch
+  int npar;
+  int par_ntaps[8];
+  int par_tap[8][8];
+  int par_oz[8], par_oy[8], par_ox[8];
   int bn;               // column-tile width (64 / 128 / 160); 0 = pick from N
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1

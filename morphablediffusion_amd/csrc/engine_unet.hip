@@ -51,6 +51,17 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 512;
   // one 256-row workgroup per CU: wins for the Linear layers and wherever weights stream (small M, long K);
   // the big shallow 3-D convs keep the 128-row gather kernel (finer tiles, 2 workgroups per CU)
+  if (g.npar > 0) {  // parity-batched launch (run_convT3d / run_upconv2d): LDS-DMA kernel, no split-K
+    if (!gemm_dma_eligible(g)) return mvd_fail("igemm_go: parity batch needs the LDS-DMA kernel");
+    int kmax = 0;
+    for (int p = 0; p < g.npar; ++p) kmax = g.par_ntaps[p] > kmax ? g.par_ntaps[p] : kmax;
+    int nch = 1, sk2 = 1;
+    gemm_dma_plan(M * g.npar, g.N, kmax * cdiv(g.Cin, 64), g.bn, 1, &nch, &sk2);
+    g.nch = nch;
+    g.splitk = 1;
+    g.partial = nullptr;
+    return launch_gemm_dma(g, s);
+  }
   const bool dense = use_dense && !halo && M >= dense_min_m && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
   int sk;
   if (halo) {
@@ -197,27 +208,46 @@ int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStre
     ga.a_f32 = 0;
     ga.lda = cw.Cin;
   }
+  static const bool no_batch = getenv("MVD_NO_PARITY_BATCH") != nullptr;
+  IGemm gb;
+  igemm_init(gb);
+  igemm_fill(gb, ga);
+  gb.B = B;
+  gb.Y = gb.PY = gb.IY = H;
+  gb.X = gb.PX = gb.IX = W;
+  gb.out_linear = 0;
+  gb.OZ = 1;
+  gb.OY = 2 * H;
+  gb.OX = 2 * W;
+  gb.ozm = 1;
+  gb.oym = gb.oxm = 2;
+  const bool batched = !no_batch && ga.force_splitk <= 1 && gemm_dma_eligible(gb);
   for (int par = 0; par < 4; ++par) {
     const int py = par >> 1, px = par & 1;
-    IGemm g;
-    igemm_init(g);
-    igemm_fill(g, ga);
-    g.B = B;
-    g.Y = g.PY = g.IY = H;
-    g.X = g.PX = g.IX = W;
-    g.ntaps = 4;
+    int taps[4];
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b)
-        g.tap[a * 2 + b] = igemm_tap(0, py == 0 ? a - 1 : a, px == 0 ? b - 1 : b, par * 4 + a * 2 + b);
-    g.out_linear = 0;
-    g.OZ = 1;
-    g.OY = 2 * H;
-    g.OX = 2 * W;
-    g.ozm = 1;
-    g.oym = g.oxm = 2;
+        taps[a * 2 + b] = igemm_tap(0, py == 0 ? a - 1 : a, px == 0 ? b - 1 : b, par * 4 + a * 2 + b);
+    if (batched) {
+      gb.par_ntaps[par] = 4;
+      for (int i = 0; i < 4; ++i) gb.par_tap[par][i] = taps[i];
+      gb.par_oz[par] = 0;
+      gb.par_oy[par] = py;
+      gb.par_ox[par] = px;
+      continue;
+    }
+    IGemm g = gb;
+    g.ntaps = 4;
+    for (int i = 0; i < 4; ++i) g.tap[i] = taps[i];
     g.oyo = py;
     g.oxo = px;
     RET_IF(igemm_go(c, g, ga.force_splitk, s));
+  }
+  if (batched) {
+    gb.npar = 4;
+    gb.ntaps = 4;
+    gb.bn = igemm_pick_bn(gb.N, 0);
+    RET_IF(igemm_go(c, gb, 0, s));
   }
   c->ws.off = mark;
   return 0;
@@ -250,35 +280,50 @@ int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int s
 // p = 0 -> k = 1, i = q ;  p = 1 -> (k = 0, i = q + 1), (k = 2, i = q)   where o = 2 q + p.
 int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s) {
   if (ga.w->taps != 27) return mvd_fail("run_convT3d: expects a 3x3x3 kernel");
+  static const bool no_batch = getenv("MVD_NO_PARITY_BATCH") != nullptr;
+  IGemm gb;  // all 8 parity classes in one launch when the LDS-DMA kernel applies
+  igemm_init(gb);
+  igemm_fill(gb, ga);
+  gb.B = B;
+  gb.Z = gb.PZ = gb.IZ = D;
+  gb.Y = gb.PY = gb.IY = H;
+  gb.X = gb.PX = gb.IX = W;
+  gb.out_linear = 0;
+  gb.OZ = 2 * D;
+  gb.OY = 2 * H;
+  gb.OX = 2 * W;
+  gb.ozm = gb.oym = gb.oxm = 2;
+  const bool batched = !no_batch && !ga.a_f32 && ga.force_splitk <= 1 && B * D * H * W >= 512 && gemm_dma_eligible(gb);
   for (int par = 0; par < 8; ++par) {
     const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
-    IGemm g;
-    igemm_init(g);
-    igemm_fill(g, ga);
-    g.B = B;
-    g.Z = g.PZ = g.IZ = D;
-    g.Y = g.PY = g.IY = H;
-    g.X = g.PX = g.IX = W;
     const int kz[2] = {pz ? 0 : 1, 2}, dzv[2] = {pz ? 1 : 0, 0}, nz = pz ? 2 : 1;
     const int ky[2] = {py ? 0 : 1, 2}, dyv[2] = {py ? 1 : 0, 0}, ny = py ? 2 : 1;
     const int kx[2] = {px ? 0 : 1, 2}, dxv[2] = {px ? 1 : 0, 0}, nx = px ? 2 : 1;
-    int t = 0;
+    int taps[8], t = 0;
     for (int a = 0; a < nz; ++a)
       for (int b = 0; b < ny; ++b)
-        for (int e = 0; e < nx; ++e) {
-          g.tap[t] = igemm_tap(dzv[a], dyv[b], dxv[e], (kz[a] * 3 + ky[b]) * 3 + kx[e]);
-          ++t;
-        }
+        for (int e = 0; e < nx; ++e) taps[t++] = igemm_tap(dzv[a], dyv[b], dxv[e], (kz[a] * 3 + ky[b]) * 3 + kx[e]);
+    if (batched) {
+      gb.par_ntaps[par] = t;
+      for (int i = 0; i < t; ++i) gb.par_tap[par][i] = taps[i];
+      gb.par_oz[par] = pz;
+      gb.par_oy[par] = py;
+      gb.par_ox[par] = px;
+      continue;
+    }
+    IGemm g = gb;
+    for (int i = 0; i < t; ++i) g.tap[i] = taps[i];
     g.ntaps = t;
-    g.out_linear = 0;
-    g.OZ = 2 * D;
-    g.OY = 2 * H;
-    g.OX = 2 * W;
-    g.ozm = g.oym = g.oxm = 2;
     g.ozo = pz;
     g.oyo = py;
     g.oxo = px;
     RET_IF(igemm_go(c, g, ga.force_splitk, s));
+  }
+  if (batched) {
+    gb.npar = 8;
+    gb.ntaps = 8;
+    gb.bn = igemm_pick_bn(gb.N, 0);
+    RET_IF(igemm_go(c, gb, 0, s));
   }
   return 0;
 }

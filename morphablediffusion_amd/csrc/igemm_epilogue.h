@@ -4,7 +4,7 @@
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-__device__ __forceinline__ long out_row(const IGemm& g, int m) {
+__device__ __forceinline__ long out_row_off(const IGemm& g, int m, int ozo, int oyo, int oxo) {
   if (g.out_linear) return m;
   int x = m % g.X;
   int t = m / g.X;
@@ -12,8 +12,9 @@ __device__ __forceinline__ long out_row(const IGemm& g, int m) {
   t /= g.Y;
   int z = t % g.Z;
   int b = t / g.Z;
-  return ((long)(b * g.OZ + z * g.ozm + g.ozo) * g.OY + (y * g.oym + g.oyo)) * g.OX + (x * g.oxm + g.oxo);
+  return ((long)(b * g.OZ + z * g.ozm + ozo) * g.OY + (y * g.oym + oyo)) * g.OX + (x * g.oxm + oxo);
 }
+__device__ __forceinline__ long out_row(const IGemm& g, int m) { return out_row_off(g, m, g.ozo, g.oyo, g.oxo); }
 
 // v: accumulator for column n (and `gate` for column n+32 when geglu)
 __device__ __forceinline__ void igemm_epilogue_store(const IGemm& g, int m, long orow, int n, float v, float gate) {

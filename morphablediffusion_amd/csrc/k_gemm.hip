@@ -59,7 +59,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   const int m0 = tm * GBM;
   const int tn_beg = gn * nch, tn_end = min(tiles_n, tn_beg + nch);
 
-  const int ksteps_all = g.ntaps * ((Cin + 63) / 64);
+  // parity-batched launch: this workgroup's tap table and output offsets
+  const int par = g.npar > 0 ? (int)blockIdx.z : 0;
+  const int ntaps = g.npar > 0 ? g.par_ntaps[par] : g.ntaps;
+  const int ozo = g.npar > 0 ? g.par_oz[par] : g.ozo, oyo = g.npar > 0 ? g.par_oy[par] : g.oyo,
+            oxo = g.npar > 0 ? g.par_ox[par] : g.oxo;
+  const int ksteps_all = ntaps * ((Cin + 63) / 64);
   int kbeg = 0, kend = ksteps_all;
   if (g.splitk > 1) {
     const int per = (ksteps_all + g.splitk - 1) / g.splitk;
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   const int cpt = (Cin + 63) / 64;  // k-steps per tap
   unsigned w_slab = 0;              // byte offset of the current tap's weight slab
   auto set_tap = [&](int tap) {
-    const int ti = g.tap[__builtin_amdgcn_readfirstlane(tap)];  // one packed dword per tap, scalar load
+    const int tu = __builtin_amdgcn_readfirstlane(tap);
+    const int ti = g.npar > 0 ? g.par_tap[par][tu] : g.tap[tu];  // one packed dword per tap, scalar load
     const int dz = (ti & 3) - 1, dy = ((ti >> 2) & 3) - 1, dx = ((ti >> 4) & 3) - 1;
     w_slab = (unsigned)(ti >> 8) * (unsigned)N * (unsigned)Cin * 2;
 #pragma unroll
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wave * 32 + (lane >> 3) + 8 * i;
         rows4[i] = m < M ? m : -1;
-        orow4[i] = m < M ? out_row(g, m) : 0;
+        orow4[i] = m < M ? out_row_off(g, m, ozo, oyo, oxo) : 0;
       }
       if (g.geglu) {
         if constexpr (FN % 2 == 0) {
@@ -262,7 +268,7 @@ int launch_gd(const IGemm& g, int M, hipStream_t s) {
     attr_set = true;
   }
   const int nch = g.nch > 0 ? g.nch : 1;
-  dim3 grid(cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch), g.splitk > 1 ? g.splitk : 1);
+  dim3 grid(cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch), g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
   hipLaunchKernelGGL((gemm_dma_kernel<BN>), grid, dim3(GNT), LDS, s, g);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -315,6 +321,7 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
   if (M <= 0 || g.N <= 0) return 0;
   if (g.splitk > 1 && !g.partial) return mvd_fail("gemm_dma: split-K without a partial buffer");
+  if (g.npar > 0 && (g.npar > 8 || g.splitk > 1)) return mvd_fail("gemm_dma: parity batch needs npar <= 8 and no split-K");
   if ((long)g.B * g.PZ * g.PY * g.PX * g.lda * 2 >= 0xFFFFFF00L || (long)MVD_MAX_TAPS * g.N * g.Cin * 2 >= 0xFFFFFF00L)
     return mvd_fail("gemm_dma: operand exceeds 4 GiB buffer addressing");
   const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
