@@ -85,10 +85,12 @@ def ellipsoid_mesh(num_vertices: int = 5023, seed: int = 1, radii=(0.22, 0.28, 0
 
 
 def make_batch(num_views: int = 16, projection: str = "perspective", num_vertices: int = 5023,
-               mesh_seed: int = 1, batch_size: int = 1, radii=(0.22, 0.28, 0.25)) -> Dict[str, torch.Tensor]:
-    """Batch dict with the keys the hot path reads (morphable_diffusion.py:205-252,281-296,389-392)."""
+               mesh_seed: int = 1, batch_size: int = 1, radii=(0.22, 0.28, 0.25),
+               image_size: int = 256) -> Dict[str, torch.Tensor]:
+    """Batch dict with the keys the hot path reads (morphable_diffusion.py:205-252,281-296,389-392).
+    ``image_size`` scales the pinhole intrinsics (focal and principal point are given for 256-pixel renders)."""
     if projection == "perspective":
-        K, RT = camera_arc(num_views)
+        K, RT = camera_arc(num_views, focal=1545.23757707405 * image_size / 256.0, center=image_size / 2.0)
     else:
         K, RT = ortho_cameras(num_views)
     verts = ellipsoid_mesh(num_vertices, mesh_seed, radii)

@@ -39,7 +39,7 @@ def make_model(ucfg, vcfg, N, workspace_gb=8.0):
               context_dim=768, use_checkpoint=True, legacy=False)
     m = SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": kw},
-        scheduler_config=None, projection=vcfg.projection, view_num=N, image_size=256, cfg_scale=2.0,
+        scheduler_config=None, projection=vcfg.projection, view_num=N, image_size=vcfg.input_image_size, cfg_scale=2.0,
         batch_view_num=4, sample_steps=50, workspace_gb=workspace_gb)
     m.load_state_dict(gi.full_weights(ucfg, vcfg))
     return m
@@ -105,6 +105,33 @@ def test_stages_and_step_small_vs_golden(name, projection):
     fd, _ = m.spatial_volume.construct_view_frustum_volume(sv, t_embed, v_embed, torch.arange(0, 2)[None], batch)
     for k, v in fd.items():
         compare(v, g, f"frustum_{k}", rel=2e-3, mx=1e-2)
+    noise = None
+    if int(g["with_noise"]):
+        torch.manual_seed(int(g["noise_seed"]))
+        noise = torch.randn(x_T.shape).cuda()
+    out = m.sampler.denoise_apply(x_T, {"x": x_in}, clip, ts, index, 2.0, batch_view_num=bvn,
+                                  is_step0=not int(g["with_noise"]), batch=batch, noise=noise)
+    compare(out, g, "x_prev")
+    m.engine.close()
+
+
+@pytest.mark.parametrize("name,projection", [
+    ("step_small_n8.npz", "perspective"),           # BASELINE config 1: N=8, 256^2
+    ("step_small_lat64_n1.npz", "perspective"),     # config 0: one view, 64^2 latent, FLAME-sized mesh, first step
+    ("step_small_smplx_n32.npz", "orthographic"),   # config 4: SMPL-X-sized mesh, N=32, 512^2 (64^2 latent), ortho
+])
+def test_step_config_variants_vs_golden(name, projection):
+    """The other BASELINE.json configurations as parity cases (reduced UNet width), against the reference's output."""
+    import dataclasses
+    g = np.load(os.path.join(G, name))
+    N, index, bvn, size = int(g["N"]), int(g["index"]), int(g["bvn"]), int(g["image_size"])
+    ucfg = dataclasses.replace(gi.SMALL_UNET, image_size=size // 8)
+    vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=size)
+    m = make_model(ucfg, vcfg, N, workspace_gb=12.0)
+    batch = to_dev(synthetic.make_batch(N, projection, int(g["nverts_in"]), mesh_seed=1, image_size=size,
+                                        radii=tuple(float(r) for r in g["radii"])))
+    x_T, x_in, clip = [t.cuda() for t in synthetic.make_latents(N, size // 8, seed=6033)]
+    ts = torch.full((1,), int(g["step"]), dtype=torch.long, device="cuda")
     noise = None
     if int(g["with_noise"]):
         torch.manual_seed(int(g["noise_seed"]))

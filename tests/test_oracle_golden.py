@@ -132,6 +132,30 @@ def test_step_and_stages_small(name, projection):
     check(out, g, "x_prev")
 
 
+@pytest.mark.parametrize("name,projection", [("step_small_n8.npz", "perspective"), ("step_small_lat64_n1.npz", "perspective")])
+def test_step_config_variants(name, projection):
+    """BASELINE configs 1 and 0 at reduced width (N=8 at 256^2; one view at a 64^2 latent, first DDIM step).
+    The N=32 / SMPL-X-sized variant (config 4) is checked on the GPU only: the oracle needs minutes for it."""
+    import dataclasses
+    g = load(name)
+    N, index, bvn, size = int(g["N"]), int(g["index"]), int(g["bvn"]), int(g["image_size"])
+    ucfg = dataclasses.replace(gi.SMALL_UNET, image_size=size // 8)
+    vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=size)
+    W = gi.full_weights(ucfg, vcfg)
+    batch = synthetic.make_batch(N, projection, int(g["nverts_in"]), mesh_seed=1, image_size=size,
+                                 radii=tuple(float(r) for r in g["radii"]))
+    x_T, x_in, clip = synthetic.make_latents(N, size // 8, seed=6033)
+    tab = O.ddim_tables(50, 1.0)
+    ts = torch.full((1,), int(g["step"]), dtype=torch.long)
+    noise = None
+    if int(g["with_noise"]):
+        torch.manual_seed(int(g["noise_seed"]))
+        noise = torch.randn(x_T.shape)
+    out = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
+                          batch_view_num=bvn, noise=noise)
+    check(out, g, "x_prev")
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "unet_full.npz")), reason="full-width golden not generated")
 def test_unet_full_forward():
     cfg = gi.FULL_UNET

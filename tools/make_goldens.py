@@ -103,9 +103,12 @@ def build_full_model(ns, ucfg, vcfg, N):
     model = md.SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": cfg_kwargs(ucfg)},
         scheduler_config=None, finetune_unet=False, projection=vcfg.projection, use_spatial_volume=False,
-        view_num=N, image_size=256, cfg_scale=2.0, output_num=8, batch_view_num=4, drop_conditions=False,
+        view_num=N, image_size=vcfg.input_image_size, cfg_scale=2.0, output_num=8, batch_view_num=4, drop_conditions=False,
         clip_image_encoder_path="", sample_type="ddim", sample_steps=50, target_elevation=0).eval()
     model.spatial_volume.smpl_feature_extractor.num_views = N  # gotcha G3: hard-wired 16 in the reference
+    if vcfg.input_image_size != 256:  # gotcha G4: the image size is not forwarded to SpatialVolumeNet
+        model.spatial_volume.input_image_size = vcfg.input_image_size
+        model.spatial_volume.frustum_volume_size = vcfg.input_image_size // 8
     W = gi.full_weights(ucfg, vcfg)
     ref_sd = model.state_dict()
     hot = {k: tuple(v.shape) for k, v in ref_sd.items()
@@ -119,17 +122,18 @@ def build_full_model(ns, ucfg, vcfg, N):
     return model, hot
 
 
-def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, stages=False):
-    vcfg = VolumeConfig(num_views=N, projection=projection)
+def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, stages=False, image_size=256,
+              radii=(0.22, 0.28, 0.25)):
+    vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=image_size)
     model, hot = build_full_model(ns, ucfg, vcfg, N)
-    batch = synthetic.make_batch(N, projection, nverts, mesh_seed=1)
-    x_T, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    batch = synthetic.make_batch(N, projection, nverts, mesh_seed=1, image_size=image_size, radii=radii)
+    x_T, x_in, clip = synthetic.make_latents(N, image_size // 8, seed=6033)
     sampler = model.sampler
     step = int(sampler.ddim_timesteps[index])
     ts = torch.full((1,), step, dtype=torch.long)
     packs = {}
     extra = {"index": index, "step": step, "N": N, "nverts_in": nverts, "bvn": bvn,
-             "with_noise": int(with_noise), "noise_seed": 99}
+             "with_noise": int(with_noise), "noise_seed": 99, "image_size": image_size, "radii": np.array(radii)}
     with torch.no_grad():
         t0 = time.time()
         torch.manual_seed(99)
@@ -193,13 +197,29 @@ def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, sta
     return hot
 
 
+def gold_variants(ns):
+    """The other BASELINE.json configs as parity cases, at reduced UNet width:
+    config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
+    config 4 (SMPL-X-sized mesh, N=32, 512^2 -> 64^2 latent, orthographic cameras)."""
+    import dataclasses
+    small64 = dataclasses.replace(gi.SMALL_UNET, image_size=64)
+    gold_step(ns, "step_small_n8.npz", gi.SMALL_UNET, 8, "perspective", 10, True, 600, 4)
+    gold_step(ns, "step_small_lat64_n1.npz", small64, 1, "perspective", 0, False, 5023, 1, image_size=512)
+    gold_step(ns, "step_small_smplx_n32.npz", small64, 32, "orthographic", 30, True, 10475, 4, image_size=512,
+              radii=(0.18, 0.45, 0.12))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     ns = ref_import.import_reference_full()
+    if args.only_variants:
+        gold_variants(ns)
+        return
     gold_basic(ns)
     gold_unet_small(ns)
     hot = gold_step(ns, "step_small_persp.npz", gi.SMALL_UNET, 4, "perspective", 25, True, 600, 2, stages=True)
