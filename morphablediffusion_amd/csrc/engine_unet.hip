@@ -87,17 +87,21 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     sk = force_splitk > 0 ? (force_splitk < ncc ? force_splitk : ncc) : best_sk;
     if (getenv("MVD_HALO_BN")) g.bn = atoi(getenv("MVD_HALO_BN"));  // tuning experiments only
     if (getenv("MVD_HALO_SK")) sk = atoi(getenv("MVD_HALO_SK"));
+    if (sk > ncc) sk = ncc;
+    if (sk > 1) sk = cdiv(ncc, cdiv(ncc, sk));  // no empty split (the kernels cut the chunk range in ceil(ncc/sk) pieces)
   } else if (dense) {
     int nch = 1, sk2 = 1;
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
     sk = g.geglu ? 1 : (force_splitk > 0 ? force_splitk : sk2);
     if (sk > ksteps) sk = ksteps;
+    if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
     g.nch = sk > 1 ? 1 : nch;
   } else {
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
     if (sk > ksteps) sk = ksteps;
+    if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
   }
   const size_t mark = c->ws.off;
   g.splitk = sk;
