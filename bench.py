@@ -73,10 +73,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test knobs (single-GPU boxes): run the multi-rank flow with gloo and every rank on one device
+    backend = os.environ.get("MVD_DIST_BACKEND", "nccl")
+    if "MVD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["MVD_FORCE_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group(backend)  # "nccl" = RCCL over xGMI
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     dev = f"cuda:{local}"
