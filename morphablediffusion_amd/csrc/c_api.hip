@@ -243,7 +243,7 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   const bool cfg = cfg_scale != 1.0f;
   const int copies = cfg ? 2 : 1, Bv = copies * TN;
   FrustumOut fo;
-  RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, s));
+  RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, s, /*half0=*/true));
   float* xin = ws_alloc<float>(c, (size_t)Bv * HW * 8);
   float* ctx = ws_alloc<float>(c, (size_t)Bv * u.context_dim);
   int64_t* tt = ws_alloc<int64_t>(c, (size_t)Bv);
@@ -259,6 +259,10 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   for (int l = 0; l < 4; ++l) {
     cl[l].p = fo.lvl[l];
     cl[l].f32 = 1;
+  }
+  if (fo.lvl0_half) {
+    cl[0].p = fo.lvl0_half;
+    cl[0].f32 = 0;
   }
   RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s));
   RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));

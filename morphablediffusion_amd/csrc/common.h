@@ -49,6 +49,13 @@ struct IGemm {
   const float* bias;    // [N] or null
   const float* rowbias; // [B][rb_ld] or null (per-sample bias, e.g. timestep embedding)
   int rb_ld;
+  const float* rowscale; // [B][rs_ld] or null: per-sample, per-column scale applied to the accumulator before the
+  int rs_ld;             // biases (a GroupNorm folded into the GEMM that produces its input)
+  // statistics-only pass (LDS-DMA kernel): nothing is stored; every 256-row tile writes (sum, sumsq) of the
+  // accumulators per GroupNorm group to gn_partial[(m0/256) * (N/gn_cpg) + group][2].  Needs N % gn_cpg == 0,
+  // gn_cpg in {8,16,32} and rows-per-sample % 256 == 0.
+  float* gn_partial;
+  int gn_cpg;
   const void* resid;    // same row mapping / ld as out, or null
   int resid_f32;
   int ldr;
@@ -102,6 +109,9 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s);
 int gn_max_slabs();
+// slab / tile partials [B][nslabs][G][2] -> per-sample scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma
+int launch_gn_finalize(const float* partial, int B, int nslabs, int rows_per_sample, int C, int G, const float* gamma,
+                       const float* beta, float eps, float* scale, float* shift, int ld, hipStream_t s);
 bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo);
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s);

@@ -163,10 +163,11 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s);
 int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s);
 struct FrustumOut {
+  half_t* lvl0_half = nullptr;  // level 0 in fp16 instead of lvl[0] when engine_frustum(..., half0 = true)
   float* lvl[4];  // channels-last fp32 [TN, D_l, s_l, s_l, C_l]
 };
 int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
-                   FrustumOut* out, hipStream_t s);
+                   FrustumOut* out, hipStream_t s, bool half0 = false);
 
 // helpers shared by the executors
 struct GemmArgs {
@@ -177,6 +178,10 @@ struct GemmArgs {
   int out_f32 = 1, ldc = 0;
   const float* rowbias = nullptr;
   int rb_ld = 0;
+  const float* rowscale = nullptr;  // per-sample per-column scale on the accumulator (folded GroupNorm)
+  int rs_ld = 0;
+  float* gn_partial = nullptr;      // statistics-only pass: per-tile (sum, sumsq) per group, nothing stored
+  int gn_cpg = 0;
   const void* resid = nullptr;
   int resid_f32 = 1, ldr = 0;
   int geglu = 0;

@@ -281,7 +281,7 @@ int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s) {
 // construct_view_frustum_volume (morphable_diffusion.py:265-320): frustum gather + FrustumTV3DNet
 // (network.py:313-347).  Outputs stay channels-last fp32 in the workspace (caller owns the mark).
 int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
-                   FrustumOut* out, hipStream_t s) {
+                   FrustumOut* out, hipStream_t s, bool half0) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   if (!c->volume || !c->cams) return mvd_fail("volume / cameras not set");
   const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
@@ -298,6 +298,14 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
     x[l] = ws_alloc<float>(c, vox(l) * fd[l]);
     WS_CHECK(x[l]);
     out->lvl[l] = x[l];
+  }
+  // the level-0 volume is only ever an MFMA operand of the UNet's context projections: fp16 on request
+  half_t* x0h = nullptr;
+  if (half0) {
+    x0h = ws_alloc<half_t>(c, vox(0) * fd[0]);
+    WS_CHECK(x0h);
+    out->lvl0_half = x0h;
+    out->lvl[0] = nullptr;
   }
   const size_t mark = c->ws.off;
   half_t* gath = ws_alloc<half_t>(c, vox(0) * 64);
@@ -338,6 +346,10 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
                           pre + c->film_off[6 + (2 - l)], a, fd[l + 1], s, FT));
     g = GemmArgs();
     g.a = a; g.lda = fd[l + 1]; g.w = &u.conv; g.out = x[l]; g.ldc = fd[l]; g.resid = x[l]; g.ldr = fd[l];
+    if (l == 0 && x0h) {
+      g.out = x0h;
+      g.out_f32 = 0;
+    }
     RET_IF(run_convT3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], s));
   }
   c->ws.off = mark;

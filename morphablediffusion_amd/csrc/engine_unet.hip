@@ -35,6 +35,10 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.bias = ga.use_bias ? ga.w->bias : nullptr;
   g.rowbias = ga.rowbias;
   g.rb_ld = ga.rb_ld;
+  g.rowscale = ga.rowscale;
+  g.rs_ld = ga.rs_ld;
+  g.gn_partial = ga.gn_partial;
+  g.gn_cpg = ga.gn_cpg;
   g.resid = ga.resid;
   g.resid_f32 = ga.resid_f32;
   g.ldr = ga.ldr;
@@ -63,6 +67,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     return launch_gemm_dma(g, s);
   }
   const bool dense = use_dense && !halo && M >= dense_min_m && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
+  if (g.gn_partial && !dense) return mvd_fail("igemm_go: the statistics-only pass needs the LDS-DMA kernel");
   int sk;
   if (halo) {
     // LDS-halo 3x3 kernel, one workgroup per CU: pick the column width and the split over 64-channel chunks that
@@ -93,6 +98,13 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     int nch = 1, sk2 = 1;
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
+    if (g.gn_partial || g.rowscale) {  // folded-GroupNorm passes walk the whole tile grid: one round of workgroups
+      if (g.bn == 160) g.bn = 128;
+      const int tiles = cdiv(M, 256) * cdiv(g.N, g.bn);
+      nch = cdiv(tiles, 256);
+      if (nch > 64) nch = 64;
+      force_splitk = 1;
+    }
     sk = g.geglu ? 1 : (force_splitk > 0 ? force_splitk : sk2);
     if (sk > ksteps) sk = ksteps;
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
@@ -364,6 +376,7 @@ struct Fwd {
   const float* context;  // [Bv][context_dim]
   const float* a2_all;   // [Bv][a2_total] folded attn2 output per SpatialTransformer
   const Ctx5* src;
+  const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
 };
 
 // ResBlock._forward, openaimodel.py:256-276
@@ -474,10 +487,31 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level) 
     g = GemmArgs();
     g.a = pn; g.lda = I; g.w = &d.wqk; g.out = qk; g.ldc = 4 * Cc; g.use_bias = false;
     RET_IF(run_linear(c, g, f.n_ctx, crow, f.s));
-    g = GemmArgs();
-    g.a = f.src[level].p; g.a_f32 = f.src[level].f32; g.lda = Cc; g.w = &d.proj_ctx; g.out = pc; g.ldc = Cc; g.use_bias = false;
-    RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
-    RET_IF(run_group_norm(c, pc, Cc, f.n_ctx, D * HW, d.gn_ctx, 8, 1e-5f, ACT_RELU, nullptr, cn, Cc, f.s));
+    const int rps = D * HW, cpg = Cc / 8;
+    static const bool fold_off = getenv("MVD_NO_CTX_FOLD") != nullptr;
+    const half_t* src16 = f.src16[level];
+    if (!fold_off && src16 && rps % 256 == 0 && (cpg == 8 || cpg == 16 || cpg == 32) && (long)crow * D >= 512) {
+      // GroupNorm(proj_context(ctx)) without materialising the projection: pass 1 re-computes the 1x1x1 conv tile by
+      // tile and keeps only (sum, sumsq) per group, pass 2 re-computes it and applies scale/shift + ReLU in the epilogue
+      const int ntile = rps / 256;
+      float* part = ws_alloc<float>(c, (size_t)f.n_ctx * ntile * 8 * 2);
+      float* sc = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
+      float* sh = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
+      WS_CHECK(part && sc && sh);
+      g = GemmArgs();
+      g.a = src16; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.gn_partial = part; g.gn_cpg = cpg; g.force_splitk = 1;
+      RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
+      RET_IF(launch_gn_finalize(part, f.n_ctx, ntile, rps, Cc, 8, d.gn_ctx.g, d.gn_ctx.b, 1e-5f, sc, sh, Cc, f.s));
+      g = GemmArgs();
+      g.a = src16; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.out = cn; g.out_f32 = 0; g.ldc = Cc;
+      g.rowscale = sc; g.rs_ld = Cc; g.rowbias = sh; g.rb_ld = Cc; g.act = ACT_RELU; g.force_splitk = 1;
+      RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
+    } else {
+      g = GemmArgs();
+      g.a = f.src[level].p; g.a_f32 = f.src[level].f32; g.lda = Cc; g.w = &d.proj_ctx; g.out = pc; g.ldc = Cc; g.use_bias = false;
+      RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
+      RET_IF(run_group_norm(c, pc, Cc, f.n_ctx, D * HW, d.gn_ctx, 8, 1e-5f, ACT_RELU, nullptr, cn, Cc, f.s));
+    }
     RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s));
   }
   if (f.Bv > f.n_ctx)  // all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every head
@@ -535,7 +569,21 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels, temb = 4 * mc;
   const size_t mark0 = c->ws.off;
-  Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src};
+  Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
+  // fp16 view of the context volumes (operand-only tensors); fp32 sources are copied once per forward
+  for (int l = 0; l < 4 && n_ctx > 0 && src; ++l) {
+    if (!src[l].p) continue;
+    if (!src[l].f32) {
+      f.src16[l] = (const half_t*)src[l].p;
+      continue;
+    }
+    const int Dl = depth0 >> l, Sl = u.image_size >> l;
+    const size_t n = (size_t)n_ctx * Dl * Sl * Sl * u.volume_dims[l];
+    half_t* h = ws_alloc<half_t>(c, n);
+    WS_CHECK(h);
+    RET_IF(launch_f32_to_f16((const float*)src[l].p, h, n, s));
+    f.src16[l] = h;
+  }
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
   float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
   float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);

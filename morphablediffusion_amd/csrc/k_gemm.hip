@@ -32,7 +32,12 @@ __device__ __forceinline__ void wait_vmg() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int BN>
+// MODE 0: the general kernel.  MODE 1 / 2 (plain row-major GEMM only: one tap, linear rows): the two passes of a
+// GroupNorm folded into the GEMM that produces its input (engine_unet: do_cond, context projection).  The workgroup
+// walks `nch` consecutive tiles of the row-major tile grid, so long-M / short-K shapes stream A through the ring;
+// MODE 1 keeps only (sum, sumsq) of the accumulators per GroupNorm group and 256-row tile (nothing is stored),
+// MODE 2 stores relu(acc * rowscale[b][n] + rowbias[b][n]) in fp16.  Both need rows-per-sample % 256 == 0.
+template <int BN, int MODE = 0>
 __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int FN = BN / 32;
@@ -47,17 +52,20 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = g.B * g.Z * g.Y * g.X, N = g.N, Cin = g.Cin;
   const int tiles_m = (M + GBM - 1) / GBM, tiles_n = (N + BN - 1) / BN;
+  constexpr bool WALK = MODE != 0;  // tiles are walked in row-major order across row tiles too
   const int nch = g.nch > 0 ? g.nch : 1;
-  const int groups_n = (tiles_n + nch - 1) / nch;
+  const int groups_n = WALK ? 1 : (tiles_n + nch - 1) / nch;
   int bid = blockIdx.x;
   {  // XCD-aware bijective remap: consecutive workgroups (same rows, next column group) share an L2
-    const int nwg = tiles_m * groups_n;
+    const int nwg = WALK ? (tiles_m * tiles_n + nch - 1) / nch : tiles_m * groups_n;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int tm = bid / groups_n, gn = bid - tm * groups_n;
-  const int m0 = tm * GBM;
-  const int tn_beg = gn * nch, tn_end = min(tiles_n, tn_beg + nch);
+  // MODE 0: fixed row tile tm, column tiles [tn_beg, tn_end).  WALK: linear tile ids [tn_beg, tn_end), id = tm*tiles_n + tn
+  const int tm = WALK ? 0 : bid / groups_n, gn = WALK ? 0 : bid - tm * groups_n;
+  int m0 = tm * GBM;
+  const int tn_beg = WALK ? bid * nch : gn * nch;
+  const int tn_end = WALK ? min(tiles_m * tiles_n, tn_beg + nch) : min(tiles_n, tn_beg + nch);
 
   // parity-batched launch: this workgroup's tap table and output offsets
   const int par = g.npar > 0 ? (int)blockIdx.z : 0;
@@ -125,13 +133,28 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 
   // step stream: (column tile, k) with k = tap * cpt + cc; the ring treats the whole walk as one stream
   int set_for = -1;
-  auto dma_step = [&](int tn, int ks, int stage) {
+  auto dma_step = [&](int tile, int ks, int stage) {
     char* sA = smem + stage * STAGE;
     char* sW = sA + A_BYTES;
-    const int tap = ks / cpt, cc = ks - tap * cpt;
-    if (tap != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
-      set_tap(tap);
-      set_for = tap;
+    int tn = tile, tap = 0, cc = ks;
+    if constexpr (WALK) {  // linear rows, one tap: the A offsets follow the row tile
+      const int tmw = tile / tiles_n;
+      tn = tile - tmw * tiles_n;
+      if (tmw != set_for) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int m = tmw * GBM + (wave + 8 * i) * 8 + (lane >> 3);
+          a_off[i] = (((unsigned)m * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(m >= M));
+        }
+        set_for = tmw;
+      }
+    } else {
+      tap = ks / cpt;
+      cc = ks - tap * cpt;
+      if (tap != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
+        set_tap(tap);
+        set_for = tap;
+      }
     }
     const int kb = cc * 64;
 #pragma unroll
@@ -215,7 +238,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     const bool tile_done = ks + 1 == kend;
     if (tile_done) {
       // ---- epilogue of column tile tn; scratch = the ring slot just consumed (free until the next prefetch) ----
-      const int n0 = tn * BN;
+      int n0 = tn * BN;
+      if constexpr (WALK) {
+        const int tmw = tn / tiles_n;
+        m0 = tmw * GBM;
+        n0 = (tn - tmw * tiles_n) * BN;
+      }
       float* scratch = (float*)(smem + stage * STAGE + wave * EPI_WAVE_BYTES);
       int rows4[4];
       long orow4[4];
@@ -225,7 +253,57 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         rows4[i] = m < M ? m : -1;
         orow4[i] = m < M ? out_row_off(g, m, ozo, oyo, oxo) : 0;
       }
-      if (g.geglu) {
+      if constexpr (MODE == 1) {
+        // statistics-only pass: (sum, sumsq) of the accumulators per GroupNorm group of this 256-row tile; nothing is
+        // stored.  Rows past M and columns past N are zero (hardware zero fill), so they do not disturb the sums.
+        const int cpg = g.gn_cpg, ng = BN / cpg, ngroups = N / cpg;
+        float* red = (float*)(smem + stage * STAGE);  // [8 waves][ng][2]
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          float sx = 0.f, sq = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[fn][r] * g.alpha;
+            sx += v;
+            sq += v * v;
+          }
+          sx += __shfl_xor(sx, 32);  // the two half-waves hold the other 16 rows of the same column
+          sq += __shfl_xor(sq, 32);
+          for (int o = 1; o < cpg; o <<= 1) {  // columns of one group are cpg adjacent lanes
+            sx += __shfl_xor(sx, o);
+            sq += __shfl_xor(sq, o);
+          }
+          if (lane < 32 && (lane & (cpg - 1)) == 0) {
+            const int gi = (fn * 32 + lane) / cpg;
+            red[(wave * ng + gi) * 2] = sx;
+            red[(wave * ng + gi) * 2 + 1] = sq;
+          }
+        }
+        __syncthreads();
+        if (tid < ng && n0 / cpg + tid < ngroups) {
+          float sx = 0.f, sq = 0.f;
+          for (int w = 0; w < GNT / 64; ++w) {
+            sx += red[(w * ng + tid) * 2];
+            sq += red[(w * ng + tid) * 2 + 1];
+          }
+          float* p = g.gn_partial + ((long)(m0 / GBM) * ngroups + n0 / cpg + tid) * 2;
+          p[0] = sx;
+          p[1] = sq;
+        }
+      } else if constexpr (MODE == 2) {
+        // relu(acc * scale[b][n] + shift[b][n]) -> fp16; the tile lies inside one sample (rows-per-sample % 256 == 0)
+        const int bsmp = m0 / (g.Z * g.Y * g.X), col = lane & 31;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          const int n = n0 + fn * 32 + col;
+          const bool okc = n < N;
+          const float sc = okc ? g.rowscale[(long)bsmp * g.rs_ld + n] : 0.f, sh = okc ? g.rowbias[(long)bsmp * g.rb_ld + n] : 0.f;
+          f32x16 v;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[fn][r] * sc + sh, 0.f);
+          epilogue_frag_store_raw(g, v, scratch, lane, rows4, orow4, n0 + fn * 32, N);
+        }
+      } else if (g.geglu) {
         if constexpr (FN % 2 == 0) {
           // value / gate fragments share the C layout: pair them in registers, then one transposed store
           const int col = lane & 31;
@@ -258,18 +336,19 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #endif
 }
 
-template <int BN>
+template <int BN, int MODE = 0>
 int launch_gd(const IGemm& g, int M, hipStream_t s) {
   constexpr int LDS = GST * (GBM * 128 + BN * 128);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int nch = g.nch > 0 ? g.nch : 1;
-  dim3 grid(cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch), g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
-  hipLaunchKernelGGL((gemm_dma_kernel<BN>), grid, dim3(GNT), LDS, s, g);
+  const int gx = MODE ? cdiv(cdiv(M, GBM) * cdiv(g.N, BN), nch) : cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch);
+  dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
+  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE>), grid, dim3(GNT), LDS, s, g);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -324,6 +403,13 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   if (g.npar > 0 && (g.npar > 8 || g.splitk > 1)) return mvd_fail("gemm_dma: parity batch needs npar <= 8 and no split-K");
   if ((long)g.B * g.PZ * g.PY * g.PX * g.lda * 2 >= 0xFFFFFF00L || (long)MVD_MAX_TAPS * g.N * g.Cin * 2 >= 0xFFFFFF00L)
     return mvd_fail("gemm_dma: operand exceeds 4 GiB buffer addressing");
+  if (g.gn_partial || g.rowscale) {  // folded-GroupNorm passes: plain GEMM, 64 / 128 wide tiles
+    if (g.ntaps != 1 || g.splitk > 1 || g.npar > 0 || g.geglu || !g.out_linear || (g.bn != 64 && g.bn != 128))
+      return mvd_fail("gemm_dma: the folded-GroupNorm passes need a plain GEMM");
+    if (g.gn_partial) return g.bn == 64 ? launch_gd<64, 1>(g, M, s) : launch_gd<128, 1>(g, M, s);
+    if (!g.rowbias || g.out_f32) return mvd_fail("gemm_dma: the apply pass needs scale, shift and an fp16 output");
+    return g.bn == 64 ? launch_gd<64, 2>(g, M, s) : launch_gd<128, 2>(g, M, s);
+  }
   const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
   if (r) return r;
   if (g.splitk > 1) return launch_splitk_reduce(g, s);

@@ -295,6 +295,48 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
   }
 }
 
+// tile / slab partials [B][nslabs][G][2] -> per-sample scale[c] = rstd*gamma[c], shift[c] = beta[c] - mean*rstd*gamma[c]
+// in global memory: a GroupNorm folded into the epilogue of the GEMM that re-computes its input (engine_unet: do_cond)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nslabs, int rows_per_sample,
+                                                          int C, int G, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int ld) {
+  __shared__ double s_pa[256], s_pq[256];
+  __shared__ float s_mean[32], s_rstd[32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int parts = 256 / G, gi = t % G, p = t / G;
+  double a = 0.0, q = 0.0;
+  if (p < parts)
+    for (int s = p; s < nslabs; s += parts) {
+      const float2 v = *(const float2*)(partial + (((long)b * nslabs + s) * G + gi) * 2);
+      a += (double)v.x;
+      q += (double)v.y;
+    }
+  s_pa[t] = a;
+  s_pq[t] = q;
+  __syncthreads();
+  if (t < G) {
+    a = q = 0.0;
+    for (int k = 0; k < parts; ++k) {
+      a += s_pa[k * G + t];
+      q += s_pq[k * G + t];
+    }
+    const double n = (double)rows_per_sample * (double)(C / G);
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[t] = (float)mean;
+    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = t; c < C; c += 256) {
+    const float sc = s_rstd[c / cpg] * gamma[c];
+    scale[(long)b * ld + c] = sc;
+    shift[(long)b * ld + c] = beta[c] - s_mean[c / cpg] * sc;
+  }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -388,6 +430,15 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
   else
     hipLaunchKernelGGL((gn_group_kernel<1024, 16>), grid, dim3(1024), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps,
                        act, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_gn_finalize(const float* partial, int B, int nslabs, int rows_per_sample, int C, int G, const float* gamma,
+                       const float* beta, float eps, float* scale, float* shift, int ld, hipStream_t s) {
+  if (G > 32 || C % G) return mvd_fail("gn_finalize: unsupported channel/group count");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, nslabs, rows_per_sample, C, G, gamma, beta, eps,
+                     scale, shift, ld);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

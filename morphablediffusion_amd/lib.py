@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvd_hip.so")
+# MVD_LIB_PATH: A/B timing of two builds of the same ABI (development aid)
+LIB_PATH = os.environ.get("MVD_LIB_PATH", os.path.join(_HERE, "libmvd_hip.so"))
 
 SYMBOLS = [
     "mvd_create", "mvd_destroy", "mvd_last_error", "mvd_upload_weight", "mvd_finalize_weights", "mvd_unet_forward",
