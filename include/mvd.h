@@ -128,6 +128,12 @@ int mvd_op_conv3d(mvd_ctx* ctx, const float* x_ncdhw, int B, int Cin, int D, int
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);
+/* First-stage decoder.  Replaces AutoencoderKL.decode (ldm/models/autoencoder.py:330-333 =
+ * post_quant_conv + Decoder.forward, ldm/modules/diffusionmodules/model.py:535-568) for a batch of latents:
+ * z [B, embed_dim, h, w] fp32 NCHW on the device (already divided by the 0.18215 scale factor, as
+ * decode_first_stage does, morphable_diffusion.py:468-471) -> out [B, out_ch, 8h, 8w] fp32 NCHW.  Needs the
+ * first_stage_model.decoder.* and first_stage_model.post_quant_conv.* tensors uploaded before finalize. */
+int mvd_vae_decode(mvd_ctx* ctx, const float* z, int B, int h, int w, float* out, void* stream);
 /* in-situ timing of the dominant kernel: while enabled, every launch of conv3_dma_kernel<160,16,16> (the level-32
  * 3x3 convs of the UNet) is bracketed by HIP events on its launch stream; read returns the summed kernel time, the
  * summed algorithmic FLOPs and the launch count since the last enable (it synchronises on the recorded events) */

@@ -116,8 +116,9 @@ int mvd_upload_weight(mvd_ctx* c, const char* name, const float* data, const int
   if (!c || !name || !data) return mvd_fail("mvd_upload_weight: null argument");
   if (c->finalized) return mvd_fail("mvd_upload_weight: weights already finalized");
   const std::string k(name);
-  if (k.rfind("model.diffusion_model.", 0) != 0 && k.rfind("spatial_volume.", 0) != 0 && k.rfind("time_embed.", 0) != 0)
-    return 0;  // VAE / CLIP / schedule buffers: not on this path
+  if (k.rfind("model.diffusion_model.", 0) != 0 && k.rfind("spatial_volume.", 0) != 0 && k.rfind("time_embed.", 0) != 0 &&
+      k.rfind("first_stage_model.decoder.", 0) != 0 && k.rfind("first_stage_model.post_quant_conv.", 0) != 0)
+    return 0;  // VAE encoder / CLIP / schedule buffers: not on this path
   HIP_CHECK_RET(hipSetDevice(c->device));
   RawTensor t;
   t.numel = 1;
@@ -460,6 +461,12 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
   *ms_out = ms / (float)iters;
   c->ws.off = mark;
   return 0;
+}
+
+int mvd_vae_decode(mvd_ctx* c, const float* z, int B, int h, int w, float* out, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (!z || !out || B <= 0) return mvd_fail("mvd_vae_decode: bad argument");
+  return engine_vae_decode(c, z, B, h, w, out, S(stream));
 }
 
 int mvd_probe_enable(mvd_ctx* c, int on) {

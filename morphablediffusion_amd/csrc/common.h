@@ -119,6 +119,7 @@ int launch_layernorm(const float* x, int rows, int C, const float* gamma, const 
                      half_t* out, hipStream_t s);
 int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
                      int heads, int d, hipStream_t s);
+int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st);
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
                       hipStream_t s);
 int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,

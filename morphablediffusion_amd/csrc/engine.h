@@ -48,6 +48,28 @@ struct CondW {
   half_t* relu_beta = nullptr;  // [4*Cc] z row for an all-zero context (CFG uncond half)
   int dim = 0, Cc = 0, I = 0;
 };
+// first-stage decoder (AutoencoderKL.decode): ResnetBlock / AttnBlock / Upsample of
+// ldm/modules/diffusionmodules/model.py
+struct VaeResW {
+  NormW n1, n2;
+  ConvW c1, c2, skip;
+  bool has_skip = false;
+  int cin = 0, cout = 0;
+};
+struct VaeW {
+  bool present = false;
+  int ch = 0, out_ch = 0, zc = 0, embed = 0, block_in = 0, nlev = 0;
+  ConvW post_quant;                // 1x1 conv embed -> zc (Cin padded to 8)
+  ConvW conv_in, conv_out;         // conv_in: Cin padded to 8; conv_out: N padded to 4
+  NormW norm_out;
+  VaeResW mid1, mid2;
+  NormW attn_norm;
+  ConvW attn_q, attn_k, attn_v, attn_proj;  // attn_v: used as the A operand of the swapped GEMM (V^T = W_v X^T);
+                                            // its bias is folded into attn_proj.bias (softmax rows sum to 1)
+  std::vector<std::vector<VaeResW>> up;     // up[level][block], level = index in ch_mult
+  std::vector<ConvW> up_conv;               // up_conv[level] (level > 0), parity-folded
+};
+
 struct UOp {
   int kind = 0;  // 0 conv_in, 1 res, 2 st, 3 down, 4 up
   int idx = 0;   // index into the per-kind weight vectors
@@ -114,6 +136,7 @@ struct mvd_ctx {
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
 
+  VaeW vae;
   // UNet
   LinW te0, te2, emb_all;
   int emb_total = 0;
@@ -151,6 +174,8 @@ struct mvd_ctx {
 
 // engine_weights.hip
 int engine_finalize(mvd_ctx* c);
+// engine_vae.hip: AutoencoderKL.decode on z [B, embed, h, w] (NCHW fp32) -> [B, out_ch, 8h, 8w]
+int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, float* out_nchw, hipStream_t s);
 // engine_unet.hip
 struct Ctx5 {  // channels-last context volume of one level for the first n_ctx samples
   const void* p = nullptr;
@@ -178,6 +203,7 @@ struct GemmArgs {
   int out_f32 = 1, ldc = 0;
   const float* rowbias = nullptr;
   int rb_ld = 0;
+  float alpha = 1.0f;  // scale on the accumulator before the biases
   const float* rowscale = nullptr;  // per-sample per-column scale on the accumulator (folded GroupNorm)
   int rs_ld = 0;
   float* gn_partial = nullptr;      // statistics-only pass: per-tile (sum, sumsq) per group, nothing stored

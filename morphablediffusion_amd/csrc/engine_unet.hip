@@ -35,6 +35,7 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.bias = ga.use_bias ? ga.w->bias : nullptr;
   g.rowbias = ga.rowbias;
   g.rb_ld = ga.rb_ld;
+  g.alpha = ga.alpha;
   g.rowscale = ga.rowscale;
   g.rs_ld = ga.rs_ld;
   g.gn_partial = ga.gn_partial;

@@ -1,0 +1,167 @@
+// First-stage decoder executor: AutoencoderKL.decode of the reference
+// (ldm/models/autoencoder.py:330-333; Decoder.forward ldm/modules/diffusionmodules/model.py:535-568) for a batch of
+// latents, on the same kernels as the UNet: GroupNorm(32, eps 1e-6)+swish -> LDS-halo 3x3 conv with the residual in
+// the epilogue, 1x1 shortcut convs, parity-folded upsample convs.  The single-head attention of the middle block has
+// d = 512 (beyond the flash kernel's register tile), so it runs as GEMMs per sample: S = q k^T (alpha = C^-1/2) ->
+// row softmax -> O = P V with V^T produced by the swapped GEMM; the v bias is folded into proj_out's bias (softmax
+// rows sum to 1).  Layout: channels-last, residual stream fp32, operand-only tensors fp16 (as in the UNet).
+#include "engine.h"
+
+namespace {
+
+// ResnetBlock.forward (model.py:121-141, temb = None): x + conv2(swish(GN(conv1(swish(GN(x))))))
+int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, int H, int W, hipStream_t s) {
+  const size_t mark = c->ws.off;
+  const size_t rows = (size_t)B * H * W;
+  half_t* a1 = ws_alloc<half_t>(c, rows * r.cin);
+  float* h1 = ws_alloc<float>(c, rows * r.cout);
+  half_t* a2 = ws_alloc<half_t>(c, rows * r.cout);
+  WS_CHECK(a1 && h1 && a2);
+  RET_IF(run_group_norm(c, in, r.cin, B, H * W, r.n1, 32, 1e-6f, ACT_SILU, nullptr, a1, r.cin, s));
+  GemmArgs g;
+  g.a = a1; g.lda = r.cin; g.w = &r.c1; g.out = h1; g.ldc = r.cout;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  RET_IF(run_group_norm(c, h1, r.cout, B, H * W, r.n2, 32, 1e-6f, ACT_SILU, nullptr, a2, r.cout, s));
+  const float* resid = in;
+  if (r.has_skip) {  // nin_shortcut: 1x1 conv on the fp32 input
+    float* sk = ws_alloc<float>(c, rows * r.cout);
+    WS_CHECK(sk);
+    GemmArgs gs;
+    gs.a = in; gs.a_f32 = 1; gs.lda = r.cin; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
+    RET_IF(run_linear(c, gs, B, (int)rows, s));
+    resid = sk;
+  }
+  g = GemmArgs();
+  g.a = a2; g.lda = r.cout; g.w = &r.c2; g.out = out; g.ldc = r.cout; g.resid = resid; g.ldr = r.cout;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// AttnBlock.forward (model.py:178-202)
+int vae_attn(mvd_ctx* c, const VaeW& v, const float* in, float* out, int B, int HW, hipStream_t s) {
+  const size_t mark = c->ws.off;
+  const int C = v.attn_norm.C;
+  const size_t rows = (size_t)B * HW;
+  half_t* hn = ws_alloc<half_t>(c, rows * C);
+  half_t* q = ws_alloc<half_t>(c, rows * C);
+  half_t* k = ws_alloc<half_t>(c, rows * C);
+  half_t* vt = ws_alloc<half_t>(c, rows * C);            // per sample [C][HW]
+  float* sc = ws_alloc<float>(c, rows * HW);              // per sample [HW][HW]
+  half_t* pr = ws_alloc<half_t>(c, rows * HW);
+  half_t* ao = ws_alloc<half_t>(c, rows * C);
+  WS_CHECK(hn && q && k && vt && sc && pr && ao);
+  RET_IF(run_group_norm(c, in, C, B, HW, v.attn_norm, 32, 1e-6f, ACT_NONE, nullptr, hn, C, s));
+  GemmArgs g;
+  g.a = hn; g.lda = C; g.w = &v.attn_q; g.out = q; g.out_f32 = 0; g.ldc = C;
+  RET_IF(run_linear(c, g, B, (int)rows, s));
+  g = GemmArgs();
+  g.a = hn; g.lda = C; g.w = &v.attn_k; g.out = k; g.out_f32 = 0; g.ldc = C;
+  RET_IF(run_linear(c, g, B, (int)rows, s));
+  const float scale = 1.0f / sqrtf((float)C);
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * HW;
+    // V^T = W_v X^T: the weight matrix is the "activation" operand, this sample's tokens are the "weights"
+    ConvW xw;
+    xw.w = hn + o * C; xw.N = HW; xw.Cin = C; xw.taps = 1;
+    g = GemmArgs();
+    g.a = v.attn_v.w; g.lda = C; g.w = &xw; g.out = vt + o * C; g.out_f32 = 0; g.ldc = HW; g.use_bias = false;
+    RET_IF(run_linear(c, g, 1, C, s));
+    // S = q k^T * C^-1/2
+    ConvW kw;
+    kw.w = k + o * C; kw.N = HW; kw.Cin = C; kw.taps = 1;
+    g = GemmArgs();
+    g.a = q + o * C; g.lda = C; g.w = &kw; g.out = sc + o * HW; g.ldc = HW; g.use_bias = false; g.alpha = scale;
+    RET_IF(run_linear(c, g, 1, HW, s));
+  }
+  RET_IF(launch_softmax_rows(sc, (long)rows, HW, pr, s));
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * HW;
+    ConvW vw;
+    vw.w = vt + o * C; vw.N = C; vw.Cin = HW; vw.taps = 1;
+    g = GemmArgs();
+    g.a = pr + o * HW; g.lda = HW; g.w = &vw; g.out = ao + o * C; g.out_f32 = 0; g.ldc = C; g.use_bias = false;
+    RET_IF(run_linear(c, g, 1, HW, s));
+  }
+  g = GemmArgs();
+  g.a = ao; g.lda = C; g.w = &v.attn_proj; g.out = out; g.ldc = C; g.resid = in; g.ldr = C;
+  RET_IF(run_linear(c, g, B, (int)rows, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+}  // namespace
+
+int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, float* out_nchw, hipStream_t s) {
+  const VaeW& v = c->vae;
+  if (!v.present) return mvd_fail("first-stage decoder weights not uploaded / finalized");
+  if ((h % 16) || (w % 16)) return mvd_fail("vae_decode: latent height and width must be multiples of 16");
+  const size_t mark = c->ws.off;
+  int H = h, W = w;
+  size_t rows = (size_t)B * H * W;
+  // post_quant_conv (1x1, embed -> z_channels), written into an 8-channel zero-padded tensor for conv_in
+  float* zin = ws_alloc<float>(c, rows * 8);
+  float* x0 = ws_alloc<float>(c, rows * 8);
+  WS_CHECK(zin && x0);
+  RET_IF(launch_nchw_to_nhwc(z_nchw, B, v.embed, H * W, zin, 8, 8, s));
+  HIP_CHECK_RET(hipMemsetAsync(x0, 0, rows * 8 * sizeof(float), s));
+  GemmArgs g;
+  g.a = zin; g.a_f32 = 1; g.lda = 8; g.w = &v.post_quant; g.out = x0; g.ldc = 8;
+  RET_IF(run_linear(c, g, B, (int)rows, s));
+  // ping-pong buffers sized for the largest level
+  size_t maxel = 0;
+  {
+    int hh = H, ww = W, ch = v.block_in;
+    maxel = (size_t)B * hh * ww * ch;
+    for (int l = v.nlev - 1; l >= 0; --l) {
+      for (auto& r : v.up[l]) {
+        ch = r.cout;
+        const size_t e = (size_t)B * hh * ww * (r.cin > r.cout ? r.cin : r.cout);
+        if (e > maxel) maxel = e;
+      }
+      if (l > 0) {
+        hh *= 2;
+        ww *= 2;
+        const size_t e = (size_t)B * hh * ww * ch;
+        if (e > maxel) maxel = e;
+      }
+    }
+  }
+  float* bufA = ws_alloc<float>(c, maxel);
+  float* bufB = ws_alloc<float>(c, maxel);
+  WS_CHECK(bufA && bufB);
+  float *cur = bufA, *nxt = bufB;
+  auto swap = [&]() { float* t = cur; cur = nxt; nxt = t; };
+  g = GemmArgs();
+  g.a = x0; g.a_f32 = 1; g.lda = 8; g.w = &v.conv_in; g.out = cur; g.ldc = v.block_in;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  RET_IF(vae_res(c, v.mid1, cur, nxt, B, H, W, s)); swap();
+  RET_IF(vae_attn(c, v, cur, nxt, B, H * W, s)); swap();
+  RET_IF(vae_res(c, v.mid2, cur, nxt, B, H, W, s)); swap();
+  int ch = v.block_in;
+  for (int l = v.nlev - 1; l >= 0; --l) {
+    for (auto& r : v.up[l]) {
+      RET_IF(vae_res(c, r, cur, nxt, B, H, W, s)); swap();
+      ch = r.cout;
+    }
+    if (l > 0) {  // Upsample: nearest x2 + conv3x3 (model.py:53-57)
+      g = GemmArgs();
+      g.a = cur; g.a_f32 = 1; g.lda = ch; g.w = &v.up_conv[l]; g.out = nxt; g.ldc = ch;
+      RET_IF(run_upconv2d(c, g, B, H, W, s));  // always the parity-folded form: results do not depend on the batch size
+      swap();
+      H *= 2;
+      W *= 2;
+    }
+  }
+  rows = (size_t)B * H * W;
+  half_t* a = ws_alloc<half_t>(c, rows * ch);
+  float* o4 = ws_alloc<float>(c, rows * 4);
+  WS_CHECK(a && o4);
+  RET_IF(run_group_norm(c, cur, ch, B, H * W, v.norm_out, 32, 1e-6f, ACT_SILU, nullptr, a, ch, s));
+  g = GemmArgs();
+  g.a = a; g.lda = ch; g.w = &v.conv_out; g.out = o4; g.ldc = 4;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  RET_IF(launch_nhwc_to_nchw(o4, 4, B, v.out_ch, H * W, out_nchw, s));
+  c->ws.off = mark;
+  return 0;
+}

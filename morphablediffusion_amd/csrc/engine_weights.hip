@@ -202,6 +202,109 @@ int build_frustum_block(mvd_ctx* c, const std::string& p, const char* norm_name,
 
 }  // namespace
 
+// ---------------- first-stage decoder: shapes are read off the uploaded tensors (no extra config struct) ----------
+int build_vae_res(mvd_ctx* c, const std::string& p, VaeResW* r) {
+  RawTensor* w1;
+  RET_IF(get_raw(c, p + ".conv1.weight", &w1));
+  r->cout = (int)w1->shape[0];
+  r->cin = (int)w1->shape[1];
+  RET_IF(load_norm(c, p + ".norm1", &r->n1));
+  RET_IF(pack_conv(c, p + ".conv1.weight", p + ".conv1.bias", false, false, &r->c1));
+  RET_IF(load_norm(c, p + ".norm2", &r->n2));
+  RET_IF(pack_conv(c, p + ".conv2.weight", p + ".conv2.bias", false, false, &r->c2));
+  r->has_skip = c->raw.count(p + ".nin_shortcut.weight") > 0;
+  if (r->has_skip) RET_IF(pack_conv(c, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", false, false, &r->skip));
+  else if (r->cin != r->cout) return mvd_fail("VAE ResnetBlock changes width but has no nin_shortcut (conv_shortcut is not used by the reference config)");
+  return 0;
+}
+
+__global__ void vae_fold_v_bias_kernel(const float* __restrict__ wp, const float* __restrict__ bv, const float* __restrict__ bp,
+                                       int C, float* __restrict__ out) {
+  // out = W_p b_v + b_p : softmax rows sum to 1, so attention(v + b_v) = attention(v) + b_v
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  double acc = bp[i];
+  for (int j = 0; j < C; ++j) acc += (double)wp[(long)i * C + j] * (double)bv[j];
+  out[i] = (float)acc;
+}
+
+int build_vae(mvd_ctx* c) {
+  const std::string V = "first_stage_model.", D = V + "decoder.";
+  VaeW& v = c->vae;
+  RawTensor *co, *ci, *pq;
+  RET_IF(get_raw(c, D + "conv_out.weight", &co));
+  RET_IF(get_raw(c, D + "conv_in.weight", &ci));
+  RET_IF(get_raw(c, V + "post_quant_conv.weight", &pq));
+  v.out_ch = (int)co->shape[0];
+  v.ch = (int)co->shape[1];
+  v.block_in = (int)ci->shape[0];
+  v.zc = (int)ci->shape[1];
+  v.embed = (int)pq->shape[1];
+  if (v.out_ch > 4 || v.zc > 8 || (v.zc & 3) || v.embed > 8)
+    return mvd_fail("VAE decoder: out_ch <= 4, z_channels in {4, 8} and embed_dim <= 8 expected");
+  RET_IF(pack_conv(c, V + "post_quant_conv.weight", V + "post_quant_conv.bias", false, false, &v.post_quant, 8));
+  RET_IF(pack_conv(c, D + "conv_in.weight", D + "conv_in.bias", false, false, &v.conv_in, 8));
+  RET_IF(build_vae_res(c, D + "mid.block_1", &v.mid1));
+  RET_IF(build_vae_res(c, D + "mid.block_2", &v.mid2));
+  RET_IF(load_norm(c, D + "mid.attn_1.norm", &v.attn_norm));
+  RET_IF(pack_conv(c, D + "mid.attn_1.q.weight", D + "mid.attn_1.q.bias", false, false, &v.attn_q));
+  RET_IF(pack_conv(c, D + "mid.attn_1.k.weight", D + "mid.attn_1.k.bias", false, false, &v.attn_k));
+  RET_IF(pack_conv(c, D + "mid.attn_1.v.weight", "", false, false, &v.attn_v));
+  RET_IF(pack_conv(c, D + "mid.attn_1.proj_out.weight", "", false, false, &v.attn_proj));
+  {
+    RawTensor *wp, *bv, *bp;
+    RET_IF(get_raw(c, D + "mid.attn_1.proj_out.weight", &wp));
+    RET_IF(get_raw(c, D + "mid.attn_1.v.bias", &bv));
+    RET_IF(get_raw(c, D + "mid.attn_1.proj_out.bias", &bp));
+    const int C = (int)bp->numel;
+    RET_IF(dmalloc(c, (void**)&v.attn_proj.bias, C * sizeof(float)));
+    hipLaunchKernelGGL(vae_fold_v_bias_kernel, dim3(cdiv(C, 128)), dim3(128), 0, 0, wp->d, bv->d, bp->d, C, v.attn_proj.bias);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  v.nlev = 0;
+  while (c->raw.count(D + "up." + std::to_string(v.nlev) + ".block.0.conv1.weight")) ++v.nlev;
+  if (v.nlev < 1) return mvd_fail("VAE decoder: no up blocks uploaded");
+  v.up.assign(v.nlev, {});
+  v.up_conv.assign(v.nlev, ConvW());
+  for (int l = 0; l < v.nlev; ++l) {
+    const std::string L = D + "up." + std::to_string(l);
+    for (int i = 0; c->raw.count(L + ".block." + std::to_string(i) + ".conv1.weight"); ++i) {
+      VaeResW r;
+      RET_IF(build_vae_res(c, L + ".block." + std::to_string(i), &r));
+      v.up[l].push_back(r);
+    }
+    if (l > 0) {
+      ConvW& uc = v.up_conv[l];
+      RET_IF(pack_conv(c, L + ".upsample.conv.weight", L + ".upsample.conv.bias", false, false, &uc));
+      RawTensor* r;
+      RET_IF(get_raw(c, L + ".upsample.conv.weight", &r));
+      RET_IF(dmalloc(c, (void**)&uc.w_up, (size_t)16 * uc.N * uc.Cin * sizeof(half_t)));
+      RET_IF(launch_pack_upconv_weight(r->d, uc.N, uc.Cin, uc.w_up, 0));
+    }
+  }
+  RET_IF(load_norm(c, D + "norm_out", &v.norm_out));
+  {  // conv_out with N padded to 4 (16-byte epilogue stores): a zero fourth filter and bias
+    RawTensor pad, padb, *b;
+    RET_IF(get_raw(c, D + "conv_out.bias", &b));
+    const size_t per = co->numel / co->shape[0];
+    pad.shape = {4, co->shape[1], co->shape[2], co->shape[3]};
+    pad.numel = 4 * per;
+    HIP_CHECK_RET(hipMalloc((void**)&pad.d, pad.numel * sizeof(float)));
+    HIP_CHECK_RET(hipMemset(pad.d, 0, pad.numel * sizeof(float)));
+    HIP_CHECK_RET(hipMemcpy(pad.d, co->d, co->numel * sizeof(float), hipMemcpyDeviceToDevice));
+    padb.shape = {4};
+    padb.numel = 4;
+    HIP_CHECK_RET(hipMalloc((void**)&padb.d, 4 * sizeof(float)));
+    HIP_CHECK_RET(hipMemset(padb.d, 0, 4 * sizeof(float)));
+    HIP_CHECK_RET(hipMemcpy(padb.d, b->d, b->numel * sizeof(float), hipMemcpyDeviceToDevice));
+    c->raw[D + "conv_out.weight.pad4"] = pad;
+    c->raw[D + "conv_out.bias.pad4"] = padb;
+    RET_IF(pack_conv(c, D + "conv_out.weight.pad4", D + "conv_out.bias.pad4", false, false, &v.conv_out));
+  }
+  v.present = true;
+  return 0;
+}
+
 int engine_finalize(mvd_ctx* c) {
   const std::string U = "model.diffusion_model.";
   const mvd_unet_config& u = c->u;
@@ -212,7 +315,10 @@ int engine_finalize(mvd_ctx* c) {
   const bool has_unet = c->raw.count(U + "time_embed.0.weight") > 0;
   const bool has_cond = c->raw.count("spatial_volume.target_encoder.init_conv.weight") > 0;
   const bool has_step = c->raw.count("time_embed.0.weight") > 0;
-  if (!has_unet && !has_cond) return mvd_fail("finalize: no UNet and no spatial_volume weights were uploaded");
+  const bool has_vae = c->raw.count("first_stage_model.decoder.conv_in.weight") > 0;
+  if (!has_unet && !has_cond && !has_vae)
+    return mvd_fail("finalize: no UNet, spatial_volume or first-stage decoder weights were uploaded");
+  if (has_vae) RET_IF(build_vae(c));
   // ---------------- UNet plan (openaimodel.py:535-720) ----------------
   auto build_unet = [&]() -> int {
   RET_IF(pack_lin(c, U + "time_embed.0.weight", U + "time_embed.0.bias", &c->te0));

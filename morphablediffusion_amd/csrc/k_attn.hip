@@ -169,7 +169,53 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk
   }
 }
 
+// rows of fp32 scores -> fp16 probabilities (single-head attention of the first-stage decoder: the scores come from a
+// GEMM because d = 512 does not fit the flash kernel's register tile); one workgroup per row, cols <= 4096
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int cols, half_t* __restrict__ p) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float* sr = s + row * cols;
+  half_t* pr = p + row * cols;
+  float v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    v[i] = c < cols ? sr[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = __expf(v[i] - mx);
+    sum += v[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < cols) pr[c] = (half_t)(v[i] * inv);
+  }
+}
+
 }  // namespace
+
+int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st) {
+  if (cols > 4096 || rows > 0x7FFFFFFF) return mvd_fail("softmax_rows: cols <= 4096 expected");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
                      int heads, int d, hipStream_t s) {

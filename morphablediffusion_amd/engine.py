@@ -64,6 +64,7 @@ class Engine:
     # ---- weights -------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing."""
+        self.has_vae_decoder = any(k.startswith("first_stage_model.decoder.") for k in sd)
         for k, v in sd.items():
             if not torch.is_tensor(v) or not v.dtype.is_floating_point:
                 continue
@@ -261,3 +262,14 @@ class Engine:
         ms, fl, n = C.c_double(0), C.c_double(0), C.c_int(0)
         L.check(self.lib.mvd_probe_read(self._ctx, C.byref(ms), C.byref(fl), C.byref(n)))
         return ms.value, fl.value, n.value
+
+    def vae_decode(self, z):
+        """AutoencoderKL.decode (autoencoder.py:330-333) for a batch of latents z [B,4,h,w] (already divided by the
+        first-stage scale factor) -> [B,3,8h,8w]; needs the first_stage_model.decoder.* weights in load_state_dict."""
+        if not getattr(self, "has_vae_decoder", False):
+            raise L.MvdError("first-stage decoder weights were not part of the uploaded state_dict")
+        z = _f32(z, self.device)
+        B, _, h, w = z.shape
+        out = torch.empty(B, 3, 8 * h, 8 * w, device=self.device)
+        L.check(self.lib.mvd_vae_decode(self._ctx, L.ptr(z), B, h, w, L.ptr(out), _stream()))
+        return out

@@ -217,8 +217,12 @@ class SyncMultiviewDiffusion(nn.Module):
             return z.detach() * self.first_stage_scale_factor
 
     def decode_first_stage(self, z):
+        """morphable_diffusion.py:468-471.  When the checkpoint's first_stage_model.decoder.* tensors were loaded the
+        decoder runs in the HIP engine (any batch size: pass all views at once); otherwise in the injected module."""
+        if getattr(self.engine, "has_vae_decoder", False):
+            return self.engine.vae_decode(z / self.first_stage_scale_factor)
         if self.first_stage_model is None:
-            raise RuntimeError("no first_stage_model injected (the frozen VAE stays in PyTorch)")
+            raise RuntimeError("no first_stage_model injected and no first_stage_model.decoder weights loaded")
         with torch.no_grad():
             return self.first_stage_model.decode(z / self.first_stage_scale_factor)
 
@@ -245,8 +249,12 @@ class SyncMultiviewDiffusion(nn.Module):
         _, clip_embed, input_info = self.prepare(batch)
         x_sample, inter = sampler.sample(input_info, clip_embed, unconditional_scale=cfg_scale,
                                          log_every_t=inter_interval, batch_view_num=batch_view_num, batch=batch)
-        N = x_sample.shape[1]
-        x_sample = torch.stack([self.decode_first_stage(x_sample[:, ni]) for ni in range(N)], 1)
+        B, N = x_sample.shape[:2]
+        if getattr(self.engine, "has_vae_decoder", False):  # all views in one batched decode
+            img = self.decode_first_stage(x_sample.reshape(B * N, *x_sample.shape[2:]))
+            x_sample = img.reshape(B, N, *img.shape[1:])
+        else:
+            x_sample = torch.stack([self.decode_first_stage(x_sample[:, ni]) for ni in range(N)], 1)
         if return_inter_results:
             inter = torch.stack(inter["x_inter"], 2)
             T = inter.shape[2]

@@ -305,3 +305,62 @@ def full_manifest(ucfg: UNetConfig, vcfg: VolumeConfig) -> Dict[str, Tuple[int, 
     m.update(volume_manifest(vcfg))
     m.update(time_embed_manifest(vcfg.time_dim))
     return m
+
+
+# ---------------------------------------------------------------------------------------------------------
+# First-stage decoder: AutoencoderKL.decode = post_quant_conv + Decoder
+# (ldm/models/autoencoder.py:330-333, ldm/modules/diffusionmodules/model.py:462-568)
+# ---------------------------------------------------------------------------------------------------------
+VAE_PREFIX = "first_stage_model."
+
+
+@dataclass(frozen=True)
+class VaeConfig:
+    """ddconfig of morphable_diffusion.py:405-416 (decoder side)."""
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    z_channels: int = 4
+    embed_dim: int = 4
+    out_ch: int = 3
+
+
+def vae_decoder_manifest(cfg: VaeConfig = VaeConfig(), prefix: str = VAE_PREFIX) -> Dict[str, Tuple[int, ...]]:
+    ks: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(p, cin, cout, k):
+        ks[p + ".weight"] = (cout, cin, k, k)
+        ks[p + ".bias"] = (cout,)
+
+    def norm(p, c):
+        ks[p + ".weight"] = (c,)
+        ks[p + ".bias"] = (c,)
+
+    def res(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".nin_shortcut", cin, cout, 1)
+
+    d = prefix + "decoder."
+    conv(prefix + "post_quant_conv", cfg.embed_dim, cfg.z_channels, 1)
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    conv(d + "conv_in", cfg.z_channels, block_in, 3)
+    res(d + "mid.block_1", block_in, block_in)
+    norm(d + "mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(d + "mid.attn_1." + n, block_in, block_in, 1)
+    res(d + "mid.block_2", block_in, block_in)
+    for lvl in reversed(range(nres)):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for i in range(cfg.num_res_blocks + 1):
+            res(d + f"up.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            conv(d + f"up.{lvl}.upsample.conv", block_in, block_in, 3)
+    norm(d + "norm_out", block_in)
+    conv(d + "conv_out", block_in, cfg.out_ch, 3)
+    return ks

@@ -1,0 +1,65 @@
+"""GPU: first-stage decoder through the C ABI against the reference's AutoencoderKL.decode goldens
+and against the CPU oracle on a batch.
+
+Tolerance: relative L2 <= 3e-3, normalised max error <= 5e-3.  The decoder is ~30 convolutions in series with no
+normalising residual structure around them; IDEAL fp16-operand / fp32-accumulate arithmetic applied to the reference
+itself (operands of every conv and bmm rounded to fp16 on the CPU) already differs from the fp32 reference by 1.8e-3
+(ch=128) / 1.9e-3 (ch=32) relative L2 on these seeded weights, and the HIP path measures 1.8e-3 / 2.0e-3, i.e. it
+sits on that floor.  The north_star 1e-3 bound is stated for the UNet outputs, where the same arithmetic gives 8.5e-4.
+In image terms the error is below half an 8-bit step."""
+REL_VAE, MAX_VAE = 3e-3, 5e-3
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from morphablediffusion_amd.spec import UNetConfig, VaeConfig, VolumeConfig, vae_decoder_manifest
+from morphablediffusion_amd.weights import seeded_state_dict
+from tests import golden_inputs as gi
+from tests.test_gpu_model import compare
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _engine(cfg, workspace_gb):
+    from morphablediffusion_amd.engine import Engine
+    e = Engine(UNetConfig(model_channels=64), VolumeConfig(), workspace_gb=workspace_gb)
+    W = seeded_state_dict(vae_decoder_manifest(cfg), gi.WEIGHT_SEED)
+    e.load_state_dict(W)
+    return e, W
+
+
+@pytest.mark.parametrize("name,ch,ws", [("vae_small.npz", 32, 2.0), ("vae_full.npz", 128, 6.0)])
+def test_vae_decode_vs_golden(name, ch, ws):
+    g = np.load(os.path.join(G, name))
+    cfg = VaeConfig(ch=ch)
+    e, _ = _engine(cfg, ws)
+    gen = torch.Generator().manual_seed(31)
+    z = torch.randn(int(g["B"]), cfg.embed_dim, 32, 32, generator=gen) * 4.0
+    compare(e.vae_decode(z.cuda()), g, "out", rel=REL_VAE, mx=MAX_VAE)
+    e.close()
+
+
+def test_vae_decode_batch_vs_oracle():
+    """A batch of 3 latents at reduced width against the CPU oracle, plus batch invariance (1 vs 3 at a time)."""
+    from oracle import vae_oracle as V
+    cfg = VaeConfig(ch=32)
+    e, W = _engine(cfg, 3.0)
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(3, cfg.embed_dim, 32, 32, generator=gen) * 4.0
+    want = V.decode(W, cfg, z)
+    got = e.vae_decode(z.cuda()).cpu()
+    rel = ((got - want).norm() / want.norm()).item()
+    mx = ((got - want).abs().max() / want.abs().max()).item()
+    print(f"[parity] vae decode batch vs oracle: relL2={rel:.2e} maxnorm={mx:.2e}")
+    assert torch.isfinite(got).all() and rel <= REL_VAE and mx <= MAX_VAE
+    one = torch.cat([e.vae_decode(z[i:i + 1].cuda()).cpu() for i in range(3)])
+    d = ((one - got).norm() / got.norm()).item()
+    print(f"[property] vae decode 1-at-a-time vs batched: relL2={d:.2e}")
+    # not bit-identical: split-K / tile choices depend on the batch, i.e. the fp32 summation order; through ~30 layers of
+    # fp16 operand rounding a 1e-7 perturbation saturates at the rounding-noise floor itself, so two batchings are two
+    # realisations of the same noise (each ~2e-3 from the fp32 result, ~1e-3 from each other)
+    assert d <= REL_VAE
+    e.close()

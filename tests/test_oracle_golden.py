@@ -181,3 +181,17 @@ def test_step_full_width_n16():
     out = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
                           batch_view_num=bvn, noise=noise)
     check(out, g, "x_prev")
+
+
+@pytest.mark.parametrize("name,ch", [("vae_small.npz", 32), ("vae_full.npz", 128)])
+def test_vae_decoder(name, ch):
+    """First-stage decoder against the reference's AutoencoderKL.decode."""
+    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    from oracle import vae_oracle as V
+    g = load(name)
+    cfg = VaeConfig(ch=ch)
+    W = seeded_state_dict(vae_decoder_manifest(cfg), gi.WEIGHT_SEED)
+    gen = torch.Generator().manual_seed(31)
+    z = torch.randn(int(g["B"]), cfg.embed_dim, 32, 32, generator=gen) * 4.0
+    check(V.decode(W, cfg, z), g, "out")

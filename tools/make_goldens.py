@@ -197,6 +197,33 @@ def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, sta
     return hot
 
 
+def gold_vae(ns):
+    """First-stage decoder (SURVEY 8(f) rank 1): the reference's AutoencoderKL.decode on seeded weights and latents;
+    reduced width (ch=32, two latents) and the real width (ch=128, one latent)."""
+    import importlib
+    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    ae = importlib.import_module("ldm.models.autoencoder")
+    for name, cfg, B in (("vae_small.npz", VaeConfig(ch=32), 2), ("vae_full.npz", VaeConfig(), 1)):
+        dd = dict(double_z=True, z_channels=cfg.z_channels, resolution=256, in_channels=3, out_ch=cfg.out_ch, ch=cfg.ch,
+                  ch_mult=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks, attn_resolutions=[], dropout=0.0)
+        model = ae.AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=cfg.embed_dim).eval()
+        man = vae_decoder_manifest(cfg)
+        W = seeded_state_dict(man, gi.WEIGHT_SEED)
+        sd = model.state_dict()
+        dec = {k: tuple(v.shape) for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        assert {("first_stage_model." + k): v for k, v in dec.items()} == {k: tuple(v) for k, v in man.items()}
+        missing, unexpected = model.load_state_dict({k[len("first_stage_model."):]: v for k, v in W.items()}, strict=False)
+        assert not unexpected, unexpected
+        g = torch.Generator().manual_seed(31)
+        z = torch.randn(B, cfg.embed_dim, 32, 32, generator=g) * 4.0  # latents / 0.18215 have a std of about 4-5
+        with torch.no_grad():
+            t0 = time.time()
+            out = model.decode(z)
+            print(name, "decode", time.time() - t0, "s", tuple(out.shape))
+        save(name, {"out": gi.pack(out)}, {"B": B, "ch": cfg.ch})
+
+
 def gold_variants(ns):
     """The other BASELINE.json configs as parity cases, at reduced UNet width:
     config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
@@ -213,12 +240,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
+    ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     ns = ref_import.import_reference_full()
     if args.only_variants:
         gold_variants(ns)
+        return
+    if args.only_vae:
+        gold_vae(ns)
         return
     gold_basic(ns)
     gold_unet_small(ns)
