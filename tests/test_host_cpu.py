@@ -153,3 +153,43 @@ def test_view_sharded_sampler_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-2000:]
+
+
+def test_decode_first_stage_dispatch_and_vae_manifest():
+    """decode_first_stage (morphable_diffusion.py:468-471) divides by the scale factor and uses the engine's decoder
+    when first_stage_model.decoder.* was loaded, else the injected module; the decoder manifest has the reference's
+    key set (checked against the imported reference by tools/make_goldens.py --only-vae)."""
+    from morphablediffusion_amd.model import SyncMultiviewDiffusion
+    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
+
+    class Eng:
+        has_vae_decoder = True
+        def vae_decode(self, z):
+            self.seen = z
+            return z.repeat(1, 1, 8, 8)[:, :3]
+
+    class Inj:
+        def decode(self, z):
+            self.seen = z
+            return z
+
+    class Stub:
+        first_stage_scale_factor = 0.18215
+    s = Stub()
+    s.engine, s.first_stage_model = Eng(), Inj()
+    z = torch.ones(2, 4, 4, 4)
+    out = SyncMultiviewDiffusion.decode_first_stage(s, z)
+    assert out.shape == (2, 3, 32, 32) and torch.allclose(s.engine.seen, z / 0.18215)
+    s.engine.has_vae_decoder = False
+    SyncMultiviewDiffusion.decode_first_stage(s, z)
+    assert torch.allclose(s.first_stage_model.seen, z / 0.18215)
+    s.first_stage_model = None
+    with pytest.raises(RuntimeError):
+        SyncMultiviewDiffusion.decode_first_stage(s, z)
+    man = vae_decoder_manifest(VaeConfig())
+    assert len(man) == 140
+    assert man["first_stage_model.decoder.conv_in.weight"] == (512, 4, 3, 3)
+    assert man["first_stage_model.decoder.up.1.block.0.nin_shortcut.weight"] == (256, 512, 1, 1)
+    assert man["first_stage_model.decoder.up.3.upsample.conv.weight"] == (512, 512, 3, 3)
+    assert "first_stage_model.decoder.up.0.upsample.conv.weight" not in man
+    assert sum(int(np.prod(v)) for v in man.values()) == 49_490_199  # decoder + post_quant_conv parameters
