@@ -52,16 +52,7 @@ def ortho_cameras(num_views: int = 16, radius: float = 1.5, scale: float = 1.666
     return torch.stack(Ks).float(), torch.stack(RTs).float()
 
 
-def voxelize(vertices: torch.Tensor):
-    """generate_face.py:211-225: zyx voxel indices at 5 mm, grid rounded up to a multiple of 4."""
-    min_xyz = vertices.min(0).values
-    max_xyz = vertices.max(0).values
-    dhw = vertices[:, [2, 1, 0]]
-    min_dhw, max_dhw = min_xyz[[2, 1, 0]], max_xyz[[2, 1, 0]]
-    coord = torch.round((dhw - min_dhw) / VOXEL).int()
-    out_sh = torch.ceil((max_dhw - min_dhw) / VOXEL).int()
-    out_sh = (out_sh | 3) + 1
-    return coord, out_sh, torch.stack([min_xyz, max_xyz], 0)
+from .batch import voxelize  # noqa: E402  (generate_face.py:211-225; one implementation, in batch.py)
 
 
 def ellipsoid_mesh(num_vertices: int = 5023, seed: int = 1, radii=(0.22, 0.28, 0.25), dedup: bool = True):

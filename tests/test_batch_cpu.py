@@ -1,0 +1,53 @@
+"""Host-side batch construction against independent implementations: scipy's Rotation (which
+the reference calls, generate_face.py:170,208) for the camera rotations and the axis-angle exponential, and the
+virtual-camera rig the goldens were generated with."""
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as Rot
+
+from morphablediffusion_amd import batch as B
+from morphablediffusion_amd import synthetic
+
+
+def test_camera_trajectory_matches_scipy_and_synthetic_rig():
+    pos, rot = B.generate_camera_trajectory(16)
+    assert len(pos) == 16 and rot[0] == (-180, -90.0, 0) and abs(pos[0][0] + 4.5) < 1e-12
+    K, RT = B.virtual_cameras(16)
+    for i in range(16):
+        R = Rot.from_euler("xyz", np.array(rot[i]), True).as_matrix()
+        assert np.allclose(RT[i, :, :3].numpy(), R, atol=1e-6)
+        assert np.allclose(RT[i, :, 3].numpy(), -R @ np.array(pos[i]), atol=1e-5)
+    Ks, RTs = synthetic.camera_arc(16)  # the rig behind tests/golden/*
+    assert torch.allclose(K, Ks, atol=1e-4) and torch.allclose(RT, RTs, atol=1e-5)
+    K5, _ = B.virtual_cameras(4, image_size=512)
+    assert abs(K5[0, 0, 0].item() - 2 * B.FOCAL_256) < 1e-3 and K5[0, 0, 2].item() == 256.0
+
+
+def test_so3_exponential_map_matches_scipy():
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(8, 3, generator=g)
+    v[0] = torch.tensor(B.FLAME_POSE[:3])
+    R = B.so3_exponential_map(v)
+    want = Rot.from_rotvec(v.numpy().astype(np.float64)).as_matrix()
+    assert np.allclose(R.numpy(), want, atol=1e-5)
+
+
+def test_align_voxelize_and_batch_schema():
+    g = torch.Generator().manual_seed(1)
+    raw = torch.randn(500, 3, generator=g) * 0.03
+    v = B.align_flame_vertices(raw)
+    # similarity: pairwise distances scale by 1.087 * 2.5
+    d0 = (raw[0] - raw[1]).norm() * B.FLAME_SCALE * 2.5
+    assert abs((v[0] - v[1]).norm() - d0) < 1e-5
+    coord, out_sh, bounds = B.voxelize(v)
+    c2, s2, b2 = synthetic.voxelize(v)
+    assert torch.equal(coord, c2) and torch.equal(out_sh, s2) and torch.equal(bounds, b2)
+    assert coord.dtype == torch.int32 and (out_sh % 4 == 0).all() and (coord.max(0).values < out_sh).all()
+    img = torch.zeros(256, 256, 3)
+    d = B.build_batch(img, v)
+    ref = synthetic.make_batch(16, "perspective", 100)
+    assert set(ref) <= set(d)
+    for k in ref:
+        assert d[k].dim() == ref[k].dim() and d[k].dtype == ref[k].dtype, k
+    assert d["target_K"].shape == (1, 16, 4, 4) and d["target_RT"].shape == (1, 16, 3, 4)
+    assert d["input_image"].shape == (1, 256, 256, 3) and d["target_image"].shape == (1, 16, 256, 256, 3)
