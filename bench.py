@@ -92,6 +92,8 @@ def main():
 
     ucfg, vcfg = UNetConfig(), VolumeConfig(num_views=N_VIEWS)
     W = seeded_state_dict(full_manifest(ucfg, vcfg), 7)  # random-init weights of the reference architecture
+    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
+    W.update(seeded_state_dict(vae_decoder_manifest(VaeConfig()), 7))  # first-stage decoder (reported separately)
     model = SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
         view_num=N_VIEWS, image_size=256, cfg_scale=2.0, device=dev, workspace_gb=32.0)
@@ -142,6 +144,31 @@ def main():
     probe_ms, probe_flops, probe_n = model.engine.probe_read()
     model.engine.probe_enable(False)
 
+    # reported next to the headline value ("plus 50-step wall-time"): one full 50-step DDIM trajectory
+    # through SyncDDIMSampler.sample, and the first-stage decode of this rank's views
+    extras = {"ddim50_wall_s": None, "vae_decode_ms": None}
+    try:
+        gen = torch.Generator(device=dev).manual_seed(6033)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        import contextlib
+        with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):  # sample() prints like the reference does
+            x50, _ = sampler.sample(info, clip, unconditional_scale=2.0, batch_view_num=bvn, batch=batch, generator=gen)
+        torch.cuda.synchronize()
+        extras["ddim50_wall_s"] = time.perf_counter() - t1
+        zl = x50[0, lo:hi].contiguous()
+        model.decode_first_stage(zl)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        img = model.decode_first_stage(zl)
+        torch.cuda.synchronize()
+        extras["vae_decode_ms"] = 1e3 * (time.perf_counter() - t1)
+        assert torch.isfinite(img).all() and tuple(img.shape) == (nl, 3, 256, 256)
+    except Exception as exc:  # never lose the headline line to an extra
+        print(f"bench extras failed: {exc!r}", file=sys.stderr)
+
     # dominant kernel: the level-32 3x3 convs (320/640/960 -> 320 at 32x32, CFG batch of this rank), LDS-halo
     # implicit GEMM conv3_dma_kernel<160,16,16>: achieved = summed algorithmic FLOPs / summed event time of ALL its
     # launches in the timed region (the rocprofv3 --stats average of that kernel name is the same quantity).
@@ -177,6 +204,7 @@ def main():
                          "traffic_unit": "bytes/launch of the 320->320 shape, rocprofv3 --pmc (algorithmic: 64.8e6)",
                          "kernel": kdesc},
             "step_tflops": 433.9e9 * N_VIEWS / (dt / args.steps) / 1e12,
+            "ddim50_wall_s": extras["ddim50_wall_s"], "vae_decode_ms_local_views": extras["vae_decode_ms"],
         }
         if args.simulate_gpus:
             out["metric"] = f"SIMULATED per-rank step rate of a {args.simulate_gpus}-way view sharding (one rank, no collective)"
