@@ -31,7 +31,7 @@ def compare(got, g, key, rel=REL_L2, mx=MAX_N):
     assert rl2 <= rel and mxe <= mx, f"{key}: relL2={rl2:.3e} maxnorm={mxe:.3e}"
 
 
-def make_model(ucfg, vcfg, N, workspace_gb=8.0):
+def make_model(ucfg, vcfg, N, workspace_gb=8.0, extra_weights=None):
     from morphablediffusion_amd.model import SyncMultiviewDiffusion
     kw = dict(volume_dims=list(ucfg.volume_dims), image_size=ucfg.image_size, in_channels=8, out_channels=4,
               model_channels=ucfg.model_channels, attention_resolutions=[4, 2, 1], num_res_blocks=2,
@@ -41,7 +41,10 @@ def make_model(ucfg, vcfg, N, workspace_gb=8.0):
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": kw},
         scheduler_config=None, projection=vcfg.projection, view_num=N, image_size=vcfg.input_image_size, cfg_scale=2.0,
         batch_view_num=4, sample_steps=50, workspace_gb=workspace_gb)
-    m.load_state_dict(gi.full_weights(ucfg, vcfg))
+    W = gi.full_weights(ucfg, vcfg)
+    if extra_weights:
+        W.update(extra_weights)
+    m.load_state_dict(W)
     return m
 
 
