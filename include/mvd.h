@@ -134,6 +134,11 @@ int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters
  * decode_first_stage does, morphable_diffusion.py:468-471) -> out [B, out_ch, 8h, 8w] fp32 NCHW.  Needs the
  * first_stage_model.decoder.* and first_stage_model.post_quant_conv.* tensors uploaded before finalize. */
 int mvd_vae_decode(mvd_ctx* ctx, const float* z, int B, int h, int w, float* out, void* stream);
+/* AutoencoderKL.encode(x).parameters (autoencoder.py:324-328 = Encoder.forward model.py:434-459 + quant_conv):
+ * x [B, 3, H, W] fp32 NCHW in [-1,1] -> moments [B, 2*embed_dim, H/8, W/8] = (mean | logvar).  Sampling from the
+ * posterior (DiagonalGaussianDistribution.sample / .mode) stays host code so the RNG stream is torch's.  Needs the
+ * first_stage_model.encoder.* and first_stage_model.quant_conv.* tensors. */
+int mvd_vae_encode(mvd_ctx* ctx, const float* x, int B, int H, int W, float* moments, void* stream);
 /* in-situ timing of the dominant kernel: while enabled, every launch of conv3_dma_kernel<160,16,16> (the level-32
  * 3x3 convs of the UNet) is bracketed by HIP events on its launch stream; read returns the summed kernel time, the
  * summed algorithmic FLOPs and the launch count since the last enable (it synchronises on the recorded events) */

@@ -117,8 +117,9 @@ int mvd_upload_weight(mvd_ctx* c, const char* name, const float* data, const int
   if (c->finalized) return mvd_fail("mvd_upload_weight: weights already finalized");
   const std::string k(name);
   if (k.rfind("model.diffusion_model.", 0) != 0 && k.rfind("spatial_volume.", 0) != 0 && k.rfind("time_embed.", 0) != 0 &&
-      k.rfind("first_stage_model.decoder.", 0) != 0 && k.rfind("first_stage_model.post_quant_conv.", 0) != 0)
-    return 0;  // VAE encoder / CLIP / schedule buffers: not on this path
+      k.rfind("first_stage_model.decoder.", 0) != 0 && k.rfind("first_stage_model.post_quant_conv.", 0) != 0 &&
+      k.rfind("first_stage_model.encoder.", 0) != 0 && k.rfind("first_stage_model.quant_conv.", 0) != 0)
+    return 0;  // CLIP / loss / schedule buffers: not on this path
   HIP_CHECK_RET(hipSetDevice(c->device));
   RawTensor t;
   t.numel = 1;
@@ -467,6 +468,12 @@ int mvd_vae_decode(mvd_ctx* c, const float* z, int B, int h, int w, float* out, 
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   if (!z || !out || B <= 0) return mvd_fail("mvd_vae_decode: bad argument");
   return engine_vae_decode(c, z, B, h, w, out, S(stream));
+}
+
+int mvd_vae_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* moments, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (!x || !moments || B <= 0) return mvd_fail("mvd_vae_encode: bad argument");
+  return engine_vae_encode(c, x, B, H, W, moments, S(stream));
 }
 
 int mvd_probe_enable(mvd_ctx* c, int on) {

@@ -56,18 +56,31 @@ struct VaeResW {
   bool has_skip = false;
   int cin = 0, cout = 0;
 };
-struct VaeW {
+struct VaeAttnW {  // AttnBlock (model.py:150-202)
+  NormW norm;
+  ConvW q, k, v, proj;  // v: used as the A operand of the swapped GEMM (V^T = W_v X^T); its bias is folded into
+                        // proj.bias (softmax rows sum to 1)
+};
+struct VaeW {  // Decoder + post_quant_conv
   bool present = false;
   int ch = 0, out_ch = 0, zc = 0, embed = 0, block_in = 0, nlev = 0;
   ConvW post_quant;                // 1x1 conv embed -> zc (Cin padded to 8)
   ConvW conv_in, conv_out;         // conv_in: Cin padded to 8; conv_out: N padded to 4
   NormW norm_out;
   VaeResW mid1, mid2;
-  NormW attn_norm;
-  ConvW attn_q, attn_k, attn_v, attn_proj;  // attn_v: used as the A operand of the swapped GEMM (V^T = W_v X^T);
-                                            // its bias is folded into attn_proj.bias (softmax rows sum to 1)
+  VaeAttnW attn;
   std::vector<std::vector<VaeResW>> up;     // up[level][block], level = index in ch_mult
   std::vector<ConvW> up_conv;               // up_conv[level] (level > 0), parity-folded
+};
+struct VaeEncW {  // Encoder (double_z) + quant_conv
+  bool present = false;
+  int in_ch = 0, nlev = 0, mom = 0;         // mom = 2 * embed_dim output channels
+  ConvW conv_in, conv_out, quant;           // conv_in: Cin padded to 8
+  NormW norm_out;
+  VaeResW mid1, mid2;
+  VaeAttnW attn;
+  std::vector<std::vector<VaeResW>> down;   // down[level][block]
+  std::vector<ConvW> down_conv;             // down_conv[level] (level < nlev-1): k3 s2 on the input padded right/bottom
 };
 
 struct UOp {
@@ -137,6 +150,7 @@ struct mvd_ctx {
   std::vector<void*> owned;  // packed device allocations
 
   VaeW vae;
+  VaeEncW vae_enc;
   // UNet
   LinW te0, te2, emb_all;
   int emb_total = 0;
@@ -176,6 +190,8 @@ struct mvd_ctx {
 int engine_finalize(mvd_ctx* c);
 // engine_vae.hip: AutoencoderKL.decode on z [B, embed, h, w] (NCHW fp32) -> [B, out_ch, 8h, 8w]
 int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, float* out_nchw, hipStream_t s);
+// AutoencoderKL.encode(x).parameters: x [B, 3, H, W] -> moments [B, 2*embed, H/8, W/8]
+int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, float* moments_nchw, hipStream_t s);
 // engine_unet.hip
 struct Ctx5 {  // channels-last context volume of one level for the first n_ctx samples
   const void* p = nullptr;
@@ -204,6 +220,8 @@ struct GemmArgs {
   const float* rowbias = nullptr;
   int rb_ld = 0;
   float alpha = 1.0f;  // scale on the accumulator before the biases
+  int tap_shift = 0;   // run_conv2d 3x3: taps at offsets {-1,0,1} + tap_shift (1 = zero padding on the right/bottom only,
+                       // the first-stage encoder's Downsample: F.pad(x,(0,1,0,1)) + conv k3 s2 p0, model.py:72-76)
   const float* rowscale = nullptr;  // per-sample per-column scale on the accumulator (folded GroupNorm)
   int rs_ld = 0;
   float* gn_partial = nullptr;      // statistics-only pass: per-tile (sum, sumsq) per group, nothing stored

@@ -200,7 +200,7 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
   g.X = (g.IX - 1) / stride + 1;
   if (ga.w->taps == 9) {
     g.ntaps = 9;
-    for (int t = 0; t < 9; ++t) g.tap[t] = igemm_tap(0, t / 3 - 1, t % 3 - 1, t);
+    for (int t = 0; t < 9; ++t) g.tap[t] = igemm_tap(0, t / 3 - 1 + ga.tap_shift, t % 3 - 1 + ga.tap_shift, t);
   } else if (ga.w->taps == 1) {
     g.ntaps = 1;
   } else {

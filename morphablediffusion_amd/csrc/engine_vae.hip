@@ -39,9 +39,9 @@ int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, in
 }
 
 // AttnBlock.forward (model.py:178-202)
-int vae_attn(mvd_ctx* c, const VaeW& v, const float* in, float* out, int B, int HW, hipStream_t s) {
+int vae_attn(mvd_ctx* c, const VaeAttnW& v, const float* in, float* out, int B, int HW, hipStream_t s) {
   const size_t mark = c->ws.off;
-  const int C = v.attn_norm.C;
+  const int C = v.norm.C;
   const size_t rows = (size_t)B * HW;
   half_t* hn = ws_alloc<half_t>(c, rows * C);
   half_t* q = ws_alloc<half_t>(c, rows * C);
@@ -51,12 +51,12 @@ int vae_attn(mvd_ctx* c, const VaeW& v, const float* in, float* out, int B, int 
   half_t* pr = ws_alloc<half_t>(c, rows * HW);
   half_t* ao = ws_alloc<half_t>(c, rows * C);
   WS_CHECK(hn && q && k && vt && sc && pr && ao);
-  RET_IF(run_group_norm(c, in, C, B, HW, v.attn_norm, 32, 1e-6f, ACT_NONE, nullptr, hn, C, s));
+  RET_IF(run_group_norm(c, in, C, B, HW, v.norm, 32, 1e-6f, ACT_NONE, nullptr, hn, C, s));
   GemmArgs g;
-  g.a = hn; g.lda = C; g.w = &v.attn_q; g.out = q; g.out_f32 = 0; g.ldc = C;
+  g.a = hn; g.lda = C; g.w = &v.q; g.out = q; g.out_f32 = 0; g.ldc = C;
   RET_IF(run_linear(c, g, B, (int)rows, s));
   g = GemmArgs();
-  g.a = hn; g.lda = C; g.w = &v.attn_k; g.out = k; g.out_f32 = 0; g.ldc = C;
+  g.a = hn; g.lda = C; g.w = &v.k; g.out = k; g.out_f32 = 0; g.ldc = C;
   RET_IF(run_linear(c, g, B, (int)rows, s));
   const float scale = 1.0f / sqrtf((float)C);
   for (int b = 0; b < B; ++b) {
@@ -65,7 +65,7 @@ int vae_attn(mvd_ctx* c, const VaeW& v, const float* in, float* out, int B, int 
     ConvW xw;
     xw.w = hn + o * C; xw.N = HW; xw.Cin = C; xw.taps = 1;
     g = GemmArgs();
-    g.a = v.attn_v.w; g.lda = C; g.w = &xw; g.out = vt + o * C; g.out_f32 = 0; g.ldc = HW; g.use_bias = false;
+    g.a = v.v.w; g.lda = C; g.w = &xw; g.out = vt + o * C; g.out_f32 = 0; g.ldc = HW; g.use_bias = false;
     RET_IF(run_linear(c, g, 1, C, s));
     // S = q k^T * C^-1/2
     ConvW kw;
@@ -84,7 +84,7 @@ int vae_attn(mvd_ctx* c, const VaeW& v, const float* in, float* out, int B, int 
     RET_IF(run_linear(c, g, 1, HW, s));
   }
   g = GemmArgs();
-  g.a = ao; g.lda = C; g.w = &v.attn_proj; g.out = out; g.ldc = C; g.resid = in; g.ldr = C;
+  g.a = ao; g.lda = C; g.w = &v.proj; g.out = out; g.ldc = C; g.resid = in; g.ldr = C;
   RET_IF(run_linear(c, g, B, (int)rows, s));
   c->ws.off = mark;
   return 0;
@@ -136,7 +136,7 @@ int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, floa
   g.a = x0; g.a_f32 = 1; g.lda = 8; g.w = &v.conv_in; g.out = cur; g.ldc = v.block_in;
   RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
   RET_IF(vae_res(c, v.mid1, cur, nxt, B, H, W, s)); swap();
-  RET_IF(vae_attn(c, v, cur, nxt, B, H * W, s)); swap();
+  RET_IF(vae_attn(c, v.attn, cur, nxt, B, H * W, s)); swap();
   RET_IF(vae_res(c, v.mid2, cur, nxt, B, H, W, s)); swap();
   int ch = v.block_in;
   for (int l = v.nlev - 1; l >= 0; --l) {
@@ -162,6 +162,61 @@ int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, floa
   g.a = a; g.lda = ch; g.w = &v.conv_out; g.out = o4; g.ldc = 4;
   RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
   RET_IF(launch_nhwc_to_nchw(o4, 4, B, v.out_ch, H * W, out_nchw, s));
+  c->ws.off = mark;
+  return 0;
+}
+
+// Encoder.forward (model.py:434-459) + quant_conv (autoencoder.py:324-328); the posterior's sample()/mode() are host code
+int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, float* moments_nchw, hipStream_t s) {
+  const VaeEncW& v = c->vae_enc;
+  if (!v.present) return mvd_fail("first-stage encoder weights not uploaded / finalized");
+  const int down = 1 << (v.nlev - 1);
+  if ((H % (16 * down)) || (W % (16 * down))) return mvd_fail("vae_encode: image size must be a multiple of 16 x the downsampling factor");
+  const size_t mark = c->ws.off;
+  size_t rows = (size_t)B * H * W;
+  float* x0 = ws_alloc<float>(c, rows * 8);
+  size_t maxel = rows * (size_t)v.conv_in.N;
+  for (auto& r : v.down[0]) maxel = rows * (size_t)(r.cout > r.cin ? r.cout : r.cin) > maxel ? rows * (size_t)(r.cout > r.cin ? r.cout : r.cin) : maxel;
+  float* bufA = ws_alloc<float>(c, maxel);
+  float* bufB = ws_alloc<float>(c, maxel);
+  WS_CHECK(x0 && bufA && bufB);
+  float *cur = bufA, *nxt = bufB;
+  auto swap = [&]() { float* t = cur; cur = nxt; nxt = t; };
+  RET_IF(launch_nchw_to_nhwc(x_nchw, B, v.in_ch, H * W, x0, 8, 8, s));
+  GemmArgs g;
+  g.a = x0; g.a_f32 = 1; g.lda = 8; g.w = &v.conv_in; g.out = cur; g.ldc = v.conv_in.N;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  int ch = v.conv_in.N;
+  for (int l = 0; l < v.nlev; ++l) {
+    for (auto& r : v.down[l]) {
+      RET_IF(vae_res(c, r, cur, nxt, B, H, W, s)); swap();
+      ch = r.cout;
+    }
+    if (l < v.nlev - 1) {  // Downsample: zero pad right/bottom, conv k3 s2 (model.py:72-76)
+      g = GemmArgs();
+      g.a = cur; g.a_f32 = 1; g.lda = ch; g.w = &v.down_conv[l]; g.out = nxt; g.ldc = ch; g.tap_shift = 1;
+      RET_IF(run_conv2d(c, g, B, H, W, 2, 0, s));
+      swap();
+      H /= 2;
+      W /= 2;
+    }
+  }
+  RET_IF(vae_res(c, v.mid1, cur, nxt, B, H, W, s)); swap();
+  RET_IF(vae_attn(c, v.attn, cur, nxt, B, H * W, s)); swap();
+  RET_IF(vae_res(c, v.mid2, cur, nxt, B, H, W, s)); swap();
+  rows = (size_t)B * H * W;
+  half_t* a = ws_alloc<half_t>(c, rows * ch);
+  float* h8 = ws_alloc<float>(c, rows * v.conv_out.N);
+  float* mo = ws_alloc<float>(c, rows * v.mom);
+  WS_CHECK(a && h8 && mo);
+  RET_IF(run_group_norm(c, cur, ch, B, H * W, v.norm_out, 32, 1e-6f, ACT_SILU, nullptr, a, ch, s));
+  g = GemmArgs();
+  g.a = a; g.lda = ch; g.w = &v.conv_out; g.out = h8; g.ldc = v.conv_out.N;
+  RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
+  g = GemmArgs();
+  g.a = h8; g.a_f32 = 1; g.lda = v.conv_out.N; g.w = &v.quant; g.out = mo; g.ldc = v.mom;
+  RET_IF(run_linear(c, g, B, (int)rows, s));
+  RET_IF(launch_nhwc_to_nchw(mo, v.mom, B, v.mom, H * W, moments_nchw, s));
   c->ws.off = mark;
   return 0;
 }

@@ -228,6 +228,57 @@ __global__ void vae_fold_v_bias_kernel(const float* __restrict__ wp, const float
   out[i] = (float)acc;
 }
 
+int build_vae_attn(mvd_ctx* c, const std::string& p, VaeAttnW* a) {
+  RET_IF(load_norm(c, p + ".norm", &a->norm));
+  RET_IF(pack_conv(c, p + ".q.weight", p + ".q.bias", false, false, &a->q));
+  RET_IF(pack_conv(c, p + ".k.weight", p + ".k.bias", false, false, &a->k));
+  RET_IF(pack_conv(c, p + ".v.weight", "", false, false, &a->v));
+  RET_IF(pack_conv(c, p + ".proj_out.weight", "", false, false, &a->proj));
+  RawTensor *wp, *bv, *bp;
+  RET_IF(get_raw(c, p + ".proj_out.weight", &wp));
+  RET_IF(get_raw(c, p + ".v.bias", &bv));
+  RET_IF(get_raw(c, p + ".proj_out.bias", &bp));
+  const int C = (int)bp->numel;
+  RET_IF(dmalloc(c, (void**)&a->proj.bias, C * sizeof(float)));
+  hipLaunchKernelGGL(vae_fold_v_bias_kernel, dim3(cdiv(C, 128)), dim3(128), 0, 0, wp->d, bv->d, bp->d, C, a->proj.bias);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int build_vae_encoder(mvd_ctx* c) {
+  const std::string V = "first_stage_model.", E = V + "encoder.";
+  VaeEncW& v = c->vae_enc;
+  RawTensor *ci, *q;
+  RET_IF(get_raw(c, E + "conv_in.weight", &ci));
+  RET_IF(get_raw(c, V + "quant_conv.weight", &q));
+  v.in_ch = (int)ci->shape[1];
+  v.mom = (int)q->shape[0];
+  if (v.in_ch > 8 || (v.mom & 3) || (q->shape[1] & 7)) return mvd_fail("VAE encoder: in_channels <= 8, moments % 4 == 0 expected");
+  RET_IF(pack_conv(c, E + "conv_in.weight", E + "conv_in.bias", false, false, &v.conv_in, 8));
+  v.nlev = 0;
+  while (c->raw.count(E + "down." + std::to_string(v.nlev) + ".block.0.conv1.weight")) ++v.nlev;
+  if (v.nlev < 1) return mvd_fail("VAE encoder: no down blocks uploaded");
+  v.down.assign(v.nlev, {});
+  v.down_conv.assign(v.nlev, ConvW());
+  for (int l = 0; l < v.nlev; ++l) {
+    const std::string L = E + "down." + std::to_string(l);
+    for (int i = 0; c->raw.count(L + ".block." + std::to_string(i) + ".conv1.weight"); ++i) {
+      VaeResW r;
+      RET_IF(build_vae_res(c, L + ".block." + std::to_string(i), &r));
+      v.down[l].push_back(r);
+    }
+    if (l < v.nlev - 1) RET_IF(pack_conv(c, L + ".downsample.conv.weight", L + ".downsample.conv.bias", false, false, &v.down_conv[l]));
+  }
+  RET_IF(build_vae_res(c, E + "mid.block_1", &v.mid1));
+  RET_IF(build_vae_attn(c, E + "mid.attn_1", &v.attn));
+  RET_IF(build_vae_res(c, E + "mid.block_2", &v.mid2));
+  RET_IF(load_norm(c, E + "norm_out", &v.norm_out));
+  RET_IF(pack_conv(c, E + "conv_out.weight", E + "conv_out.bias", false, false, &v.conv_out));
+  RET_IF(pack_conv(c, V + "quant_conv.weight", V + "quant_conv.bias", false, false, &v.quant));
+  v.present = true;
+  return 0;
+}
+
 int build_vae(mvd_ctx* c) {
   const std::string V = "first_stage_model.", D = V + "decoder.";
   VaeW& v = c->vae;
@@ -246,21 +297,7 @@ int build_vae(mvd_ctx* c) {
   RET_IF(pack_conv(c, D + "conv_in.weight", D + "conv_in.bias", false, false, &v.conv_in, 8));
   RET_IF(build_vae_res(c, D + "mid.block_1", &v.mid1));
   RET_IF(build_vae_res(c, D + "mid.block_2", &v.mid2));
-  RET_IF(load_norm(c, D + "mid.attn_1.norm", &v.attn_norm));
-  RET_IF(pack_conv(c, D + "mid.attn_1.q.weight", D + "mid.attn_1.q.bias", false, false, &v.attn_q));
-  RET_IF(pack_conv(c, D + "mid.attn_1.k.weight", D + "mid.attn_1.k.bias", false, false, &v.attn_k));
-  RET_IF(pack_conv(c, D + "mid.attn_1.v.weight", "", false, false, &v.attn_v));
-  RET_IF(pack_conv(c, D + "mid.attn_1.proj_out.weight", "", false, false, &v.attn_proj));
-  {
-    RawTensor *wp, *bv, *bp;
-    RET_IF(get_raw(c, D + "mid.attn_1.proj_out.weight", &wp));
-    RET_IF(get_raw(c, D + "mid.attn_1.v.bias", &bv));
-    RET_IF(get_raw(c, D + "mid.attn_1.proj_out.bias", &bp));
-    const int C = (int)bp->numel;
-    RET_IF(dmalloc(c, (void**)&v.attn_proj.bias, C * sizeof(float)));
-    hipLaunchKernelGGL(vae_fold_v_bias_kernel, dim3(cdiv(C, 128)), dim3(128), 0, 0, wp->d, bv->d, bp->d, C, v.attn_proj.bias);
-    HIP_CHECK_RET(hipGetLastError());
-  }
+  RET_IF(build_vae_attn(c, D + "mid.attn_1", &v.attn));
   v.nlev = 0;
   while (c->raw.count(D + "up." + std::to_string(v.nlev) + ".block.0.conv1.weight")) ++v.nlev;
   if (v.nlev < 1) return mvd_fail("VAE decoder: no up blocks uploaded");
@@ -316,9 +353,11 @@ int engine_finalize(mvd_ctx* c) {
   const bool has_cond = c->raw.count("spatial_volume.target_encoder.init_conv.weight") > 0;
   const bool has_step = c->raw.count("time_embed.0.weight") > 0;
   const bool has_vae = c->raw.count("first_stage_model.decoder.conv_in.weight") > 0;
-  if (!has_unet && !has_cond && !has_vae)
+  const bool has_vae_enc = c->raw.count("first_stage_model.encoder.conv_in.weight") > 0;
+  if (!has_unet && !has_cond && !has_vae && !has_vae_enc)
     return mvd_fail("finalize: no UNet, spatial_volume or first-stage decoder weights were uploaded");
   if (has_vae) RET_IF(build_vae(c));
+  if (has_vae_enc) RET_IF(build_vae_encoder(c));
   // ---------------- UNet plan (openaimodel.py:535-720) ----------------
   auto build_unet = [&]() -> int {
   RET_IF(pack_lin(c, U + "time_embed.0.weight", U + "time_embed.0.bias", &c->te0));

@@ -65,6 +65,7 @@ class Engine:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing."""
         self.has_vae_decoder = any(k.startswith("first_stage_model.decoder.") for k in sd)
+        self.has_vae_encoder = any(k.startswith("first_stage_model.encoder.") for k in sd)
         for k, v in sd.items():
             if not torch.is_tensor(v) or not v.dtype.is_floating_point:
                 continue
@@ -272,4 +273,15 @@ class Engine:
         B, _, h, w = z.shape
         out = torch.empty(B, 3, 8 * h, 8 * w, device=self.device)
         L.check(self.lib.mvd_vae_decode(self._ctx, L.ptr(z), B, h, w, L.ptr(out), _stream()))
+        return out
+
+    def vae_encode_moments(self, x):
+        """AutoencoderKL.encode(x).parameters (autoencoder.py:324-328): x [B,3,H,W] in [-1,1] -> [B,8,H/8,W/8]
+        (mean | logvar); needs the first_stage_model.encoder.* weights in load_state_dict."""
+        if not getattr(self, "has_vae_encoder", False):
+            raise L.MvdError("first-stage encoder weights were not part of the uploaded state_dict")
+        x = _f32(x, self.device)
+        B, _, H, W = x.shape
+        out = torch.empty(B, 8, H // 8, W // 8, device=self.device)
+        L.check(self.lib.mvd_vae_encode(self._ctx, L.ptr(x), B, H, W, L.ptr(out), _stream()))
         return out

@@ -209,8 +209,14 @@ class SyncMultiviewDiffusion(nn.Module):
         return self.engine.embed_time(t)
 
     def encode_first_stage(self, x, sample=True):
+        """morphable_diffusion.py:460-466.  With first_stage_model.encoder.* loaded the encoder runs in the HIP engine and
+        only the posterior's sample()/mode() (torch RNG) stays on the host; otherwise the injected module is used."""
+        if getattr(self.engine, "has_vae_encoder", False):
+            posterior = DiagonalGaussianDistribution(self.engine.vae_encode_moments(x))
+            z = posterior.sample() if sample else posterior.mode()
+            return z.detach() * self.first_stage_scale_factor
         if self.first_stage_model is None:
-            raise RuntimeError("no first_stage_model injected (the frozen VAE stays in PyTorch)")
+            raise RuntimeError("no first_stage_model injected and no first_stage_model.encoder weights loaded")
         with torch.no_grad():
             posterior = self.first_stage_model.encode(x)
             z = posterior.sample() if sample else posterior.mode()
@@ -262,6 +268,23 @@ class SyncMultiviewDiffusion(nn.Module):
                    for ni in range(0, N, inter_view_interval)]
             return x_sample, torch.stack(res, 1)
         return x_sample
+
+
+class DiagonalGaussianDistribution:
+    """ldm/modules/distributions/distributions.py:24-37 (the part encode_first_stage uses): host code on the moments
+    the engine's encoder returns, so the random draw is torch's own."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)
+
+    def mode(self):
+        return self.mean
 
 
 class SyncDDIMSampler:

@@ -364,3 +364,46 @@ def vae_decoder_manifest(cfg: VaeConfig = VaeConfig(), prefix: str = VAE_PREFIX)
     norm(d + "norm_out", block_in)
     conv(d + "conv_out", block_in, cfg.out_ch, 3)
     return ks
+
+
+def vae_encoder_manifest(cfg: VaeConfig = VaeConfig(), prefix: str = VAE_PREFIX, in_channels: int = 3) -> Dict[str, Tuple[int, ...]]:
+    """AutoencoderKL.encode = Encoder (model.py:368-459, double_z) + quant_conv (autoencoder.py:302,324-328)."""
+    ks: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(p, cin, cout, k):
+        ks[p + ".weight"] = (cout, cin, k, k)
+        ks[p + ".bias"] = (cout,)
+
+    def norm(p, c):
+        ks[p + ".weight"] = (c,)
+        ks[p + ".bias"] = (c,)
+
+    def res(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".nin_shortcut", cin, cout, 1)
+
+    e = prefix + "encoder."
+    conv(e + "conv_in", in_channels, cfg.ch, 3)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    block_in = cfg.ch
+    for lvl in range(len(cfg.ch_mult)):
+        block_in = cfg.ch * in_mult[lvl]
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for i in range(cfg.num_res_blocks):
+            res(e + f"down.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != len(cfg.ch_mult) - 1:
+            conv(e + f"down.{lvl}.downsample.conv", block_in, block_in, 3)
+    res(e + "mid.block_1", block_in, block_in)
+    norm(e + "mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(e + "mid.attn_1." + n, block_in, block_in, 1)
+    res(e + "mid.block_2", block_in, block_in)
+    norm(e + "norm_out", block_in)
+    conv(e + "conv_out", block_in, 2 * cfg.z_channels, 3)
+    conv(prefix + "quant_conv", 2 * cfg.z_channels, 2 * cfg.embed_dim, 1)
+    return ks

@@ -61,3 +61,22 @@ def decode(W, cfg, z):
             h = _conv(W, d + f"up.{lvl}.upsample.conv", h, 1)
     h = _swish(_gn(W, d + "norm_out", h))
     return _conv(W, d + "conv_out", h, 1)
+
+
+def encode_moments(W, cfg, x):
+    """AutoencoderKL.encode(x).parameters (autoencoder.py:324-328): Encoder.forward (model.py:434-459) then quant_conv.
+    x [B,3,H,W] -> moments [B, 2*embed_dim, H/8, W/8] = (mean | logvar); the posterior's sample()/mode() are host code."""
+    e = P + "encoder."
+    h = _conv(W, e + "conv_in", x, 1)
+    nlev = len(cfg.ch_mult)
+    for lvl in range(nlev):
+        for i in range(cfg.num_res_blocks):
+            h = resnet_block(W, e + f"down.{lvl}.block.{i}", h)
+        if lvl != nlev - 1:  # Downsample (model.py:72-76): zero pad right/bottom by one, conv k3 s2 p0
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), W[e + f"down.{lvl}.downsample.conv.weight"],
+                         W[e + f"down.{lvl}.downsample.conv.bias"], stride=2)
+    h = resnet_block(W, e + "mid.block_1", h)
+    h = attn_block(W, e + "mid.attn_1", h)
+    h = resnet_block(W, e + "mid.block_2", h)
+    h = _conv(W, e + "conv_out", _swish(_gn(W, e + "norm_out", h)), 1)
+    return _conv(W, P + "quant_conv", h, 0)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from morphablediffusion_amd.spec import UNetConfig, VaeConfig, VolumeConfig, vae_decoder_manifest
+from morphablediffusion_amd.spec import UNetConfig, VaeConfig, VolumeConfig, vae_decoder_manifest, vae_encoder_manifest
 from morphablediffusion_amd.weights import seeded_state_dict
 from tests import golden_inputs as gi
 from tests.test_gpu_model import compare
@@ -27,6 +27,7 @@ def _engine(cfg, workspace_gb):
     from morphablediffusion_amd.engine import Engine
     e = Engine(UNetConfig(model_channels=64), VolumeConfig(), workspace_gb=workspace_gb)
     W = seeded_state_dict(vae_decoder_manifest(cfg), gi.WEIGHT_SEED)
+    W.update(seeded_state_dict(vae_encoder_manifest(cfg), gi.WEIGHT_SEED))
     e.load_state_dict(W)
     return e, W
 
@@ -39,6 +40,20 @@ def test_vae_decode_vs_golden(name, ch, ws):
     gen = torch.Generator().manual_seed(31)
     z = torch.randn(int(g["B"]), cfg.embed_dim, 32, 32, generator=gen) * 4.0
     compare(e.vae_decode(z.cuda()), g, "out", rel=REL_VAE, mx=MAX_VAE)
+    e.close()
+
+
+@pytest.mark.parametrize("name,ch,ws", [("vae_small.npz", 32, 3.0), ("vae_full.npz", 128, 8.0)])
+def test_vae_encode_vs_golden(name, ch, ws):
+    """Encoder + quant_conv (moments) against the reference's AutoencoderKL.encode(x).parameters."""
+    g = np.load(os.path.join(G, name))
+    cfg = VaeConfig(ch=ch)
+    e, _ = _engine(cfg, ws)
+    gen = torch.Generator().manual_seed(31)
+    B = int(g["B"])
+    torch.randn(B, cfg.embed_dim, 32, 32, generator=gen)  # the decoder golden's latent draw comes first
+    x = torch.rand(B, 3, 256, 256, generator=gen) * 2.0 - 1.0
+    compare(e.vae_encode_moments(x.cuda()), g, "moments", rel=REL_VAE, mx=MAX_VAE)
     e.close()
 
 

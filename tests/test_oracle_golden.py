@@ -195,3 +195,19 @@ def test_vae_decoder(name, ch):
     gen = torch.Generator().manual_seed(31)
     z = torch.randn(int(g["B"]), cfg.embed_dim, 32, 32, generator=gen) * 4.0
     check(V.decode(W, cfg, z), g, "out")
+
+
+@pytest.mark.parametrize("name,ch", [("vae_small.npz", 32), ("vae_full.npz", 128)])
+def test_vae_encoder(name, ch):
+    """First-stage encoder against the reference's AutoencoderKL.encode(x).parameters."""
+    from morphablediffusion_amd.spec import VaeConfig, vae_encoder_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    from oracle import vae_oracle as V
+    g = load(name)
+    cfg = VaeConfig(ch=ch)
+    W = seeded_state_dict(vae_encoder_manifest(cfg), gi.WEIGHT_SEED)
+    gen = torch.Generator().manual_seed(31)
+    B = int(g["B"])
+    torch.randn(B, cfg.embed_dim, 32, 32, generator=gen)  # the latent draw of the decoder golden comes first
+    x = torch.rand(B, 3, 256, 256, generator=gen) * 2.0 - 1.0
+    check(V.encode_moments(W, cfg, x), g, "moments")

@@ -201,17 +201,19 @@ def gold_vae(ns):
     """First-stage decoder (SURVEY 8(f) rank 1): the reference's AutoencoderKL.decode on seeded weights and latents;
     reduced width (ch=32, two latents) and the real width (ch=128, one latent)."""
     import importlib
-    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
+    from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest, vae_encoder_manifest
     from morphablediffusion_amd.weights import seeded_state_dict
     ae = importlib.import_module("ldm.models.autoencoder")
     for name, cfg, B in (("vae_small.npz", VaeConfig(ch=32), 2), ("vae_full.npz", VaeConfig(), 1)):
         dd = dict(double_z=True, z_channels=cfg.z_channels, resolution=256, in_channels=3, out_ch=cfg.out_ch, ch=cfg.ch,
                   ch_mult=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks, attn_resolutions=[], dropout=0.0)
         model = ae.AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=cfg.embed_dim).eval()
-        man = vae_decoder_manifest(cfg)
+        man = dict(vae_decoder_manifest(cfg))
+        man.update(vae_encoder_manifest(cfg))
         W = seeded_state_dict(man, gi.WEIGHT_SEED)
         sd = model.state_dict()
-        dec = {k: tuple(v.shape) for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        dec = {k: tuple(v.shape) for k, v in sd.items()
+               if k.startswith(("decoder.", "post_quant_conv.", "encoder.", "quant_conv."))}
         assert {("first_stage_model." + k): v for k, v in dec.items()} == {k: tuple(v) for k, v in man.items()}
         missing, unexpected = model.load_state_dict({k[len("first_stage_model."):]: v for k, v in W.items()}, strict=False)
         assert not unexpected, unexpected
@@ -221,7 +223,10 @@ def gold_vae(ns):
             t0 = time.time()
             out = model.decode(z)
             print(name, "decode", time.time() - t0, "s", tuple(out.shape))
-        save(name, {"out": gi.pack(out)}, {"B": B, "ch": cfg.ch})
+        x = torch.rand(B, 3, 256, 256, generator=g) * 2.0 - 1.0  # images in [-1, 1]
+        with torch.no_grad():
+            mom = model.encode(x).parameters
+        save(name, {"out": gi.pack(out), "moments": gi.pack(mom)}, {"B": B, "ch": cfg.ch})
 
 
 def gold_variants(ns):
