@@ -137,8 +137,10 @@ int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, con
       auto& s = sites[i];
       if (s[0] < 0 || s[1] < 0 || s[2] < 0 || s[0] >= shape[0] || s[1] >= shape[1] || s[2] >= shape[2])
         return mvd_fail("set_mesh: voxel coordinate outside out_sh");
-      if (!idx.emplace(key3(s[0], s[1], s[2]), i).second)
-        return mvd_fail("set_mesh: duplicate voxel coordinates (undefined in spconv; de-duplicate the mesh)");
+      // several vertices in one voxel: the FIRST one is the voxel's representative (spconv's hash table also keeps one
+      // row per voxel and resolves every neighbour lookup, the centre tap included, through it; which row wins there is
+      // a race).  Later duplicates still get an output row, identical to the representative's.
+      idx.emplace(key3(s[0], s[1], s[2]), i);
     }
     m.n_sites[lvl] = (int)sites.size();
     for (int a = 0; a < 3; ++a) m.shape[lvl][a] = shape[a];

@@ -400,10 +400,22 @@ def _strided_conv(feats, coords, shape, weight):
 
 def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net."):
     """SparseConvNet.forward network.py:85-96 (double_conv :109, stride_conv :152, triple_conv :127),
-    eval-mode BatchNorm1d(eps 1e-3).  feats [Nv,16], coords [Nv,3] (z,y,x) int, unique; returns the
-    dense [1,64,D/4,H/4,W/4] volume.  PARITY UNPINNED (spconv absent) -- see module header."""
+    eval-mode BatchNorm1d(eps 1e-3).  feats [Nv,16], coords [Nv,3] (z,y,x) int; returns the
+    dense [1,64,D/4,H/4,W/4] volume.  PARITY UNPINNED (spconv absent) -- see module header.
+    Several vertices in one voxel (real FLAME meshes at 5 mm have them): spconv's hash table keeps ONE row per voxel
+    and every neighbour lookup -- the centre tap included -- goes through it, so all rows of a voxel compute the same
+    output from that representative's feature.  Which row wins is a race in spconv; here (and in the HIP engine) the
+    FIRST occurrence is the representative, i.e. later duplicates are dropped."""
     coords = coords.long()
     shape = [int(s) for s in out_sh]
+    key = (coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]
+    seen, keep = set(), []
+    for i, k in enumerate(key.tolist()):
+        if k not in seen:
+            seen.add(k)
+            keep.append(i)
+    if len(keep) != coords.shape[0]:
+        coords, feats = coords[keep], feats[keep]
     x = feats
     for blk, n in (("conv0", 2), ("down0", 1), ("conv1", 2), ("down1", 1), ("conv2", 3)):
         for i in range(n):
