@@ -192,3 +192,35 @@ def test_spatial_volume_with_duplicate_voxels_vs_oracle():
     print(f"[parity] spatial volume with {ndup} duplicate voxels vs oracle: relL2={rel:.2e}")
     assert torch.isfinite(got).all() and want.abs().max() > 0 and rel <= 1e-4
     m.engine.close()
+
+
+def test_batch_of_two_samples_matches_single_samples():
+    """B > 1 (the eval driver's case, eval/generate_all_facescape.py): samples are looped on the host with the mesh
+    tables rebuilt per sample, so a batch must equal the samples run one by one (different meshes, latents, CLIP)."""
+    N, index = 4, 30
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    m = make_model(ucfg, vcfg, N, workspace_gb=4.0)
+    b0 = synthetic.make_batch(N, "perspective", 500, mesh_seed=1)
+    b1 = synthetic.make_batch(N, "perspective", 500, mesh_seed=2, radii=(0.2, 0.25, 0.27))
+    nv = min(b0["vertices"].shape[1], b1["vertices"].shape[1])  # same vertex count as a fixed-topology mesh has
+    def cut(b):
+        v = b["vertices"][:, :nv]
+        from morphablediffusion_amd.batch import voxelize
+        coord, out_sh, bounds = voxelize(v[0])
+        return dict(b, vertices=v, coord=coord[None], out_sh=out_sh[None], bounds=bounds[None])
+    b0, b1 = cut(b0), cut(b1)
+    both = {k: torch.cat([b0[k], b1[k]]) for k in b0}
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, N, 4, 32, 32, generator=g)
+    x_in = torch.randn(2, 4, 32, 32, generator=g) * 0.18215
+    clip = torch.randn(2, 1, 768, generator=g)
+    noise = torch.randn(2, N, 4, 32, 32, generator=g)
+    ts = torch.full((2,), int(m.sampler.ddim_timesteps[index]), dtype=torch.long, device="cuda")
+    run = lambda xb, xi, cl, ba, no, t: m.sampler.denoise_apply(xb.cuda(), {"x": xi.cuda()}, cl.cuda(), t, index, 2.0,
+                                                               batch_view_num=N, batch=to_dev(ba), noise=no.cuda())
+    out2 = run(x, x_in, clip, both, noise, ts)
+    for i, b in enumerate((b0, b1)):
+        one = run(x[i:i + 1], x_in[i:i + 1], clip[i:i + 1], b, noise[i:i + 1], ts[i:i + 1])
+        assert torch.equal(one[0], out2[i]), i
+    assert not torch.allclose(out2[0], out2[1])
+    m.engine.close()
