@@ -91,8 +91,10 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     }
     g.bn = best_bn;
     sk = force_splitk > 0 ? (force_splitk < ncc ? force_splitk : ncc) : best_sk;
-    if (getenv("MVD_HALO_BN")) g.bn = atoi(getenv("MVD_HALO_BN"));  // tuning experiments only
-    if (getenv("MVD_HALO_SK")) sk = atoi(getenv("MVD_HALO_SK"));
+    static const int tune_bn = getenv("MVD_HALO_BN") ? atoi(getenv("MVD_HALO_BN")) : 0;  // tools/conv_bench3.py sweeps
+    static const int tune_sk = getenv("MVD_HALO_SK") ? atoi(getenv("MVD_HALO_SK")) : 0;
+    if (tune_bn) g.bn = tune_bn;
+    if (tune_sk) sk = tune_sk;
     if (sk > ncc) sk = ncc;
     if (sk > 1) sk = cdiv(ncc, cdiv(ncc, sk));  // no empty split (the kernels cut the chunk range in ceil(ncc/sk) pieces)
   } else if (dense) {
