@@ -177,14 +177,19 @@ __global__ __launch_bounds__(NT3, 2) void conv3_dma_kernel(const IGemm g) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
-      // pin the order: the LDS reads of kk+1 are in flight while the MFMAs of kk run (without this the
-      // scheduler sinks every ds_read next to its MFMA to save registers and exposes the LDS latency)
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      // issue order within the kk block: one LDS read of kk+1 between consecutive MFMAs of kk, so the eight waves
+      // (in lockstep after the step barrier) do not hit the LDS with 48 reads at once
+      if (kk < 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // everything issued BEFORE this step (W(s+1), earlier halos) must have landed; only this step's own

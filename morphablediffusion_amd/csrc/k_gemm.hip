@@ -224,12 +224,19 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);  // LDS reads of kk+1 stay in flight behind the MFMAs of kk
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      // issue order within the kk block: one LDS read of kk+1 between consecutive MFMAs of kk (the eight waves run in
+      // lockstep after the step barrier; a burst of 8 x (FN+1) reads would queue in the LDS while the MFMA pipe idles)
+      if (kk < 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // step s+1 must have landed before anyone reads it; only this step's own prefetch may stay in flight
