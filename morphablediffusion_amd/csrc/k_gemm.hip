@@ -205,13 +205,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   int tn = tn_beg, ks = kbeg, stage = 0;
   h8 af[2], bf[2][FN];
   for (int s = 0; s < nsteps; ++s) {
-    const bool pf = s + 2 < nsteps;
-    if (pf) {  // into the ring slot that was read at step s-1 (all waves passed the barrier that ended it)
-      int st2 = stage + 2;
-      if (st2 >= GST) st2 -= GST;
-      dma_step(p_tn, p_ks, st2);
-      advance(p_tn, p_ks);
-    }
+    const bool pf = s + 2 < nsteps;  // prefetch of step s+2, issued inside the kk loop
     const char* sA = smem + stage * STAGE;
     const char* sW = sA + A_BYTES;
     auto read_frags = [&](int kk, h8& a, h8 (&b)[FN]) {
@@ -238,6 +232,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (kk == 1 && pf) {
+        // into the ring slot that was read at step s-1 (all waves passed the barrier that ended it); mid-step, so the
+        // DMA address set-up does not delay the first fragment reads of the step (see k_conv3.hip)
+        int st2 = stage + 2;
+        if (st2 >= GST) st2 -= GST;
+        dma_step(p_tn, p_ks, st2);
+        advance(p_tn, p_ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // step s+1 must have landed before anyone reads it; only this step's own prefetch may stay in flight
     if (pf) wait_vmg<NA + NW_MIN>();
