@@ -224,3 +224,27 @@ def test_batch_of_two_samples_matches_single_samples():
         assert torch.equal(one[0], out2[i]), i
     assert not torch.allclose(out2[0], out2[1])
     m.engine.close()
+
+
+def test_step_without_guidance_vs_oracle():
+    """unconditional_scale = 1: s_uc + 1*(s - s_uc) = s, so the engine runs only the conditional half (UNet batch N, not
+    2N); the reference always runs both (morphable_diffusion.py:132-149).  Checked against the CPU oracle."""
+    from oracle import mvd_oracle as O
+    N, index = 4, 12
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    m = make_model(ucfg, vcfg, N, workspace_gb=4.0)
+    W = gi.full_weights(ucfg, vcfg)
+    batch = synthetic.make_batch(N, "perspective", 600, mesh_seed=1)
+    x_T, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    g = torch.Generator().manual_seed(8)
+    noise = torch.randn(x_T.shape, generator=g)
+    tab = O.ddim_tables(50, 1.0)
+    ts = torch.full((1,), int(tab["timesteps"][index]), dtype=torch.long)
+    want = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 1.0, batch, batch_view_num=N,
+                           noise=noise)
+    got = m.sampler.denoise_apply(x_T.cuda(), {"x": x_in.cuda()}, clip.cuda(), ts.cuda(), index, 1.0, batch_view_num=N,
+                                  batch=to_dev(batch), noise=noise.cuda()).cpu()
+    rel = ((got - want).norm() / want.norm()).item()
+    print(f"[parity] step without guidance vs oracle: relL2={rel:.2e}")
+    assert torch.isfinite(got).all() and rel <= REL_L2
+    m.engine.close()
