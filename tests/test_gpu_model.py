@@ -248,3 +248,20 @@ def test_step_without_guidance_vs_oracle():
     print(f"[parity] step without guidance vs oracle: relL2={rel:.2e}")
     assert torch.isfinite(got).all() and rel <= REL_L2
     m.engine.close()
+
+
+def test_ragged_view_chunks_small():
+    """batch_view_num that does not divide the view count (chunks of 3 + 1) against one chunk of 4."""
+    N, index = 4, 40
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    m = make_model(ucfg, vcfg, N, workspace_gb=4.0)
+    batch = to_dev(synthetic.make_batch(N, "orthographic", 600, mesh_seed=1))
+    x_T, x_in, clip = [t.cuda() for t in synthetic.make_latents(N, 32, seed=6033)]
+    noise = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(2)).cuda()
+    ts = torch.full((1,), int(m.sampler.ddim_timesteps[index]), dtype=torch.long, device="cuda")
+    run = lambda bvn: m.sampler.denoise_apply(x_T, {"x": x_in}, clip, ts, index, 2.0, batch_view_num=bvn, batch=batch, noise=noise)
+    a, b = run(3), run(4)
+    d = ((a - b).norm() / b.norm()).item()
+    print(f"[property] batch_view_num 3 vs 4: relL2={d:.2e}")
+    assert torch.isfinite(a).all() and d <= 5e-4
+    m.engine.close()
