@@ -116,6 +116,70 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
   }
 }
 
+// Two-phase form of the fragment epilogue: epilogue_prefetch issues every global load the epilogue of one fragment
+// needs (bias, per-sample bias, residual) and returns their sum; a kernel calls it for ALL its fragments before the
+// first LDS transpose, so the residual reads of a 42 MB tensor are in flight together instead of one fragment at a time
+// behind each transpose (the in-situ conv ran ~20 us above its isolated time mostly for that).
+__device__ __forceinline__ void epilogue_prefetch(const IGemm& g, int lane, const int (&rows4)[4], const long (&orow4)[4],
+                                                  int n_base, float4 (&pre)[4]) {
+  const int n = n_base + (lane & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int m = rows4[i];
+    if (m >= 0 && n < g.N) {
+      if (g.bias) {
+        const float4 b = *(const float4*)(g.bias + n);
+        p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
+      }
+      if (g.rowbias) {
+        const int bs = m / (g.Z * g.Y * g.X);
+        const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
+        p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
+      }
+      if (g.resid) {
+        if (g.resid_f32) {
+          const float4 q = *(const float4*)((const float*)g.resid + orow4[i] * g.ldr + n);
+          p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+        } else {
+          const h4 q = *(const h4*)((const half_t*)g.resid + orow4[i] * g.ldr + n);
+          p.x += (float)q[0]; p.y += (float)q[1]; p.z += (float)q[2]; p.w += (float)q[3];
+        }
+      }
+    }
+    pre[i] = p;
+  }
+}
+
+__device__ __forceinline__ void epilogue_frag_store_pre(const IGemm& g, const f32x16& acc, float* scratch, int lane,
+                                                        const int (&rows4)[4], const long (&orow4)[4], int n_base,
+                                                        const float4 (&pre)[4]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cq = (lane & 7) * 4;
+  const int n = n_base + cq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int fr = (lane >> 3) + 8 * i;
+    if (rows4[i] < 0 || n >= g.N) continue;
+    float4 v = *(const float4*)(scratch + fr * EPI_LD + cq);
+    v.x = v.x * g.alpha + pre[i].x; v.y = v.y * g.alpha + pre[i].y;
+    v.z = v.z * g.alpha + pre[i].z; v.w = v.w * g.alpha + pre[i].w;
+    if (g.act == ACT_SILU) {
+      v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
+      v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
+    }
+    if (g.out_f32) {
+      *(float4*)((float*)g.out + orow4[i] * g.ldc + n) = v;
+    } else {
+      h4 hv;
+      hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+      *(h4*)((half_t*)g.out + orow4[i] * g.ldc + n) = hv;
+    }
+  }
+}
+
 // transposed store of an already-final fragment (no bias / residual): columns ncol_base + [0, 32) of g.out, < ncols
 __device__ __forceinline__ void epilogue_frag_store_raw(const IGemm& g, const f32x16& v, float* scratch, int lane,
                                                         const int (&rows4)[4], const long (&orow4)[4], int ncol_base,

@@ -40,7 +40,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 template <int BN, int IW, int IH>
-__global__ __launch_bounds__(NT3, 2) void conv3_dma_kernel(const IGemm g) {
+__global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
 #if defined(__HIP_DEVICE_COMPILE__)  // LDS-DMA builtins exist only in the gfx950 device pass; the host pass needs just the stub
   constexpr int NI = BMP / (IW * IH);
   constexpr int HW_ = IW + 2, HH = IH + 2, HPB = HW_ * HH, HP = NI * HPB;
@@ -232,8 +232,16 @@ __global__ __launch_bounds__(NT3, 2) void conv3_dma_kernel(const IGemm g) {
       rows4[i] = b < g.B ? (b * H + y) * W + x : -1;
       orow4[i] = rows4[i];
     }
+    if (part) {
 #pragma unroll
-    for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+      for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+    } else {
+      float4 pre[FN][4];  // all bias / residual loads of the tile in flight before the first transpose
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) epilogue_prefetch(g, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) epilogue_frag_store_pre(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
+    }
     return;
   }
   const int ncol0 = n0 + (lane & 31);
