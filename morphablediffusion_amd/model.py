@@ -3,8 +3,9 @@
 Same class names, constructor kwargs, method names, argument meaning, batch-dict schema and state_dict keys
 as the reference (ldm/models/diffusion/morphable_diffusion.py, ldm/models/diffusion/attention.py), so a
 caller written against the reference (generate_face.py:227-243) runs unchanged; all arithmetic of the
-denoising step executes in libmvd_hip.so.  The frozen VAE / CLIP encoders are host plumbing that stays in
-PyTorch (north_star) and are injected by the caller (``first_stage_model`` / ``clip_image_encoder``).
+denoising step executes in libmvd_hip.so.  The frozen CLIP image encoder is host plumbing that stays in PyTorch
+(north_star) and is injected by the caller (``clip_image_encoder``); the first-stage VAE runs in the engine when the
+checkpoint's ``first_stage_model.*`` tensors are loaded, else an injected ``first_stage_model`` module is used.
 """
 from typing import Dict, Optional
 
