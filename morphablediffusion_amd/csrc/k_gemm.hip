@@ -396,7 +396,7 @@ void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, in
   if (!geglu && tiles_m * tiles_n < CUS) {
     for (int sk = 2; sk <= 16 && sk * 2 <= ksteps; ++sk) {
       const int blocks = tiles_m * tiles_n * sk;
-      const long cost = (long)cdiv(blocks, CUS) * (cdiv(ksteps, sk) + 6) + 3;  // + the reduce pass
+      const long cost = (long)cdiv(blocks, CUS) * (cdiv(ksteps, sk) + 6) + 1;  // + the reduce pass (swept 0..20: 0-1 best)
       if (cost < best) {
         best = cost;
         best_nch = 1;
