@@ -351,7 +351,7 @@ int igemm_pick_bn(int N, int geglu) {
 int igemm_pick_splitk(int M, int N, int ksteps, int bn) {
   const int tiles = cdiv(M, BM) * cdiv(N, bn);
   if (tiles >= 192 || ksteps < 8) return 1;
-  int sk = cdiv(512, tiles);
+  int sk = cdiv(256, tiles);  // one workgroup per CU (swept 128..1024 on the 2- and 16-views-per-rank steps)
   if (sk > ksteps / 4) sk = ksteps / 4;
   if (sk > 16) sk = 16;
   return sk < 1 ? 1 : sk;
