@@ -139,6 +139,15 @@ int mvd_vae_decode(mvd_ctx* ctx, const float* z, int B, int h, int w, float* out
  * posterior (DiagonalGaussianDistribution.sample / .mode) stays host code so the RNG stream is torch's.  Needs the
  * first_stage_model.encoder.* and first_stage_model.quant_conv.* tensors. */
 int mvd_vae_encode(mvd_ctx* ctx, const float* x, int B, int H, int W, float* moments, void* stream);
+/* CLIP image embedding.  Replaces FrozenCLIPImageEmbedder.forward
+ * (ldm/modules/encoders/modules.py:373-379 = preprocess :363-371 + clip's VisionTransformer.forward) as
+ * SyncMultiviewDiffusion.prepare calls it (morphable_diffusion.py:487-488): x [B, 3, H, W] fp32 NCHW in [-1,1] on the
+ * device -> out [B, embed] fp32 (the caller adds FrozenCLIPImageEmbedder.encode's unsqueeze(1)).  Needs the
+ * clip_image_encoder.model.visual.* tensors (openai/CLIP key names; geometry is read off their shapes,
+ * heads = width / 64 as clip's build_model does) uploaded before finalize. */
+int mvd_clip_encode(mvd_ctx* ctx, const float* x, int B, int H, int W, float* out, void* stream);
+/* embedding width of the uploaded CLIP vision tower (768 for ViT-L/14), 0 when none was uploaded */
+int mvd_clip_embed_dim(mvd_ctx* ctx);
 /* in-situ timing of the dominant kernel: while enabled, every launch of conv3_dma_kernel<160,16,16> (the level-32
  * 3x3 convs of the UNet) is bracketed by HIP events on its launch stream; read returns the summed kernel time, the
  * summed algorithmic FLOPs and the launch count since the last enable (it synchronises on the recorded events) */

@@ -118,8 +118,9 @@ int mvd_upload_weight(mvd_ctx* c, const char* name, const float* data, const int
   const std::string k(name);
   if (k.rfind("model.diffusion_model.", 0) != 0 && k.rfind("spatial_volume.", 0) != 0 && k.rfind("time_embed.", 0) != 0 &&
       k.rfind("first_stage_model.decoder.", 0) != 0 && k.rfind("first_stage_model.post_quant_conv.", 0) != 0 &&
-      k.rfind("first_stage_model.encoder.", 0) != 0 && k.rfind("first_stage_model.quant_conv.", 0) != 0)
-    return 0;  // CLIP / loss / schedule buffers: not on this path
+      k.rfind("first_stage_model.encoder.", 0) != 0 && k.rfind("first_stage_model.quant_conv.", 0) != 0 &&
+      k.rfind("clip_image_encoder.model.visual.", 0) != 0)
+    return 0;  // CLIP text tower / loss / schedule buffers: not on this path
   HIP_CHECK_RET(hipSetDevice(c->device));
   RawTensor t;
   t.numel = 1;
@@ -475,6 +476,14 @@ int mvd_vae_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* momen
   if (!x || !moments || B <= 0) return mvd_fail("mvd_vae_encode: bad argument");
   return engine_vae_encode(c, x, B, H, W, moments, S(stream));
 }
+
+int mvd_clip_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* out, void* stream) {
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (!x || !out || B <= 0) return mvd_fail("mvd_clip_encode: bad argument");
+  return engine_clip_encode(c, x, B, H, W, out, S(stream));
+}
+
+int mvd_clip_embed_dim(mvd_ctx* c) { return (c && c->finalized && c->clip.present) ? c->clip.embed : 0; }
 
 int mvd_probe_enable(mvd_ctx* c, int on) {
   if (!c) return mvd_fail("mvd_probe_enable: null context");

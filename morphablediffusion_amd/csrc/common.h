@@ -117,8 +117,15 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s);
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                      half_t* out, hipStream_t s);
+int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
+                         float* out, hipStream_t s);
+// Tstride (0 = T): rows between consecutive samples when the token axis is padded (CLIP: 257 tokens in 264 rows)
 int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
-                     int heads, int d, hipStream_t s);
+                     int heads, int d, hipStream_t s, int Tstride = 0);
+int launch_clip_patches(const float* img, int B, int H, int W, int S, int P, int Kp, half_t* out, hipStream_t s);
+int launch_clip_tokens(const float* pe, const float* cls, const float* pos, int B, int T, int Tp, int C, float* x,
+                       hipStream_t s);
+int launch_scale_copy(const float* src, size_t n, float k, float* dst, hipStream_t s);
 int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st);
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
                       hipStream_t s);

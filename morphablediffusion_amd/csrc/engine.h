@@ -83,6 +83,27 @@ struct VaeEncW {  // Encoder (double_z) + quant_conv
   std::vector<ConvW> down_conv;             // down_conv[level] (level < nlev-1): k3 s2 on the input padded right/bottom
 };
 
+// CLIP vision tower (FrozenCLIPImageEmbedder, ldm/modules/encoders/modules.py:343-382; openai/CLIP VisionTransformer)
+struct ClipLayerW {
+  NormW ln1, ln2;
+  ConvW qk;    // rows [0, 2w) of attn.in_proj_weight with their biases
+  ConvW v;     // rows [2w, 3w): A operand of the swapped GEMM; its bias is folded into out.bias
+  ConvW out;   // attn.out_proj, bias = b_o + W_o b_v
+  ConvW fc;    // mlp.c_fc; QuickGELU(v) = silu(1.702 v) / 1.702: run with alpha = 1.702 and the bias pre-scaled
+  ConvW proj;  // mlp.c_proj, run with alpha = 1 / 1.702
+};
+struct ClipW {
+  bool present = false;
+  int width = 0, layers = 0, heads = 0, patch = 0, image = 0, embed = 0;
+  int T = 0, Tp = 0, Kp = 0;  // tokens, tokens padded to 8, patch-conv K padded to 8
+  ConvW conv1;                // [width][Kp], no bias
+  float* cls = nullptr;       // class_embedding [width]
+  float* pos = nullptr;       // positional_embedding [T][width]
+  NormW ln_pre, ln_post;
+  LinW proj;                  // proj^T as [embed][width]
+  std::vector<ClipLayerW> blk;
+};
+
 struct UOp {
   int kind = 0;  // 0 conv_in, 1 res, 2 st, 3 down, 4 up
   int idx = 0;   // index into the per-kind weight vectors
@@ -151,6 +172,7 @@ struct mvd_ctx {
 
   VaeW vae;
   VaeEncW vae_enc;
+  ClipW clip;
   // UNet
   LinW te0, te2, emb_all;
   int emb_total = 0;
@@ -192,6 +214,8 @@ int engine_finalize(mvd_ctx* c);
 int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, float* out_nchw, hipStream_t s);
 // AutoencoderKL.encode(x).parameters: x [B, 3, H, W] -> moments [B, 2*embed, H/8, W/8]
 int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, float* moments_nchw, hipStream_t s);
+// engine_clip.hip: FrozenCLIPImageEmbedder.forward on x [B, 3, H, W] in [-1, 1] -> [B, embed]
+int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, float* out, hipStream_t s);
 // engine_unet.hip
 struct Ctx5 {  // channels-last context volume of one level for the first n_ctx samples
   const void* p = nullptr;

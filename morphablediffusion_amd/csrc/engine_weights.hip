@@ -245,6 +245,85 @@ int build_vae_attn(mvd_ctx* c, const std::string& p, VaeAttnW* a) {
   return 0;
 }
 
+// CLIP vision tower (openai/CLIP VisionTransformer key names under clip_image_encoder.model.visual.)
+int pack_rows(mvd_ctx* c, const float* src, int N, int Cin, int cin_src, ConvW* o) {
+  o->N = N;
+  o->Cin = Cin;
+  o->taps = 1;
+  RET_IF(dmalloc(c, (void**)&o->w, (size_t)N * Cin * sizeof(half_t)));
+  return launch_pack_weight(src, N, Cin, 1, 0, 0, o->w, 0, cin_src);
+}
+
+int build_clip(mvd_ctx* c) {
+  const std::string P = "clip_image_encoder.model.visual.";
+  ClipW& k = c->clip;
+  RawTensor *c1, *pos, *pj;
+  RET_IF(get_raw(c, P + "conv1.weight", &c1));
+  RET_IF(get_raw(c, P + "positional_embedding", &pos));
+  RET_IF(get_raw(c, P + "proj", &pj));
+  if (c1->shape.size() != 4 || c1->shape[1] != 3 || c1->shape[2] != c1->shape[3] || pos->shape.size() != 2 ||
+      pj->shape.size() != 2)
+    return mvd_fail("CLIP: unexpected conv1 / positional_embedding / proj shapes");
+  k.width = (int)c1->shape[0];
+  k.patch = (int)c1->shape[2];
+  k.T = (int)pos->shape[0];
+  k.embed = (int)pj->shape[1];
+  int grid = 1;
+  while (grid * grid < k.T - 1) ++grid;
+  if (grid * grid != k.T - 1 || (int)pos->shape[1] != k.width || (int)pj->shape[0] != k.width)
+    return mvd_fail("CLIP: positional_embedding must hold 1 + grid^2 tokens of `width` channels");
+  k.image = grid * k.patch;
+  k.heads = k.width / 64;  // clip/model.py build_model: vision_heads = vision_width // 64
+  if (k.width % 64 || k.width > 1536) return mvd_fail("CLIP: width must be a multiple of 64, at most 1536");
+  k.Tp = (k.T + 7) & ~7;
+  const int K = 3 * k.patch * k.patch;
+  k.Kp = (K + 7) & ~7;
+  RET_IF(pack_rows(c, c1->d, k.width, k.Kp, K, &k.conv1));
+  RET_IF(copy_f32(c, P + "class_embedding", &k.cls));
+  RET_IF(copy_f32(c, P + "positional_embedding", &k.pos));
+  RET_IF(load_norm(c, P + "ln_pre", &k.ln_pre));
+  RET_IF(load_norm(c, P + "ln_post", &k.ln_post));
+  {  // proj [width][embed] -> [embed][width]
+    ConvW t;
+    RET_IF(pack_conv(c, P + "proj", "", true, false, &t));
+    k.proj.w = t.w;
+    k.proj.N = k.embed;
+    k.proj.K = k.width;
+  }
+  k.layers = 0;
+  while (c->raw.count(P + "transformer.resblocks." + std::to_string(k.layers) + ".attn.in_proj_weight")) ++k.layers;
+  if (k.layers < 1) return mvd_fail("CLIP: no transformer.resblocks uploaded");
+  const int w = k.width;
+  k.blk.assign(k.layers, ClipLayerW());
+  for (int i = 0; i < k.layers; ++i) {
+    const std::string L = P + "transformer.resblocks." + std::to_string(i);
+    ClipLayerW& b = k.blk[i];
+    RawTensor *iw, *ib, *ow, *ob, *fb;
+    RET_IF(get_raw(c, L + ".attn.in_proj_weight", &iw));
+    RET_IF(get_raw(c, L + ".attn.in_proj_bias", &ib));
+    RET_IF(get_raw(c, L + ".attn.out_proj.weight", &ow));
+    RET_IF(get_raw(c, L + ".attn.out_proj.bias", &ob));
+    RET_IF(get_raw(c, L + ".mlp.c_fc.bias", &fb));
+    if ((long)iw->numel != 3L * w * w || (long)ib->numel != 3L * w) return mvd_fail("CLIP: in_proj shape");
+    RET_IF(load_norm(c, L + ".ln_1", &b.ln1));
+    RET_IF(load_norm(c, L + ".ln_2", &b.ln2));
+    RET_IF(pack_rows(c, iw->d, 2 * w, w, w, &b.qk));
+    RET_IF(dmalloc(c, (void**)&b.qk.bias, (size_t)2 * w * sizeof(float)));
+    HIP_CHECK_RET(hipMemcpy(b.qk.bias, ib->d, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToDevice));
+    RET_IF(pack_rows(c, iw->d + (size_t)2 * w * w, w, w, w, &b.v));
+    RET_IF(pack_conv(c, L + ".attn.out_proj.weight", "", false, false, &b.out));
+    RET_IF(dmalloc(c, (void**)&b.out.bias, (size_t)w * sizeof(float)));
+    hipLaunchKernelGGL(vae_fold_v_bias_kernel, dim3(cdiv(w, 128)), dim3(128), 0, 0, ow->d, ib->d + 2 * w, ob->d, w, b.out.bias);
+    HIP_CHECK_RET(hipGetLastError());
+    RET_IF(pack_conv(c, L + ".mlp.c_fc.weight", "", false, false, &b.fc));
+    RET_IF(dmalloc(c, (void**)&b.fc.bias, fb->numel * sizeof(float)));
+    RET_IF(launch_scale_copy(fb->d, fb->numel, 1.702f, b.fc.bias, 0));
+    RET_IF(pack_conv(c, L + ".mlp.c_proj.weight", L + ".mlp.c_proj.bias", false, false, &b.proj));
+  }
+  k.present = true;
+  return 0;
+}
+
 int build_vae_encoder(mvd_ctx* c) {
   const std::string V = "first_stage_model.", E = V + "encoder.";
   VaeEncW& v = c->vae_enc;
@@ -354,8 +433,10 @@ int engine_finalize(mvd_ctx* c) {
   const bool has_step = c->raw.count("time_embed.0.weight") > 0;
   const bool has_vae = c->raw.count("first_stage_model.decoder.conv_in.weight") > 0;
   const bool has_vae_enc = c->raw.count("first_stage_model.encoder.conv_in.weight") > 0;
-  if (!has_unet && !has_cond && !has_vae && !has_vae_enc)
-    return mvd_fail("finalize: no UNet, spatial_volume or first-stage decoder weights were uploaded");
+  const bool has_clip = c->raw.count("clip_image_encoder.model.visual.conv1.weight") > 0;
+  if (!has_unet && !has_cond && !has_vae && !has_vae_enc && !has_clip)
+    return mvd_fail("finalize: no UNet, spatial_volume, first-stage or CLIP weights were uploaded");
+  if (has_clip) RET_IF(build_clip(c));
   if (has_vae) RET_IF(build_vae(c));
   if (has_vae_enc) RET_IF(build_vae_encoder(c));
   // ---------------- UNet plan (openaimodel.py:535-720) ----------------

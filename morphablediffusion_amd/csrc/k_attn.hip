@@ -17,7 +17,8 @@ namespace {
 template <int D>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
                                                    const half_t* __restrict__ vt, int ldvt,
-                                                   half_t* __restrict__ out, int ldo, int T, int heads, float scale) {
+                                                   half_t* __restrict__ out, int ldo, int T, int heads, float scale,
+                                                   int Tstride) {
   constexpr int KS = (D + 15) / 16;        // k-steps of the QK^T product
   constexpr int DK = KS * 16;
   constexpr int DVF = (D + 31) / 32;       // 32-row fragments of O^T
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk
   const int head = blockIdx.y, b = blockIdx.z;
   const int C = heads * D;
   const int q_row = blockIdx.x * 128 + wave * 32 + lq;
-  const long tok0 = (long)b * T;
+  const long tok0 = (long)b * Tstride;  // samples are Tstride rows apart (Tstride > T: padded token axis)
 
   // Q fragment (B operand): lane (q, hh) holds d = ks*16 + hh*8 .. +8
   h8 qf[KS];
@@ -218,12 +219,15 @@ int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStrea
 }
 
 int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
-                     int heads, int d, hipStream_t s) {
-  if (T % 8 || ldqk % 8 || ldvt % 8 || ldo % 4 || d % 8) return mvd_fail("attention: alignment (T, ld, d multiples of 8)");
+                     int heads, int d, hipStream_t s, int Tstride) {
+  if (Tstride <= 0) Tstride = T;
+  // the V^T tile loads fetch 8 tokens at a time: rows T..Tstride-1 of a sample must exist (and hold finite values)
+  if (Tstride % 8 || Tstride < T || ldqk % 8 || ldvt % 8 || ldo % 4 || d % 8)
+    return mvd_fail("attention: alignment (token stride, ld, d multiples of 8)");
   dim3 grid(cdiv(T, 128), heads, B);
   const float scale = 1.4426950408889634f / sqrtf((float)d);  // softmax scale * log2(e): the kernel uses exp2
 #define MVD_ATTN(DD) \
-  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, vt, ldvt, out, ldo, T, heads, scale); break;
+  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, vt, ldvt, out, ldo, T, heads, scale, Tstride); break;
   switch (d) {
     MVD_ATTN(8)
     MVD_ATTN(16)

@@ -338,13 +338,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // one wave per row
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int C,
+template <typename OT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, int rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, half_t* __restrict__ out) {
+                                                        float eps, OT* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (long)row * C;
+  const float* xr = x + (long)row * ldx;
   constexpr int MAXI = 24;  // C <= 1536
   float v[MAXI];
   float s = 0.f;
@@ -367,11 +368,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = rsqrtf(q / (float)C + eps);
-  half_t* orow = out + (long)row * C;
+  OT* orow = out + (long)row * C;
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int c = lane + 64 * i;
-    if (c < C) orow[c] = (half_t)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    if (c < C) orow[c] = (OT)((v[i] - mean) * rstd * gamma[c] + beta[c]);
   }
 }
 
@@ -446,7 +447,16 @@ int launch_gn_finalize(const float* partial, int B, int nslabs, int rows_per_sam
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, half_t* out,
                      hipStream_t s) {
   if (C > 64 * 24) return mvd_fail("layernorm: C too large");
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, C, gamma, beta, eps, out);
+  hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (long)C, rows, C, gamma, beta, eps, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// fp32 output (a residual stream) from rows `ldx` floats apart (e.g. the class token of every sample)
+int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
+                         float* out, hipStream_t s) {
+  if (C > 64 * 24) return mvd_fail("layernorm: C too large");
+  hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, rows, C, gamma, beta, eps, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -66,6 +66,7 @@ class Engine:
         """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing."""
         self.has_vae_decoder = any(k.startswith("first_stage_model.decoder.") for k in sd)
         self.has_vae_encoder = any(k.startswith("first_stage_model.encoder.") for k in sd)
+        self.has_clip = any(k.startswith("clip_image_encoder.model.visual.") for k in sd)
         for k, v in sd.items():
             if not torch.is_tensor(v) or not v.dtype.is_floating_point:
                 continue
@@ -274,6 +275,19 @@ class Engine:
         out = torch.empty(B, 3, 8 * h, 8 * w, device=self.device)
         L.check(self.lib.mvd_vae_decode(self._ctx, L.ptr(z), B, h, w, L.ptr(out), _stream()))
         return out
+
+    def clip_encode(self, x):
+        """FrozenCLIPImageEmbedder.encode (ldm/modules/encoders/modules.py:363-382): x [B,3,H,W] in [-1,1] ->
+        [B,1,embed]; needs the clip_image_encoder.model.visual.* weights in load_state_dict."""
+        if not getattr(self, "has_clip", False):
+            raise L.MvdError("CLIP vision-tower weights were not part of the uploaded state_dict")
+        x = _f32(x, self.device)
+        B, ch, H, W = x.shape
+        if ch != 3:
+            raise ValueError("clip_encode expects [B,3,H,W]")
+        out = torch.empty(B, int(self.lib.mvd_clip_embed_dim(self._ctx)), device=self.device)
+        L.check(self.lib.mvd_clip_encode(self._ctx, L.ptr(x), B, H, W, L.ptr(out), _stream()))
+        return out.unsqueeze(1)
 
     def vae_encode_moments(self, x):
         """AutoencoderKL.encode(x).parameters (autoencoder.py:324-328): x [B,3,H,W] in [-1,1] -> [B,8,H/8,W/8]

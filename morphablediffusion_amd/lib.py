@@ -15,6 +15,7 @@ SYMBOLS = [
     "mvd_embed_time", "mvd_set_mesh", "mvd_set_cameras", "mvd_vertex_features", "mvd_volume_from_fused",
     "mvd_frustum_volumes", "mvd_denoise_views", "mvd_op_conv", "mvd_op_linear", "mvd_op_group_norm",
     "mvd_op_layer_norm", "mvd_op_attention", "mvd_op_conv3d", "mvd_bench_conv", "mvd_bench_linear", "mvd_probe_enable", "mvd_probe_read", "mvd_vae_decode", "mvd_vae_encode",
+    "mvd_clip_encode", "mvd_clip_embed_dim",
 ]
 
 

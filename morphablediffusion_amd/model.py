@@ -3,9 +3,9 @@
 Same class names, constructor kwargs, method names, argument meaning, batch-dict schema and state_dict keys
 as the reference (ldm/models/diffusion/morphable_diffusion.py, ldm/models/diffusion/attention.py), so a
 caller written against the reference (generate_face.py:227-243) runs unchanged; all arithmetic of the
-denoising step executes in libmvd_hip.so.  The frozen CLIP image encoder is host plumbing that stays in PyTorch
-(north_star) and is injected by the caller (``clip_image_encoder``); the first-stage VAE runs in the engine when the
-checkpoint's ``first_stage_model.*`` tensors are loaded, else an injected ``first_stage_model`` module is used.
+denoising step executes in libmvd_hip.so.  The frozen CLIP image encoder and the first-stage VAE run in the engine
+too when the checkpoint's ``clip_image_encoder.model.visual.*`` / ``first_stage_model.*`` tensors are loaded; otherwise
+modules injected by the caller (``clip_image_encoder``, ``first_stage_model``) are used.
 """
 from typing import Dict, Optional
 
@@ -239,8 +239,13 @@ class SyncMultiviewDiffusion(nn.Module):
         image_input = batch["input_image"].permute(0, 3, 1, 2)
         x_input = self.encode_first_stage(image_input)
         input_info = {"image": image_input, "elevation": batch["input_elevation"][:, 0], "x": x_input}
-        with torch.no_grad():
-            clip_embed = self.clip_image_encoder.encode(image_input)
+        if getattr(self.engine, "has_clip", False):  # clip_image_encoder.model.visual.* were in the state_dict
+            clip_embed = self.engine.clip_encode(image_input)
+        elif self.clip_image_encoder is None:
+            raise RuntimeError("no clip_image_encoder injected and no clip_image_encoder.model.visual weights loaded")
+        else:
+            with torch.no_grad():
+                clip_embed = self.clip_image_encoder.encode(image_input)
         return None, clip_embed, input_info
 
     def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):

@@ -407,3 +407,50 @@ def vae_encoder_manifest(cfg: VaeConfig = VaeConfig(), prefix: str = VAE_PREFIX,
     conv(e + "conv_out", block_in, 2 * cfg.z_channels, 3)
     conv(prefix + "quant_conv", 2 * cfg.z_channels, 2 * cfg.embed_dim, 1)
     return ks
+
+
+CLIP_PREFIX = "clip_image_encoder.model.visual."
+
+
+@dataclass(frozen=True)
+class ClipConfig:
+    """Vision tower of the CLIP model FrozenCLIPImageEmbedder loads (ldm/modules/encoders/modules.py:343-382;
+    `clip.load('ViT-L/14')`, openai/CLIP clip/model.py VisionTransformer): ViT-L/14 at 224^2."""
+    width: int = 1024
+    layers: int = 24
+    heads: int = 16
+    patch: int = 14
+    image: int = 224
+    embed: int = 768
+
+    @property
+    def tokens(self) -> int:
+        return (self.image // self.patch) ** 2 + 1
+
+
+def clip_manifest(cfg: ClipConfig = ClipConfig(), prefix: str = CLIP_PREFIX) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys / shapes of `clip_image_encoder.model.visual` (openai/CLIP naming)."""
+    w = cfg.width
+    ks: Dict[str, Tuple[int, ...]] = {
+        prefix + "conv1.weight": (w, 3, cfg.patch, cfg.patch),
+        prefix + "class_embedding": (w,),
+        prefix + "positional_embedding": (cfg.tokens, w),
+        prefix + "proj": (w, cfg.embed),
+    }
+    for n in ("ln_pre", "ln_post"):
+        ks[prefix + n + ".weight"] = (w,)
+        ks[prefix + n + ".bias"] = (w,)
+    for i in range(cfg.layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        ks[p + "attn.in_proj_weight"] = (3 * w, w)
+        ks[p + "attn.in_proj_bias"] = (3 * w,)
+        ks[p + "attn.out_proj.weight"] = (w, w)
+        ks[p + "attn.out_proj.bias"] = (w,)
+        for n in ("ln_1", "ln_2"):
+            ks[p + n + ".weight"] = (w,)
+            ks[p + n + ".bias"] = (w,)
+        ks[p + "mlp.c_fc.weight"] = (4 * w, w)
+        ks[p + "mlp.c_fc.bias"] = (4 * w,)
+        ks[p + "mlp.c_proj.weight"] = (w, 4 * w)
+        ks[p + "mlp.c_proj.bias"] = (w,)
+    return ks

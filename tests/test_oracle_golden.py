@@ -211,3 +211,19 @@ def test_vae_encoder(name, ch):
     torch.randn(B, cfg.embed_dim, 32, 32, generator=gen)  # the latent draw of the decoder golden comes first
     x = torch.rand(B, 3, 256, 256, generator=gen) * 2.0 - 1.0
     check(V.encode_moments(W, cfg, x), g, "moments")
+
+
+@pytest.mark.parametrize("name,kw", [("clip_small.npz", dict(width=128, layers=2, heads=2, embed=64)), ("clip_full.npz", {})])
+def test_clip_image_embedding(name, kw):
+    """CLIP image embedding: the oracle against transformers' CLIPVisionModelWithProjection on
+    the same seeded weights (openai/CLIP itself is not importable here; see oracle/clip_oracle.py)."""
+    from morphablediffusion_amd.spec import ClipConfig, clip_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    from oracle import clip_oracle as CO
+    g = load(name)
+    cfg = ClipConfig(**kw)
+    W = seeded_state_dict(clip_manifest(cfg), gi.WEIGHT_SEED)
+    gen = torch.Generator().manual_seed(47)
+    x = torch.rand(int(g["B"]), 3, 256, 256, generator=gen) * 2.0 - 1.0
+    check(CO.preprocess(x, cfg.image), g, "pixels")
+    check(CO.encode(W, cfg, x), g, "embed")

@@ -229,6 +229,52 @@ def gold_vae(ns):
         save(name, {"out": gi.pack(out), "moments": gi.pack(mom)}, {"B": B, "ch": cfg.ch})
 
 
+def gold_clip(ns=None):
+    """CLIP image embedding.  openai/CLIP and kornia are not importable here, so the goldens come
+    from transformers' CLIPVisionModelWithProjection -- an independent implementation of the same published model --
+    loaded with the seeded weights under the openai key names (mapping below); the input is the oracle's preprocess of a
+    seeded 256^2 image (F.interpolate bicubic, what kornia's resize calls)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from morphablediffusion_amd.spec import ClipConfig, clip_manifest, CLIP_PREFIX as P
+    from morphablediffusion_amd.weights import seeded_state_dict
+    from oracle import clip_oracle as CO
+    for name, cfg, B in (("clip_small.npz", ClipConfig(width=128, layers=2, heads=2, embed=64), 2),
+                         ("clip_full.npz", ClipConfig(), 1)):
+        W = seeded_state_dict(clip_manifest(cfg), gi.WEIGHT_SEED)
+        hc = CLIPVisionConfig(hidden_size=cfg.width, intermediate_size=4 * cfg.width, projection_dim=cfg.embed,
+                              num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, image_size=cfg.image,
+                              patch_size=cfg.patch, hidden_act="quick_gelu", layer_norm_eps=1e-5, attention_dropout=0.0)
+        model = CLIPVisionModelWithProjection(hc).eval()
+        w = cfg.width
+        sd = {"vision_model.embeddings.class_embedding": W[P + "class_embedding"],
+              "vision_model.embeddings.patch_embedding.weight": W[P + "conv1.weight"],
+              "vision_model.embeddings.position_embedding.weight": W[P + "positional_embedding"],
+              "visual_projection.weight": W[P + "proj"].t().contiguous()}
+        for a, b in (("pre_layrnorm", "ln_pre"), ("post_layernorm", "ln_post")):
+            for x in ("weight", "bias"):
+                sd[f"vision_model.{a}.{x}"] = W[f"{P}{b}.{x}"]
+        for i in range(cfg.layers):
+            h, o = f"vision_model.encoder.layers.{i}.", f"{P}transformer.resblocks.{i}."
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                sd[h + f"self_attn.{n}.weight"] = W[o + "attn.in_proj_weight"][j * w:(j + 1) * w]
+                sd[h + f"self_attn.{n}.bias"] = W[o + "attn.in_proj_bias"][j * w:(j + 1) * w]
+            for a, b in (("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"),
+                         ("mlp.fc1", "mlp.c_fc"), ("mlp.fc2", "mlp.c_proj")):
+                for x in ("weight", "bias"):
+                    sd[h + a + "." + x] = W[o + b + "." + x]
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        missing = [k for k in missing if "position_ids" not in k]
+        assert not missing and not unexpected, (missing, unexpected)
+        g = torch.Generator().manual_seed(47)
+        x = torch.rand(B, 3, 256, 256, generator=g) * 2.0 - 1.0
+        with torch.no_grad():
+            t0 = time.time()
+            pix = CO.preprocess(x, cfg.image)
+            out = model(pixel_values=pix).image_embeds
+            print(name, time.time() - t0, "s", tuple(out.shape), float(out.abs().max()))
+        save(name, {"embed": gi.pack(out.unsqueeze(1)), "pixels": gi.pack(pix)}, {"B": B, "width": cfg.width})
+
+
 def gold_variants(ns):
     """The other BASELINE.json configs as parity cases, at reduced UNet width:
     config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
@@ -246,9 +292,13 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
+    ap.add_argument("--only-clip", action="store_true", help="only the CLIP image-embedding goldens (needs transformers, not the reference)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if args.only_clip:
+        gold_clip()
+        return
     ns = ref_import.import_reference_full()
     if args.only_variants:
         gold_variants(ns)
