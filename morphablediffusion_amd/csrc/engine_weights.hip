@@ -161,7 +161,19 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   RET_IF(get_raw(c, bn + ".bias", &b));
   RET_IF(get_raw(c, bn + ".running_mean", &rm));
   RET_IF(get_raw(c, bn + ".running_var", &rv));
-  const int cout = (int)w->shape[0], cin = (int)w->shape[1];
+  // three layouts of the same 3x3x3 kernel (offset index k = (kd*3 + kh)*3 + kw in all of them):
+  //   [cout][cin][3][3][3]   nn.Conv3d order (the dense emulation the goldens were generated with)
+  //   [cout][3][3][3][cin]   spconv >= 2.2 (KRSC, what an un-pinned `spconv-cu113` installs, requirements.txt:18)
+  //   [3][3][3][cin][cout]   spconv 1.x / 2.1
+  // told apart by where the three 3s sit (channel counts are 16 / 32 / 64, never 3)
+  if (w->shape.size() != 5) return mvd_fail("sparse conv weight: rank 5 expected");
+  const int64_t* sh5 = w->shape.data();
+  int layout = -1, cout = 0, cin = 0;
+  if (sh5[2] == 3 && sh5[3] == 3 && sh5[4] == 3 && sh5[0] != 3) { layout = 0; cout = (int)sh5[0]; cin = (int)sh5[1]; }
+  else if (sh5[1] == 3 && sh5[2] == 3 && sh5[3] == 3 && sh5[0] != 3) { layout = 1; cout = (int)sh5[0]; cin = (int)sh5[4]; }
+  else if (sh5[0] == 3 && sh5[1] == 3 && sh5[2] == 3) { layout = 2; cin = (int)sh5[3]; cout = (int)sh5[4]; }
+  else return mvd_fail("sparse conv weight: not a 3x3x3 kernel in a known layout");
+  if ((int)g->numel != cout) return mvd_fail("sparse conv weight: channel count does not match its BatchNorm");
   L->cin = cin;
   L->cout = cout;
   L->strided = strided;
@@ -171,10 +183,15 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   HIP_CHECK_RET(hipMemcpy(hb.data(), b->d, cout * 4, hipMemcpyDeviceToHost));
   HIP_CHECK_RET(hipMemcpy(hm.data(), rm->d, cout * 4, hipMemcpyDeviceToHost));
   HIP_CHECK_RET(hipMemcpy(hv.data(), rv->d, cout * 4, hipMemcpyDeviceToHost));
-  // dense-emulation layout [cout][cin][kd][kh][kw] -> [27][cin][cout]
+  // -> [27][cin][cout]
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
-      for (int k = 0; k < 27; ++k) pk[((size_t)k * cin + ci) * cout + co] = hw[((size_t)co * cin + ci) * 27 + k];
+      for (int k = 0; k < 27; ++k) {
+        const size_t src = layout == 0 ? ((size_t)co * cin + ci) * 27 + k
+                         : layout == 1 ? ((size_t)co * 27 + k) * cin + ci
+                                       : ((size_t)k * cin + ci) * cout + co;
+        pk[((size_t)k * cin + ci) * cout + co] = hw[src];
+      }
   for (int co = 0; co < cout; ++co) {  // eval BatchNorm1d(eps 1e-3), network.py:105
     sc[co] = hg[co] / sqrtf(hv[co] + 1e-3f);
     sh[co] = hb[co] - hm[co] * sc[co];

@@ -261,8 +261,8 @@ def volume_manifest(cfg: VolumeConfig, prefix: str = SV_PREFIX) -> Dict[str, Tup
                               ("down1", 1, 32, 64), ("conv2", 3, 64, 64)):
         for i in range(n):
             ci = cin if i == 0 else cout
-            # dense-emulation layout [cout, cin, kd, kh, kw]; real spconv checkpoints use spconv's own
-            # layout (unverified) and are converted by the uploader.
+            # dense-emulation layout [cout, cin, kd, kh, kw]; real spconv checkpoints use spconv's own layout
+            # ([cout,3,3,3,cin] or [3,3,3,cin,cout]), recognised by shape in csrc/engine_weights.hip
             ks[f"xyzc_net.{blk}.{3 * i}.weight"] = (cout, ci, 3, 3, 3)
             for s in ("weight", "bias", "running_mean", "running_var"):
                 ks[f"xyzc_net.{blk}.{3 * i + 1}.{s}"] = (cout,)

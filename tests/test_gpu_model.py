@@ -194,6 +194,34 @@ def test_spatial_volume_with_duplicate_voxels_vs_oracle():
     m.engine.close()
 
 
+def test_spconv_checkpoint_weight_layouts():
+    """A real checkpoint stores the sparse convs in spconv's own layout: [cout,3,3,3,cin] (spconv >= 2.2, KRSC) or
+    [3,3,3,cin,cout] (spconv 1.x / 2.1); the goldens use nn.Conv3d's [cout,cin,3,3,3].  The uploader tells them apart
+    by shape, so all three must give the same 32^3 volume bit for bit."""
+    from oracle import mvd_oracle as O
+    N = 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    W = gi.full_weights(ucfg, vcfg)
+    data = synthetic.make_batch(N, "perspective", 600, mesh_seed=1)
+    x_T, _, _ = synthetic.make_latents(N, 32, seed=11)
+    t_embed, v_embed = O.embed_time(W, torch.full((1,), 481, dtype=torch.long)), O.viewpoint_embedding(data)
+    outs = []
+    for perm in (None, (0, 2, 3, 4, 1), (2, 3, 4, 1, 0)):
+        Wp = dict(W)
+        n = 0
+        for k, v in W.items():
+            if ".xyzc_net." in k and v.dim() == 5:
+                n += 1
+                if perm is not None:
+                    Wp[k] = v.permute(*perm).contiguous()
+        assert n == 9
+        m = make_model(ucfg, vcfg, N, workspace_gb=4.0, extra_weights=Wp)
+        outs.append(m.spatial_volume.construct_spatial_volume(x_T.cuda(), t_embed.cuda(), v_embed.cuda(), to_dev(data)).cpu())
+        m.engine.close()
+    assert outs[0].abs().max() > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_batch_of_two_samples_matches_single_samples():
     """B > 1 (the eval driver's case, eval/generate_all_facescape.py): samples are looped on the host with the mesh
     tables rebuilt per sample, so a batch must equal the samples run one by one (different meshes, latents, CLIP)."""
