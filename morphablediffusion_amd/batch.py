@@ -108,3 +108,39 @@ def build_batch(input_image: torch.Tensor, vertices: torch.Tensor, num_views: in
          "target_elevation": torch.zeros(num_views), "target_azimuth": torch.zeros(num_views),
          "target_K": K, "target_RT": RT, "vertices": vertices.float(), "out_sh": out_sh, "coord": coord, "bounds": bounds}
     return {k: v.unsqueeze(0).to(device) for k, v in d.items()}
+
+
+def views_to_uint8(x_sample: torch.Tensor, input_image: torch.Tensor) -> np.ndarray:
+    """The image strip generate_face.py:244-252 saves: the input view followed by the N generated views side by side,
+    samples stacked vertically.  x_sample [B,N,3,H,W] in [-1,1] (``model.sample``), input_image [B,H,W,3] -> uint8
+    [B*H, (N+1)*W, 3]."""
+    x = torch.cat([input_image.unsqueeze(1).permute(0, 1, 4, 2, 3).to(x_sample), x_sample], 1)
+    x = (torch.clamp(x, -1.0, 1.0) + 1.0) * 0.5
+    x = (x.permute(0, 1, 3, 4, 2).cpu().numpy() * 255).astype(np.uint8)
+    rows = np.concatenate([x[:, i] for i in range(x.shape[1])], 2)
+    return np.concatenate(list(rows), 0)
+
+
+def neus2_transform(Ks: torch.Tensor, RTs: torch.Tensor, image_size: int = 256) -> Dict:
+    """The ``transform.json`` dictionary of generate_face.py:145-154,173-186 (NeuS2 input): per view the camera-to-world
+    matrix with the y and z axes flipped (OpenCV -> OpenGL camera) and the 3x3 intrinsics."""
+    d = {"w": image_size, "h": image_size, "aabb_scale": 1.0, "scale": 1.0, "offset": [0.5, 0.5, 0.5], "frames": []}
+    for i in range(RTs.shape[0]):
+        E = np.eye(4)
+        E[:3, :4] = RTs[i].double().cpu().numpy()
+        c2w = np.linalg.inv(E)
+        c2w[:, 1] *= -1
+        c2w[:, 2] *= -1
+        d["frames"].append({"file_path": f"images/{str(i).zfill(2)}.png", "transform_matrix": c2w.tolist(),
+                            "intrinsic_matrix": Ks[i, :3, :3].double().cpu().numpy().tolist()})
+    return d
+
+
+def neus2_view_bgra(strip: np.ndarray, idx: int, image_size: int = 256) -> np.ndarray:
+    """generate_face.py:256-261: view ``idx`` of the first sample's strip as BGRA, alpha = 0 where the pixel is
+    near-white background (all channels > 240)."""
+    img = strip[:image_size, idx * image_size:(idx + 1) * image_size, :]
+    out = np.zeros((image_size, image_size, 4))
+    out[:, :, :3] = img[:, :, ::-1]
+    out[:, :, 3] = (~np.all(img > 240, axis=-1)).astype(np.float64) * 255  # 255 = foreground
+    return out

@@ -51,3 +51,32 @@ def test_align_voxelize_and_batch_schema():
         assert d[k].dim() == ref[k].dim() and d[k].dtype == ref[k].dtype, k
     assert d["target_K"].shape == (1, 16, 4, 4) and d["target_RT"].shape == (1, 16, 3, 4)
     assert d["input_image"].shape == (1, 256, 256, 3) and d["target_image"].shape == (1, 16, 256, 256, 3)
+
+
+def test_output_strip_and_neus2_export():
+    """generate_face.py:145-186,244-261: image strip, transform.json contents, BGRA views."""
+    g = torch.Generator().manual_seed(2)
+    xs = torch.rand(2, 3, 3, 256, 256, generator=g) * 3.0 - 1.5        # out-of-range values are clamped
+    inp = torch.rand(2, 256, 256, 3, generator=g) * 2.0 - 1.0
+    strip = B.views_to_uint8(xs, inp)
+    assert strip.shape == (512, 4 * 256, 3) and strip.dtype == np.uint8
+    want = ((inp[1].clamp(-1, 1) + 1) * 0.5 * 255).numpy().astype(np.uint8)
+    assert np.array_equal(strip[256:, :256], want)
+    v = ((xs[0, 2].clamp(-1, 1) + 1) * 0.5).permute(1, 2, 0).numpy() * 255
+    assert np.array_equal(strip[:256, 3 * 256:], v.astype(np.uint8))
+    Ks, RTs = B.virtual_cameras(16)
+    d = B.neus2_transform(Ks, RTs)
+    assert len(d["frames"]) == 16 and d["frames"][3]["file_path"] == "images/03.png" and d["offset"] == [0.5, 0.5, 0.5]
+    c2w = np.array(d["frames"][5]["transform_matrix"])
+    # undo the axis flip: the matrix inverts the extrinsics
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    E = np.eye(4)
+    E[:3, :4] = RTs[5].numpy()
+    assert np.allclose(c2w @ E, np.eye(4), atol=1e-5)
+    assert np.allclose(np.array(d["frames"][5]["intrinsic_matrix"]), Ks[5, :3, :3].numpy())
+    strip[:256, 256:512] = 255
+    strip[10, 300] = (0, 10, 250)
+    bgra = B.neus2_view_bgra(strip, 1)
+    assert bgra.shape == (256, 256, 4) and bgra[0, 0, 3] == 0 and bgra[10, 300 - 256, 3] == 255
+    assert tuple(bgra[10, 300 - 256, :3]) == (250, 10, 0)
