@@ -33,9 +33,10 @@ def unet_kwargs(cfg):
                 context_dim=768, use_checkpoint=True, legacy=False)
 
 
-def cpu_baseline(W, ucfg, sample_views=1, threads=16):
+def cpu_baseline(W, ucfg, sample_views=8, threads=16):
     """The oracle (CPU restatement, validated against the reference goldens) timed on this host's cores on a
-    bounded sample: one full denoise_apply at `sample_views` views instead of 16 (cost is linear in N)."""
+    bounded sample (10-30 s of CPU work): one full denoise_apply at `sample_views` views instead of 16 (cost is
+    linear in N)."""
     from morphablediffusion_amd import synthetic
     from morphablediffusion_amd.spec import VolumeConfig, build_unet_plan
     from oracle import mvd_oracle as O
