@@ -156,7 +156,8 @@ int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
 
 int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream) {
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int td = c->v.time_dim;
   float* e0 = ws_alloc<float>(c, (size_t)B * td);
   float* e1 = ws_alloc<float>(c, (size_t)B * td);
@@ -175,7 +176,8 @@ int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const
   if (n_ctx < 0 || n_ctx > Bv) return mvd_fail("mvd_unet_forward: n_ctx out of range");
   hipStream_t s = S(stream);
   const mvd_unet_config& u = c->u;
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int HW = u.image_size * u.image_size;
   const int cin = u.in_channels;
   if (cin % 8) return mvd_fail("in_channels must be a multiple of 8");
@@ -219,7 +221,8 @@ int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, voi
 int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
                         float* out0, float* out1, float* out2, float* out3, void* stream) {
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   FrustumOut fo;
   RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, S(stream)));
   float* outs[4] = {out0, out1, out2, out3};
@@ -241,7 +244,8 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   hipStream_t s = S(stream);
   const mvd_unet_config& u = c->u;
   if (u.in_channels != 8 || u.out_channels != 4) return mvd_fail("denoise_views: expects the 8-in / 4-out latent UNet");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int HW = u.image_size * u.image_size;
   const bool cfg = cfg_scale != 1.0f;
   const int copies = cfg ? 2 : 1, Bv = copies * TN;
@@ -281,7 +285,8 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
                 int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
                 void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int cpad = (Cin + 7) / 8 * 8, taps = ksize * ksize;
   const int Hv = H << upsample, Wv = W << upsample;
   const int Ho = (Hv - 1) / stride + 1, Wo = (Wv - 1) / stride + 1;
@@ -323,7 +328,8 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
 int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int W, const float* w, const float* bias,
                   int Cout, int stride, int transposed, const float* resid, float* out, void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   if (Cin % 8) return mvd_fail("op_conv3d: Cin must be a multiple of 8");
   const int Do = transposed ? 2 * D : (D - 1) / stride + 1, Ho = transposed ? 2 * H : (H - 1) / stride + 1,
             Wo = transposed ? 2 * W : (W - 1) / stride + 1;
@@ -356,7 +362,8 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
 int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu,
                   const float* resid, int a_half, int force_splitk, float* out, void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   if (K % 8) return mvd_fail("op_linear: K must be a multiple of 8");
   half_t* wp = ws_alloc<half_t>(c, (size_t)N * K);
   float* bp = ws_alloc<float>(c, (size_t)N);
@@ -389,7 +396,8 @@ int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, cons
 int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int groups, const float* gamma,
                       const float* beta, float eps, int act, float* out_nchw, void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   float* xn = ws_alloc<float>(c, (size_t)B * HW * C);
   half_t* y = ws_alloc<half_t>(c, (size_t)B * HW * C);
   float* yf = ws_alloc<float>(c, (size_t)B * HW * C);
@@ -407,7 +415,8 @@ int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int
 int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* gamma, const float* beta, float* out,
                       void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   half_t* y = ws_alloc<half_t>(c, (size_t)rows * C);
   WS_CHECK(y);
   RET_IF(launch_layernorm(x, rows, C, gamma, beta, 1e-5f, y, s));
@@ -420,7 +429,8 @@ int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* 
 int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v, int B, int T, int heads, int d, float* out,
                      void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int C = heads * d, rows = B * T;
   half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
   half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
@@ -436,7 +446,8 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
 
 int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const size_t na = (size_t)B * H * W * C, nw = (size_t)9 * Cout * C;
   half_t* a = ws_alloc<half_t>(c, na);
   half_t* w = ws_alloc<half_t>(c, nw);
@@ -512,7 +523,8 @@ int mvd_probe_read(mvd_ctx* c, double* total_ms, double* total_flops, int* launc
 
 int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, float* ms_out, void* stream) {
   hipStream_t s = S(stream);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
   half_t* a = ws_alloc<half_t>(c, na);
   half_t* w = ws_alloc<half_t>(c, nw);

@@ -270,6 +270,16 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 // GroupNorm(+act) -> fp16
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
                    int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0);
+// restores the workspace bump pointer when the scope is left, on the error returns too (a failed call must not leak
+// workspace into the calls that follow it)
+struct WsScope {
+  Workspace& w;
+  const size_t mark;
+  explicit WsScope(mvd_ctx* c) : w(c->ws), mark(c->ws.off) {}
+  ~WsScope() { w.off = mark; }
+  WsScope(const WsScope&) = delete;
+  WsScope& operator=(const WsScope&) = delete;
+};
 template <typename T>
 inline T* ws_alloc(mvd_ctx* c, size_t n) {
   return (T*)c->ws.alloc(n * sizeof(T));

@@ -16,7 +16,8 @@ int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, flo
   const ClipW& k = c->clip;
   if (!k.present) return mvd_fail("clip_encode: no clip_image_encoder.model.visual.* weights were uploaded");
   if (B < 1 || H < 2 || W < 2) return mvd_fail("clip_encode: bad image shape");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int C = k.width, G2 = (k.image / k.patch) * (k.image / k.patch), T = k.T, Tp = k.Tp;
   const size_t rows = (size_t)B * Tp, prow = (size_t)B * G2;
   half_t* patches = ws_alloc<half_t>(c, prow * k.Kp);

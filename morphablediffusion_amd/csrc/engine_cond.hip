@@ -206,7 +206,8 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int S = c->u.image_size, HW = S * S, rows = n_local * HW, td = c->v.time_dim, vd = c->v.view_dim;
   float* x8 = ws_alloc<float>(c, (size_t)rows * 8);
   float* h = ws_alloc<float>(c, (size_t)rows * 16);
@@ -309,7 +310,8 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
     out->lvl0_half = x0h;
     out->lvl[0] = nullptr;
   }
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   half_t* gath = ws_alloc<half_t>(c, vox(0) * 64);
   float* tmp = ws_alloc<float>(c, vox(1) * fd[1]);  // largest intermediate (conv1 output == level-1 size)
   half_t* a = ws_alloc<half_t>(c, vox(0) * fd[0]);

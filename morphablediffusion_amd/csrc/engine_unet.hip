@@ -118,7 +118,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     if (sk > ksteps) sk = ksteps;
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
   }
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   g.splitk = sk;
   g.partial = nullptr;
   if (sk > 1) {
@@ -213,7 +214,8 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
 
 int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStream_t s) {
   if (!ga_in.w->w_up) return mvd_fail("run_upconv2d: weights were not folded");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   GemmArgs ga = ga_in;
   ConvW cw = *ga_in.w;
   cw.w = cw.w_up;
@@ -353,7 +355,8 @@ int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sampl
   if (!two_pass && gn_group_eligible(ld, rows_per_sample, n.C, groups, preadd ? (preadd_ld ? preadd_ld : n.C) : 0, ldo))
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
                            ldo, s);
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
   int nslabs = 0;
@@ -385,7 +388,8 @@ struct Fwd {
 // ResBlock._forward, openaimodel.py:256-276
 int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int rows = f.Bv * H * W;
   half_t* a1 = ws_alloc<half_t>(c, (size_t)rows * r.cin);
   float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
@@ -418,7 +422,8 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
 // SpatialTransformer.forward modules/attention.py:325-336, BasicTransformerBlock._forward :265-269
 int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int C = t.C, T = H * W, rows = f.Bv * T;
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
@@ -469,7 +474,8 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
 // DepthTransformer._forward attention.py:78-84 with DepthAttention folded (see k_depth.hip)
 int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level) {
   mvd_ctx* c = f.c;
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
   const int crow = f.n_ctx * HW;
   float* p = ws_alloc<float>(c, (size_t)rows * I);
@@ -571,7 +577,8 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels, temb = 4 * mc;
-  const size_t mark0 = c->ws.off;
+  WsScope ws_scope0(c);
+  const size_t mark0 = ws_scope0.mark;
   Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
   // fp16 view of the context volumes (operand-only tensors); fp32 sources are copied once per forward
   for (int l = 0; l < 4 && n_ctx > 0 && src; ++l) {
@@ -644,7 +651,8 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   WS_CHECK(final_h);
 
   auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W) -> int {
-    const size_t mark = c->ws.off;
+    WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
     View cur = in;
     const int nstage = (int)ops.size() + (cond ? 1 : 0);
     for (int k = 0; k < nstage; ++k) {

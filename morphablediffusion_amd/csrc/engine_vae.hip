@@ -11,7 +11,8 @@ namespace {
 
 // ResnetBlock.forward (model.py:121-141, temb = None): x + conv2(swish(GN(conv1(swish(GN(x))))))
 int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, int H, int W, hipStream_t s) {
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const size_t rows = (size_t)B * H * W;
   half_t* a1 = ws_alloc<half_t>(c, rows * r.cin);
   float* h1 = ws_alloc<float>(c, rows * r.cout);
@@ -40,7 +41,8 @@ int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, in
 
 // AttnBlock.forward (model.py:178-202)
 int vae_attn(mvd_ctx* c, const VaeAttnW& v, const float* in, float* out, int B, int HW, hipStream_t s) {
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   const int C = v.norm.C;
   const size_t rows = (size_t)B * HW;
   half_t* hn = ws_alloc<half_t>(c, rows * C);
@@ -96,7 +98,8 @@ int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, floa
   const VaeW& v = c->vae;
   if (!v.present) return mvd_fail("first-stage decoder weights not uploaded / finalized");
   if ((h % 16) || (w % 16)) return mvd_fail("vae_decode: latent height and width must be multiples of 16");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   int H = h, W = w;
   size_t rows = (size_t)B * H * W;
   // post_quant_conv (1x1, embed -> z_channels), written into an 8-channel zero-padded tensor for conv_in
@@ -172,7 +175,8 @@ int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, floa
   if (!v.present) return mvd_fail("first-stage encoder weights not uploaded / finalized");
   const int down = 1 << (v.nlev - 1);
   if ((H % (16 * down)) || (W % (16 * down))) return mvd_fail("vae_encode: image size must be a multiple of 16 x the downsampling factor");
-  const size_t mark = c->ws.off;
+  WsScope ws_scope(c);
+  const size_t mark = ws_scope.mark;
   size_t rows = (size_t)B * H * W;
   float* x0 = ws_alloc<float>(c, rows * 8);
   size_t maxel = rows * (size_t)v.conv_in.N;
