@@ -15,7 +15,7 @@
 namespace {
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
+__global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
                                                    const half_t* __restrict__ vt, int ldvt,
                                                    half_t* __restrict__ out, int ldo, int T, int heads, float scale,
                                                    int Tstride) {
@@ -103,36 +103,44 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ qk
         s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
       }
     }
-    // online softmax over the key axis (rows of S^T)
+    // online softmax over the key axis (rows of S^T).  The running maximum is tracked on the scaled scores; the
+    // scale (> 0) is applied inside the exponent's fma, so a score costs max + fma + exp2 + add
     float mx = -INFINITY;
+    if (k0 + 64 > T) {  // last, partial tile: keys >= T are masked out
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= T) s[f][r] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float v = key < T ? s[f][r] * scale : -INFINITY;
-        s[f][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[f][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // scores carry log2(e): exp(x) == exp2(x log2 e)
+    const float m_new = fmaxf(m_run, mx * scale);
     float psum = 0.f;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[f][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], scale, -m_new));  // scores carry log2(e)
         s[f][r] = p;
         psum += p;
       }
     psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {  // wave-uniform: once the maxima settle nothing is rescaled
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int f = 0; f < DVF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+    }
+    l_run += psum;
     m_run = m_new;
-#pragma unroll
-    for (int f = 0; f < DVF; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
     // O^T += V^T P^T : 4 k-steps of 16 keys
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
