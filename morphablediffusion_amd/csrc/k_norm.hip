@@ -422,15 +422,17 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s) {
   const int n2 = rows * (C / G) / 2;
   const dim3 grid(B * G);
-  if (n2 <= 256 * 4)
-    hipLaunchKernelGGL((gn_group_kernel<256, 4>), grid, dim3(256), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act,
-                       out, ldo);
-  else if (n2 <= 1024 * 4)
-    hipLaunchKernelGGL((gn_group_kernel<1024, 4>), grid, dim3(1024), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act,
-                       out, ldo);
-  else
-    hipLaunchKernelGGL((gn_group_kernel<1024, 16>), grid, dim3(1024), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps,
-                       act, out, ldo);
+#define MVD_GN(NT, ME) \
+  hipLaunchKernelGGL((gn_group_kernel<NT, ME>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, out, ldo)
+  // the smallest register tile that holds the group (unused slots still cost predicated loop iterations), 512-thread
+  // workgroups up to 8192 pairs: swept on the UNet's shapes (tools/gn_bench.py), e.g. C=320 @32x32: 35 -> 27 us
+  if (n2 <= 256 * 4) MVD_GN(256, 4);
+  else if (n2 <= 512 * 4) MVD_GN(512, 4);
+  else if (n2 <= 512 * 10) MVD_GN(512, 10);
+  else if (n2 <= 512 * 16) MVD_GN(512, 16);
+  else if (n2 <= 1024 * 10) MVD_GN(1024, 10);
+  else MVD_GN(1024, 16);
+#undef MVD_GN
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
