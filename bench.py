@@ -70,6 +70,12 @@ def main():
                          "reported as a per-rank step time, never as the headline value")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: whatever libraries print there (gloo / RCCL connection chatter, sample()'s
+    # progress lines) is sent to stderr at the file-descriptor level; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +218,8 @@ def main():
             out["n_gpus"] = 1
         if not args.no_cpu_baseline and world == 1 and not args.simulate_gpus:
             out["cpu_baseline"] = cpu_baseline(W, ucfg)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
