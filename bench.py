@@ -180,7 +180,7 @@ def main():
     # implicit GEMM conv3_dma_kernel<160,16,16>: achieved = summed algorithmic FLOPs / summed event time of ALL its
     # launches in the timed region (the rocprofv3 --stats average of that kernel name is the same quantity).
     # HBM traffic of one launch at the 16-view batch comes from the committed rocprofv3 --pmc passes
-    # (profiles/r01_d_pmc_conv3.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); other batches: not measured.
+    # (profiles/r01_g_pmc_conv3.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); other batches: not measured.
     Bc = 2 * nl
     conv_ms = model.engine.bench_conv(Bc, 320, 32, 32, 320, iters=20)
     conv_flops = 2.0 * (Bc * 1024) * 320 * (9 * 320)
@@ -207,7 +207,7 @@ def main():
                                    "one denoise_apply per step", "views_per_gpu": nl, "batch_view_num": bvn,
                        "parallelism": f"view-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": 77.9e6 if Bc == 32 else None,
+                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": 78.1e6 if Bc == 32 else None,
                          "traffic_unit": "bytes/launch of the 320->320 shape, rocprofv3 --pmc (algorithmic: 64.8e6)",
                          "kernel": kdesc},
             "step_tflops": 433.9e9 * N_VIEWS / (dt / args.steps) / 1e12,
