@@ -24,14 +24,14 @@ __global__ void f16_to_f32_kernel(const half_t* in, float* out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = (float)in[i];
 }
-// q,k [rows][C] fp32 -> qk fp16 [rows][2C];  v [rows][C] -> vt fp16 [C][rows]
-__global__ void pack_qkv_kernel(const float* q, const float* k, const float* v, int rows, int C, half_t* qk, half_t* vt) {
+// q,k,v [rows][C] fp32 -> fp16 [rows][3C] (the layout of a fused q|k|v projection)
+__global__ void pack_qkv_rows_kernel(const float* q, const float* k, const float* v, int rows, int C, half_t* qkv) {
   const long total = (long)rows * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / C), c = (int)(i % C);
-    qk[(long)r * 2 * C + c] = (half_t)q[i];
-    qk[(long)r * 2 * C + C + c] = (half_t)k[i];
-    vt[(long)c * rows + r] = (half_t)v[i];
+    qkv[(long)r * 3 * C + c] = (half_t)q[i];
+    qkv[(long)r * 3 * C + C + c] = (half_t)k[i];
+    qkv[(long)r * 3 * C + 2 * C + c] = (half_t)v[i];
   }
 }
 // UNetWrapper.predict_with_unconditional_scale input assembly (morphable_diffusion.py:133-146), channels-last:
@@ -432,12 +432,11 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
   WsScope ws_scope(c);
   const size_t mark = ws_scope.mark;
   const int C = heads * d, rows = B * T;
-  half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
-  half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* o = ws_alloc<half_t>(c, (size_t)rows * C);
-  WS_CHECK(qk && vt && o);
-  hipLaunchKernelGGL(pack_qkv_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, q, k, v, rows, C, qk, vt);
-  RET_IF(launch_attention(qk, 2 * C, vt, rows, o, C, B, T, heads, d, s));
+  WS_CHECK(qkv && o);
+  hipLaunchKernelGGL(pack_qkv_rows_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, q, k, v, rows, C, qkv);
+  RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, o, C, B, T, heads, d, s));
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, o, out, (size_t)rows * C);
   HIP_CHECK_RET(hipGetLastError());
   c->ws.off = mark;

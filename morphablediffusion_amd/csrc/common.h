@@ -119,9 +119,11 @@ int launch_layernorm(const float* x, int rows, int C, const float* gamma, const 
                      half_t* out, hipStream_t s);
 int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
                          float* out, hipStream_t s);
-// Tstride (0 = T): rows between consecutive samples when the token axis is padded (CLIP: 257 tokens in 264 rows)
-int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
-                     int heads, int d, hipStream_t s, int Tstride = 0);
+// q | k rows at `qk` (k at column offset heads*d), V row-major at `v` (row strides ldqk / ldv: all three normally live
+// in one fused projection buffer).  Tstride (0 = T): rows between consecutive samples when the token axis is padded
+// (CLIP: 257 tokens in 264 rows)
+int launch_attention(const half_t* qk, int ldqk, const half_t* v, int ldv, half_t* out, int ldo, int B, int T, int heads,
+                     int d, hipStream_t s, int Tstride = 0);
 int launch_clip_patches(const float* img, int B, int H, int W, int S, int P, int Kp, half_t* out, hipStream_t s);
 int launch_clip_tokens(const float* pe, const float* cls, const float* pos, int B, int T, int Tp, int C, float* x,
                        hipStream_t s);

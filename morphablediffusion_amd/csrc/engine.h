@@ -39,7 +39,7 @@ struct ResW {
 };
 struct STW {
   NormW norm, ln1, ln3;
-  ConvW proj_in, qk, vt, attn_out, ff1, ff2, proj_out;
+  ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;  // qkv: to_q | to_k | to_v rows stacked
   int C = 0, heads = 8, a2_off = 0;
 };
 struct CondW {
@@ -86,9 +86,8 @@ struct VaeEncW {  // Encoder (double_z) + quant_conv
 // CLIP vision tower (FrozenCLIPImageEmbedder, ldm/modules/encoders/modules.py:343-382; openai/CLIP VisionTransformer)
 struct ClipLayerW {
   NormW ln1, ln2;
-  ConvW qk;    // rows [0, 2w) of attn.in_proj_weight with their biases
-  ConvW v;     // rows [2w, 3w): A operand of the swapped GEMM; its bias is folded into out.bias
-  ConvW out;   // attn.out_proj, bias = b_o + W_o b_v
+  ConvW qkv;   // attn.in_proj_weight (q | k | v rows) with the q and k biases; b_v is folded into out.bias
+  ConvW out;   // attn.out_proj, bias = b_o + W_o b_v (softmax rows sum to 1)
   ConvW fc;    // mlp.c_fc; QuickGELU(v) = silu(1.702 v) / 1.702: run with alpha = 1.702 and the bias pre-scaled
   ConvW proj;  // mlp.c_proj, run with alpha = 1 / 1.702
 };

@@ -2,9 +2,9 @@
 // (ldm/modules/encoders/modules.py:363-379) = preprocess + `clip.load(...)`'s VisionTransformer.forward, as
 // SyncMultiviewDiffusion.prepare calls it once per sample (morphable_diffusion.py:487-488).  Runs on the UNet's
 // kernels: the patch convolution (k14 s14, no bias) is a GEMM over an im2col written by the preprocess kernel; each
-// ResidualAttentionBlock is LayerNorm -> q|k GEMM + V^T swapped GEMM -> flash attention -> out_proj GEMM with the
+// ResidualAttentionBlock is LayerNorm -> q|k|v GEMM -> flash attention (V transposed while staged) -> out_proj GEMM with the
 // residual in the epilogue -> LayerNorm -> c_fc GEMM -> c_proj GEMM with the residual in the epilogue.
-//   * token axis: 257 tokens live in 264 rows per sample (the attention kernel loads V^T 8 tokens at a time); the pad
+//   * token axis: 257 tokens live in 264 rows per sample (row counts stay multiples of 8 for the GEMM tiles); the pad
 //     rows start at zero, never enter a softmax (keys >= T are masked) and stay finite
 //   * the v bias is folded into out_proj's bias (softmax rows sum to 1)
 //   * QuickGELU(v) = v sigmoid(1.702 v) = silu(1.702 v) / 1.702: c_fc runs with alpha = 1.702 (bias pre-scaled) and
@@ -26,12 +26,11 @@ int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, flo
   float* x = ws_alloc<float>(c, rows * C);
   float* x2 = ws_alloc<float>(c, rows * C);
   half_t* l1 = ws_alloc<half_t>(c, rows * C);
-  half_t* qk = ws_alloc<half_t>(c, rows * 2 * C);
-  half_t* vt = ws_alloc<half_t>(c, rows * C);
+  half_t* qkv = ws_alloc<half_t>(c, rows * 3 * C);
   half_t* ao = ws_alloc<half_t>(c, rows * C);
   half_t* hh = ws_alloc<half_t>(c, rows * 4 * C);
   float* cl = ws_alloc<float>(c, (size_t)B * C);
-  WS_CHECK(patches && pe && x0 && x && x2 && l1 && qk && vt && ao && hh && cl);
+  WS_CHECK(patches && pe && x0 && x && x2 && l1 && qkv && ao && hh && cl);
 
   RET_IF(launch_clip_patches(x_nchw, B, H, W, k.image, k.patch, k.Kp, patches, s));
   GemmArgs g;
@@ -45,14 +44,9 @@ int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, flo
   for (const ClipLayerW& L : k.blk) {
     RET_IF(launch_layernorm(x, (int)rows, C, L.ln1.g, L.ln1.b, 1e-5f, l1, s));
     g = GemmArgs();
-    g.a = l1; g.lda = C; g.w = &L.qk; g.out = qk; g.out_f32 = 0; g.ldc = 2 * C;
+    g.a = l1; g.lda = C; g.w = &L.qkv; g.out = qkv; g.out_f32 = 0; g.ldc = 3 * C;
     RET_IF(run_linear(c, g, B, (int)rows, s));
-    ConvW xw;  // V^T = W_v X^T
-    xw.w = l1; xw.N = (int)rows; xw.Cin = C; xw.taps = 1;
-    g = GemmArgs();
-    g.a = L.v.w; g.lda = C; g.w = &xw; g.out = vt; g.out_f32 = 0; g.ldc = (int)rows; g.use_bias = false;
-    RET_IF(run_linear(c, g, 1, C, s));
-    RET_IF(launch_attention(qk, 2 * C, vt, (int)rows, ao, C, B, T, k.heads, C / k.heads, s, Tp));
+    RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, B, T, k.heads, C / k.heads, s, Tp));
     g = GemmArgs();
     g.a = ao; g.lda = C; g.w = &L.out; g.out = x2; g.ldc = C; g.resid = x; g.ldr = C;
     RET_IF(run_linear(c, g, B, (int)rows, s));

@@ -428,29 +428,22 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);
-  half_t* qk = ws_alloc<half_t>(c, (size_t)rows * 2 * C);
-  half_t* vt = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t2 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
   half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C);  // x + ff(x): only ever the proj_out operand -> fp16
-  WS_CHECK(n0 && t0 && l1 && qk && vt && ao && t2 && gg && t3);
+  WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3);
   RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C, f.s));
   GemmArgs g;
   g.a = n0; g.lda = C; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
-  // q | k projection
+  // q | k | v projection in one GEMM; the attention kernel transposes V while staging it
   g = GemmArgs();
-  g.a = l1; g.lda = C; g.w = &t.qk; g.out = qk; g.out_f32 = 0; g.ldc = 2 * C; g.use_bias = false;
+  g.a = l1; g.lda = C; g.w = &t.qkv; g.out = qkv; g.out_f32 = 0; g.ldc = 3 * C; g.use_bias = false;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  // V^T = W_v X^T : the weight matrix is the "activation" operand, the tokens are the "weights"
-  ConvW xw;
-  xw.w = l1; xw.N = rows; xw.Cin = C; xw.taps = 1;
-  g = GemmArgs();
-  g.a = t.vt.w; g.lda = C; g.w = &xw; g.out = vt; g.out_f32 = 0; g.ldc = rows; g.use_bias = false;
-  RET_IF(run_linear(c, g, 1, C, f.s));
-  RET_IF(launch_attention(qk, 2 * C, vt, rows, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
+  RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
   // attn2 (single CLIP token -> per-sample constant, precomputed for all blocks in engine_unet) rides on the
   // attn1 output projection as a per-sample bias
   g = GemmArgs();

@@ -103,16 +103,18 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(pack_conv(c, p + ".proj_out.weight", p + ".proj_out.bias", false, false, &s->proj_out));
   RET_IF(load_norm(c, t + ".norm1", &s->ln1));
   RET_IF(load_norm(c, t + ".norm3", &s->ln3));
-  RawTensor *q, *k;
+  // to_q | to_k | to_v stacked: one projection GEMM, the attention kernel reads V row-major out of its third block
+  RawTensor *q, *k, *v;
   RET_IF(get_raw(c, t + ".attn1.to_q.weight", &q));
   RET_IF(get_raw(c, t + ".attn1.to_k.weight", &k));
-  s->qk.N = 2 * C;
-  s->qk.Cin = C;
-  s->qk.taps = 1;
-  RET_IF(dmalloc(c, (void**)&s->qk.w, (size_t)2 * C * C * sizeof(half_t)));
-  RET_IF(launch_f32_to_f16(q->d, s->qk.w, (size_t)C * C, 0));
-  RET_IF(launch_f32_to_f16(k->d, s->qk.w + (size_t)C * C, (size_t)C * C, 0));
-  RET_IF(pack_conv(c, t + ".attn1.to_v.weight", "", false, false, &s->vt));
+  RET_IF(get_raw(c, t + ".attn1.to_v.weight", &v));
+  s->qkv.N = 3 * C;
+  s->qkv.Cin = C;
+  s->qkv.taps = 1;
+  RET_IF(dmalloc(c, (void**)&s->qkv.w, (size_t)3 * C * C * sizeof(half_t)));
+  RET_IF(launch_f32_to_f16(q->d, s->qkv.w, (size_t)C * C, 0));
+  RET_IF(launch_f32_to_f16(k->d, s->qkv.w + (size_t)C * C, (size_t)C * C, 0));
+  RET_IF(launch_f32_to_f16(v->d, s->qkv.w + (size_t)2 * C * C, (size_t)C * C, 0));
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
@@ -324,10 +326,10 @@ int build_clip(mvd_ctx* c) {
     if ((long)iw->numel != 3L * w * w || (long)ib->numel != 3L * w) return mvd_fail("CLIP: in_proj shape");
     RET_IF(load_norm(c, L + ".ln_1", &b.ln1));
     RET_IF(load_norm(c, L + ".ln_2", &b.ln2));
-    RET_IF(pack_rows(c, iw->d, 2 * w, w, w, &b.qk));
-    RET_IF(dmalloc(c, (void**)&b.qk.bias, (size_t)2 * w * sizeof(float)));
-    HIP_CHECK_RET(hipMemcpy(b.qk.bias, ib->d, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToDevice));
-    RET_IF(pack_rows(c, iw->d + (size_t)2 * w * w, w, w, w, &b.v));
+    RET_IF(pack_rows(c, iw->d, 3 * w, w, w, &b.qkv));  // in_proj_weight is q | k | v stacked already
+    RET_IF(dmalloc(c, (void**)&b.qkv.bias, (size_t)3 * w * sizeof(float)));
+    HIP_CHECK_RET(hipMemcpy(b.qkv.bias, ib->d, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_CHECK_RET(hipMemset(b.qkv.bias + 2 * w, 0, (size_t)w * sizeof(float)));  // b_v lives in out.bias
     RET_IF(pack_conv(c, L + ".attn.out_proj.weight", "", false, false, &b.out));
     RET_IF(dmalloc(c, (void**)&b.out.bias, (size_t)w * sizeof(float)));
     hipLaunchKernelGGL(vae_fold_v_bias_kernel, dim3(cdiv(w, 128)), dim3(128), 0, 0, ow->d, ib->d + 2 * w, ob->d, w, b.out.bias);

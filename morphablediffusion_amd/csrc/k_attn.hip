@@ -8,15 +8,16 @@
 // cross-half exchange, and the running rescale of O^T is lane-local.  The fp16 P^T fragment that feeds
 // the second MFMA is exactly the accumulator register order, provided V^T is read with the same key
 // permutation (two 8-byte LDS reads per fragment instead of one 16-byte read) -- no shuffles, no LDS
-// round trip for P.  V arrives already transposed ([head*d + dv][token]) because the V projection is
-// issued as the swapped GEMM  V^T = W_v X^T.
+// round trip for P.  q, k and v come out of ONE fused projection GEMM ([token][q | k | v]); the V^T image in LDS is
+// built by the staging pass (16-byte row-major loads, 2-byte transposing LDS stores) -- that costs the kernel ~10 % at
+// d = 40 and saves a swapped V^T = W_v X^T GEMM launch per attention (step: +1.6 %, 2-views-per-rank step: +3 %).
 #include "common.h"
 
 namespace {
 
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
-                                                   const half_t* __restrict__ vt, int ldvt,
+                                                   const half_t* __restrict__ v, int ldv,
                                                    half_t* __restrict__ out, int ldo, int T, int heads, float scale,
                                                    int Tstride) {
   constexpr int KS = (D + 15) / 16;        // k-steps of the QK^T product
@@ -51,9 +52,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
     for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // K / V^T tiles are register-staged one tile ahead: the global loads of tile i+1 are in flight behind the
-  // MFMAs and the softmax of tile i
-  constexpr int KSLOTS = (64 * (DK / 8) + 255) / 256, VSLOTS = (DVP * 8 + 255) / 256;
+  // K / V tiles are register-staged one tile ahead: the global loads of tile i+1 are in flight behind the MFMAs and the
+  // softmax of tile i.  V arrives row-major ([token][head*d + dv], the third block of the fused q|k|v projection) and is
+  // transposed by the LDS write pass (eight 2-byte stores per 16-byte load) into the V^T image the second MFMA reads.
+  constexpr int KSLOTS = (64 * (DK / 8) + 255) / 256, VSLOTS = (64 * (D / 8) + 255) / 256;
   h8 kreg[KSLOTS], vreg[VSLOTS];
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -67,9 +69,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
 #pragma unroll
     for (int i = 0; i < VSLOTS; ++i) {
       const int idx = tid + i * 256;
-      const int dv = idx >> 3, ch = idx & 7;
-      vreg[i] = (h8)(half_t)0;
-      if (idx < DVP * 8 && dv < D && k0 + ch * 8 < T) vreg[i] = *(const h8*)(vt + (long)(head * D + dv) * ldvt + tok0 + k0 + ch * 8);
+      const int key = idx / (D / 8), ch = idx - key * (D / 8);
+      vreg[i] = (h8)(half_t)0;  // keys >= T must be zeros: their P is 0, but 0 x garbage could be NaN
+      if (idx < 64 * (D / 8) && k0 + key < T) vreg[i] = *(const h8*)(v + (tok0 + k0 + key) * ldv + head * D + ch * 8);
     }
   };
   auto store_tiles = [&]() {
@@ -82,9 +84,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
 #pragma unroll
     for (int i = 0; i < VSLOTS; ++i) {
       const int idx = tid + i * 256;
-      if (idx < DVP * 8) *(h8*)(sV + (idx >> 3) * VLD + (idx & 7) * 8) = vreg[i];
+      const int key = idx / (D / 8), ch = idx - key * (D / 8);
+      if (idx < 64 * (D / 8)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sV[(ch * 8 + e) * VLD + key] = vreg[i][e];
+      }
     }
   };
+  // rows D..DVP-1 of the V^T image are padding of the last 32-row fragment: zeroed once, never rewritten
+  for (int idx = tid; idx < (DVP - D) * 64; idx += 256) sV[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
   load_tiles(0);
   for (int k0 = 0; k0 < T; k0 += 64) {
     __syncthreads();  // every wave is done reading the previous tile
@@ -226,16 +234,15 @@ int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStrea
   return 0;
 }
 
-int launch_attention(const half_t* qk, int ldqk, const half_t* vt, int ldvt, half_t* out, int ldo, int B, int T,
-                     int heads, int d, hipStream_t s, int Tstride) {
+int launch_attention(const half_t* qk, int ldqk, const half_t* v, int ldv, half_t* out, int ldo, int B, int T, int heads,
+                     int d, hipStream_t s, int Tstride) {
   if (Tstride <= 0) Tstride = T;
-  // the V^T tile loads fetch 8 tokens at a time: rows T..Tstride-1 of a sample must exist (and hold finite values)
-  if (Tstride % 8 || Tstride < T || ldqk % 8 || ldvt % 8 || ldo % 4 || d % 8)
-    return mvd_fail("attention: alignment (token stride, ld, d multiples of 8)");
+  if (Tstride < T || ldqk % 8 || ldv % 8 || ldo % 4 || d % 8 || ((uintptr_t)qk & 15) || ((uintptr_t)v & 15))
+    return mvd_fail("attention: alignment (row strides and d multiples of 8, 16-byte aligned operands)");
   dim3 grid(cdiv(T, 128), heads, B);
   const float scale = 1.4426950408889634f / sqrtf((float)d);  // softmax scale * log2(e): the kernel uses exp2
 #define MVD_ATTN(DD) \
-  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, vt, ldvt, out, ldo, T, heads, scale, Tstride); break;
+  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, v, ldv, out, ldo, T, heads, scale, Tstride); break;
   switch (d) {
     MVD_ATTN(8)
     MVD_ATTN(16)
