@@ -109,6 +109,10 @@ void mvd_destroy(mvd_ctx* c) {
   hipFree(c->volume);
   hipFree(c->ws.base);
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->side) hipStreamDestroy(c->side);
   delete c;
 }
 

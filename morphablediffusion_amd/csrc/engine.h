@@ -161,6 +161,11 @@ struct mvd_ctx {
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
+  // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
+  // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<hipEvent_t> ev_cond;
   // in-situ timing of the dominant kernel (conv3_dma_kernel<160,16,16>): HIP events around each of its launches
   bool probe_on = false;
   std::vector<hipEvent_t> probe_ev;   // pool, two events per probed launch

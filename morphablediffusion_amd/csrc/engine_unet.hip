@@ -383,6 +383,8 @@ struct Fwd {
   const float* a2_all;   // [Bv][a2_total] folded attn2 output per SpatialTransformer
   const Ctx5* src;
   const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
+  // relu(GroupNorm(proj_context(volume))) of every DepthTransformer, produced on the side stream (nullptr: inline)
+  const half_t* cn_pre[16] = {nullptr};
 };
 
 // ResBlock._forward, openaimodel.py:256-276
@@ -465,7 +467,33 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
 }
 
 // DepthTransformer._forward attention.py:78-84 with DepthAttention folded (see k_depth.hip)
-int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level) {
+// GroupNorm(proj_context(ctx)) without materialising the projection: pass 1 re-computes the 1x1x1 conv tile by tile and keeps
+// only (sum, sumsq) per group, pass 2 re-computes it and applies scale/shift + ReLU in the epilogue.  Depends on the context
+// volume and the weights only, so engine_unet issues it on the side stream for every DepthTransformer up front.
+bool ctx_fold_ok(const Fwd& f, const CondW& d, int HW, int D, int level) {
+  static const bool fold_off = getenv("MVD_NO_CTX_FOLD") != nullptr;
+  const int rps = D * HW, cpg = d.Cc / 8;
+  return !fold_off && f.n_ctx > 0 && f.src16[level] && rps % 256 == 0 && (cpg == 8 || cpg == 16 || cpg == 32) &&
+         (long)f.n_ctx * HW * D >= 512;
+}
+int ctx_fold(Fwd& f, const CondW& d, int HW, int D, int level, half_t* cn, hipStream_t s) {
+  mvd_ctx* c = f.c;
+  const int Cc = d.Cc, crow = f.n_ctx * HW, rps = D * HW, cpg = Cc / 8, ntile = rps / 256;
+  float* part = ws_alloc<float>(c, (size_t)f.n_ctx * ntile * 8 * 2);
+  float* sc = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
+  float* sh = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
+  WS_CHECK(part && sc && sh);
+  GemmArgs g;
+  g.a = f.src16[level]; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.gn_partial = part; g.gn_cpg = cpg; g.force_splitk = 1;
+  RET_IF(run_linear(c, g, f.n_ctx, crow * D, s));
+  RET_IF(launch_gn_finalize(part, f.n_ctx, ntile, rps, Cc, 8, d.gn_ctx.g, d.gn_ctx.b, 1e-5f, sc, sh, Cc, s));
+  g = GemmArgs();
+  g.a = f.src16[level]; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.out = cn; g.out_f32 = 0; g.ldc = Cc;
+  g.rowscale = sc; g.rs_ld = Cc; g.rowbias = sh; g.rb_ld = Cc; g.act = ACT_RELU; g.force_splitk = 1;
+  return run_linear(c, g, f.n_ctx, crow * D, s);
+}
+
+int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
   const size_t mark = ws_scope.mark;
@@ -483,32 +511,20 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level) 
   RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, I, f.s));
   if (f.n_ctx > 0) {
     float* qk = ws_alloc<float>(c, (size_t)crow * 4 * Cc);
-    float* pc = ws_alloc<float>(c, (size_t)crow * D * Cc);
-    half_t* cn = ws_alloc<half_t>(c, (size_t)crow * D * Cc);
-    WS_CHECK(qk && pc && cn);
+    half_t* cn = cond_idx >= 0 && f.cn_pre[cond_idx] ? nullptr : ws_alloc<half_t>(c, (size_t)crow * D * Cc);
+    WS_CHECK(qk && (cn || (cond_idx >= 0 && f.cn_pre[cond_idx])));
     g = GemmArgs();
     g.a = pn; g.lda = I; g.w = &d.wqk; g.out = qk; g.ldc = 4 * Cc; g.use_bias = false;
     RET_IF(run_linear(c, g, f.n_ctx, crow, f.s));
-    const int rps = D * HW, cpg = Cc / 8;
-    static const bool fold_off = getenv("MVD_NO_CTX_FOLD") != nullptr;
-    const half_t* src16 = f.src16[level];
-    if (!fold_off && src16 && rps % 256 == 0 && (cpg == 8 || cpg == 16 || cpg == 32) && (long)crow * D >= 512) {
-      // GroupNorm(proj_context(ctx)) without materialising the projection: pass 1 re-computes the 1x1x1 conv tile by
-      // tile and keeps only (sum, sumsq) per group, pass 2 re-computes it and applies scale/shift + ReLU in the epilogue
-      const int ntile = rps / 256;
-      float* part = ws_alloc<float>(c, (size_t)f.n_ctx * ntile * 8 * 2);
-      float* sc = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
-      float* sh = ws_alloc<float>(c, (size_t)f.n_ctx * Cc);
-      WS_CHECK(part && sc && sh);
-      g = GemmArgs();
-      g.a = src16; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.gn_partial = part; g.gn_cpg = cpg; g.force_splitk = 1;
-      RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
-      RET_IF(launch_gn_finalize(part, f.n_ctx, ntile, rps, Cc, 8, d.gn_ctx.g, d.gn_ctx.b, 1e-5f, sc, sh, Cc, f.s));
-      g = GemmArgs();
-      g.a = src16; g.lda = Cc; g.w = &d.proj_ctx; g.use_bias = false; g.out = cn; g.out_f32 = 0; g.ldc = Cc;
-      g.rowscale = sc; g.rs_ld = Cc; g.rowbias = sh; g.rb_ld = Cc; g.act = ACT_RELU; g.force_splitk = 1;
-      RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
+    const half_t* cnp = cond_idx >= 0 ? f.cn_pre[cond_idx] : nullptr;
+    if (cnp) {  // prepared on the side stream
+      HIP_CHECK_RET(hipStreamWaitEvent(f.s, c->ev_cond[cond_idx], 0));
+      cn = const_cast<half_t*>(cnp);
+    } else if (ctx_fold_ok(f, d, HW, D, level)) {
+      RET_IF(ctx_fold(f, d, HW, D, level, cn, f.s));
     } else {
+      float* pc = ws_alloc<float>(c, (size_t)crow * D * Cc);
+      WS_CHECK(pc);
       g = GemmArgs();
       g.a = f.src[level].p; g.a_f32 = f.src[level].f32; g.lda = Cc; g.w = &d.proj_ctx; g.out = pc; g.ldc = Cc; g.use_bias = false;
       RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
@@ -586,6 +602,59 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     WS_CHECK(h);
     RET_IF(launch_f32_to_f16((const float*)src[l].p, h, n, s));
     f.src16[l] = h;
+  }
+  // Fork: the context half of every DepthTransformer depends on the frustum volumes and the weights only.  Issued up front
+  // on the side stream it runs beside the trunk (which leaves CUs idle whenever a rank holds few views); each block waits
+  // for its own event just before its depth attention.  The guard joins the side stream back on every exit path, so the
+  // workspace these launches use is never handed out again while they may still be running.
+  struct SideJoin {
+    hipStream_t main, side = nullptr;
+    hipEvent_t ev = nullptr;
+    ~SideJoin() {
+      if (!side) return;
+      hipEventRecord(ev, side);
+      hipStreamWaitEvent(main, ev, 0);
+    }
+  } join{s};
+  static const bool side_off = getenv("MVD_NO_SIDE_STREAM") != nullptr;
+  if (!side_off && n_ctx > 0 && src && c->conds.size() <= 16) {
+    if (!c->side) {
+      HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      c->ev_cond.resize(c->conds.size());
+      for (auto& ev : c->ev_cond) HIP_CHECK_RET(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    auto level_of = [&](int Hx) {
+      int l = 0;
+      for (int r = u.image_size; r > Hx; r >>= 1) ++l;
+      return l;
+    };
+    std::vector<int> cH(c->conds.size(), 0);
+    int Hc = u.image_size;
+    for (auto& blk : c->in_blocks) Hc = out_res_of(blk, Hc);
+    cH[0] = out_res_of(c->mid_block, Hc);
+    for (size_t i = 0; i < c->out_blocks.size(); ++i) {
+      Hc = out_res_of(c->out_blocks[i], Hc);
+      if (i >= 3 && 1 + (i - 3) < cH.size()) cH[1 + (i - 3)] = Hc;
+    }
+    for (size_t k = 0; k < c->conds.size(); ++k) {
+      if (cH[k] <= 0) continue;
+      const CondW& d = c->conds[k];
+      const int lv = level_of(cH[k]), HW = cH[k] * cH[k], D = depth0 >> lv;
+      if (lv > 3 || !ctx_fold_ok(f, d, HW, D, lv)) continue;
+      if (!join.side) {
+        HIP_CHECK_RET(hipEventRecord(c->ev_fork, s));
+        HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        join.side = c->side;
+        join.ev = c->ev_join;
+      }
+      half_t* cn = ws_alloc<half_t>(c, (size_t)n_ctx * HW * D * d.Cc);
+      WS_CHECK(cn);
+      RET_IF(ctx_fold(f, d, HW, D, lv, cn, c->side));
+      HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
+      f.cn_pre[k] = cn;
+    }
   }
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
   float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
@@ -665,7 +734,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       if (is_cond) {
         int level = 0;
         for (int r = u.image_size; r > H; r >>= 1) ++level;
-        RET_IF(do_cond(f, *cond, cur, o, H, W, level));
+        RET_IF(do_cond(f, *cond, cur, o, H, W, level, (int)(cond - c->conds.data())));
       } else {
         RET_IF(do_op(f, ops[k], cur, o, H, W));
       }
