@@ -110,8 +110,8 @@ void mvd_destroy(mvd_ctx* c) {
   hipFree(c->ws.base);
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
+  for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx})
+    if (ev) hipEventDestroy(ev);
   if (c->side) hipStreamDestroy(c->side);
   delete c;
 }
@@ -161,7 +161,6 @@ int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
 int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream) {
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int td = c->v.time_dim;
   float* e0 = ws_alloc<float>(c, (size_t)B * td);
   float* e1 = ws_alloc<float>(c, (size_t)B * td);
@@ -169,7 +168,6 @@ int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream
   RET_IF(launch_timestep_embedding(t, B, td, e0, S(stream)));
   RET_IF(launch_small_linear(e0, td, B, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, e1, td, 0, S(stream)));
   RET_IF(launch_small_linear(e1, td, B, td, c->step_te2.w, c->step_te2.bias, td, ACT_SILU, out, td, 0, S(stream)));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -181,7 +179,6 @@ int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const
   hipStream_t s = S(stream);
   const mvd_unet_config& u = c->u;
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int HW = u.image_size * u.image_size;
   const int cin = u.in_channels;
   if (cin % 8) return mvd_fail("in_channels must be a multiple of 8");
@@ -202,7 +199,6 @@ int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const
   }
   RET_IF(engine_unet(c, xn, cin, timesteps, context, Bv, n_ctx, depth0, cl, eps, s));
   RET_IF(launch_nhwc_to_nchw(eps, u.out_channels, Bv, u.out_channels, HW, out, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -226,7 +222,6 @@ int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, 
                         float* out0, float* out1, float* out2, float* out3, void* stream) {
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   FrustumOut fo;
   RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, S(stream)));
   float* outs[4] = {out0, out1, out2, out3};
@@ -236,7 +231,6 @@ int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, 
     D = (D - 1) / 2 + 1;
     Sz = (Sz - 1) / 2 + 1;
   }
-  c->ws.off = mark;
   return 0;
 }
 
@@ -249,12 +243,25 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   const mvd_unet_config& u = c->u;
   if (u.in_channels != 8 || u.out_channels != 4) return mvd_fail("denoise_views: expects the 8-in / 4-out latent UNet");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int HW = u.image_size * u.image_size;
   const bool cfg = cfg_scale != 1.0f;
   const int copies = cfg ? 2 : 1, Bv = copies * TN;
+  // The frustum network feeds the DepthTransformers only (middle block onwards): engine_unet enqueues it (through this
+  // producer) on its side stream after the full-resolution input blocks, beside the lower-resolution ones.
   FrustumOut fo;
-  RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, s, /*half0=*/true));
+  Ctx5 cl[4];
+  const CtxProducer produce = [&](hipStream_t ps) -> int {
+    RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, ps, /*half0=*/true));
+    for (int l = 0; l < 4; ++l) {
+      cl[l].p = fo.lvl[l];
+      cl[l].f32 = 1;
+    }
+    if (fo.lvl0_half) {
+      cl[0].p = fo.lvl0_half;
+      cl[0].f32 = 0;
+    }
+    return 0;
+  };
   float* xin = ws_alloc<float>(c, (size_t)Bv * HW * 8);
   float* ctx = ws_alloc<float>(c, (size_t)Bv * u.context_dim);
   int64_t* tt = ws_alloc<int64_t>(c, (size_t)Bv);
@@ -266,21 +273,11 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)Bv * u.context_dim)), dim3(256), 0, s, clip, TN,
                      u.context_dim, copies, ctx, tt, timestep);
   HIP_CHECK_RET(hipGetLastError());
-  Ctx5 cl[4];
-  for (int l = 0; l < 4; ++l) {
-    cl[l].p = fo.lvl[l];
-    cl[l].f32 = 1;
-  }
-  if (fo.lvl0_half) {
-    cl[0].p = fo.lvl0_half;
-    cl[0].f32 = 0;
-  }
-  RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s));
+  RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s, &produce));
   RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));
   const size_t n = (size_t)TN * 4 * HW;
   RET_IF(launch_cfg_ddim(eps_nchw, cfg ? eps_nchw + n : nullptr, cfg_scale, x_noisy, noise, sqrt_one_minus_at, sqrt_at,
                          sqrt_aprev, dir_coef, sigma, eps_out, x_prev, n, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -290,7 +287,6 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
                 void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int cpad = (Cin + 7) / 8 * 8, taps = ksize * ksize;
   const int Hv = H << upsample, Wv = W << upsample;
   const int Ho = (Hv - 1) / stride + 1, Wo = (Wv - 1) / stride + 1;
@@ -325,7 +321,6 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
     RET_IF(run_conv2d(c, g, B, H, W, stride, upsample, s));
   }
   RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Ho * Wo, out_nchw, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -333,7 +328,6 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
                   int Cout, int stride, int transposed, const float* resid, float* out, void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   if (Cin % 8) return mvd_fail("op_conv3d: Cin must be a multiple of 8");
   const int Do = transposed ? 2 * D : (D - 1) / stride + 1, Ho = transposed ? 2 * H : (H - 1) / stride + 1,
             Wo = transposed ? 2 * W : (W - 1) / stride + 1;
@@ -359,7 +353,6 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
   if (transposed) RET_IF(run_convT3d(c, g, B, D, H, W, s));
   else RET_IF(run_conv3d(c, g, B, D, H, W, stride, s));
   RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Do * Ho * Wo, out, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -367,7 +360,6 @@ int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, cons
                   const float* resid, int a_half, int force_splitk, float* out, void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   if (K % 8) return mvd_fail("op_linear: K must be a multiple of 8");
   half_t* wp = ws_alloc<half_t>(c, (size_t)N * K);
   float* bp = ws_alloc<float>(c, (size_t)N);
@@ -393,7 +385,6 @@ int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, cons
     g.a = ah; g.a_f32 = 0;
   }
   RET_IF(run_linear(c, g, 1, M, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -401,7 +392,6 @@ int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int
                       const float* beta, float eps, int act, float* out_nchw, void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   float* xn = ws_alloc<float>(c, (size_t)B * HW * C);
   half_t* y = ws_alloc<half_t>(c, (size_t)B * HW * C);
   float* yf = ws_alloc<float>(c, (size_t)B * HW * C);
@@ -412,7 +402,6 @@ int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int
   RET_IF(run_group_norm(c, xn, C, B, HW, n, groups, eps, act, nullptr, y, C, s));
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)B * HW * C)), dim3(256), 0, s, y, yf, (size_t)B * HW * C);
   RET_IF(launch_nhwc_to_nchw(yf, C, B, C, HW, out_nchw, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -420,13 +409,11 @@ int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* 
                       void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   half_t* y = ws_alloc<half_t>(c, (size_t)rows * C);
   WS_CHECK(y);
   RET_IF(launch_layernorm(x, rows, C, gamma, beta, 1e-5f, y, s));
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, y, out, (size_t)rows * C);
   HIP_CHECK_RET(hipGetLastError());
-  c->ws.off = mark;
   return 0;
 }
 
@@ -434,7 +421,6 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
                      void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int C = heads * d, rows = B * T;
   half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* o = ws_alloc<half_t>(c, (size_t)rows * C);
@@ -443,14 +429,12 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
   RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, o, C, B, T, heads, d, s));
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, o, out, (size_t)rows * C);
   HIP_CHECK_RET(hipGetLastError());
-  c->ws.off = mark;
   return 0;
 }
 
 int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const size_t na = (size_t)B * H * W * C, nw = (size_t)9 * Cout * C;
   half_t* a = ws_alloc<half_t>(c, na);
   half_t* w = ws_alloc<half_t>(c, nw);
@@ -475,7 +459,6 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *ms_out = ms / (float)iters;
-  c->ws.off = mark;
   return 0;
 }
 
@@ -527,7 +510,6 @@ int mvd_probe_read(mvd_ctx* c, double* total_ms, double* total_flops, int* launc
 int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, float* ms_out, void* stream) {
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
   half_t* a = ws_alloc<half_t>(c, na);
   half_t* w = ws_alloc<half_t>(c, nw);
@@ -558,7 +540,6 @@ int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, floa
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *ms_out = ms / (float)iters;
-  c->ws.off = mark;
   return 0;
 }
 

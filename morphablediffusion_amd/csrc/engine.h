@@ -1,6 +1,7 @@
 // Host-side engine: weight store, block plan, workspace, and the executors that turn one denoising step
 // into a fixed sequence of kernel launches on one HIP stream (no Python in the loop, no allocation).
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -132,6 +133,8 @@ struct EncBlockW {
 struct Workspace {
   char* base = nullptr;
   size_t size = 0, off = 0, peak = 0;
+  int hold = 0;  // > 0: scopes that end now keep their allocations (work enqueued on the side stream is still using them);
+                 // the enclosing scope opened before the hold releases everything
   void* alloc(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
     if (o + bytes > size) return nullptr;
@@ -164,7 +167,7 @@ struct mvd_ctx {
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
   // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr;
   std::vector<hipEvent_t> ev_cond;
   // in-situ timing of the dominant kernel (conv3_dma_kernel<160,16,16>): HIP events around each of its launches
   bool probe_on = false;
@@ -225,8 +228,11 @@ struct Ctx5 {  // channels-last context volume of one level for the first n_ctx 
   const void* p = nullptr;
   int f32 = 1;
 };
+// produce (optional): fills src[] by enqueueing the context-volume producer (the frustum network) on the stream it is given;
+// engine_unet calls it after its full-resolution input blocks, on the side stream (see engine_unet.hip)
+typedef std::function<int(hipStream_t)> CtxProducer;
 int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
-                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s);
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce = nullptr);
 // engine_cond.hip
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s);
@@ -280,10 +286,28 @@ struct WsScope {
   Workspace& w;
   const size_t mark;
   explicit WsScope(mvd_ctx* c) : w(c->ws), mark(c->ws.off) {}
-  ~WsScope() { w.off = mark; }
+  ~WsScope() {
+    if (!w.hold) w.off = mark;
+  }
   WsScope(const WsScope&) = delete;
   WsScope& operator=(const WsScope&) = delete;
 };
+// Joins the side stream back into the caller's stream when the scope is left (on the error returns too): nothing enqueued
+// after that point can overtake side-stream work that still reads workspace memory.  Declare it AFTER the WsScope whose
+// memory the side stream uses.
+struct SideJoin {
+  hipStream_t main;
+  hipStream_t side = nullptr;
+  hipEvent_t ev = nullptr;
+  explicit SideJoin(hipStream_t m) : main(m) {}
+  ~SideJoin() {
+    if (!side) return;
+    hipEventRecord(ev, side);
+    hipStreamWaitEvent(main, ev, 0);
+  }
+};
+// creates the side stream and its events on first use
+int engine_side_init(mvd_ctx* c);
 template <typename T>
 inline T* ws_alloc(mvd_ctx* c, size_t n) {
   return (T*)c->ws.alloc(n * sizeof(T));

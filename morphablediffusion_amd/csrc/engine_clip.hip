@@ -17,7 +17,6 @@ int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, flo
   if (!k.present) return mvd_fail("clip_encode: no clip_image_encoder.model.visual.* weights were uploaded");
   if (B < 1 || H < 2 || W < 2) return mvd_fail("clip_encode: bad image shape");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int C = k.width, G2 = (k.image / k.patch) * (k.image / k.patch), T = k.T, Tp = k.Tp;
   const size_t rows = (size_t)B * Tp, prow = (size_t)B * G2;
   half_t* patches = ws_alloc<half_t>(c, prow * k.Kp);
@@ -61,6 +60,5 @@ int engine_clip_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, flo
   // ln_post on the class token of every sample, then @ proj
   RET_IF(launch_layernorm_f32(x, (long)Tp * C, B, C, k.ln_post.g, k.ln_post.b, 1e-5f, cl, s));
   RET_IF(launch_small_linear(cl, C, B, C, k.proj.w, nullptr, k.embed, ACT_NONE, out, k.embed, 0, s));
-  c->ws.off = mark;
   return 0;
 }

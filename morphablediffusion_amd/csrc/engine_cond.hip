@@ -207,7 +207,6 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int S = c->u.image_size, HW = S * S, rows = n_local * HW, td = c->v.time_dim, vd = c->v.view_dim;
   float* x8 = ws_alloc<float>(c, (size_t)rows * 8);
   float* h = ws_alloc<float>(c, (size_t)rows * 16);
@@ -249,7 +248,6 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
                               c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
   RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
                            0, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -311,7 +309,6 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
     out->lvl[0] = nullptr;
   }
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   half_t* gath = ws_alloc<half_t>(c, vox(0) * 64);
   float* tmp = ws_alloc<float>(c, vox(1) * fd[1]);  // largest intermediate (conv1 output == level-1 size)
   half_t* a = ws_alloc<half_t>(c, vox(0) * fd[0]);
@@ -356,6 +353,5 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
     }
     RET_IF(run_convT3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], s));
   }
-  c->ws.off = mark;
   return 0;
 }

@@ -119,7 +119,6 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
   }
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   g.splitk = sk;
   g.partial = nullptr;
   if (sk > 1) {
@@ -170,7 +169,6 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     fprintf(stderr, "[gemm] M=%d N=%d Cin=%d taps=%d f32=%d halo=%d bn=%d sk=%d geglu=%d  %.1f us  %.0f TF\n", M, g.N, g.Cin,
             g.ntaps, g.a_f32, halo ? 1 : (dense ? 2 : 0), g.bn, g.splitk, g.geglu, ms * 1e3, fl / (ms * 1e-3) * 1e-12);
   }
-  c->ws.off = mark;  // stream-ordered reuse
   return r;
 }
 
@@ -215,7 +213,6 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
 int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStream_t s) {
   if (!ga_in.w->w_up) return mvd_fail("run_upconv2d: weights were not folded");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   GemmArgs ga = ga_in;
   ConvW cw = *ga_in.w;
   cw.w = cw.w_up;
@@ -270,7 +267,6 @@ int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStre
     gb.bn = igemm_pick_bn(gb.N, 0);
     RET_IF(igemm_go(c, gb, 0, s));
   }
-  c->ws.off = mark;
   return 0;
 }
 
@@ -356,14 +352,12 @@ int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sampl
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
                            ldo, s);
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
   int nslabs = 0;
   RET_IF(launch_gn_stats(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, &nslabs, s));
   RET_IF(launch_gn_apply(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, nslabs, n.g, n.b, eps, act, out,
                          ldo, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -385,13 +379,13 @@ struct Fwd {
   const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
   // relu(GroupNorm(proj_context(volume))) of every DepthTransformer, produced on the side stream (nullptr: inline)
   const half_t* cn_pre[16] = {nullptr};
+  bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
 };
 
 // ResBlock._forward, openaimodel.py:256-276
 int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int rows = f.Bv * H * W;
   half_t* a1 = ws_alloc<half_t>(c, (size_t)rows * r.cin);
   float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
@@ -417,7 +411,6 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   GemmArgs g2;
   g2.a = a2; g2.lda = r.cout; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
   RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -425,7 +418,6 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
 int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int C = t.C, T = H * W, rows = f.Bv * T;
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
@@ -462,7 +454,6 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   g = GemmArgs();
   g.a = t3; g.lda = C; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -496,7 +487,6 @@ int ctx_fold(Fwd& f, const CondW& d, int HW, int D, int level, half_t* cn, hipSt
 int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
   const int crow = f.n_ctx * HW;
   float* p = ws_alloc<float>(c, (size_t)rows * I);
@@ -521,8 +511,10 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
       HIP_CHECK_RET(hipStreamWaitEvent(f.s, c->ev_cond[cond_idx], 0));
       cn = const_cast<half_t*>(cnp);
     } else if (ctx_fold_ok(f, d, HW, D, level)) {
+      if (f.ctx_side) HIP_CHECK_RET(hipStreamWaitEvent(f.s, c->ev_ctx, 0));
       RET_IF(ctx_fold(f, d, HW, D, level, cn, f.s));
     } else {
+      if (f.ctx_side) HIP_CHECK_RET(hipStreamWaitEvent(f.s, c->ev_ctx, 0));
       float* pc = ws_alloc<float>(c, (size_t)crow * D * Cc);
       WS_CHECK(pc);
       g = GemmArgs();
@@ -545,7 +537,6 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
   g = GemmArgs();
   g.a = pn; g.lda = I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -581,50 +572,71 @@ int out_res_of(const std::vector<UOp>& ops, int H) {
 
 }  // namespace
 
+int engine_side_init(mvd_ctx* c) {
+  if (c->side) return 0;
+  HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (hipEvent_t* ev : {&c->ev_fork, &c->ev_join, &c->ev_join2, &c->ev_ctx}) HIP_CHECK_RET(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  c->ev_cond.resize(c->conds.size());
+  for (auto& ev : c->ev_cond) HIP_CHECK_RET(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  return 0;
+}
+
 int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
-                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s) {
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce) {
   if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels, temb = 4 * mc;
   WsScope ws_scope0(c);
-  const size_t mark0 = ws_scope0.mark;
   Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
-  // fp16 view of the context volumes (operand-only tensors); fp32 sources are copied once per forward
-  for (int l = 0; l < 4 && n_ctx > 0 && src; ++l) {
-    if (!src[l].p) continue;
-    if (!src[l].f32) {
-      f.src16[l] = (const half_t*)src[l].p;
-      continue;
-    }
-    const int Dl = depth0 >> l, Sl = u.image_size >> l;
-    const size_t n = (size_t)n_ctx * Dl * Sl * Sl * u.volume_dims[l];
-    half_t* h = ws_alloc<half_t>(c, n);
-    WS_CHECK(h);
-    RET_IF(launch_f32_to_f16((const float*)src[l].p, h, n, s));
-    f.src16[l] = h;
-  }
-  // Fork: the context half of every DepthTransformer depends on the frustum volumes and the weights only.  Issued up front
-  // on the side stream it runs beside the trunk (which leaves CUs idle whenever a rank holds few views); each block waits
-  // for its own event just before its depth attention.  The guard joins the side stream back on every exit path, so the
-  // workspace these launches use is never handed out again while they may still be running.
-  struct SideJoin {
-    hipStream_t main, side = nullptr;
-    hipEvent_t ev = nullptr;
-    ~SideJoin() {
-      if (!side) return;
-      hipEventRecord(ev, side);
-      hipStreamWaitEvent(main, ev, 0);
-    }
-  } join{s};
+  // The context half of every DepthTransformer depends on the frustum volumes and the weights only.  Issued up front on the
+  // side stream it runs beside the trunk (which leaves CUs idle whenever a rank holds few views); each block waits for its
+  // own event just before its depth attention.  When the caller produced the volumes on the side stream already
+  // (ctx_on_side: the frustum network overlaps the UNet's input blocks) everything that reads them stays there.  The guard
+  // joins the side stream back on every exit path, so the workspace these launches use is never handed out again while
+  // they may still be running.
+  SideJoin join(s);
   static const bool side_off = getenv("MVD_NO_SIDE_STREAM") != nullptr;
-  if (!side_off && n_ctx > 0 && src && c->conds.size() <= 16) {
-    if (!c->side) {
-      HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-      c->ev_cond.resize(c->conds.size());
-      for (auto& ev : c->ev_cond) HIP_CHECK_RET(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  const bool use_side = !side_off && n_ctx > 0 && src && c->conds.size() <= 16;
+  bool forked = false;
+  // fork_ctx: everything that produces or only reads the context volumes.  With a producer (the frustum network of
+  // mvd_denoise_views) it is called after the full-resolution input blocks, so the side stream shares the CUs with the
+  // lower-resolution blocks (which do not fill them) and not with the level-0 convs; without one, at the start.
+  auto fork_ctx = [&]() -> int {
+    forked = true;
+    hipStream_t cs = s;  // the stream the context volumes are produced / read on
+    if (use_side) {
+      RET_IF(engine_side_init(c));
+      HIP_CHECK_RET(hipEventRecord(c->ev_fork, s));
+      HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      join.side = c->side;
+      join.ev = c->ev_join;
+      cs = c->side;
     }
+    f.ctx_side = use_side;
+    if (produce) {
+      // the producer's scratch is freed scope by scope on the host while the side stream may still be using it: keep it
+      // allocated until this forward's own scope ends (after the join)
+      c->ws.hold = use_side ? 1 : 0;
+      const int r = (*produce)(cs);
+      c->ws.hold = 0;
+      RET_IF(r);
+    }
+    // fp16 view of the context volumes (operand-only tensors); fp32 sources are copied once per forward
+    for (int l = 0; l < 4 && n_ctx > 0 && src; ++l) {
+      if (!src[l].p) continue;
+      if (!src[l].f32) {
+        f.src16[l] = (const half_t*)src[l].p;
+        continue;
+      }
+      const int Dl = depth0 >> l, Sl = u.image_size >> l;
+      const size_t n = (size_t)n_ctx * Dl * Sl * Sl * u.volume_dims[l];
+      half_t* h = ws_alloc<half_t>(c, n);
+      WS_CHECK(h);
+      RET_IF(launch_f32_to_f16((const float*)src[l].p, h, n, cs));
+      f.src16[l] = h;
+    }
+    if (!use_side) return 0;
+    HIP_CHECK_RET(hipEventRecord(c->ev_ctx, c->side));  // volumes + fp16 views complete: inline consumers wait for this
     auto level_of = [&](int Hx) {
       int l = 0;
       for (int r = u.image_size; r > Hx; r >>= 1) ++l;
@@ -643,19 +655,15 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       const CondW& d = c->conds[k];
       const int lv = level_of(cH[k]), HW = cH[k] * cH[k], D = depth0 >> lv;
       if (lv > 3 || !ctx_fold_ok(f, d, HW, D, lv)) continue;
-      if (!join.side) {
-        HIP_CHECK_RET(hipEventRecord(c->ev_fork, s));
-        HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        join.side = c->side;
-        join.ev = c->ev_join;
-      }
       half_t* cn = ws_alloc<half_t>(c, (size_t)n_ctx * HW * D * d.Cc);
       WS_CHECK(cn);
       RET_IF(ctx_fold(f, d, HW, D, lv, cn, c->side));
       HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
       f.cn_pre[k] = cn;
     }
-  }
+    return 0;
+  };
+  if (!produce) RET_IF(fork_ctx());
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
   float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
   float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);
@@ -714,7 +722,6 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
 
   auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W) -> int {
     WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
     View cur = in;
     const int nstage = (int)ops.size() + (cond ? 1 : 0);
     for (int k = 0; k < nstage; ++k) {
@@ -740,7 +747,6 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       }
       cur = o;
     }
-    c->ws.off = mark;
     return 0;
   };
 
@@ -757,6 +763,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.C = in_ch[j];
     RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
     cur = dst;
+    if (!forked && (H < u.image_size || j == nb - 1)) RET_IF(fork_ctx());
   }
   {
     View dst;
@@ -790,6 +797,5 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     g.a = a; g.lda = mc; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
     RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));
   }
-  c->ws.off = mark0;
   return 0;
 }

@@ -12,7 +12,6 @@ namespace {
 // ResnetBlock.forward (model.py:121-141, temb = None): x + conv2(swish(GN(conv1(swish(GN(x))))))
 int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, int H, int W, hipStream_t s) {
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const size_t rows = (size_t)B * H * W;
   half_t* a1 = ws_alloc<half_t>(c, rows * r.cin);
   float* h1 = ws_alloc<float>(c, rows * r.cout);
@@ -35,14 +34,12 @@ int vae_res(mvd_ctx* c, const VaeResW& r, const float* in, float* out, int B, in
   g = GemmArgs();
   g.a = a2; g.lda = r.cout; g.w = &r.c2; g.out = out; g.ldc = r.cout; g.resid = resid; g.ldr = r.cout;
   RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
-  c->ws.off = mark;
   return 0;
 }
 
 // AttnBlock.forward (model.py:178-202)
 int vae_attn(mvd_ctx* c, const VaeAttnW& v, const float* in, float* out, int B, int HW, hipStream_t s) {
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   const int C = v.norm.C;
   const size_t rows = (size_t)B * HW;
   half_t* hn = ws_alloc<half_t>(c, rows * C);
@@ -88,7 +85,6 @@ int vae_attn(mvd_ctx* c, const VaeAttnW& v, const float* in, float* out, int B, 
   g = GemmArgs();
   g.a = ao; g.lda = C; g.w = &v.proj; g.out = out; g.ldc = C; g.resid = in; g.ldr = C;
   RET_IF(run_linear(c, g, B, (int)rows, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -99,7 +95,6 @@ int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, floa
   if (!v.present) return mvd_fail("first-stage decoder weights not uploaded / finalized");
   if ((h % 16) || (w % 16)) return mvd_fail("vae_decode: latent height and width must be multiples of 16");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   int H = h, W = w;
   size_t rows = (size_t)B * H * W;
   // post_quant_conv (1x1, embed -> z_channels), written into an 8-channel zero-padded tensor for conv_in
@@ -165,7 +160,6 @@ int engine_vae_decode(mvd_ctx* c, const float* z_nchw, int B, int h, int w, floa
   g.a = a; g.lda = ch; g.w = &v.conv_out; g.out = o4; g.ldc = 4;
   RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));
   RET_IF(launch_nhwc_to_nchw(o4, 4, B, v.out_ch, H * W, out_nchw, s));
-  c->ws.off = mark;
   return 0;
 }
 
@@ -176,7 +170,6 @@ int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, floa
   const int down = 1 << (v.nlev - 1);
   if ((H % (16 * down)) || (W % (16 * down))) return mvd_fail("vae_encode: image size must be a multiple of 16 x the downsampling factor");
   WsScope ws_scope(c);
-  const size_t mark = ws_scope.mark;
   size_t rows = (size_t)B * H * W;
   float* x0 = ws_alloc<float>(c, rows * 8);
   size_t maxel = rows * (size_t)v.conv_in.N;
@@ -221,6 +214,5 @@ int engine_vae_encode(mvd_ctx* c, const float* x_nchw, int B, int H, int W, floa
   g.a = h8; g.a_f32 = 1; g.lda = v.conv_out.N; g.w = &v.quant; g.out = mo; g.ldc = v.mom;
   RET_IF(run_linear(c, g, B, (int)rows, s));
   RET_IF(launch_nhwc_to_nchw(mo, v.mom, B, v.mom, H * W, moments_nchw, s));
-  c->ws.off = mark;
   return 0;
 }
