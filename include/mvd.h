@@ -5,6 +5,9 @@
  * point names the reference interface it replaces.  Plain pointers and sizes only, no torch types.
  * Device pointers are HIP device memory on the context's device; ``stream`` is a hipStream_t (NULL = the
  * default stream).  Tensors at the boundary use the reference's own layouts (NCHW / NCDHW, fp32).
+ * All work of a call is ordered on ``stream``: mvd_denoise_views / mvd_unet_forward overlap part of it on one internal side
+ * stream per context, forked from and joined back into ``stream`` with events inside the call (MVD_NO_SIDE_STREAM=1 in the
+ * environment disables that).
  * Every function returns 0 on success, non-zero on failure; mvd_last_error() gives the text.
  * A context is thread-compatible (one thread at a time per context).  No allocation happens on the step
  * path: weights and the workspace are allocated at create / finalize / set_mesh time.
