@@ -692,6 +692,7 @@ int engine_finalize(mvd_ctx* c) {
   HIP_CHECK_RET(hipDeviceSynchronize());
   for (auto& kv : c->raw) hipFree(kv.second.d);
   c->raw.clear();
+  if (c->has_unet) RET_IF(engine_side_init(c));  // side stream + events now, so that nothing is created on the step path
   c->finalized = true;
   return 0;
 }
