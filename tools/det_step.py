@@ -6,7 +6,8 @@ from morphablediffusion_amd import synthetic
 from morphablediffusion_amd.spec import VolumeConfig
 import os
 N = int(os.environ.get("DET_N", "4")); BVN = int(os.environ.get("DET_BVN", str(N)))
-m = make_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, workspace_gb=float(os.environ.get("DET_WS", "6")))
+UCFG = gi.FULL_UNET if os.environ.get("DET_FULL") else gi.SMALL_UNET
+m = make_model(UCFG, VolumeConfig(num_views=N), N, workspace_gb=float(os.environ.get("DET_WS", "6")))
 batch = to_dev(synthetic.make_batch(N, "perspective", 600, mesh_seed=1))
 x_T, x_in, clip = [t.cuda() for t in synthetic.make_latents(N, 32, seed=6033)]
 noise = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(1)).cuda()
