@@ -588,12 +588,11 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   const int mc = u.model_channels, temb = 4 * mc;
   WsScope ws_scope0(c);
   Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
-  // The context half of every DepthTransformer depends on the frustum volumes and the weights only.  Issued up front on the
-  // side stream it runs beside the trunk (which leaves CUs idle whenever a rank holds few views); each block waits for its
-  // own event just before its depth attention.  When the caller produced the volumes on the side stream already
-  // (ctx_on_side: the frustum network overlaps the UNet's input blocks) everything that reads them stays there.  The guard
-  // joins the side stream back on every exit path, so the workspace these launches use is never handed out again while
-  // they may still be running.
+  // The context volumes (frustum network) and the context half of every DepthTransformer feed nothing before the middle
+  // block.  Issued on the side stream they run beside the trunk (which leaves CUs idle at the lower resolutions and whenever
+  // a rank holds few views); each DepthTransformer waits for its own event just before its depth attention.  The guard joins
+  // the side stream back on every exit path, so the workspace these launches use is never handed out again while they may
+  // still be running.
   SideJoin join(s);
   static const bool side_off = getenv("MVD_NO_SIDE_STREAM") != nullptr;
   const bool use_side = !side_off && n_ctx > 0 && src && c->conds.size() <= 16;
