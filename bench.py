@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 N_VIEWS = 16
 PEAK_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0     # HBM3E, same guide
 
 
 def unet_kwargs(cfg):
@@ -33,29 +34,54 @@ def unet_kwargs(cfg):
                 context_dim=768, use_checkpoint=True, legacy=False)
 
 
-def cpu_baseline(W, ucfg, sample_views=8, threads=16):
-    """The oracle (CPU restatement, validated against the reference goldens) timed on this host's cores on a
-    bounded sample (10-30 s of CPU work): one full denoise_apply at `sample_views` views instead of 16 (cost is
-    linear in N)."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(W, ucfg):
+    """The oracle (CPU restatement, pinned to the reference's goldens: kind "port") timed on this host's cores
+    (SURVEY 8(d) / BASELINE.md section 3): ONE full denoise_apply of the headline configuration (N=16 views, CFG 2.0,
+    full-width UNet, 5023-vertex mesh), fp32 eager with torch.set_num_threads(os.cpu_count()), and one step of the plumbing
+    configuration (configs[0]: one view, 64x64 latent, first DDIM step).  About 20-40 s of CPU work in total."""
+    import dataclasses
     from morphablediffusion_amd import synthetic
-    from morphablediffusion_amd.spec import VolumeConfig, build_unet_plan
+    from morphablediffusion_amd.spec import VolumeConfig, build_unet_plan, full_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
     from oracle import mvd_oracle as O
-    # eager PyTorch on many small ops stops scaling (and thrashes) well before the box's core count
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
-    vcfg = VolumeConfig(num_views=sample_views)
-    batch = synthetic.make_batch(sample_views, "perspective", 5023, mesh_seed=1)
-    x_T, x_in, clip = synthetic.make_latents(sample_views, 32, seed=6033)
+    threads = int(os.environ.get("MVD_CPU_THREADS", os.cpu_count() or 1))
+    torch.set_num_threads(max(1, threads))
     tab = O.ddim_tables(50, 1.0)
-    ts = torch.full((1,), int(tab["timesteps"][49]), dtype=torch.long)
-    noise = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(1))
-    plan = build_unet_plan(ucfg)
-    t0 = time.time()
-    with torch.no_grad():
-        O.denoise_apply(W, plan, vcfg, tab, x_T, x_in, clip, ts, 49, 2.0, batch, batch_view_num=sample_views, noise=noise)
-    dt = time.time() - t0
-    return {"value": (sample_views / N_VIEWS) / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one denoise_apply (CFG 2.0, full-width UNet, 5023-vertex mesh) at {sample_views} of {N_VIEWS} views: "
-                      f"{dt:.1f} s; value = ({sample_views}/{N_VIEWS}) / t, cost is linear in the view count"}
+
+    def one(N, size, index, ucfg_, W_):
+        vcfg = VolumeConfig(num_views=N, input_image_size=size)
+        batch = synthetic.make_batch(N, "perspective", 5023, mesh_seed=1, image_size=size)
+        x_T, x_in, clip = synthetic.make_latents(N, size // 8, seed=6033)
+        ts = torch.full((1,), int(tab["timesteps"][index]), dtype=torch.long)
+        noise = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(1)) if index else None
+        plan = build_unet_plan(ucfg_)
+        t0 = time.time()
+        with torch.no_grad():
+            out = O.denoise_apply(W_, plan, vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch, batch_view_num=N, noise=noise)
+        assert torch.isfinite(out).all()
+        return time.time() - t0
+
+    dt16 = one(N_VIEWS, 256, 49, ucfg, W)
+    ucfg64 = dataclasses.replace(ucfg, image_size=64)
+    W64 = seeded_state_dict(full_manifest(ucfg64, VolumeConfig(num_views=1, input_image_size=512)), 7)
+    dt1 = one(1, 512, 0, ucfg64, W64)
+    return {"value": 1.0 / dt16, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(),
+            "sample": f"ONE full denoise_apply of the headline configuration (N={N_VIEWS}, CFG 2.0, full-width UNet, "
+                      f"5023-vertex mesh, fp32 eager): {dt16:.1f} s; plus configs[0] (one view, 64x64 latent, first DDIM "
+                      f"step, full width): {dt1:.1f} s",
+            "config0_step_s": dt1}
 
 
 def main():
@@ -65,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-view-num", type=int, default=0, help="views per UNet pass (0 = all local views)")
+    ap.add_argument("--probe-stride", type=int, default=4,
+                    help="bracket 1 in N launches of the dominant kernel family with HIP events inside the timed region")
     ap.add_argument("--simulate-gpus", type=int, default=0,
                     help="timing aid: run ONE rank's share of a G-way view sharding on one GPU (no collective); "
                          "reported as a per-rank step time, never as the headline value")
@@ -123,21 +151,32 @@ def main():
 
     def one_step(i, xx):
         index = nsteps - 1 - (i % nsteps)
-        ts = torch.full((1,), int(sampler.ddim_timesteps[index]), device=dev, dtype=torch.long)
+        step = int(sampler.ddim_timesteps[index])
+        ts = torch.full((1,), step, device=dev, dtype=torch.long)
         return sampler.denoise_apply(xx, info, clip, ts, index, 2.0, batch_view_num=bvn, is_step0=index == 0,
-                                     batch=batch, noise=noise)
+                                     batch=batch, noise=noise, host_steps=[step])
 
     with torch.no_grad():
         for i in range(args.warmup):
             x = one_step(i, x)
+        # survey pass (NOT timed): HIP events on the launch stream around EVERY launch of every kernel family for two
+        # steps -> per-family table (time, algorithmic FLOPs / bytes); the family with the largest summed time is the
+        # dominant kernel, and only that one is bracketed (a 1-in-stride sample of its launches) in the timed region
+        model.engine.probe_config(1)
+        for i in range(2):
+            x = one_step(args.warmup + i, x)
+        torch.cuda.synchronize()
+        families = model.engine.probe_report()
+        model.engine.probe_config(0)
+        dominant = max(families, key=lambda f: f["ms"])["family"] if families else None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        # HIP events on the launch stream around every launch of the dominant kernel inside the timed region
-        model.engine.probe_enable(True)
+        if dominant:
+            model.engine.probe_config(2, dominant, args.probe_stride)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            x = one_step(args.warmup + i, x)
+            x = one_step(args.warmup + 2 + i, x)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -148,8 +187,8 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(x).all()
 
-    probe_ms, probe_flops, probe_n = model.engine.probe_read()
-    model.engine.probe_enable(False)
+    timed = {f["family"]: f for f in model.engine.probe_report()} if dominant else {}
+    model.engine.probe_config(0)
 
     # reported next to the headline value ("plus 50-step wall-time"): one full 50-step DDIM trajectory
     # through SyncDDIMSampler.sample, and the first-stage decode of this rank's views
@@ -176,26 +215,30 @@ def main():
     except Exception as exc:  # never lose the headline line to an extra
         print(f"bench extras failed: {exc!r}", file=sys.stderr)
 
-    # dominant kernel: the level-32 3x3 convs (320/640/960 -> 320 at 32x32, CFG batch of this rank), LDS-halo
-    # implicit GEMM conv3_dma_kernel<160,16,16>: achieved = summed algorithmic FLOPs / summed event time of ALL its
-    # launches in the timed region (the rocprofv3 --stats average of that kernel name is the same quantity).
-    # HBM traffic of one launch at the 16-view batch comes from the committed rocprofv3 --pmc passes
-    # (profiles/r01_g_pmc_conv3.txt: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); other batches: not measured.
-    Bc = 2 * nl
-    conv_ms = model.engine.bench_conv(Bc, 320, 32, 32, 320, iters=20)
-    conv_flops = 2.0 * (Bc * 1024) * 320 * (9 * 320)
-    isolated = conv_flops / (conv_ms * 1e-3) / 1e12
-    if probe_n > 0:
-        achieved = probe_flops / (probe_ms * 1e-3) / 1e12
-        kdesc = (f"conv3_dma_kernel<160,16,16> (3x3 convs into 320 channels @32x32, batch {Bc}): {probe_n} launches in the "
-                 f"timed region, {probe_ms * 1e3 / probe_n:.1f} us and {probe_flops / probe_n / 1e9:.1f} GFLOP per launch on "
-                 f"average (HIP events on the launch stream); the 320->320 shape alone, back to back on warm buffers: "
-                 f"{conv_ms * 1e3:.1f} us = {isolated:.0f} TFLOP/s")
-    else:  # this rank's batch routes the level-32 convs through another tile variant: isolated measurement only
-        achieved = isolated
-        kdesc = (f"3x3 conv 320->320 @32x32, batch {Bc} (M={Bc * 1024}, N=320, K=2880), back to back: "
-                 f"{conv_ms * 1e3:.1f} us/launch (HIP events on the launch stream)")
+    # Roofline of the dominant kernel family (largest summed time in the survey pass).  For the bracketed launches of the
+    # timed region:  t_mfma = sum(flops) / peak,  t_hbm = sum(algorithmic bytes) / peak;  the larger one is the roof that
+    # bounds the family, `achieved` is the family's aggregate rate in that roof's unit, frac = achieved / peak.
+    def roof(f):
+        t = f["ms"] * 1e-3
+        if t <= 0 or f["sampled"] == 0:
+            return None
+        tf, tb = f["flops"] / (PEAK_F16_TFLOPS * 1e12), f["bytes"] / (PEAK_HBM_GBS * 1e9)
+        bound = "mfma" if tf >= tb else "hbm"
+        return {"bound": bound, "achieved": (f["flops"] / t / 1e12) if bound == "mfma" else (f["bytes"] / t / 1e9),
+                "peak": PEAK_F16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "tflops": f["flops"] / t / 1e12, "gbs": f["bytes"] / t / 1e9, "us_per_launch": 1e6 * t / f["sampled"],
+                "launches_bracketed": f["sampled"], "launches": f["launches"]}
 
+    fam_rows = []
+    tot_ms = sum(f["ms"] for f in families) or 1.0
+    for f in sorted(families, key=lambda f: -f["ms"]):
+        r = roof(f) or {}
+        fam_rows.append({"family": f["family"], "launches_per_step": f["launches"] / 2.0, "ms_per_step": f["ms"] / 2.0,
+                         "share": f["ms"] / tot_ms, "tflops": r.get("tflops"), "gbs": r.get("gbs"), "bound": r.get("bound"),
+                         "frac": (r["achieved"] / r["peak"]) if r else None})
+    dom = roof(timed[dominant]) if dominant and dominant in timed else None
+    if dom is None and families:  # nothing bracketed in the timed region (stride too large for the step count)
+        dom = roof(max(families, key=lambda f: f["ms"]))
     if rank == 0:
         out = {
             "metric": "multi-view denoising steps/sec (N=16 views, 256x256, CFG 2.0, DDIM-50 step)",
@@ -206,10 +249,20 @@ def main():
                                    "5023-vertex mesh, full-width UNet (916.9M params, random init), CFG 2.0, "
                                    "one denoise_apply per step", "views_per_gpu": nl, "batch_view_num": bvn,
                        "parallelism": f"view-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": 78.1e6 if Bc == 32 else None,
-                         "traffic_unit": "bytes/launch of the 320->320 shape, rocprofv3 --pmc (algorithmic: 64.8e6)",
-                         "kernel": kdesc},
+            "roofline": None if dom is None else {
+                "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                "frac": dom["achieved"] / dom["peak"], "traffic": None,
+                "kernel": dominant,
+                "how": f"HIP events on the launch stream around a deterministic 1-in-{args.probe_stride} sample of this "
+                       f"family's launches INSIDE the timed region ({dom['launches_bracketed']} of {dom['launches']} launches, "
+                       f"{dom['us_per_launch']:.1f} us average); achieved = summed algorithmic "
+                       f"{'FLOPs' if dom['bound'] == 'mfma' else 'bytes'} / summed event time; the family was picked as the one "
+                       f"with the largest summed time in a 2-step survey pass that brackets every launch of every family",
+                "tflops": dom["tflops"], "gbs": dom["gbs"],
+                "mfma_frac": dom["tflops"] / PEAK_F16_TFLOPS, "hbm_frac": dom["gbs"] / PEAK_HBM_GBS},
+            "families": fam_rows,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": dist.get_backend() if world > 1 else None,
             "step_tflops": 433.9e9 * N_VIEWS / (dt / args.steps) / 1e12,
             "ddim50_wall_s": extras["ddim50_wall_s"], "vae_decode_ms_local_views": extras["vae_decode_ms"],
         }

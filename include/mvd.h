@@ -79,9 +79,15 @@ int mvd_embed_time(mvd_ctx* ctx, const int64_t* t, int B, float* out, void* stre
 
 /* Step-invariant per-sample metadata (batch dict, generate_face.py:227-241), HOST pointers:
  * vertices [Nv,3] fp32 (+-0.5 cube frame), coord [Nv,3] int32 (z,y,x), out_sh [3] int32, bounds [2,3] fp32.
- * Builds the sparse-convolution neighbour tables (replaces spconv's indice generation, morphable_diffusion.py:245-254). */
+ * Builds the sparse-convolution neighbour tables (replaces spconv's indice generation, morphable_diffusion.py:245-254).
+ * Transactional: on failure the previously set mesh stays active and intact. */
 int mvd_set_mesh(mvd_ctx* ctx, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
                  int Nv);
+/* A context keeps up to 64 independent sets of per-sample tables (mesh + cameras): mvd_select_sample makes set `slot` the
+ * active one -- mvd_set_mesh / mvd_set_cameras write it, the stage calls read it.  A batch of B samples (the reference's
+ * ``for bi in range(B)`` loop, morphable_diffusion.py:245) uploads each sample's tables once and switches between them at
+ * every step instead of rebuilding them.  Slot 0 is active after mvd_create. */
+int mvd_select_sample(mvd_ctx* ctx, int slot);
 /* target_K [N,4,4], target_RT [N,3,4] fp32 HOST pointers (batch['target_K'], batch['target_RT']) */
 int mvd_set_cameras(mvd_ctx* ctx, const float* K, const float* RT, int N);
 
@@ -91,6 +97,20 @@ int mvd_set_cameras(mvd_ctx* ctx, const float* K, const float* RT, int N);
  * conv bias is included (exactly one rank adds it).  Summing fused_out over ranks gives the full tensor. */
 int mvd_vertex_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed,
                         const int32_t* view_idx, int n_local, int add_bias, float* fused_out, void* stream);
+/* The same stage split for the exact view exchange ("equivalently an all-gather of [N,16,Nv] if bit-exact
+ * view-order summation is wanted"): mvd_vertex_view_features writes the per-view features vf_out [n_local,Nv,16]
+ * (morphable_diffusion.py:203-229) without reducing them; after the ranks' slices are gathered in view order,
+ * mvd_fuse_vertex_features applies SMPLFeatureExtractor (network.py:41-72) to vf_all [num_views,Nv,16] -> fused_out
+ * [Nv,16].  Summation runs over the views in index order, so a sharded step is bit-identical to the single-GPU one. */
+int mvd_vertex_view_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed,
+                             const int32_t* view_idx, int n_local, float* vf_out, void* stream);
+int mvd_fuse_vertex_features(mvd_ctx* ctx, const float* vf_all, int n_views, float* fused_out, void* stream);
+/* Cross-stream hand-over of the volume.  The exchange + mvd_fuse_vertex_features + mvd_volume_from_fused may run on a
+ * communication stream of the caller while `stream` of mvd_denoise_views already executes the UNet's input blocks (which
+ * need none of it): record a hipEvent_t after mvd_volume_from_fused on that stream and register it here; every later reader
+ * of the volume inside the library (the frustum stage of mvd_denoise_views / mvd_frustum_volumes) makes ITS stream wait for
+ * the event before the first read.  The event is caller-owned and must stay alive while registered; NULL unregisters. */
+int mvd_set_volume_ready_event(mvd_ctx* ctx, void* event);
 /* Second half (morphable_diffusion.py:232-257): sparse voxel CNN + lattice gather. fused [Nv,16] ->
  * volume_out [64,V,V,V] (reference layout, may be NULL); the result is also kept in the context for
  * mvd_frustum_volumes / mvd_denoise_views. */
@@ -151,11 +171,17 @@ int mvd_vae_encode(mvd_ctx* ctx, const float* x, int B, int H, int W, float* mom
 int mvd_clip_encode(mvd_ctx* ctx, const float* x, int B, int H, int W, float* out, void* stream);
 /* embedding width of the uploaded CLIP vision tower (768 for ViT-L/14), 0 when none was uploaded */
 int mvd_clip_embed_dim(mvd_ctx* ctx);
-/* in-situ timing of the dominant kernel: while enabled, every launch of conv3_dma_kernel<160,16,16> (the level-32
- * 3x3 convs of the UNet) is bracketed by HIP events on its launch stream; read returns the summed kernel time, the
- * summed algorithmic FLOPs and the launch count since the last enable (it synchronises on the recorded events) */
-int mvd_probe_enable(mvd_ctx* ctx, int on);
-int mvd_probe_read(mvd_ctx* ctx, double* total_ms, double* total_flops, int* launches);
+/* In-situ per-kernel-family timing for the roofline report (bench.py).  While enabled, launches are bracketed by HIP events
+ * on their launch stream and booked under the kernel's template instance ("gemm_dma_kernel<128,0>",
+ * "conv3_dma_kernel<160,16,16>", "igemm_kernel<1,128>", "splitk_reduce_kernel", "group_norm", "layernorm", "attn_kernel",
+ * "depth_attn_kernel") together with their ALGORITHMIC flops and bytes (each operand and the result once).
+ * mode 0: off.  mode 1: every launch of every family (a survey pass: it perturbs the step, use it outside the timed region).
+ * mode 2: only `family`, a deterministic pseudo-random 1-in-`stride` sample of its launches (for the timed region).
+ * A non-zero mode resets the counters.  mvd_probe_report synchronises on the recorded events and writes a JSON array
+ * [{"family", "launches", "sampled", "ms", "flops", "bytes", "all_flops", "all_bytes"}, ...] (ms / flops / bytes: the bracketed
+ * launches; all_*: every launch seen) into buf. */
+int mvd_probe_config(mvd_ctx* ctx, int mode, const char* family, int stride);
+int mvd_probe_report(mvd_ctx* ctx, char* buf, size_t cap);
 /* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,
  * 4 = GEGLU epilogue */
 int mvd_bench_linear(mvd_ctx* ctx, int M, int K, int N, int flags, int iters, float* ms_out, void* stream);

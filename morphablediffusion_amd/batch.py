@@ -7,7 +7,11 @@ generate_face.py of the reference so that a caller can go from (image, FLAME mes
   align_flame_vertices         generate_face.py:203-213 hard-coded similarity that maps MICA-optimised FLAME meshes
                                                         into the +-0.5 cube frame used in training
   voxelize                     generate_face.py:215-225 5 mm voxel indices (zyx), grid size rounded up to 4k
+  cameras_from_dict            generate_face.py:137-139,161-164 the 'real' trajectory: intrinsics / extrinsics lists of a
+                                                        camera dict (assets/facescape_test_traj.pkl, cameras.json)
   build_batch                  generate_face.py:227-243 the batch dict (leading batch dimension of 1)
+  stack_batches                eval/generate_all_facescape.py:176-186 B > 1: per-sample dicts concatenated on dim 0
+  load_model                   generate_face.py:71-78   YAML -> instantiate_from_config -> torch.load(ckpt)['state_dict']
 """
 import math
 from typing import Dict, Tuple
@@ -60,6 +64,22 @@ def virtual_cameras(num_cameras: int = 16, image_size: int = 256) -> Tuple[torch
     return torch.tensor(np.array(Ks)).float(), torch.tensor(np.array(RTs)).float()
 
 
+def cameras_from_dict(camera_dict, num_views: int = 16, views=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The 'real' camera trajectory (generate_face.py:137-139,161-164): ``camera_dict['intrinsics'][i]`` is a 3x3 K placed
+    in the top-left of eye(4), ``camera_dict['extrinsics'][i]`` a 3x4 world->camera [R|t].  ``views``: the indices (or keys)
+    to take, default 0..num_views-1.  Raises KeyError / IndexError like the reference if an entry is missing."""
+    Ks, RTs = [], []
+    for idx in (range(num_views) if views is None else views):
+        K = np.eye(4)
+        K[:3, :3] = np.array(camera_dict["intrinsics"][idx], dtype=np.float64)
+        RT = np.array(camera_dict["extrinsics"][idx], dtype=np.float64)
+        if K[:3, :3].shape != (3, 3) or RT.shape != (3, 4):
+            raise ValueError(f"camera {idx}: expected 3x3 intrinsics and 3x4 extrinsics")
+        Ks.append(K)
+        RTs.append(RT)
+    return torch.tensor(np.array(Ks)).float(), torch.tensor(np.array(RTs)).float()
+
+
 def so3_exponential_map(log_rot: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
     """Rodrigues' formula, the arithmetic of pytorch3d.transforms.so3_exponential_map (generate_face.py:18,208):
     R = I + sin(t)/t K + (1 - cos t)/t^2 K^2 with K the cross-product matrix of the axis-angle vector, t = |v|
@@ -99,15 +119,42 @@ def voxelize(vertices: torch.Tensor):
 
 
 def build_batch(input_image: torch.Tensor, vertices: torch.Tensor, num_views: int = 16, image_size: int = 256,
-                device="cpu") -> Dict[str, torch.Tensor]:
-    """input_image [H,W,3] in [-1,1]; vertices [Nv,3] already in the cube frame (see align_flame_vertices)."""
-    K, RT = virtual_cameras(num_views, image_size)
+                device="cpu", cameras=None) -> Dict[str, torch.Tensor]:
+    """input_image [H,W,3] in [-1,1]; vertices [Nv,3] already in the cube frame (see align_flame_vertices).
+    ``cameras``: (K [N,4,4], RT [N,3,4]) of a 'real' trajectory (cameras_from_dict); default: the virtual arc."""
+    K, RT = virtual_cameras(num_views, image_size) if cameras is None else cameras
+    if K.shape[0] != num_views or RT.shape[0] != num_views:
+        raise ValueError("cameras must hold num_views entries")
     coord, out_sh, bounds = voxelize(vertices)
     d = {"target_image": input_image[None].repeat(num_views, 1, 1, 1), "input_image": input_image,
          "input_elevation": torch.zeros(1), "input_azimuth": torch.zeros(1),
          "target_elevation": torch.zeros(num_views), "target_azimuth": torch.zeros(num_views),
          "target_K": K, "target_RT": RT, "vertices": vertices.float(), "out_sh": out_sh, "coord": coord, "bounds": bounds}
     return {k: v.unsqueeze(0).to(device) for k, v in d.items()}
+
+
+def stack_batches(samples) -> Dict[str, torch.Tensor]:
+    """eval/generate_all_facescape.py:176-186: per-sample batch dicts (leading dimension 1) concatenated into one batch of
+    B samples.  All samples must share the vertex count (a fixed-topology mesh), as torch.concat requires there too."""
+    return {k: torch.cat([s[k] for s in samples], 0) for k in samples[0]}
+
+
+def load_model(cfg, ckpt, device="cuda:0", **overrides):
+    """generate_face.py:71-78 ``load_model``: read the YAML (configs/facescape.yaml layout), instantiate ``config.model``
+    through the ``target:`` reflection, torch.load the checkpoint and load ``ckpt['state_dict']`` with strict=False.
+    ``cfg`` is a path or an already parsed dict; ``overrides`` are extra constructor kwargs (e.g. workspace_gb)."""
+    from .model import instantiate_from_config
+    if isinstance(cfg, (str, bytes)) or hasattr(cfg, "__fspath__"):
+        import yaml
+        with open(cfg) as f:
+            cfg = yaml.safe_load(f)
+    mc = dict(cfg["model"])
+    mc["params"] = dict(mc.get("params", {}), device=device, **overrides)
+    model = instantiate_from_config(mc)
+    print(f"loading model from {ckpt} ...")
+    state = torch.load(ckpt, map_location="cpu")
+    model.load_state_dict(state["state_dict"], strict=False)
+    return model.eval()
 
 
 def views_to_uint8(x_sample: torch.Tensor, input_image: torch.Tensor) -> np.ndarray:

@@ -10,6 +10,8 @@
 int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N);
 int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
                     int Nv);
+int engine_select_sample(mvd_ctx* c, int slot);
+void mesh_free(MeshTables& m);
 
 static thread_local std::string g_err;
 int mvd_fail(const char* msg) {
@@ -100,12 +102,12 @@ void mvd_destroy(mvd_ctx* c) {
   hipDeviceSynchronize();
   for (auto& kv : c->raw) hipFree(kv.second.d);
   for (void* p : c->owned) hipFree(p);
-  MeshTables& m = c->mesh;
-  hipFree(m.verts);
-  for (int i = 0; i < 3; ++i) hipFree(m.nbr_subm[i]);
-  for (int i = 0; i < 2; ++i) { hipFree(m.nbr_down[i]); hipFree(m.feat[i]); }
-  hipFree(m.grid2);
+  mesh_free(c->mesh);
   hipFree(c->cams);
+  for (auto& sl : c->slots) {
+    mesh_free(sl.mesh);
+    hipFree(sl.cams);
+  }
   hipFree(c->volume);
   hipFree(c->ws.base);
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
@@ -152,6 +154,12 @@ int mvd_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const 
   return engine_set_mesh(c, vertices, coord, out_sh, bounds, Nv);
 }
 
+int mvd_select_sample(mvd_ctx* c, int slot) {
+  if (!c) return mvd_fail("null context");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_select_sample(c, slot);
+}
+
 int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
   if (!c || !K || !RT || N <= 0) return mvd_fail("mvd_set_cameras: bad argument");
   HIP_CHECK_RET(hipSetDevice(c->device));
@@ -159,6 +167,7 @@ int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
 }
 
 int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   WsScope ws_scope(c);
   const int td = c->v.time_dim;
@@ -174,6 +183,7 @@ int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream
 int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const float* context, int Bv, int n_ctx,
                      const float* src0, const float* src1, const float* src2, const float* src3, int depth0, float* out,
                      void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   if (n_ctx < 0 || n_ctx > Bv) return mvd_fail("mvd_unet_forward: n_ctx out of range");
   hipStream_t s = S(stream);
@@ -204,11 +214,32 @@ int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const
 
 int mvd_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                         const int32_t* view_idx, int n_local, int add_bias, float* fused_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c) return mvd_fail("null context");
   return engine_vertex_features(c, x_noisy, t_embed, v_embed, view_idx, n_local, add_bias, fused_out, S(stream));
 }
 
+int mvd_vertex_view_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
+                             const int32_t* view_idx, int n_local, float* vf_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !vf_out) return mvd_fail("mvd_vertex_view_features: null argument");
+  return engine_vertex_features(c, x_noisy, t_embed, v_embed, view_idx, n_local, 0, nullptr, S(stream), vf_out);
+}
+
+int mvd_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !vf_all || !fused_out) return mvd_fail("mvd_fuse_vertex_features: null argument");
+  return engine_fuse_vertex_features(c, vf_all, n_views, fused_out, S(stream));
+}
+
+int mvd_set_volume_ready_event(mvd_ctx* c, void* event) {
+  if (!c) return mvd_fail("null context");
+  c->vol_ready = (hipEvent_t)event;
+  return 0;
+}
+
 int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   RET_IF(engine_volume_from_fused(c, fused, S(stream)));
   if (volume_out) {
@@ -220,6 +251,7 @@ int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, voi
 
 int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
                         float* out0, float* out1, float* out2, float* out3, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   WsScope ws_scope(c);
   FrustumOut fo;
@@ -238,6 +270,7 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
                       const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
                       const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
                       float sigma, float* eps_out, float* x_prev, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   hipStream_t s = S(stream);
   const mvd_unet_config& u = c->u;
@@ -285,6 +318,7 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
 int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout,
                 int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
                 void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const int cpad = (Cin + 7) / 8 * 8, taps = ksize * ksize;
@@ -326,6 +360,7 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
 
 int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int W, const float* w, const float* bias,
                   int Cout, int stride, int transposed, const float* resid, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   if (Cin % 8) return mvd_fail("op_conv3d: Cin must be a multiple of 8");
@@ -358,6 +393,7 @@ int mvd_op_conv3d(mvd_ctx* c, const float* x, int B, int Cin, int D, int H, int 
 
 int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int geglu,
                   const float* resid, int a_half, int force_splitk, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   if (K % 8) return mvd_fail("op_linear: K must be a multiple of 8");
@@ -390,6 +426,7 @@ int mvd_op_linear(mvd_ctx* c, const float* a, int M, int K, const float* w, cons
 
 int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int groups, const float* gamma,
                       const float* beta, float eps, int act, float* out_nchw, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   float* xn = ws_alloc<float>(c, (size_t)B * HW * C);
@@ -407,6 +444,7 @@ int mvd_op_group_norm(mvd_ctx* c, const float* x_nchw, int B, int C, int HW, int
 
 int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* gamma, const float* beta, float* out,
                       void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   half_t* y = ws_alloc<half_t>(c, (size_t)rows * C);
@@ -419,6 +457,7 @@ int mvd_op_layer_norm(mvd_ctx* c, const float* x, int rows, int C, const float* 
 
 int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v, int B, int T, int heads, int d, float* out,
                      void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const int C = heads * d, rows = B * T;
@@ -433,6 +472,7 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
 }
 
 int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const size_t na = (size_t)B * H * W * C, nw = (size_t)9 * Cout * C;
@@ -463,18 +503,21 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
 }
 
 int mvd_vae_decode(mvd_ctx* c, const float* z, int B, int h, int w, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   if (!z || !out || B <= 0) return mvd_fail("mvd_vae_decode: bad argument");
   return engine_vae_decode(c, z, B, h, w, out, S(stream));
 }
 
 int mvd_vae_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* moments, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   if (!x || !moments || B <= 0) return mvd_fail("mvd_vae_encode: bad argument");
   return engine_vae_encode(c, x, B, H, W, moments, S(stream));
 }
 
 int mvd_clip_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
   if (!x || !out || B <= 0) return mvd_fail("mvd_clip_encode: bad argument");
   return engine_clip_encode(c, x, B, H, W, out, S(stream));
@@ -482,32 +525,50 @@ int mvd_clip_encode(mvd_ctx* c, const float* x, int B, int H, int W, float* out,
 
 int mvd_clip_embed_dim(mvd_ctx* c) { return (c && c->finalized && c->clip.present) ? c->clip.embed : 0; }
 
-int mvd_probe_enable(mvd_ctx* c, int on) {
-  if (!c) return mvd_fail("mvd_probe_enable: null context");
-  c->probe_on = on != 0;
-  if (on) {
+int mvd_probe_config(mvd_ctx* c, int mode, const char* family, int stride) {
+  if (!c) return mvd_fail("mvd_probe_config: null context");
+  if (mode < 0 || mode > 2 || (mode == 2 && !family)) return mvd_fail("mvd_probe_config: bad mode");
+  c->probe_mode = mode;
+  c->probe_only = family ? family : "";
+  c->probe_stride = stride > 1 ? stride : 1;
+  if (mode) {  // a new measurement starts
     c->probe_used = 0;
-    c->probe_flops = 0.0;
+    c->probe_counter = 0;
+    c->probe_fam.clear();
   }
   return 0;
 }
 
-int mvd_probe_read(mvd_ctx* c, double* total_ms, double* total_flops, int* launches) {
-  if (!c || !total_ms || !total_flops || !launches) return mvd_fail("mvd_probe_read: null argument");
-  double ms = 0.0;
-  for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
-    HIP_CHECK_RET(hipEventSynchronize(c->probe_ev[i + 1]));
-    float t = 0.f;
-    HIP_CHECK_RET(hipEventElapsedTime(&t, c->probe_ev[i], c->probe_ev[i + 1]));
-    ms += t;
+int mvd_probe_report(mvd_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap < 3) return mvd_fail("mvd_probe_report: bad argument");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  std::string out = "[";
+  bool first = true;
+  for (auto& kv : c->probe_fam) {
+    double ms = 0.0;
+    for (size_t slot : kv.second.ev) {
+      HIP_CHECK_RET(hipEventSynchronize(c->probe_ev[slot + 1]));
+      float t = 0.f;
+      HIP_CHECK_RET(hipEventElapsedTime(&t, c->probe_ev[slot], c->probe_ev[slot + 1]));
+      ms += t;
+    }
+    char line[512];
+    snprintf(line, sizeof line,
+             "%s{\"family\": \"%s\", \"launches\": %ld, \"sampled\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, "
+             "\"all_flops\": %.6e, \"all_bytes\": %.6e}",
+             first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.sampled, ms, kv.second.s_flops, kv.second.s_bytes,
+             kv.second.flops, kv.second.bytes);
+    out += line;
+    first = false;
   }
-  *total_ms = ms;
-  *total_flops = c->probe_flops;
-  *launches = (int)(c->probe_used / 2);
+  out += "]";
+  if (out.size() + 1 > cap) return mvd_fail("mvd_probe_report: buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
   return 0;
 }
 
 int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, float* ms_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;

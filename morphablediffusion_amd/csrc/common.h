@@ -88,6 +88,12 @@ struct MvdStream {
 int mvd_fail(const char* msg);  // records thread-local error text, returns -1
 const char* mvd_error_text();
 
+#define MVD_MAX_DEVICES 64
+static inline int mvd_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MVD_MAX_DEVICES) d = 0;
+  return d;
+}
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int igemm_tap(int dz, int dy, int dx, int slab) { return (dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4) | (slab << 8); }
 

@@ -169,11 +169,22 @@ struct mvd_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr;
   std::vector<hipEvent_t> ev_cond;
-  // in-situ timing of the dominant kernel (conv3_dma_kernel<160,16,16>): HIP events around each of its launches
-  bool probe_on = false;
-  std::vector<hipEvent_t> probe_ev;   // pool, two events per probed launch
+  // in-situ per-kernel-family timing (bench.py's roofline object): HIP events on the launch stream around launches, keyed
+  // by the kernel's template instance.  mode 0 off; 1 every launch of every family; 2 only family `probe_only`, a
+  // pseudo-random 1-in-`probe_stride` sample of its launches (keeps the timed region undisturbed)
+  int probe_mode = 0;
+  int probe_stride = 1;
+  unsigned probe_counter = 0;
+  std::string probe_only;
+  struct ProbeFam {
+    long launches = 0, sampled = 0;
+    double flops = 0.0, bytes = 0.0;      // algorithmic work of ALL launches seen
+    double s_flops = 0.0, s_bytes = 0.0;  // ... of the bracketed ones
+    std::vector<size_t> ev;               // indices into probe_ev (start event; stop = +1)
+  };
+  std::map<std::string, ProbeFam> probe_fam;
+  std::vector<hipEvent_t> probe_ev;   // pool, two events per bracketed launch
   size_t probe_used = 0;
-  double probe_flops = 0.0;
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
 
@@ -209,10 +220,21 @@ struct mvd_ctx {
   int film_total = 0, film_off[9] = {0};
 
   Workspace ws;
+  // per-sample, step-invariant tables.  `mesh` / `cams` / `n_cams` are the ACTIVE sample's; mvd_select_sample parks them
+  // in `slots[cur_slot]` and activates another slot, so a batch of B samples keeps B sets resident across the steps
+  // instead of rebuilding them (hipFree / hipMalloc / host hash maps) for every sample at every step.
   MeshTables mesh;
   ViewCam* cams = nullptr;  // device [n_cams]
   int n_cams = 0;
+  struct SampleSlot {
+    MeshTables mesh;
+    ViewCam* cams = nullptr;
+    int n_cams = 0;
+  };
+  std::vector<SampleSlot> slots;
+  int cur_slot = 0;
   float* volume = nullptr;  // device [V][V][V][64] fp32 (channels-last)
+  hipEvent_t vol_ready = nullptr;  // caller-owned: recorded after the mvd_volume_from_fused that the next readers need
 };
 
 // engine_weights.hip
@@ -235,7 +257,9 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
                 int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce = nullptr);
 // engine_cond.hip
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
-                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s);
+                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
+                           float* vf_out = nullptr);
+int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, hipStream_t s);
 int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s);
 struct FrustumOut {
   half_t* lvl0_half = nullptr;  // level 0 in fp16 instead of lvl[0] when engine_frustum(..., half0 = true)
@@ -305,6 +329,44 @@ struct SideJoin {
     hipEventRecord(ev, side);
     hipStreamWaitEvent(main, ev, 0);
   }
+};
+// Brackets the launches enqueued on `s` during its lifetime with two HIP events and books them under `family` (see
+// mvd_ctx::probe_*).  flops / bytes: the ALGORITHMIC work of the bracketed launch (each operand and the result once).
+struct ProbeScope {
+  mvd_ctx* c;
+  hipStream_t s;
+  size_t slot = (size_t)-1;
+  ProbeScope(mvd_ctx* c_, hipStream_t s_, const char* family, double flops, double bytes) : c(c_), s(s_) {
+    if (!c->probe_mode) return;
+    if (c->probe_mode == 2 && c->probe_only != family) return;
+    mvd_ctx::ProbeFam& f = c->probe_fam[family];
+    ++f.launches;
+    f.flops += flops;
+    f.bytes += bytes;
+    if (c->probe_mode == 2 && c->probe_stride > 1) {
+      unsigned h = ++c->probe_counter * 2654435761u;  // deterministic, unbiased 1-in-stride sample
+      h ^= h >> 15;
+      if (h % (unsigned)c->probe_stride) return;
+    }
+    if (c->probe_used + 2 > c->probe_ev.size())
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        c->probe_ev.push_back(ev);
+      }
+    slot = c->probe_used;
+    c->probe_used += 2;
+    ++f.sampled;
+    f.s_flops += flops;
+    f.s_bytes += bytes;
+    f.ev.push_back(slot);
+    hipEventRecord(c->probe_ev[slot], s);
+  }
+  ~ProbeScope() {
+    if (slot != (size_t)-1) hipEventRecord(c->probe_ev[slot + 1], s);
+  }
+  ProbeScope(const ProbeScope&) = delete;
+  ProbeScope& operator=(const ProbeScope&) = delete;
 };
 // creates the side stream and its events on first use
 int engine_side_init(mvd_ctx* c);

@@ -105,9 +105,15 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
     v.near_ = (float)dist - c->v.frustum_volume_length;
     v.far_ = (float)dist + c->v.frustum_volume_length;
   }
+  ViewCam* dn = nullptr;  // new table first, swap on success
+  HIP_CHECK_RET(hipMalloc((void**)&dn, N * sizeof(ViewCam)));
+  if (hipMemcpy(dn, cams.data(), N * sizeof(ViewCam), hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(dn);
+    return mvd_fail("set_cameras: upload failed");
+  }
+  HIP_CHECK_RET(hipDeviceSynchronize());
   if (c->cams) hipFree(c->cams);
-  HIP_CHECK_RET(hipMalloc((void**)&c->cams, N * sizeof(ViewCam)));
-  HIP_CHECK_RET(hipMemcpy(c->cams, cams.data(), N * sizeof(ViewCam), hipMemcpyHostToDevice));
+  c->cams = dn;
   c->n_cams = N;
   return 0;
 }
@@ -115,11 +121,28 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
 // ----------------------------------------------------------------------------------------------------
 // mvd_set_mesh: the "rulebook" spconv would build per call (SubMConv3d k3 / SparseConv3d k3 s2 p1), built
 // once per mesh on the host because coord/out_sh/bounds are step-invariant (SURVEY gotcha G15).
-int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
-                    int Nv) {
-  MeshTables& m = c->mesh;
+void mesh_free(MeshTables& m) {
+  hipFree(m.verts);
+  for (int i = 0; i < 3; ++i) hipFree(m.nbr_subm[i]);
+  for (int i = 0; i < 2; ++i) {
+    hipFree(m.nbr_down[i]);
+    hipFree(m.feat[i]);
+  }
+  hipFree(m.grid2);
+  m = MeshTables();
+}
+
+namespace {
+// builds every table of the new mesh into `m` (fresh allocations); on failure the caller frees `m`
+int mesh_build(MeshTables& m, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+               int Nv) {
+  // validate first: nothing is allocated for a mesh that cannot be used
+  for (int i = 0; i < Nv; ++i)
+    for (int a = 0; a < 3; ++a)
+      if (coord[i * 3 + a] < 0 || coord[i * 3 + a] >= out_sh[a]) return mvd_fail("set_mesh: voxel coordinate outside out_sh");
+  for (int a = 0; a < 3; ++a)
+    if (out_sh[a] <= 0 || out_sh[a] >= (1 << 20)) return mvd_fail("set_mesh: out_sh out of range");
   m.Nv = Nv;
-  if (m.verts) hipFree(m.verts);
   HIP_CHECK_RET(hipMalloc((void**)&m.verts, (size_t)Nv * 3 * sizeof(float)));
   HIP_CHECK_RET(hipMemcpy(m.verts, vertices, (size_t)Nv * 3 * sizeof(float), hipMemcpyHostToDevice));
   for (int a = 0; a < 3; ++a) {
@@ -135,8 +158,6 @@ int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, con
     idx.reserve(sites.size() * 2);
     for (int i = 0; i < (int)sites.size(); ++i) {
       auto& s = sites[i];
-      if (s[0] < 0 || s[1] < 0 || s[2] < 0 || s[0] >= shape[0] || s[1] >= shape[1] || s[2] >= shape[2])
-        return mvd_fail("set_mesh: voxel coordinate outside out_sh");
       // several vertices in one voxel: the FIRST one is the voxel's representative (spconv's hash table also keeps one
       // row per voxel and resolves every neighbour lookup, the centre tap included, through it; which row wins there is
       // a race).  Later duplicates still get an output row, identical to the representative's.
@@ -188,14 +209,50 @@ int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, con
     for (int a = 0; a < 3; ++a) shape[a] = oshape[a];
     max_sites = std::max(max_sites, (int)sites.size());
   }
-  for (int b = 0; b < 2; ++b) {
-    if (m.feat[b]) hipFree(m.feat[b]);
-    HIP_CHECK_RET(hipMalloc((void**)&m.feat[b], (size_t)max_sites * 64 * sizeof(float)));
+  for (int b = 0; b < 2; ++b) HIP_CHECK_RET(hipMalloc((void**)&m.feat[b], (size_t)max_sites * 64 * sizeof(float)));
+  return 0;
+}
+}  // namespace
+
+// Transactional: the new tables are built beside the old ones and swapped in only when complete; a failed call (bad
+// coordinates, allocation failure) leaves the active mesh exactly as it was.
+int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+                    int Nv) {
+  MeshTables nm;
+  const int r = mesh_build(nm, vertices, coord, out_sh, bounds, Nv);
+  if (r) {
+    mesh_free(nm);
+    return r;
   }
   if (!c->volume) {
     const int V = c->v.spatial_volume_size;
-    HIP_CHECK_RET(hipMalloc((void**)&c->volume, (size_t)V * V * V * 64 * sizeof(float)));
+    if (hipMalloc((void**)&c->volume, (size_t)V * V * V * 64 * sizeof(float)) != hipSuccess) {
+      mesh_free(nm);
+      return mvd_fail("set_mesh: volume allocation failed");
+    }
   }
+  HIP_CHECK_RET(hipDeviceSynchronize());  // nothing in flight may still read the tables being replaced
+  mesh_free(c->mesh);
+  c->mesh = nm;
+  return 0;
+}
+
+// mvd_select_sample: park the active tables, activate another slot (empty slots start with no mesh / no cameras)
+int engine_select_sample(mvd_ctx* c, int slot) {
+  if (slot < 0 || slot >= 64) return mvd_fail("mvd_select_sample: slot out of range (0..63)");
+  if (slot == c->cur_slot) return 0;
+  const int need = std::max(slot, c->cur_slot) + 1;
+  if ((int)c->slots.size() < need) c->slots.resize(need);
+  mvd_ctx::SampleSlot& cur = c->slots[c->cur_slot];
+  cur.mesh = c->mesh;
+  cur.cams = c->cams;
+  cur.n_cams = c->n_cams;
+  mvd_ctx::SampleSlot& nxt = c->slots[slot];
+  c->mesh = nxt.mesh;
+  c->cams = nxt.cams;
+  c->n_cams = nxt.n_cams;
+  nxt = mvd_ctx::SampleSlot();  // the active copy is the owner now
+  c->cur_slot = slot;
   return 0;
 }
 
@@ -203,7 +260,8 @@ int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, con
 // NoisyTargetViewEncoder (network.py:181-207) for n_local views + fused unprojection/vertex gather + this
 // rank's share of the view mean (morphable_diffusion.py:203-231).
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
-                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s) {
+                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
+                           float* vf_out) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
   WsScope ws_scope(c);
@@ -216,11 +274,14 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   float* pre = ws_alloc<float>(c, (size_t)n_local * 48);
   float* tpart = ws_alloc<float>(c, 16);
   float* feats = ws_alloc<float>(c, (size_t)rows * 16);
-  float* vf = ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
+  // vf_out: the per-view vertex features themselves [n_local][Nv][16] (the all-gather variant of the view exchange)
+  float* vf = vf_out ? vf_out : ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
   WS_CHECK(x8 && h && h2 && r1 && a && pre && tpart && feats && vf);
   RET_IF(launch_nchw_to_nhwc(x_noisy, n_local, 4, HW, x8, 8, 8, s));
   GemmArgs g;
-  g.a = x8; g.a_f32 = 1; g.lda = 8; g.w = &c->enc_init; g.out = h; g.ldc = 16;
+  // no split-K anywhere in the encoder: a view's features must not depend on how many views share the launch (the sharded
+  // step is bit-identical to the single-GPU one only if every per-view quantity is)
+  g.a = x8; g.a_f32 = 1; g.lda = 8; g.w = &c->enc_init; g.out = h; g.ldc = 16; g.force_splitk = 1;
   RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
   float* cur = h;
   float* nxt = h2;
@@ -232,23 +293,33 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
     const EncBlockW& e = c->enc_blocks[i];
     RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre + 16 * i, a, 16, s, 48));
     g = GemmArgs();
-    g.a = a; g.lda = 16; g.w = &e.c1; g.out = r1; g.ldc = 16;
+    g.a = a; g.lda = 16; g.w = &e.c1; g.out = r1; g.ldc = 16; g.force_splitk = 1;
     RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
     RET_IF(run_group_norm(c, r1, 16, n_local, HW, e.n2, 8, 1e-5f, ACT_SILU, nullptr, a, 16, s));
     g = GemmArgs();
-    g.a = a; g.lda = 16; g.w = &e.c2; g.out = nxt; g.ldc = 16; g.resid = cur; g.ldr = 16;
+    g.a = a; g.lda = 16; g.w = &e.c2; g.out = nxt; g.ldc = 16; g.resid = cur; g.ldr = 16; g.force_splitk = 1;
     RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
     std::swap(cur, nxt);
   }
   RET_IF(run_group_norm(c, cur, 16, n_local, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, a, 16, s));
   g = GemmArgs();
-  g.a = a; g.lda = 16; g.w = &c->enc_final; g.out = feats; g.ldc = 16;
+  g.a = a; g.lda = 16; g.w = &c->enc_final; g.out = feats; g.ldc = 16; g.force_splitk = 1;
   RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
   RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
                               c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
-  RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
-                           0, s));
+  if (fused_out)
+    RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
+                             0, s));
   return 0;
+}
+
+// SMPLFeatureExtractor (network.py:41-72) on the per-view features of ALL views, summed in view order: the same
+// arithmetic, in the same order, whether the views were computed on one GPU or gathered from several
+int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, hipStream_t s) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->mesh.Nv) return mvd_fail("mvd_set_mesh must be called first");
+  if (n_views != c->v.num_views) return mvd_fail("mvd_fuse_vertex_features: expects the features of all num_views views");
+  return launch_fuse_views(vf_all, n_views, c->mesh.Nv, c->v.num_views, c->fuse_w, c->fuse_b, fused_out, 0, s);
 }
 
 // SparseConvNet (network.py:74-96) + latent-code volume gather (morphable_diffusion.py:232-257)
@@ -285,6 +356,8 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
                    FrustumOut* out, hipStream_t s, bool half0) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   if (!c->volume || !c->cams) return mvd_fail("volume / cameras not set");
+  // the volume may have been produced on another stream (mvd_set_volume_ready_event): its first reader waits here
+  if (c->vol_ready) HIP_CHECK_RET(hipStreamWaitEvent(s, c->vol_ready, 0));
   const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
   const int* fd = c->v.frustum_dims;
   int D[4], S[4];

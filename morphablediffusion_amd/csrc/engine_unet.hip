@@ -65,6 +65,13 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     g.nch = nch;
     g.splitk = 1;
     g.partial = nullptr;
+    double fl = 0.0;
+    for (int p = 0; p < g.npar; ++p) fl += 2.0 * M * g.N * (double)g.Cin * g.par_ntaps[p];
+    const double by = (double)g.B * g.PZ * g.PY * g.PX * g.Cin * 2 + (double)g.npar * kmax * g.N * g.Cin * 2 +
+                      (double)M * g.npar * g.N * (g.out_f32 ? 4 : 2) + (g.resid ? (double)M * g.npar * g.N * (g.resid_f32 ? 4 : 2) : 0.0);
+    char fam[64];
+    snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,0>", g.bn);
+    ProbeScope ps(c, s, fam, fl, by);
     return launch_gemm_dma(g, s);
   }
   const bool dense = use_dense && !halo && M >= dense_min_m && (g.ntaps == 1 || M <= 16384) && gemm_dma_eligible(g);
@@ -135,30 +142,33 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     hipEventRecord(ev0, s);
   }
   int r;
+  // algorithmic work of this launch: every operand and the result once (gathered taps re-read the same input pixels)
+  const double flops = 2.0 * M * g.N * (double)g.Cin * (g.npar > 0 ? 1 : g.ntaps);
+  const double in_rows = (double)g.B * g.PZ * g.PY * g.PX;
+  const double out_cols = g.geglu ? g.N / 2 : g.N;
+  double bytes = in_rows * g.Cin * (g.a_f32 ? 4 : 2) + (double)g.ntaps * g.N * g.Cin * 2 +
+                 (g.gn_partial ? 0.0 : (double)M * out_cols * (g.out_f32 ? 4 : 2));
+  if (g.resid) bytes += (double)M * g.N * (g.resid_f32 ? 4 : 2);
+  char fam[64];
   if (halo) {
-    // measurement probe: only the <160,16,16> instantiation without split-K (the level-32 convs)
-    const bool probe = c->probe_on && g.bn == 160 && g.X % 16 == 0 && g.splitk <= 1;
-    if (probe) {
-      if (c->probe_used + 2 > c->probe_ev.size()) {
-        for (int i = 0; i < 2; ++i) {
-          hipEvent_t ev;
-          if (hipEventCreate(&ev) != hipSuccess) return mvd_fail("probe: hipEventCreate failed");
-          c->probe_ev.push_back(ev);
-        }
-      }
-      hipEventRecord(c->probe_ev[c->probe_used], s);
+    snprintf(fam, sizeof fam, "conv3_dma_kernel<%d,%d,%d>", g.bn == 160 ? 160 : 128, g.X % 16 == 0 ? 16 : 8, g.X % 16 == 0 ? 16 : 8);
+    {
+      ProbeScope ps(c, s, fam, flops, g.splitk > 1 ? bytes - (double)M * out_cols * (g.out_f32 ? 4 : 2) : bytes);
+      r = launch_conv3_halo(g, s);
     }
-    r = launch_conv3_halo(g, s);
-    if (probe) {
-      hipEventRecord(c->probe_ev[c->probe_used + 1], s);
-      c->probe_used += 2;
-      c->probe_flops += 2.0 * M * g.N * g.Cin * 9.0;
-    }
-    if (!r && g.splitk > 1) r = launch_splitk_reduce(g, s);
   } else if (dense) {
+    snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d>", g.bn, g.gn_partial ? 1 : (g.rowscale ? 2 : 0));
+    ProbeScope ps(c, s, fam, flops, bytes);
     r = launch_gemm_dma(g, s);
   } else {
+    const int bn = g.bn ? g.bn : igemm_pick_bn(g.N, g.geglu);
+    snprintf(fam, sizeof fam, "igemm_kernel<%d,%d>", g.a_f32, bn);
+    ProbeScope ps(c, s, fam, flops, bytes);
     r = launch_igemm(g, s);
+  }
+  if (!r && g.splitk > 1) {  // the slabs are written once and read once: 2 x splitk x M x N x 4 bytes that no roofline needs
+    ProbeScope ps(c, s, "splitk_reduce_kernel", 0.0, (double)M * g.N * 4.0 * (g.splitk + 1));
+    r = launch_splitk_reduce(g, s);
   }
   if (timing) {
     hipEventRecord(ev1, s);
@@ -347,6 +357,8 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
                    int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld) {
+  // algorithmic: x read once (fp32), fp16 result written once
+  ProbeScope ps(c, s, "group_norm", 0.0, (double)B * rows_per_sample * n.C * 6.0);
   static const bool two_pass = getenv("MVD_GN_TWO_PASS") != nullptr;
   if (!two_pass && gn_group_eligible(ld, rows_per_sample, n.C, groups, preadd ? (preadd_ld ? preadd_ld : n.C) : 0, ldo))
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
@@ -432,19 +444,28 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   GemmArgs g;
   g.a = n0; g.lda = C; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
+  {
+    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
+    RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
+  }
   // q | k | v projection in one GEMM; the attention kernel transposes V while staging it
   g = GemmArgs();
   g.a = l1; g.lda = C; g.w = &t.qkv; g.out = qkv; g.out_f32 = 0; g.ldc = 3 * C; g.use_bias = false;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
+  {
+    ProbeScope ps(c, f.s, "attn_kernel", 4.0 * f.Bv * (double)T * T * C, (double)rows * C * 8.0);
+    RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
+  }
   // attn2 (single CLIP token -> per-sample constant, precomputed for all blocks in engine_unet) rides on the
   // attn1 output projection as a per-sample bias
   g = GemmArgs();
   g.a = ao; g.lda = C; g.w = &t.attn_out; g.out = t2; g.ldc = C; g.resid = t0; g.ldr = C;
   g.rowbias = f.a2_all + t.a2_off; g.rb_ld = c->a2_total;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l1, f.s));
+  {
+    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
+    RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l1, f.s));
+  }
   g = GemmArgs();
   g.a = l1; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
@@ -522,7 +543,11 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
       RET_IF(run_linear(c, g, f.n_ctx, crow * D, f.s));
       RET_IF(run_group_norm(c, pc, Cc, f.n_ctx, D * HW, d.gn_ctx, 8, 1e-5f, ACT_RELU, nullptr, cn, Cc, f.s));
     }
-    RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s));
+    {
+      ProbeScope ps(c, f.s, "depth_attn_kernel", 4.0 * crow * (double)D * 4 * Cc,
+                    (double)crow * D * Cc * 2.0 + (double)crow * 4 * Cc * 6.0);
+      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s));
+    }
   }
   if (f.Bv > f.n_ctx)  // all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every head
     RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc, 4 * Cc, rows - crow, d.relu_beta, 4 * Cc, f.s));

@@ -278,7 +278,8 @@ int launch_c3_dma(const IGemm& g, hipStream_t s) {
   constexpr int HP = NI * (IW + 2) * (IH + 2);
   constexpr int LDS = 2 * ((HP + 7) / 8) * 1024 + 3 * BN * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
+  bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3_dma_kernel<BN, IW, IH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;

@@ -100,7 +100,8 @@ int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond
   const int per_wave = x_bytes + 4 * Cc * 4 + 64 * 4 * 4;
   const int lds = per_wave * 4;
   if (lds > 160 * 1024) return mvd_fail("depth_attn: LDS budget exceeded");
-  static bool attr_set = false;
+  static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
+  bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)depth_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;

@@ -352,7 +352,8 @@ template <int BN, int MODE = 0>
 int launch_gd(const IGemm& g, int M, hipStream_t s) {
   constexpr int LDS = GST * (GBM * 128 + BN * 128);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
+  bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -423,7 +424,5 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
     return g.bn == 64 ? launch_gd<64, 2>(g, M, s) : launch_gd<128, 2>(g, M, s);
   }
   const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
-  if (r) return r;
-  if (g.splitk > 1) return launch_splitk_reduce(g, s);
-  return 0;
+  return r;  // split-K: the caller (igemm_go) runs launch_splitk_reduce
 }

@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
 template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
 int launch_variant(const IGemm& g, int M, hipStream_t s) {
   constexpr int LDS = 2 * (BM * 128 + BN * 128);
-  static bool attr_set = false;
+  static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
+  bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<A_F32, BN, WAVES_M, WAVES_N>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -374,7 +375,5 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
   if (bn == 160) r = g.a_f32 ? launch_variant<true, 160, 4, 1>(g, M, s) : launch_variant<false, 160, 4, 1>(g, M, s);
   else if (bn == 64) r = g.a_f32 ? launch_variant<true, 64, 4, 1>(g, M, s) : launch_variant<false, 64, 4, 1>(g, M, s);
   else r = g.a_f32 ? launch_variant<true, 128, 2, 2>(g, M, s) : launch_variant<false, 128, 2, 2>(g, M, s);
-  if (r) return r;
-  if (g.splitk > 1) return launch_splitk_reduce(g, s);
-  return 0;
+  return r;  // split-K: the caller (igemm_go) runs launch_splitk_reduce
 }

@@ -1,5 +1,6 @@
 """Thin object wrapper over the C ABI: owns one mvd_ctx on one GPU, hands torch device tensors to the
 library by pointer (PyTorch is used for device memory and streams only)."""
+import collections
 import ctypes as C
 from typing import Dict, Optional
 
@@ -17,6 +18,10 @@ def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+MAX_SAMPLE_SLOTS = 8  # per-sample mesh / camera tables kept resident in the context (mvd_select_sample)
+
+
 class Engine:
     def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0):
         if not torch.cuda.is_available():
@@ -25,6 +30,13 @@ class Engine:
         ucfg.validate()
         self.ucfg, self.vcfg = ucfg, vcfg
         self.device = torch.device(device)
+        self._workspace_gb = workspace_gb
+        self._ctx = None
+        self._loaded = False
+        self._create()
+
+    def _create(self):
+        ucfg, vcfg, workspace_gb = self.ucfg, self.vcfg, self._workspace_gb
         uc = L.UNetConfigC()
         uc.image_size, uc.in_channels, uc.out_channels = ucfg.image_size, ucfg.in_channels, ucfg.out_channels
         uc.model_channels, uc.num_res_blocks = ucfg.model_channels, ucfg.num_res_blocks
@@ -48,7 +60,9 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.mvd_create(C.byref(uc), C.byref(vc), self.device.index or 0,
                                         C.c_size_t(int(workspace_gb * (1 << 30))), C.byref(self._ctx)))
-        self._keep = []
+        self._loaded = False
+        self.num_vertices = 0
+        self._slot_nv = {}
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -62,8 +76,28 @@ class Engine:
             pass
 
     # ---- weights -------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
-        """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing."""
+    def expected_keys(self, sd):
+        """Keys the engine consumes: the hot-path manifest (always) plus the VAE / CLIP groups present in ``sd``."""
+        from .spec import full_manifest
+        return set(full_manifest(self.ucfg, self.vcfg))
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing.  Like nn.Module it may be
+        called again (another checkpoint, EMA weights): the context is rebuilt, so every call must carry the complete set.
+        Returns (missing_keys, unexpected_keys) w.r.t. the hot-path manifest; ``strict`` raises on either, as torch does.
+        Keys outside the path (``num_batches_tracked``, schedule buffers, the CLIP text tower, ...) count as unexpected only
+        under strict=True, exactly as they would for a module that does not declare them."""
+        if self._loaded:  # packed weights are immutable: start from a fresh context
+            self.close()
+            self._create()
+        want = self.expected_keys(sd)
+        have = {k for k, v in sd.items() if torch.is_tensor(v)}
+        missing = sorted(want - have)
+        side = ("first_stage_model.", "clip_image_encoder.")
+        unexpected = sorted(k for k in have - want if not k.startswith(side))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} (+{max(0, len(missing) - 5)}), "
+                               f"unexpected {unexpected[:5]} (+{max(0, len(unexpected) - 5)})")
         self.has_vae_decoder = any(k.startswith("first_stage_model.decoder.") for k in sd)
         self.has_vae_encoder = any(k.startswith("first_stage_model.encoder.") for k in sd)
         self.has_clip = any(k.startswith("clip_image_encoder.model.visual.") for k in sd)
@@ -75,6 +109,8 @@ class Engine:
             on_dev = 1 if t.is_cuda else 0
             L.check(self.lib.mvd_upload_weight(self._ctx, k.encode(), L.ptr(t), shape, t.dim(), on_dev))
         L.check(self.lib.mvd_finalize_weights(self._ctx))
+        self._loaded = True
+        return IncompatibleKeys(missing, unexpected)
 
     # ---- stages --------------------------------------------------------------------------------
     def unet_forward(self, x, timesteps, context, source_dict, n_ctx: Optional[int] = None):
@@ -108,14 +144,22 @@ class Engine:
         L.check(self.lib.mvd_embed_time(self._ctx, L.ptr(t), t.shape[0], L.ptr(out), _stream()))
         return out
 
+    def select_sample(self, slot: int):
+        """Makes slot ``slot`` (0..MAX_SAMPLE_SLOTS-1) of per-sample mesh / camera tables the active one; set_mesh /
+        set_cameras write into the active slot.  With B > 1 every sample keeps its tables across steps."""
+        L.check(self.lib.mvd_select_sample(self._ctx, int(slot)))
+        self._slot = int(slot)
+        self.num_vertices = self._slot_nv.get(self._slot, 0)
+
     def set_mesh(self, vertices, coord, out_sh, bounds):
         """Per-sample, step-invariant mesh metadata (hoists the .tolist() sync of morphable_diffusion.py:251-252)."""
         v = vertices.detach().cpu().float().contiguous()
         c = coord.detach().cpu().to(torch.int32).contiguous()
         o = out_sh.detach().cpu().to(torch.int32).contiguous()
         b = bounds.detach().cpu().float().contiguous()
-        self.num_vertices = v.shape[0]
         L.check(self.lib.mvd_set_mesh(self._ctx, L.ptr(v), L.ptr(c), L.ptr(o), L.ptr(b), v.shape[0]))
+        self.num_vertices = v.shape[0]
+        self._slot_nv[getattr(self, "_slot", 0)] = v.shape[0]
 
     def set_cameras(self, K, RT):
         K = K.detach().cpu().float().contiguous()
@@ -133,6 +177,31 @@ class Engine:
         L.check(self.lib.mvd_vertex_features(self._ctx, L.ptr(x), L.ptr(te), L.ptr(ve), L.ptr(vi), x.shape[0],
                                              1 if add_bias else 0, L.ptr(out), _stream()))
         return out
+
+    def vertex_view_features(self, x_noisy, t_embed, v_embed, view_idx, out=None):
+        """Per-view vertex features [n_local,Nv,16] (no view reduction): the operand of the all-gather view exchange."""
+        dev = self.device
+        x = _f32(x_noisy, dev)
+        te, ve = _f32(t_embed, dev), _f32(v_embed, dev)
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty(x.shape[0], self.num_vertices, 16, device=dev, dtype=torch.float32)
+        L.check(self.lib.mvd_vertex_view_features(self._ctx, L.ptr(x), L.ptr(te), L.ptr(ve), L.ptr(vi), x.shape[0],
+                                                  L.ptr(out), _stream()))
+        return out
+
+    def fuse_vertex_features(self, vf_all, out=None):
+        """SMPLFeatureExtractor over all views in index order: [num_views,Nv,16] -> [Nv,16]."""
+        vf = _f32(vf_all, self.device)
+        if out is None:
+            out = torch.empty(self.num_vertices, 16, device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_fuse_vertex_features(self._ctx, L.ptr(vf), vf.shape[0], L.ptr(out), _stream()))
+        return out
+
+    def set_volume_ready_event(self, event):
+        """event: torch.cuda.Event recorded after volume_from_fused on another stream (kept alive by the caller), or None."""
+        h = C.c_void_p(0) if event is None else C.c_void_p(event.cuda_event)
+        L.check(self.lib.mvd_set_volume_ready_event(self._ctx, h))
 
     def volume_from_fused(self, fused, want_output=True):
         V = self.vcfg.spatial_volume_size
@@ -256,14 +325,16 @@ class Engine:
         L.check(self.lib.mvd_bench_linear(self._ctx, M, K, N, flags, iters, C.byref(ms), _stream()))
         return ms.value
 
-    def probe_enable(self, on=True):
-        L.check(self.lib.mvd_probe_enable(self._ctx, 1 if on else 0))
+    def probe_config(self, mode, family=None, stride=1):
+        """mvd_probe_config: 0 off, 1 every launch of every kernel family, 2 a 1-in-stride sample of ``family``."""
+        L.check(self.lib.mvd_probe_config(self._ctx, int(mode), None if family is None else family.encode(), int(stride)))
 
-    def probe_read(self):
-        """(total kernel ms, total algorithmic FLOPs, launches) of conv3_dma_kernel<160,16,16> since probe_enable."""
-        ms, fl, n = C.c_double(0), C.c_double(0), C.c_int(0)
-        L.check(self.lib.mvd_probe_read(self._ctx, C.byref(ms), C.byref(fl), C.byref(n)))
-        return ms.value, fl.value, n.value
+    def probe_report(self):
+        """Per-family table since the last probe_config: list of dicts (family, launches, sampled, ms, flops, bytes, ...)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        L.check(self.lib.mvd_probe_report(self._ctx, buf, C.c_size_t(len(buf))))
+        return json.loads(buf.value.decode())
 
     def vae_decode(self, z):
         """AutoencoderKL.decode (autoencoder.py:330-333) for a batch of latents z [B,4,h,w] (already divided by the

@@ -63,8 +63,12 @@ class DepthWiseAttention(nn.Module):
         if self._engine is None:
             self._engine = Engine(self.cfg, VolumeConfig())
             self._owns_engine = True
-        self._engine.load_state_dict({"model.diffusion_model." + k: v for k, v in state_dict.items()})
-        return [], []
+        from .spec import unet_manifest
+        sd = {"model.diffusion_model." + k: v for k, v in state_dict.items()}
+        self._engine.expected_keys = lambda _sd: set(unet_manifest(self.cfg))
+        inc = self._engine.load_state_dict(sd, strict=strict)
+        n = len("model.diffusion_model.")
+        return type(inc)([k[n:] for k in inc.missing_keys], [k[n:] for k in inc.unexpected_keys])
 
     def forward(self, x, timesteps=None, context=None, source_dict=None, **kwargs):
         if self._engine is None:
@@ -127,17 +131,34 @@ class SpatialVolumeNet(nn.Module):
         self.frustum_volume_depth = frustum_volume_depth
         self.spatial_volume_size = spatial_volume_size
         self._engine: Optional[Engine] = None
-        self._mesh_key = None
+        self._slots = {}  # slot -> (key, tensors): per-sample tables resident in the engine
 
     def bind(self, engine: Engine):
         self._engine = engine
 
+    _SAMPLE_KEYS = ("vertices", "coord", "out_sh", "bounds", "target_K", "target_RT")
+
+    def invalidate(self):
+        """Forget which meshes / cameras are resident: the next step re-reads the batch (SyncDDIMSampler.sample does this
+        on entry, so every sampling run uploads at least once -- the reference re-reads the batch at every step)."""
+        self._slots = {}
+
     def _set_sample(self, batch, bi):
-        key = (id(batch.get("vertices")), bi)
-        if key != self._mesh_key:
+        """Makes sample ``bi`` of ``batch`` the engine's active mesh + cameras.  The tables are step-invariant, so they are
+        rebuilt only when the batch content changes: the key covers every tensor that feeds them -- storage address, shape
+        and torch's in-place version counter -- and the cache holds references to those tensors, so a freed tensor's address
+        cannot come back under the same key."""
+        from .engine import MAX_SAMPLE_SLOTS
+        ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
+        key = (bi,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in ts)
+        slot = bi % MAX_SAMPLE_SLOTS
+        self._engine.select_sample(slot)
+        held = self._slots.get(slot)
+        if held is None or held[0] != key:
+            self._slots.pop(slot, None)  # a failed upload must not leave a stale key behind
             self._engine.set_mesh(batch["vertices"][bi], batch["coord"][bi], batch["out_sh"][bi], batch["bounds"][bi])
             self._engine.set_cameras(batch["target_K"][bi], batch["target_RT"][bi])
-            self._mesh_key = key
+            self._slots[slot] = (key, ts)
 
     def construct_spatial_volume(self, x, t_embed, v_embed, batch):
         B, N = x.shape[:2]
@@ -198,8 +219,10 @@ class SyncMultiviewDiffusion(nn.Module):
         return self._device
 
     def load_state_dict(self, state_dict, strict=False):
-        self.engine.load_state_dict(state_dict)
-        return [], []
+        """generate_face.py:76 calls this with strict=False on ``ckpt['state_dict']``; returns torch's
+        (missing_keys, unexpected_keys) pair w.r.t. the keys the denoising path consumes."""
+        self.spatial_volume.invalidate()
+        return self.engine.load_state_dict(state_dict, strict=strict)
 
     def get_viewpoint_embedding(self, batch):
         d_e = torch.deg2rad(batch["target_elevation"]) - torch.deg2rad(batch["input_elevation"])
@@ -235,7 +258,15 @@ class SyncMultiviewDiffusion(nn.Module):
 
     def prepare(self, batch):
         """morphable_diffusion.py:473-489.  The reference also VAE-encodes the 16 target images and then
-        discards them at inference (:475-479,568); that dead work is skipped."""
+        discards them at inference (:475-479,568); that dead work is skipped, but its side effect on the global RNG
+        stream is not: each of those N encodes draws ``posterior.sample()`` noise (distributions.py:36) BEFORE the input
+        image is encoded and before x_T is drawn, so the same draws are consumed here -- a run seeded with
+        torch.manual_seed sees the same stream position as the reference."""
+        if "target_image" in batch and batch["target_image"] is not None:
+            B, N = batch["target_image"].shape[:2]
+            h, w = batch["target_image"].shape[2] // 8, batch["target_image"].shape[3] // 8
+            for _ in range(N):
+                torch.randn([B, 4, h, w])
         image_input = batch["input_image"].permute(0, 3, 1, 2)
         x_input = self.encode_first_stage(image_input)
         input_info = {"image": image_input, "elevation": batch["input_elevation"][:, 0], "x": x_input}
@@ -295,11 +326,21 @@ class DiagonalGaussianDistribution:
 
 class SyncDDIMSampler:
     """morphable_diffusion.py:648-776.  With torch.distributed initialised and ``shard_views=True`` the N views
-    are partitioned over the ranks (contiguous slices); the only per-step exchange is one all-reduce of the
-    [Nv,16] fused vertex features."""
+    are partitioned over the ranks (contiguous slices); the only per-step exchange is ONE collective on the per-vertex
+    features:
+
+    * ``exchange="all_gather"`` (default): all-gather of the per-view features [N,Nv,16] (5.1 MB at N=16, FLAME), then every
+      rank sums the views in index order -- the sharded step is BIT-IDENTICAL to the single-GPU step;
+    * ``exchange="all_reduce"``: all-reduce of each rank's share of the view mean [Nv,16] (321 KB); the fp32 summation order
+      then depends on the rank count (differences ~1e-7 relative).
+
+    The exchange, the view fusion, the sparse voxel CNN and the lattice gather are enqueued on a separate communication
+    stream: the UNet's full-resolution input blocks need none of it, so ``mvd_denoise_views`` starts on the caller's stream
+    at once and only its frustum stage waits for the volume (``mvd_set_volume_ready_event``).  ``overlap=False`` (or
+    MVD_NO_COMM_OVERLAP=1) keeps everything on the caller's stream."""
 
     def __init__(self, model, ddim_num_steps, ddim_discretize="uniform", ddim_eta=1.0, latent_size=32,
-                 shard_views=False):
+                 shard_views=False, exchange="all_gather", overlap=True):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.latent_size = latent_size
@@ -312,7 +353,14 @@ class SyncDDIMSampler:
         self.ddim_sqrt_one_minus_alphas = self.schedule.ddim_sqrt_one_minus_alphas
         self.eta = ddim_eta
         self.shard_views = shard_views
+        if exchange not in ("all_gather", "all_reduce"):
+            raise ValueError(f"unknown exchange {exchange!r}")
+        self.exchange = exchange
+        import os
+        self.overlap = overlap and not os.environ.get("MVD_NO_COMM_OVERLAP")
         self.simulate_world = 0  # timing aid (bench.py --simulate-gpus): run ONE rank's share without a process group
+        self._comm = None  # (stream, event after the vertex features, event after the volume), created on first use
+        self._bufs = {}    # persistent exchange buffers: never handed back to the allocator while the side stream uses them
 
     # -- distributed helpers -------------------------------------------------------------------------
     def _world(self):
@@ -331,10 +379,12 @@ class SyncDDIMSampler:
         return rank * per, (rank + 1) * per
 
     def denoise_apply(self, x_target_noisy, input_info, clip_embed, time_steps, index, unconditional_scale,
-                      batch_view_num=1, is_step0=False, batch=None, noise=None):
+                      batch_view_num=1, is_step0=False, batch=None, noise=None, return_eps=False, host_steps=None):
         """One multi-view denoising step.  x_target_noisy [B,N_local,4,H,W] holds this rank's views
         (all N when not sharded).  ``noise``: optional explicit N(0,1) draw [B,N_local,4,H,W]; default is a
-        fresh torch.randn_like as in the reference (:695-697)."""
+        fresh torch.randn_like as in the reference (:695-697).  ``return_eps``: also return the guided noise prediction
+        e_t (:736), the tensor denoise_apply_impl consumes.  ``host_steps``: the values of ``time_steps`` as python ints
+        (the sampling loop knows them), so that no device->host read happens on the step path."""
         import torch.distributed as dist
         m = self.model
         eng = m.engine
@@ -351,28 +401,92 @@ class SyncDDIMSampler:
         if noise is None and not is_step0:
             noise = torch.randn_like(x_target_noisy)
         out = torch.empty_like(x_target_noisy)
+        eps_out = torch.empty_like(x_target_noisy) if return_eps else None
         local_idx = torch.arange(lo, lo + NL)
+        if host_steps is None:  # one read for the whole call (none at all when the caller passes host_steps)
+            host_steps = [int(v) for v in time_steps.tolist()]
         for bi in range(B):
             m.spatial_volume._set_sample(batch, bi)
-            fused = eng.vertex_features(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx,
-                                        add_bias=(rank == 0))
-            if world > 1 and not self.simulate_world:
-                dist.all_reduce(fused)  # RCCL over xGMI: Nv*16 fp32, latency-bound
-            eng.volume_from_fused(fused, want_output=False)
+            self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N)
             for ni in range(0, NL, batch_view_num):
                 sl = slice(ni, min(NL, ni + batch_view_num))
                 idx = local_idx[sl]
-                out[bi, sl] = eng.denoise_views(
-                    x_target_noisy[bi, sl], x_input[bi], clip_embed[bi].reshape(-1), int(time_steps[bi]), t_embed[bi],
+                r = eng.denoise_views(
+                    x_target_noisy[bi, sl], x_input[bi], clip_embed[bi].reshape(-1), host_steps[bi], t_embed[bi],
                     v_embed[bi, idx], idx, float(unconditional_scale),
-                    None if is_step0 else noise[bi, sl], coef)
-        return out
+                    None if is_step0 else noise[bi, sl], coef, want_eps=return_eps)
+                if return_eps:
+                    out[bi, sl], eps_out[bi, sl] = r
+                else:
+                    out[bi, sl] = r
+        return (out, eps_out) if return_eps else out
+
+    def _buf(self, name, shape, device):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
+            t = torch.empty(shape, device=device, dtype=torch.float32)
+            self._bufs[name] = t
+        return t
+
+    def _build_volume(self, x_local, t_embed, v_embed_local, local_idx, rank, world, N):
+        """2-D encoder + vertex gather for this rank's views (caller's stream), then exchange -> view fusion -> sparse voxel
+        CNN -> lattice gather on the communication stream; leaves the 32^3 volume in the engine, guarded by an event."""
+        import torch.distributed as dist
+        eng = self.model.engine
+        dev = x_local.device
+        real = world > 1 and not self.simulate_world
+        side = self.overlap and dev.type == "cuda"
+        if side and self._comm is None:
+            self._comm = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+        NL = x_local.shape[0]
+        if self.exchange == "all_gather":
+            Nv = eng.num_vertices
+            if dev.type == "cuda":
+                vf_all = self._buf("vf_all", (N, Nv, 16), dev)
+                lo = rank * NL if world > 1 else 0
+                vf_loc = vf_all[lo:lo + NL] if not real else self._buf("vf_loc", (NL, Nv, 16), dev)
+                eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx, out=vf_loc)
+            else:  # CPU stand-ins of the engine (tests)
+                vf_loc = eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx)
+                vf_all = vf_loc if world == 1 else torch.empty((N,) + tuple(vf_loc.shape[1:]), dtype=vf_loc.dtype)
+            fused_buf = self._buf("fused", (Nv, 16), dev) if dev.type == "cuda" else None
+
+            def tail():
+                if real:
+                    dist.all_gather_into_tensor(vf_all, vf_loc)  # RCCL over xGMI; rank r's slice lands at views [r*NL, ...)
+                elif world > 1:  # --simulate-gpus: stand in for the other ranks' slices
+                    for r in range(1, world):
+                        vf_all[r * NL:(r + 1) * NL].copy_(vf_all[:NL])
+                eng.volume_from_fused(eng.fuse_vertex_features(vf_all, out=fused_buf), want_output=False)
+        else:
+            fused = eng.vertex_features(x_local, t_embed, v_embed_local, local_idx, add_bias=(rank == 0))
+            if dev.type == "cuda":  # persistent: the communication stream reads it after this call returns
+                fused = self._buf("fused", tuple(fused.shape), dev).copy_(fused)
+
+            def tail():
+                if real:
+                    dist.all_reduce(fused)  # Nv*16 fp32, latency-bound
+                eng.volume_from_fused(fused, want_output=False)
+        if not side:
+            if dev.type == "cuda":
+                eng.set_volume_ready_event(None)
+            tail()
+            return
+        comm, ev_in, ev_vol = self._comm
+        ev_in.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_in)  # after the vertex features AND after every earlier reader of the volume on that stream
+            tail()
+            ev_vol.record(comm)
+        eng.set_volume_ready_event(ev_vol)
 
     def sample(self, input_info, clip_embed, unconditional_scale=1.0, log_every_t=50, batch_view_num=1, batch=None,
-               generator=None):
-        """Returns (x [B,N,4,h,w], {'x_inter': [...]}) like the reference; with view sharding every rank
-        returns the gathered full tensor."""
-        import torch.distributed as dist
+               generator=None, return_eps=False):
+        """Returns (x [B,N,4,h,w], {'x_inter': [...]}) like the reference (:742-776); with view sharding every rank
+        returns the gathered full tensor.  RNG: x_T is drawn first, then one N(0,1) tensor per step except the last
+        (index 0), in the order the reference consumes its stream.  ``generator``: a torch.Generator; a CPU generator
+        makes the draws on the host (bit-identical to the reference run on CPU with the same seed), a device generator or
+        None draws on the device.  ``return_eps``: adds 'eps' (one [B,N,4,h,w] per step) to the returned dict."""
         print(f"unconditional scale {unconditional_scale:.1f}")
         C, H, W = 4, self.latent_size, self.latent_size
         B = clip_embed.shape[0]
@@ -380,21 +494,33 @@ class SyncDDIMSampler:
         device = self.model.device
         rank, world = self._world()
         lo, hi = self.view_range(N)
-        # full-size draws on every rank (same generator state) then slice: matches the single-GPU RNG stream
-        x_full = torch.randn([B, N, C, H, W], device=device, generator=generator)
-        x = x_full[:, lo:hi].contiguous()
+        self.model.spatial_volume.invalidate()  # every run re-reads the batch at least once
+        on_host = generator is not None and generator.device.type == "cpu"
+
+        def draw():
+            # full-size draws on every rank (same generator state) then slice: matches the single-GPU RNG stream
+            if on_host:
+                full = torch.randn([B, N, C, H, W], generator=generator)
+                return full[:, lo:hi].contiguous().to(device)
+            return torch.randn([B, N, C, H, W], device=device, generator=generator)[:, lo:hi].contiguous()
+
+        x = draw()
         intermediates = {"x_inter": []}
+        if return_eps:
+            intermediates["eps"] = []
         time_range = np.flip(self.ddim_timesteps)
         total_steps = self.ddim_timesteps.shape[0]
         with torch.no_grad():
             for i, step in enumerate(time_range):
                 index = total_steps - i - 1
                 time_steps = torch.full((B,), int(step), device=device, dtype=torch.long)
-                noise = None
-                if index != 0:
-                    noise = torch.randn([B, N, C, H, W], device=device, generator=generator)[:, lo:hi].contiguous()
+                noise = draw() if index != 0 else None
                 x = self.denoise_apply(x, input_info, clip_embed, time_steps, index, unconditional_scale,
-                                       batch_view_num=batch_view_num, is_step0=index == 0, batch=batch, noise=noise)
+                                       batch_view_num=batch_view_num, is_step0=index == 0, batch=batch, noise=noise,
+                                       return_eps=return_eps, host_steps=[int(step)] * B)
+                if return_eps:
+                    x, e = x
+                    intermediates["eps"].append(self._gather(e, world))
                 if index % log_every_t == 0 or index == total_steps - 1:
                     intermediates["x_inter"].append(self._gather(x, world))
         return self._gather(x, world), intermediates

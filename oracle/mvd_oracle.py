@@ -527,9 +527,10 @@ def construct_view_frustum_volume(W, vcfg, spatial_volume, t_embed, v_embed, tar
 
 # ---------------------------------------------------------------------------------------- one DDIM step
 def denoise_apply(W, plan, vcfg, tab, x_target_noisy, x_input, clip_embed, time_steps, index, scale,
-                  batch, batch_view_num=1, noise=None):
+                  batch, batch_view_num=1, noise=None, return_eps=False):
     """SyncDDIMSampler.denoise_apply, morphable_diffusion.py:701-739 -- the BASELINE unit of work.
-    ``noise``: explicit N(0,1) tensor for the eta=1 stochastic term (None -> is_step0 behaviour)."""
+    ``noise``: explicit N(0,1) tensor for the eta=1 stochastic term (None -> is_step0 behaviour).
+    ``return_eps``: also return the guided noise prediction e_t (:736) that denoise_apply_impl consumes."""
     B, N, C, H, Wd = x_target_noisy.shape
     v_embed = viewpoint_embedding(batch)
     t_embed = embed_time(W, time_steps, vcfg.time_dim)
@@ -549,4 +550,29 @@ def denoise_apply(W, plan, vcfg, tab, x_target_noisy, x_input, clip_embed, time_
             xc[:, :4] = xc[:, :4] / 0.18215
             e = unet_forward(W, plan, torch.cat([xs_, xc], 1), rep(time_steps), rep(clip_embed), vf)
         e_t.append(e.reshape(B, VN, 4, H, Wd))
-    return ddim_update(x_target_noisy, torch.cat(e_t, 1), tab, index, noise)
+    e_t = torch.cat(e_t, 1)
+    x_prev = ddim_update(x_target_noisy, e_t, tab, index, noise)
+    return (x_prev, e_t) if return_eps else x_prev
+
+
+def sample(W, plan, vcfg, x_input, clip_embed, scale, batch, num_ddim=50, eta=1.0, batch_view_num=1, log_every_t=50,
+           generator=None, latent_size=32):
+    """SyncDDIMSampler.sample, morphable_diffusion.py:742-776: x_T ~ N(0,1) drawn first, then the steps in
+    flip(ddim_timesteps) order with index = total-1-i, one randn_like per step except index 0 (:695-697), intermediates
+    at index % log_every_t == 0 or the first step (:772-773).  Returns (x, x_inter, eps_per_step)."""
+    tab = ddim_tables(num_ddim, eta)
+    B, N = clip_embed.shape[0], vcfg.num_views
+    x = torch.randn([B, N, 4, latent_size, latent_size], generator=generator)
+    ts = tab["timesteps"]
+    total = len(ts)
+    inter, eps_all = [], []
+    for i, step in enumerate(torch.flip(ts, [0]).tolist()):
+        index = total - i - 1
+        time_steps = torch.full((B,), int(step), dtype=torch.long)
+        noise = torch.randn(x.shape, generator=generator) if index != 0 else None
+        x, e = denoise_apply(W, plan, vcfg, tab, x, x_input, clip_embed, time_steps, index, scale, batch,
+                             batch_view_num=batch_view_num, noise=noise, return_eps=True)
+        eps_all.append(e)
+        if index % log_every_t == 0 or index == total - 1:
+            inter.append(x)
+    return x, inter, eps_all

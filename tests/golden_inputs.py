@@ -10,7 +10,7 @@ FULL_UNET = UNetConfig()
 WEIGHT_SEED = 7
 
 
-def pack(t, limit=65536, target=16384):
+def pack(t, limit=65536, target=16384):  # limit: largest tensor stored whole
     """Full tensor when small, else a strided sample + two checksums."""
     t = t.detach().float().contiguous()
     flat = t.flatten()
@@ -58,9 +58,12 @@ def unet_inputs(cfg: UNetConfig, Bv=2, seed=11, zero_uncond=True):
     return x, t, ctx, sd
 
 
-def unet_weights(cfg: UNetConfig):
-    return seeded_state_dict(unet_manifest(cfg), WEIGHT_SEED)
+TRAINED_SEED = 23  # second weight set: trained-checkpoint-like statistics (weights.py, style "trained")
 
 
-def full_weights(ucfg: UNetConfig, vcfg: VolumeConfig):
-    return seeded_state_dict(full_manifest(ucfg, vcfg), WEIGHT_SEED)
+def unet_weights(cfg: UNetConfig, style="init"):
+    return seeded_state_dict(unet_manifest(cfg), WEIGHT_SEED if style == "init" else TRAINED_SEED, style)
+
+
+def full_weights(ucfg: UNetConfig, vcfg: VolumeConfig, style="init"):
+    return seeded_state_dict(full_manifest(ucfg, vcfg), WEIGHT_SEED if style == "init" else TRAINED_SEED, style)

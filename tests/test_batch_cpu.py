@@ -80,3 +80,25 @@ def test_output_strip_and_neus2_export():
     bgra = B.neus2_view_bgra(strip, 1)
     assert bgra.shape == (256, 256, 4) and bgra[0, 0, 3] == 0 and bgra[10, 300 - 256, 3] == 255
     assert tuple(bgra[10, 300 - 256, :3]) == (250, 10, 0)
+
+
+def test_real_camera_dict_and_stacked_batches():
+    """generate_face.py:137-139,161-164 ('real' trajectory from a camera dict) and the eval driver's B > 1 batch
+    (eval/generate_all_facescape.py:176-186)."""
+    from morphablediffusion_amd import batch as BT
+    K, RT = BT.virtual_cameras(4)
+    d = {"intrinsics": [K[i, :3, :3].tolist() for i in range(4)], "extrinsics": [RT[i].tolist() for i in range(4)]}
+    K2, RT2 = BT.cameras_from_dict(d, 4)
+    assert torch.equal(K2, K) and torch.equal(RT2, RT)
+    K3, _ = BT.cameras_from_dict(d, 2, views=[3, 1])
+    assert torch.equal(K3, K[[3, 1]])
+    v = torch.rand(50, 3) * 0.4 - 0.2
+    img = torch.zeros(256, 256, 3)
+    s0 = BT.build_batch(img, v, num_views=4)
+    s1 = BT.build_batch(img, v * 0.9, num_views=4, cameras=(K2 * 1.0, RT2 + 0.01))
+    both = BT.stack_batches([s0, s1])
+    assert both["target_RT"].shape == (2, 4, 3, 4) and both["coord"].shape == (2, 50, 3)
+    assert torch.equal(both["target_RT"][1], RT + 0.01) and torch.equal(both["vertices"][0], v)
+    import pytest
+    with pytest.raises(ValueError):
+        BT.build_batch(img, v, num_views=4, cameras=(K[:3], RT[:3]))

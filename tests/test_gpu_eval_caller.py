@@ -1,0 +1,154 @@
+"""GPU: the callers either side of the hot path, as the reference's scripts drive them:
+
+* generate_face.py:71-78 ``load_model``: YAML (the full configs/facescape.yaml ``model`` block: scheduler_config,
+  finetune_unet, clip_image_encoder_path, ...) -> ``instantiate_from_config`` -> ``torch.load(ckpt)['state_dict']`` ->
+  ``load_state_dict(strict=False)`` on a checkpoint FILE in the reference's format (first-stage VAE, fp16 CLIP tower,
+  schedule buffers, ``num_batches_tracked`` counters, unrelated keys);
+* eval/generate_all_facescape.py:106-129,176-187: per-sample dicts concatenated into a B = 2 batch, one of them on a
+  'real' camera dict (generate_face.py:137-139,161-164), ``model.sample(sampler, data, cfg_scale, batch_view_num)``.
+
+The B = 2 trajectory is checked against the CPU oracle's ``sample`` on the same seed (a1 with B > 1)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from morphablediffusion_amd import batch as BT
+from morphablediffusion_amd import synthetic
+from morphablediffusion_amd.spec import (ClipConfig, UNetConfig, VaeConfig, VolumeConfig, build_unet_plan, clip_manifest,
+                                         full_manifest, vae_decoder_manifest, vae_encoder_manifest)
+from morphablediffusion_amd.weights import seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+N = 4
+UCFG = UNetConfig(model_channels=64)
+VCFG = VolumeConfig(num_views=N)
+
+
+def facescape_yaml(width=64, view_num=N):
+    """configs/facescape.yaml:1-42 with the reduced test width; every key of the ``model`` block is kept."""
+    return {"model": {
+        "base_learning_rate": 5e-5,
+        "target": "ldm.models.diffusion.morphable_diffusion.SyncMultiviewDiffusion",
+        "params": {
+            "view_num": view_num, "image_size": 256, "cfg_scale": 2.0, "output_num": 8, "batch_view_num": 4,
+            "finetune_unet": True, "drop_conditions": False, "projection": "perspective", "use_spatial_volume": False,
+            "clip_image_encoder_path": "./ckpt/ViT-L-14.pt", "target_elevation": 0,
+            "scheduler_config": {"target": "ldm.lr_scheduler.LambdaLinearScheduler",
+                                 "params": {"warm_up_steps": [100], "cycle_lengths": [100000], "f_start": [0.02],
+                                            "f_max": [1.0], "f_min": [1.0]}},
+            "unet_config": {"target": "ldm.models.diffusion.attention.DepthWiseAttention",
+                            "params": {"volume_dims": [64, 128, 256, 512], "image_size": 32, "in_channels": 8,
+                                       "out_channels": 4, "model_channels": width, "attention_resolutions": [4, 2, 1],
+                                       "num_res_blocks": 2, "channel_mult": [1, 2, 4, 4], "num_heads": 8,
+                                       "use_spatial_transformer": True, "transformer_depth": 1, "context_dim": 768,
+                                       "use_checkpoint": True, "legacy": False}}}},
+        "data": {"target": "ldm.data.facescape.FaceScapeDataset", "params": {"batch_size": 70}}}
+
+
+def reference_style_checkpoint():
+    """What torch.save(trainer checkpoint) of the reference's Lightning module holds, at reduced width."""
+    W = seeded_state_dict(full_manifest(UCFG, VCFG), 7)
+    hot = dict(W)
+    vae = VaeConfig(ch=32)
+    W.update(seeded_state_dict(vae_decoder_manifest(vae), 7))
+    W.update(seeded_state_dict(vae_encoder_manifest(vae), 7))
+    clip = seeded_state_dict(clip_manifest(ClipConfig(width=128, layers=2, heads=2, embed=768)), 7)
+    W.update({k: v.half() for k, v in clip.items()})  # the CLIP tower is stored in fp16
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+    ac = torch.cumprod(1 - betas, 0)
+    W.update({"betas": betas, "alphas": 1 - betas, "alphas_cumprod": ac, "sqrt_alphas_cumprod": ac.sqrt(),
+              "sqrt_one_minus_alphas_cumprod": (1 - ac).sqrt(), "posterior_variance": betas.clone(),
+              "posterior_log_variance_clipped": betas.log()})
+    for k in list(hot):
+        if k.endswith("running_mean"):
+            W[k[:-len("running_mean")] + "num_batches_tracked"] = torch.tensor(12345)
+    W["clip_image_encoder.model.logit_scale"] = torch.tensor(4.6)
+    W["first_stage_model.loss.logvar"] = torch.zeros(())
+    return {"state_dict": W, "global_step": 2000, "epoch": 3}, hot
+
+
+def two_samples():
+    """Two subjects with the same topology (vertex count), different geometry; the second one on a 'real' camera dict."""
+    g = torch.Generator().manual_seed(3)
+    v0 = synthetic.ellipsoid_mesh(700, 1, radii=(0.22, 0.28, 0.25))
+    v1 = synthetic.ellipsoid_mesh(700, 2, radii=(0.2, 0.25, 0.27))
+    nv = min(v0.shape[0], v1.shape[0])
+    K, RT = BT.virtual_cameras(N)
+    cam_dict = {"intrinsics": [(K[i, :3, :3] * 1.01).tolist() for i in range(N)],
+                "extrinsics": [(RT[i] + torch.tensor([[0, 0, 0, 0.01], [0, 0, 0, -0.02], [0, 0, 0, 0.05]])).tolist()
+                               for i in range(N)]}
+    img0 = torch.rand(256, 256, 3, generator=g) * 2 - 1
+    img1 = torch.rand(256, 256, 3, generator=g) * 2 - 1
+    s0 = BT.build_batch(img0, v0[:nv].contiguous(), num_views=N)
+    s1 = BT.build_batch(img1, v1[:nv].contiguous(), num_views=N, cameras=BT.cameras_from_dict(cam_dict, N))
+    return [s0, s1]
+
+
+def test_checkpoint_file_yaml_and_eval_style_batch(tmp_path):
+    from morphablediffusion_amd.model import SyncDDIMSampler, SyncMultiviewDiffusion
+    from oracle import mvd_oracle as O
+    ckpt, hot = reference_style_checkpoint()
+    ckpt_path, cfg_path = tmp_path / "model.ckpt", tmp_path / "facescape.yaml"
+    torch.save(ckpt, ckpt_path)
+    cfg_path.write_text(yaml.safe_dump(facescape_yaml()))
+    model = BT.load_model(str(cfg_path), str(ckpt_path), workspace_gb=6.0)  # generate_face.py:71-78
+    assert isinstance(model, SyncMultiviewDiffusion)
+    model = model.cuda().eval()  # generate_face.py:77: a no-op here, but it must not break
+    assert model.engine.has_vae_decoder and model.engine.has_vae_encoder and model.engine.has_clip
+    assert model.view_num == N and model.cfg_scale == 2.0 and model.batch_view_num == 4
+
+    # a second load on the same module (EMA weights, another checkpoint) works like nn.Module's; strict reports like torch
+    inc = model.load_state_dict(ckpt["state_dict"], strict=False)
+    assert inc.missing_keys == [] and "betas" in inc.unexpected_keys
+    with pytest.raises(RuntimeError):
+        model.load_state_dict({k: v for k, v in ckpt["state_dict"].items() if "middle_conditions" not in k}, strict=True)
+    model.load_state_dict(ckpt["state_dict"], strict=False)
+
+    data = BT.stack_batches(two_samples())
+    data = {k: v.cuda() for k, v in data.items()}
+    assert data["target_K"].shape == (2, N, 4, 4) and data["vertices"].shape[0] == 2
+
+    # prepare(): the reference VAE-encodes the N target images first (each draws posterior noise from the global CPU
+    # generator), then the input image: N + 1 draws of [B,4,32,32] in total -- the stream position must match
+    torch.manual_seed(11)
+    _, clip_embed, input_info = model.prepare(data)
+    after = torch.randn(3)
+    torch.manual_seed(11)
+    for _ in range(N + 1):
+        torch.randn(2, 4, 32, 32)
+    assert torch.equal(after, torch.randn(3))
+    assert clip_embed.shape == (2, 1, 768) and input_info["x"].shape == (2, 4, 32, 32)
+
+    # B = 2 trajectory, 4 DDIM steps, against the oracle on the same seed (CPU generator -> identical draws)
+    sampler = SyncDDIMSampler(model, 4)
+    x, inter = sampler.sample(input_info, clip_embed, unconditional_scale=2.0, log_every_t=1, batch_view_num=3, batch=data,
+                              generator=torch.Generator().manual_seed(5), return_eps=True)
+    cpu = {k: v.cpu() for k, v in data.items()}
+    want, w_inter, w_eps = O.sample(hot, build_unet_plan(UCFG), VCFG, input_info["x"].cpu(), clip_embed.cpu(), 2.0, cpu,
+                                    num_ddim=4, batch_view_num=3, log_every_t=1, generator=torch.Generator().manual_seed(5))
+    for i in range(4):
+        for name, a, b in (("eps", inter["eps"][i], w_eps[i]), ("x", inter["x_inter"][i], w_inter[i])):
+            rel = ((a.cpu() - b).norm() / b.norm()).item()
+            print(f"[parity] B=2 trajectory step {i} {name}: relL2={rel:.2e}")
+            assert rel <= 1e-3 * (i + 1), (name, i, rel)
+    assert not torch.allclose(x[0], x[1])
+
+    # the whole caller: model.sample -> images, the strip generate_face.py / the eval script save
+    torch.manual_seed(6033)
+    imgs = model.sample(sampler, data, 2.0, 4)
+    assert imgs.shape == (2, N, 3, 256, 256) and torch.isfinite(imgs).all()
+    strip = BT.views_to_uint8(imgs, data["input_image"])
+    assert strip.shape == (2 * 256, (N + 1) * 256, 3) and strip.dtype == np.uint8
+    model.engine.close()
+
+
+def test_real_camera_dict_errors():
+    K, RT = BT.virtual_cameras(N)
+    d = {"intrinsics": [K[i, :3, :3].tolist() for i in range(N - 1)], "extrinsics": [RT[i].tolist() for i in range(N)]}
+    with pytest.raises(IndexError):
+        BT.cameras_from_dict(d, N)
+    with pytest.raises(KeyError):
+        BT.cameras_from_dict({"intrinsics": [K[0, :3, :3].tolist()]}, 1)

@@ -100,11 +100,18 @@ from morphablediffusion_amd import synthetic
 class FakeEngine:
     """Test-only stand-in for the HIP engine with the same call surface; arithmetic is trivial but
     view-order sensitive, so a wrong partition / reduction / index mapping changes the result."""
-    def __init__(self, N): self.N = N
+    def __init__(self, N): self.N = N; self.num_vertices = 7
     def vertex_features(self, x, t_embed, v_embed, view_idx, add_bias=True):
         w = (view_idx.float() + 1.0).view(-1, 1)
         f = (x.reshape(x.shape[0], -1)[:, :16] * w).sum(0, keepdim=True).repeat(7, 1) / self.N
         return f + (0.5 if add_bias else 0.0)
+    def vertex_view_features(self, x, t_embed, v_embed, view_idx, out=None):
+        w = (view_idx.float() + 1.0).view(-1, 1, 1)
+        return (x.reshape(x.shape[0], 1, -1)[:, :, :16] * w).repeat(1, 7, 1)
+    def fuse_vertex_features(self, vf_all, out=None):
+        acc = torch.zeros_like(vf_all[0])
+        for v in range(vf_all.shape[0]): acc = acc + vf_all[v]  # fixed view order
+        return acc / self.N + 0.5
     def volume_from_fused(self, fused, want_output=True): self.fused = fused.clone()
     def denoise_views(self, x, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg, noise, coef, want_eps=False):
         s = self.fused.sum()
@@ -117,14 +124,15 @@ class FakeModel:
         self.view_num = N; self.engine = FakeEngine(N); self.device = torch.device("cpu")
         class SV:
             def _set_sample(self, batch, bi): pass
+            def invalidate(self): pass
         self.spatial_volume = SV()
     def get_viewpoint_embedding(self, batch): return torch.zeros(1, self.view_num, 4)
     def embed_time(self, t): return torch.zeros(t.shape[0], 256)
 
-def run(shard):
+def run(shard, exchange="all_gather"):
     N = 8
     m = FakeModel(N)
-    s = SyncDDIMSampler(m, 50, shard_views=shard)
+    s = SyncDDIMSampler(m, 50, shard_views=shard, exchange=exchange)
     g = torch.Generator().manual_seed(7)
     x, _ = s.sample({"x": torch.zeros(1, 4, 32, 32)}, torch.zeros(1, 1, 768), unconditional_scale=2.0,
                     batch_view_num=2, batch=synthetic.make_batch(N, "perspective", 50), generator=g)
@@ -134,7 +142,9 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int
 sharded = run(True)
 single = run(False)
 assert sharded.shape == single.shape == (1, 8, 4, 32, 32)
-err = ((sharded - single).abs().max() / single.abs().max()).item()  # fp32 summation order differs (all-reduce)
+assert torch.equal(sharded, single)  # all-gather + fixed view-order sum: bit-identical to the single-rank trajectory
+legacy = run(True, "all_reduce")
+err = ((legacy - run(False, "all_reduce")).abs().max() / single.abs().max()).item()  # fp32 summation order differs
 assert err < 1e-5, err
 lo, hi = SyncDDIMSampler(FakeModel(8), 50, shard_views=True).view_range(8)
 assert (lo, hi) == ((0, 4) if dist.get_rank() == 0 else (4, 8))

@@ -128,8 +128,10 @@ def test_step_and_stages_small(name, projection):
     if int(g["with_noise"]):
         torch.manual_seed(int(g["noise_seed"]))
         noise = torch.randn(x_T.shape)
-    out = O.denoise_apply(W, plan, vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch, batch_view_num=bvn, noise=noise)
+    out, eps = O.denoise_apply(W, plan, vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch, batch_view_num=bvn, noise=noise,
+                               return_eps=True)
     check(out, g, "x_prev")
+    check(eps, g, "eps")
 
 
 @pytest.mark.parametrize("name,projection", [("step_small_n8.npz", "perspective"), ("step_small_lat64_n1.npz", "perspective")])
@@ -151,9 +153,58 @@ def test_step_config_variants(name, projection):
     if int(g["with_noise"]):
         torch.manual_seed(int(g["noise_seed"]))
         noise = torch.randn(x_T.shape)
-    out = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
-                          batch_view_num=bvn, noise=noise)
+    out, eps = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
+                               batch_view_num=bvn, noise=noise, return_eps=True)
     check(out, g, "x_prev")
+    check(eps, g, "eps")
+
+
+def test_trajectory_small():
+    """a1: SyncDDIMSampler.sample (morphable_diffusion.py:742-776) -- the oracle's loop against the reference's own loop on
+    4- and 5-step schedules: time-step table, index order, RNG consumption (x_T, then one draw per step but the last),
+    every intermediate x and every step's eps."""
+    g = load("traj_small.npz")
+    N = int(g["N"])
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    W = gi.full_weights(ucfg, vcfg)
+    batch = synthetic.make_batch(N, "perspective", int(g["nverts_in"]), mesh_seed=1)
+    _, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    for steps in (4, 5):
+        assert np.array_equal(O.ddim_tables(steps, 1.0)["timesteps"].numpy(), g[f"timesteps{steps}"])
+        gen = torch.Generator().manual_seed(int(g["seed"]))
+        x, inter, eps = O.sample(W, build_unet_plan(ucfg), vcfg, x_in, clip, 2.0, batch, num_ddim=steps,
+                                 batch_view_num=int(g["bvn"]), log_every_t=1, generator=gen)
+        assert len(inter) == steps and len(eps) == steps
+        for i in range(steps):
+            check(eps[i], g, f"s{steps}_eps{i}", 5e-4)  # later steps see the accumulated fp32 differences
+            check(inter[i], g, f"s{steps}_x{i}", 5e-4)
+        check(x, g, f"s{steps}_final", 5e-4)
+
+
+def test_unet_small_trained_weights():
+    """Second weight set (trained-checkpoint-like statistics, weights.py style "trained")."""
+    cfg = gi.SMALL_UNET
+    g = load("unet_small_trained.npz")
+    W = gi.unet_weights(cfg, "trained")
+    x, t, ctx, sd = gi.unet_inputs(cfg, Bv=2, seed=13)
+    check(O.unet_forward(W, build_unet_plan(cfg), x, t, ctx, sd), g, "unet_out")
+
+
+def test_step_small_trained_weights():
+    g = load("step_small_trained.npz")
+    N, index, bvn = int(g["N"]), int(g["index"]), int(g["bvn"])
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    W = gi.full_weights(ucfg, vcfg, "trained")
+    batch = synthetic.make_batch(N, "perspective", int(g["nverts_in"]), mesh_seed=1)
+    x_T, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    tab = O.ddim_tables(50, 1.0)
+    ts = torch.full((1,), int(g["step"]), dtype=torch.long)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.randn(x_T.shape)
+    out, eps = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
+                               batch_view_num=bvn, noise=noise, return_eps=True)
+    check(out, g, "x_prev")
+    check(eps, g, "eps")
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "unet_full.npz")), reason="full-width golden not generated")
@@ -178,9 +229,10 @@ def test_step_full_width_n16():
     ts = torch.full((1,), int(g["step"]), dtype=torch.long)
     torch.manual_seed(int(g["noise_seed"]))
     noise = torch.randn(x_T.shape)
-    out = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
-                          batch_view_num=bvn, noise=noise)
+    out, eps = O.denoise_apply(W, build_unet_plan(ucfg), vcfg, tab, x_T, x_in, clip, ts, index, 2.0, batch,
+                               batch_view_num=bvn, noise=noise, return_eps=True)
     check(out, g, "x_prev")
+    check(eps, g, "eps")
 
 
 @pytest.mark.parametrize("name,ch", [("vae_small.npz", 32), ("vae_full.npz", 128)])

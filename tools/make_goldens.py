@@ -40,9 +40,9 @@ def cfg_kwargs(cfg: UNetConfig):
                 transformer_depth=1, context_dim=cfg.context_dim, use_checkpoint=False, legacy=False)
 
 
-def load_unet(ns, cfg):
+def load_unet(ns, cfg, style="init"):
     m = ns.attention.DepthWiseAttention(**cfg_kwargs(cfg)).eval()
-    W = gi.unet_weights(cfg)
+    W = gi.unet_weights(cfg, style)
     sd = {k[len("model.diffusion_model."):]: v for k, v in W.items()}
     ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert set(ref_keys) == set(sd), (set(ref_keys) ^ set(sd))
@@ -98,7 +98,19 @@ def gold_unet_full(ns):
     save("unet_full.npz", {"unet_out": gi.pack(out)})
 
 
-def build_full_model(ns, ucfg, vcfg, N):
+def gold_unet_trained(ns):
+    """UNet eps on the second weight set (trained-checkpoint-like statistics), reduced and full width."""
+    for name, cfg in (("unet_small_trained.npz", gi.SMALL_UNET), ("unet_full_trained.npz", gi.FULL_UNET)):
+        m = load_unet(ns, cfg, "trained")
+        x, t, ctx, sd = gi.unet_inputs(cfg, Bv=2, seed=13)
+        with torch.no_grad():
+            out = m(x, t, ctx, source_dict=sd)
+        print(name, "std", float(out.std()), "absmax", float(out.abs().max()))
+        assert torch.isfinite(out).all() and out.std() > 1e-3
+        save(name, {"unet_out": gi.pack(out)})
+
+
+def build_full_model(ns, ucfg, vcfg, N, style="init"):
     md = ns.md
     model = md.SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": cfg_kwargs(ucfg)},
@@ -109,7 +121,7 @@ def build_full_model(ns, ucfg, vcfg, N):
     if vcfg.input_image_size != 256:  # gotcha G4: the image size is not forwarded to SpatialVolumeNet
         model.spatial_volume.input_image_size = vcfg.input_image_size
         model.spatial_volume.frustum_volume_size = vcfg.input_image_size // 8
-    W = gi.full_weights(ucfg, vcfg)
+    W = gi.full_weights(ucfg, vcfg, style)
     ref_sd = model.state_dict()
     hot = {k: tuple(v.shape) for k, v in ref_sd.items()
            if k.startswith(("model.diffusion_model.", "spatial_volume.", "time_embed."))
@@ -122,10 +134,22 @@ def build_full_model(ns, ucfg, vcfg, N):
     return model, hot
 
 
+def record_eps(sampler, sink):
+    """Wraps the reference's denoise_apply_impl (morphable_diffusion.py:675-698) so that the noise prediction it receives
+    -- eps after classifier-free guidance, BEFORE the DDIM update dilutes it -- is stored next to x_prev."""
+    impl = sampler.denoise_apply_impl
+
+    def wrapped(x_target_noisy, index, noise_pred, is_step0=False):
+        sink.append(noise_pred.detach().clone())
+        return impl(x_target_noisy, index, noise_pred, is_step0)
+
+    sampler.denoise_apply_impl = wrapped
+
+
 def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, stages=False, image_size=256,
-              radii=(0.22, 0.28, 0.25)):
+              radii=(0.22, 0.28, 0.25), style="init", frustum_views=0):
     vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=image_size)
-    model, hot = build_full_model(ns, ucfg, vcfg, N)
+    model, hot = build_full_model(ns, ucfg, vcfg, N, style)
     batch = synthetic.make_batch(N, projection, nverts, mesh_seed=1, image_size=image_size, radii=radii)
     x_T, x_in, clip = synthetic.make_latents(N, image_size // 8, seed=6033)
     sampler = model.sampler
@@ -134,6 +158,8 @@ def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, sta
     packs = {}
     extra = {"index": index, "step": step, "N": N, "nverts_in": nverts, "bvn": bvn,
              "with_noise": int(with_noise), "noise_seed": 99, "image_size": image_size, "radii": np.array(radii)}
+    eps_sink = []
+    record_eps(sampler, eps_sink)
     with torch.no_grad():
         t0 = time.time()
         torch.manual_seed(99)
@@ -141,6 +167,17 @@ def gold_step(ns, name, ucfg, N, projection, index, with_noise, nverts, bvn, sta
                                     2.0, batch_view_num=bvn, is_step0=not with_noise, batch=batch)
         print(name, "denoise_apply", time.time() - t0, "s")
         packs["x_prev"] = gi.pack(out)
+        packs["eps"] = gi.pack(eps_sink[0])
+        if frustum_views and not stages:  # per-view frustum volumes through the real conditioner (full width)
+            v_embed = model.get_viewpoint_embedding(batch)
+            t_embed = model.embed_time(ts)
+            sv_ = model.spatial_volume.construct_spatial_volume(x_T, t_embed, v_embed, batch)
+            packs["spatial_volume"] = gi.pack(sv_)
+            idx = torch.tensor([[0, N - 1][:frustum_views]])
+            fd, _ = model.spatial_volume.construct_view_frustum_volume(sv_, t_embed, v_embed, idx, batch)
+            for k, v in fd.items():
+                packs[f"frustum_{k}"] = gi.pack(v)
+            extra["frustum_idx"] = idx[0].numpy()
         if stages:
             v_embed = model.get_viewpoint_embedding(batch)
             t_embed = model.embed_time(ts)
@@ -275,6 +312,40 @@ def gold_clip(ns=None):
         save(name, {"embed": gi.pack(out.unsqueeze(1)), "pixels": gi.pack(pix)}, {"B": B, "width": cfg.width})
 
 
+def gold_traj(ns):
+    """Multi-step trajectory (a1: SyncDDIMSampler.sample, morphable_diffusion.py:742-776): the reference's own loop on a
+    4- and a 5-step DDIM schedule at reduced width -- loop order, ``index``, time-step table, and the consumption of the
+    global RNG stream (x_T first, then one randn_like per step except the last).  Every step's x and eps are stored."""
+    N = 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    model, _ = build_full_model(ns, ucfg, vcfg, N)
+    batch = synthetic.make_batch(N, "perspective", 600, mesh_seed=1)
+    _, x_in, clip = synthetic.make_latents(N, 32, seed=6033)
+    packs, extra = {}, {"N": N, "nverts_in": 600, "seed": 321, "bvn": 2}
+    for steps in (4, 5):
+        sampler = ns.md.SyncDDIMSampler(model, steps, ddim_discretize="uniform", ddim_eta=1.0, latent_size=32)
+        eps_sink = []
+        record_eps(sampler, eps_sink)
+        torch.manual_seed(321)
+        x, inter = sampler.sample({"x": x_in, "elevation": batch["input_elevation"][:, 0]}, clip, unconditional_scale=2.0,
+                                  log_every_t=1, batch_view_num=2, batch=batch)
+        assert len(inter["x_inter"]) == steps and len(eps_sink) == steps
+        extra[f"timesteps{steps}"] = sampler.ddim_timesteps.astype(np.int64)
+        for i in range(steps):
+            packs[f"s{steps}_x{i}"] = gi.pack(inter["x_inter"][i].detach())
+            packs[f"s{steps}_eps{i}"] = gi.pack(eps_sink[i])
+        packs[f"s{steps}_final"] = gi.pack(x.detach())
+    save("traj_small.npz", packs, extra)
+
+
+def gold_trained(ns, full=True):
+    """Second weight set (weights.py style "trained"): UNet eps and one whole step, reduced and full width."""
+    gold_unet_trained(ns)
+    gold_step(ns, "step_small_trained.npz", gi.SMALL_UNET, 4, "perspective", 33, True, 600, 2, style="trained")
+    if full:
+        gold_step(ns, "step_full_trained.npz", gi.FULL_UNET, 16, "perspective", 20, True, 5023, 16, style="trained")
+
+
 def gold_variants(ns):
     """The other BASELINE.json configs as parity cases, at reduced UNet width:
     config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
@@ -292,6 +363,8 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
+    ap.add_argument("--only-traj", action="store_true", help="only the multi-step trajectory golden")
+    ap.add_argument("--only-trained", action="store_true", help="only the goldens on the trained-like weight set")
     ap.add_argument("--only-clip", action="store_true", help="only the CLIP image-embedding goldens (needs transformers, not the reference)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -306,13 +379,22 @@ def main():
     if args.only_vae:
         gold_vae(ns)
         return
+    if args.only_traj:
+        gold_traj(ns)
+        return
+    if args.only_trained:
+        gold_trained(ns, not args.skip_full)
+        return
     gold_basic(ns)
     gold_unet_small(ns)
     hot = gold_step(ns, "step_small_persp.npz", gi.SMALL_UNET, 4, "perspective", 25, True, 600, 2, stages=True)
     gold_step(ns, "step_small_ortho.npz", gi.SMALL_UNET, 4, "orthographic", 0, False, 600, 4, stages=True)
     if not args.skip_full:
         gold_unet_full(ns)
-        hot = gold_step(ns, "step_full.npz", gi.FULL_UNET, 16, "perspective", 49, True, 5023, 8)
+        hot = gold_step(ns, "step_full.npz", gi.FULL_UNET, 16, "perspective", 49, True, 5023, 8, frustum_views=2)
+    gold_traj(ns)
+    gold_variants(ns)
+    gold_trained(ns, not args.skip_full)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump({k: list(v) for k, v in sorted(hot.items())}, f)
     # DDIM tables from the reference sampler
