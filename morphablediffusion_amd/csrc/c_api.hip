@@ -142,6 +142,14 @@ int mvd_upload_weight(mvd_ctx* c, const char* name, const float* data, const int
   return 0;
 }
 
+int mvd_set_precision_level(mvd_ctx* c, int level) {
+  if (!c) return mvd_fail("null context");
+  if (c->finalized) return mvd_fail("mvd_set_precision_level: weights already finalized");
+  if (level < 0 || level > 6) return mvd_fail("mvd_set_precision_level: level must be 0..6");
+  c->precision_level = level;
+  return 0;
+}
+
 int mvd_finalize_weights(mvd_ctx* c) {
   if (!c) return mvd_fail("null context");
   if (c->finalized) return 0;

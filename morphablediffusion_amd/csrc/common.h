@@ -59,6 +59,9 @@ struct IGemm {
   const void* resid;    // same row mapping / ld as out, or null
   int resid_f32;
   int ldr;
+  int out_split;        // fp16 output only, 0 or the logical width C: column n is written three times, as
+                        // hi = fp16(v) at n and n + 2C and lo = fp16(v - hi) at n + C (ldc >= 3C): the [hi | lo | hi] operand
+                        // of an extended-precision consumer (see ConvW::xp)
   int geglu;            // pairs 32-column blocks (x | gate): out cols = N/2
   float alpha;          // scale on the accumulator before bias
   int act;              // ACT_SILU applied last (non-GEGLU path)
@@ -113,14 +116,15 @@ int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, i
                     float* partial, int* nslabs_out, hipStream_t s);
 int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
-                    half_t* out, int ldo, hipStream_t s);
+                    half_t* out, int ldo, hipStream_t s, int split = 0);
 int gn_max_slabs();
 // slab / tile partials [B][nslabs][G][2] -> per-sample scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma
 int launch_gn_finalize(const float* partial, int B, int nslabs, int rows_per_sample, int C, int G, const float* gamma,
                        const float* beta, float eps, float* scale, float* shift, int ld, hipStream_t s);
 bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo);
+// split != 0: out rows hold [hi | lo | hi] (3C halfs, ldo >= 3C), see IGemm::out_split
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
-                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s);
+                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split = 0);
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                      half_t* out, hipStream_t s);
 int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
@@ -136,23 +140,27 @@ int launch_clip_tokens(const float* pe, const float* cls, const float* pos, int 
 int launch_scale_copy(const float* src, size_t n, float k, float* dst, hipStream_t s);
 int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st);
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s);
+                      hipStream_t s, int split = 0);
 int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,
                         int act_in, float* out, int ldo, int accumulate, hipStream_t s);
 int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, int ldo, int cpad, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int ld, int B, int C, int HW, float* out, hipStream_t s);
+// xp != 0: Cin is the packed width 3 * Cl and each row holds [w_hi | w_hi | w_lo] (w_hi = fp16(w), w_lo = fp16(w - w_hi))
 int launch_pack_weight(const float* src, int N, int Cin, int taps, int transposed, int geglu, half_t* dst,
-                       hipStream_t s, int cin_src = -1);
+                       hipStream_t s, int cin_src = -1, int xp = 0);
+// fp32 rows -> fp16 [hi | lo | hi] rows of 3C halfs
+int launch_rows_f32_to_f16_split(const float* in, int lda, long rows, int C, half_t* out, hipStream_t s);
 int launch_permute_geglu_bias(const float* src, int N, float* dst, hipStream_t s);
 int launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
 int launch_rows_f32_to_f16(const float* in, int lda, long rows, int C, half_t* out, hipStream_t s);
 int launch_pack_upconv_weight(const float* src, int N, int Cin, half_t* dst, hipStream_t s);
 int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n, hipStream_t s);
 int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
-                   hipStream_t s);
-int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s);
-int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s);
+                   hipStream_t s, float* out32 = nullptr);
+int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s,
+                   float* out32 = nullptr);
+int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s, int split = 0);
 int launch_cfg_ddim(const float* eps_c, const float* eps_u, float scale, const float* x, const float* noise,
                     float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,
                     float* eps_out, float* x_prev, size_t n, hipStream_t s);

@@ -16,6 +16,15 @@ struct RawTensor {
 };
 
 struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
+  // Extended precision (xp): fp16 MFMA operands carry 11 significand bits, which puts ~4e-4 of relative error on every
+  // GEMM output.  For the few layers whose error reaches the UNet output almost undamped (tools/precision_probe4.py: the
+  // output conv, conv_in and the cheap layers of the last output block(s) carry half of the end-to-end error variance) both
+  // operands are split into fp16 hi + lo parts and three products are accumulated: a_hi w_hi + a_lo w_hi + a_hi w_lo.  This
+  // is done by CONCATENATION along K, so every kernel runs unchanged: Cin is the packed width 3 * cin_l, weights hold
+  // [w_hi | w_hi | w_lo], the producer of the activation writes [a_hi | a_lo | a_hi] (IGemm::out_split, the GroupNorm /
+  // depth-attention kernels' split mode, or launch_rows_f32_to_f16_split for fp32 sources).
+  int xp = 0;
+  int cin_l = 0;  // logical input width when xp (Cin / 3)
   half_t* w = nullptr;
   half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
   float* bias = nullptr;
@@ -37,17 +46,20 @@ struct ResW {
   ConvW c1, c2, skip;
   bool has_skip = false;
   int cin = 0, cout = 0, emb_off = 0;
+  std::string key;  // state_dict prefix (for the extended-precision re-pack)
 };
 struct STW {
   NormW norm, ln1, ln3;
   ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;  // qkv: to_q | to_k | to_v rows stacked
   int C = 0, heads = 8, a2_off = 0;
+  std::string key;
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;
   NormW gn_in, gn_ctx, gn_o1, gn_o2;
-  half_t* relu_beta = nullptr;  // [4*Cc] z row for an all-zero context (CFG uncond half)
+  half_t* relu_beta = nullptr;  // [4*Cc] z row for an all-zero context (CFG uncond half); [hi | lo | hi] when wov.xp
   int dim = 0, Cc = 0, I = 0;
+  std::string key;
 };
 // first-stage decoder (AutoencoderKL.decode): ResnetBlock / AttnBlock / Upsample of
 // ldm/modules/diffusionmodules/model.py
@@ -163,6 +175,7 @@ struct mvd_ctx {
   int device = 0;
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
+  int precision_level = 2;  // extended-precision policy (engine_weights.hip: apply_xp_policy), mvd_set_precision_level
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
   // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
@@ -290,6 +303,7 @@ struct GemmArgs {
   int act = 0;
   bool use_bias = true;
   int force_splitk = 0;
+  int out_split = 0;  // fp16 output as [hi | lo | hi] of this logical width (IGemm::out_split)
 };
 // plain GEMM / 1x1 conv over `rows` rows grouped in `B` samples (rows % B == 0)
 int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s);
@@ -302,8 +316,9 @@ int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int s
 // ConvTranspose3d(k3,s2,p1,op1): 8 output-parity classes
 int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s);
 // GroupNorm(+act) -> fp16
+// split: out rows are [hi | lo | hi] (3 * n.C halfs), the operand of an extended-precision consumer
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0);
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0, int split = 0);
 // restores the workspace bump pointer when the scope is left, on the error returns too (a failed call must not leak
 // workspace into the calls that follow it)
 struct WsScope {

@@ -45,6 +45,7 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.ldr = ga.ldr;
   g.geglu = ga.geglu;
   g.act = ga.act;
+  g.out_split = ga.out_split;
 }
 
 int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
@@ -356,20 +357,20 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 }
 
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld) {
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld, int split) {
   // algorithmic: x read once (fp32), fp16 result written once
   ProbeScope ps(c, s, "group_norm", 0.0, (double)B * rows_per_sample * n.C * 6.0);
   static const bool two_pass = getenv("MVD_GN_TWO_PASS") != nullptr;
   if (!two_pass && gn_group_eligible(ld, rows_per_sample, n.C, groups, preadd ? (preadd_ld ? preadd_ld : n.C) : 0, ldo))
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
-                           ldo, s);
+                           ldo, s, split);
   WsScope ws_scope(c);
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
   int nslabs = 0;
   RET_IF(launch_gn_stats(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, &nslabs, s));
   RET_IF(launch_gn_apply(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld, partial, nslabs, n.g, n.b, eps, act, out,
-                         ldo, s));
+                         ldo, s, split));
   return 0;
 }
 
@@ -399,16 +400,18 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
   const int rows = f.Bv * H * W;
-  half_t* a1 = ws_alloc<half_t>(c, (size_t)rows * r.cin);
+  // extended-precision layers (ConvW::xp) read [hi | lo | hi] operands: three times the logical width
+  const int w1 = r.c1.xp ? 3 : 1, w2 = r.c2.xp ? 3 : 1;
+  half_t* a1 = ws_alloc<half_t>(c, (size_t)rows * r.cin * w1);
   float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
-  half_t* a2 = ws_alloc<half_t>(c, (size_t)rows * r.cout);
+  half_t* a2 = ws_alloc<half_t>(c, (size_t)rows * r.cout * w2);
   WS_CHECK(a1 && h1 && a2);
-  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin, f.s));
+  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp));
   GemmArgs g1;
-  g1.a = a1; g1.lda = r.cin; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
+  g1.a = a1; g1.lda = r.cin * w1; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
   g1.rowbias = f.emb_all + r.emb_off; g1.rb_ld = c->emb_total;
   RET_IF(run_conv2d(c, g1, f.Bv, H, W, 1, 0, f.s));
-  RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout, f.s));
+  RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout * w2, f.s, 0, r.c2.xp));
   const float* resid = in.p;
   int ldr = in.ld;
   if (r.has_skip) {
@@ -416,12 +419,18 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
     WS_CHECK(sk);
     GemmArgs gs;
     gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
+    if (r.skip.xp) {  // fp32 source -> [hi | lo | hi] copy
+      half_t* as = ws_alloc<half_t>(c, (size_t)rows * 3 * r.cin);
+      WS_CHECK(as);
+      RET_IF(launch_rows_f32_to_f16_split(in.p, in.ld, rows, r.cin, as, f.s));
+      gs.a = as; gs.a_f32 = 0; gs.lda = 3 * r.cin;
+    }
     RET_IF(run_linear(c, gs, f.Bv, rows, f.s));
     resid = sk;
     ldr = r.cout;
   }
   GemmArgs g2;
-  g2.a = a2; g2.lda = r.cout; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
+  g2.a = a2; g2.lda = r.cout * w2; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
   RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));
   return 0;
 }
@@ -431,18 +440,19 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c);
   const int C = t.C, T = H * W, rows = f.Bv * T;
-  half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C);
+  const int wi = t.proj_in.xp ? 3 : 1, wo = t.proj_out.xp ? 3 : 1;  // extended precision: [hi | lo | hi] operands
+  half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C * wi);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);
   half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t2 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
-  half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C);  // x + ff(x): only ever the proj_out operand -> fp16
+  half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
   WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3);
-  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C, f.s));
+  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
-  g.a = n0; g.lda = C; g.w = &t.proj_in; g.out = t0; g.ldc = C;
+  g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
     ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
@@ -470,10 +480,11 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   g.a = l1; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
-  g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C; g.resid = t2; g.ldr = C;
+  g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C * wo; g.resid = t2; g.ldr = C;
+  g.out_split = t.proj_out.xp ? C : 0;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
-  g.a = t3; g.lda = C; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
+  g.a = t3; g.lda = C * wo; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   return 0;
 }
@@ -510,22 +521,25 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
   WsScope ws_scope(c);
   const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
   const int crow = f.n_ctx * HW;
+  // extended precision (ConvW::xp): operands are [hi | lo | hi]
+  const int xq = d.wqk.xp, xo = d.wov.xp, x1 = d.conv1.xp, x2 = d.conv2.xp;
+  const int wpn = (xq || x1 || x2) ? 3 : 1, wz = xo ? 3 : 1;
   float* p = ws_alloc<float>(c, (size_t)rows * I);
-  half_t* pn = ws_alloc<half_t>(c, (size_t)rows * I);
-  half_t* z = ws_alloc<half_t>(c, (size_t)rows * 4 * Cc);
+  half_t* pn = ws_alloc<half_t>(c, (size_t)rows * I * wpn);
+  half_t* z = ws_alloc<half_t>(c, (size_t)rows * 4 * Cc * wz);
   float* o = ws_alloc<float>(c, (size_t)rows * I);
   float* o2 = ws_alloc<float>(c, (size_t)rows * I);
   WS_CHECK(p && pn && z && o && o2);
   GemmArgs g;
   g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &d.proj_in; g.out = p; g.ldc = I;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, I, f.s));
+  RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq));
   if (f.n_ctx > 0) {
     float* qk = ws_alloc<float>(c, (size_t)crow * 4 * Cc);
     half_t* cn = cond_idx >= 0 && f.cn_pre[cond_idx] ? nullptr : ws_alloc<half_t>(c, (size_t)crow * D * Cc);
     WS_CHECK(qk && (cn || (cond_idx >= 0 && f.cn_pre[cond_idx])));
     g = GemmArgs();
-    g.a = pn; g.lda = I; g.w = &d.wqk; g.out = qk; g.ldc = 4 * Cc; g.use_bias = false;
+    g.a = pn; g.lda = xq ? 3 * I : I; g.w = &d.wqk; g.out = qk; g.ldc = 4 * Cc; g.use_bias = false;
     RET_IF(run_linear(c, g, f.n_ctx, crow, f.s));
     const half_t* cnp = cond_idx >= 0 ? f.cn_pre[cond_idx] : nullptr;
     if (cnp) {  // prepared on the side stream
@@ -546,21 +560,21 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
     {
       ProbeScope ps(c, f.s, "depth_attn_kernel", 4.0 * crow * (double)D * 4 * Cc,
                     (double)crow * D * Cc * 2.0 + (double)crow * 4 * Cc * 6.0);
-      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s));
+      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo));
     }
   }
   if (f.Bv > f.n_ctx)  // all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every head
-    RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc, 4 * Cc, rows - crow, d.relu_beta, 4 * Cc, f.s));
+    RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc * wz, 4 * Cc * wz, rows - crow, d.relu_beta, 4 * Cc * wz, f.s));
   g = GemmArgs();
-  g.a = z; g.lda = 4 * Cc; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
+  g.a = z; g.lda = 4 * Cc * wz; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, I, f.s));
+  RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1));
   g = GemmArgs();
-  g.a = pn; g.lda = I; g.w = &d.conv1; g.out = o2; g.ldc = I; g.use_bias = false;
+  g.a = pn; g.lda = x1 ? 3 * I : I; g.w = &d.conv1; g.out = o2; g.ldc = I; g.use_bias = false;
   RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
-  RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, I, f.s));
+  RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2));
   g = GemmArgs();
-  g.a = pn; g.lda = I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
+  g.a = pn; g.lda = x2 ? 3 * I : I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
   return 0;
 }
@@ -576,6 +590,14 @@ int do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W) {
       GemmArgs g;
       g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &c->convs[op.idx]; g.out = out.p; g.ldc = out.ld;
       const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
+      WsScope ws_scope(c);
+      if (c->convs[op.idx].xp) {  // extended precision (conv_in): fp32 source -> [hi | lo | hi] copy
+        const int Cl = c->convs[op.idx].cin_l;
+        half_t* as = ws_alloc<half_t>(c, (size_t)f.Bv * H * W * 3 * Cl);
+        WS_CHECK(as);
+        RET_IF(launch_rows_f32_to_f16_split(in.p, in.ld, (long)f.Bv * H * W, Cl, as, f.s));
+        g.a = as; g.a_f32 = 0; g.lda = 3 * Cl;
+      }
       // weight-streaming regime (few pixels): the 9-tap form moves 9 slabs instead of 16
       if (ups && c->convs[op.idx].w_up && f.Bv * H * W >= 2048) RET_IF(run_upconv2d(c, g, f.Bv, H, W, f.s));
       else RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
@@ -819,11 +841,12 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   // out: GroupNorm32 + SiLU + zero-init conv (openaimodel.py:717-721)
   {
     const int rows = Bv * H * W;
-    half_t* a = ws_alloc<half_t>(c, (size_t)rows * mc);
+    const int wx = c->out_conv.xp ? 3 : 1;  // extended precision: [hi | lo | hi] operand
+    half_t* a = ws_alloc<half_t>(c, (size_t)rows * mc * wx);
     WS_CHECK(a);
-    RET_IF(run_group_norm(c, final_h, mc, Bv, H * W, c->out_norm, 32, 1e-5f, ACT_SILU, nullptr, a, mc, s));
+    RET_IF(run_group_norm(c, final_h, mc, Bv, H * W, c->out_norm, 32, 1e-5f, ACT_SILU, nullptr, a, mc * wx, s, 0, c->out_conv.xp));
     GemmArgs g;
-    g.a = a; g.lda = mc; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
+    g.a = a; g.lda = mc * wx; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
     RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));
   }
   return 0;

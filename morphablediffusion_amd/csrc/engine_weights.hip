@@ -43,7 +43,7 @@ int load_norm(mvd_ctx* c, const std::string& p, NormW* n) {
 
 // conv / linear weight -> fp16 [taps][N][Cin(+pad)]
 int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool transposed, bool geglu, ConvW* o,
-              int cin_pad = 0) {
+              int cin_pad = 0, bool xp = false) {
   RawTensor* r;
   RET_IF(get_raw(c, wkey, &r));
   if (r->shape.size() < 2) return mvd_fail("pack_conv: weight rank < 2");
@@ -51,12 +51,15 @@ int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool
   int taps = 1;
   for (size_t i = 2; i < r->shape.size(); ++i) taps *= (int)r->shape[i];
   const int N = transposed ? d1 : d0, cin_src = transposed ? d0 : d1;
-  const int Cin = cin_pad > cin_src ? cin_pad : cin_src;
+  const int Cl = cin_pad > cin_src ? cin_pad : cin_src;
+  const int Cin = xp ? 3 * Cl : Cl;
   o->N = N;
   o->Cin = Cin;
+  o->xp = xp ? 1 : 0;
+  o->cin_l = Cl;
   o->taps = taps;
   RET_IF(dmalloc(c, (void**)&o->w, (size_t)taps * N * Cin * sizeof(half_t)));
-  RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, 0, cin_src));
+  RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, 0, cin_src, xp ? 1 : 0));
   if (!bkey.empty()) {
     if (geglu) {
       RawTensor* b;
@@ -82,6 +85,7 @@ int pack_lin(mvd_ctx* c, const std::string& wkey, const std::string& bkey, LinW*
 }
 
 int build_res(mvd_ctx* c, const std::string& p, int cin, int cout, ResW* r) {
+  r->key = p;
   r->cin = cin;
   r->cout = cout;
   RET_IF(load_norm(c, p + ".in_layers.0", &r->n1));
@@ -95,6 +99,7 @@ int build_res(mvd_ctx* c, const std::string& p, int cin, int cout, ResW* r) {
 }
 
 int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
+  s->key = p;
   s->C = C;
   s->heads = c->u.num_heads;
   const std::string t = p + ".transformer_blocks.0";
@@ -123,6 +128,7 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
 
 int build_cond(mvd_ctx* c, const std::string& p, int dim, int Cc, CondW* d) {
   const int heads = 4, hd = Cc / 2, I = 2 * Cc;
+  d->key = p;
   d->dim = dim;
   d->Cc = Cc;
   d->I = I;
@@ -440,6 +446,95 @@ int build_vae(mvd_ctx* c) {
   return 0;
 }
 
+// Extended-precision policy (ConvW::xp), level = mvd_set_precision_level (MVD_XP in the environment overrides it):
+//   0 none;  1 the output conv and conv_in;
+//   2 (default) + the cheap layers of the LAST output block: ResBlock skip conv, SpatialTransformer proj_in / proj_out, its
+//     DepthTransformer's folded attention projections and two 3x3 convs;
+//   3 + that block's ResBlock 3x3 convs;   4 + the level-2 set of the block before it;
+//   5 every such layer (3x3 convs included) of ALL full-resolution output blocks;   6 + of the full-resolution input blocks.
+// Share of the end-to-end error variance removed on the full-width UNet (tools/precision_probe4.py; measured on the GPU in
+// DESIGN.md): 25 % / 52 % / 60 % / 70 % for levels 1-4, at +0.6 % / +2.2 % / +3.6 % / +5.1 % step time.
+// The re-pack needs the fp32 source tensors, so it runs inside finalize before they are released.
+int repack_xp(mvd_ctx* c, const std::string& wkey, ConvW* o, int cin_pad = 0) {
+  if (o->xp) return 0;
+  ConvW n;
+  RET_IF(pack_conv(c, wkey, "", false, false, &n, cin_pad, true));
+  n.bias = o->bias;
+  n.w_up = nullptr;
+  *o = n;
+  return 0;
+}
+
+int xp_cond(mvd_ctx* c, CondW& d) {
+  if (d.wqk.xp) return 0;
+  const int heads = 4, hd = d.Cc / 2;
+  RET_IF(repack_xp(c, d.key + ".proj_out.2.weight", &d.conv1));
+  RET_IF(repack_xp(c, d.key + ".proj_out.5.weight", &d.conv2));
+  RawTensor *wq, *wk, *wv, *wo;
+  RET_IF(get_raw(c, d.key + ".depth_attn.to_q.weight", &wq));
+  RET_IF(get_raw(c, d.key + ".depth_attn.to_k.weight", &wk));
+  RET_IF(get_raw(c, d.key + ".depth_attn.to_v.weight", &wv));
+  RET_IF(get_raw(c, d.key + ".depth_attn.to_out.weight", &wo));
+  const size_t nf = (size_t)heads * d.Cc * d.I;
+  float* tmp = nullptr;
+  HIP_CHECK_RET(hipMalloc((void**)&tmp, nf * sizeof(float)));
+  auto fold = [&](ConvW& w, int N, int Cl, bool qk) -> int {
+    if (qk) RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, d.Cc, d.I, 1.0f / sqrtf((float)hd), nullptr, 0, tmp));
+    else RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, d.Cc, d.I, nullptr, 0, tmp));
+    w.N = N;
+    w.cin_l = Cl;
+    w.Cin = 3 * Cl;
+    w.xp = 1;
+    w.taps = 1;
+    RET_IF(dmalloc(c, (void**)&w.w, (size_t)N * 3 * Cl * sizeof(half_t)));
+    return launch_pack_weight(tmp, N, 3 * Cl, 1, 0, 0, w.w, 0, Cl, 1);
+  };
+  int r = fold(d.wqk, heads * d.Cc, d.I, true);
+  if (!r) r = fold(d.wov, d.I, heads * d.Cc, false);
+  hipDeviceSynchronize();
+  hipFree(tmp);
+  RET_IF(r);
+  RET_IF(dmalloc(c, (void**)&d.relu_beta, (size_t)3 * heads * d.Cc * sizeof(half_t)));
+  return launch_relu_beta_tile(d.gn_ctx.b, d.Cc, heads, d.relu_beta, 0, 1);
+}
+
+int xp_ops(mvd_ctx* c, const std::vector<UOp>& ops, bool convs3) {
+  for (const UOp& op : ops) {
+    if (op.kind == OP_RES) {
+      ResW& r = c->res[op.idx];
+      if (r.has_skip) RET_IF(repack_xp(c, r.key + ".skip_connection.weight", &r.skip));
+      if (convs3) {
+        RET_IF(repack_xp(c, r.key + ".in_layers.2.weight", &r.c1));
+        RET_IF(repack_xp(c, r.key + ".out_layers.3.weight", &r.c2));
+      }
+    } else if (op.kind == OP_ST) {
+      STW& t = c->st[op.idx];
+      RET_IF(repack_xp(c, t.key + ".proj_in.weight", &t.proj_in));
+      RET_IF(repack_xp(c, t.key + ".proj_out.weight", &t.proj_out));
+    }
+  }
+  return 0;
+}
+
+int apply_xp_policy(mvd_ctx* c) {
+  const int lvl = getenv("MVD_XP") ? atoi(getenv("MVD_XP")) : c->precision_level;
+  if (lvl <= 0 || !c->has_unet) return 0;
+  const std::string U = "model.diffusion_model.";
+  RET_IF(repack_xp(c, U + "out.2.weight", &c->out_conv));
+  RET_IF(repack_xp(c, U + "input_blocks.0.0.weight", &c->convs[c->in_blocks[0][0].idx], 8));
+  if (lvl < 2) return 0;
+  const int nb = (int)c->out_blocks.size();
+  const int nblk = lvl >= 5 ? 3 : (lvl >= 4 ? 2 : 1);
+  for (int k = 0; k < nblk && k < nb; ++k) {
+    const int bi = nb - 1 - k;
+    RET_IF(xp_ops(c, c->out_blocks[bi], lvl >= 5 || (lvl >= 3 && k == 0)));
+    if (bi >= 3 && 1 + (bi - 3) < (int)c->conds.size()) RET_IF(xp_cond(c, c->conds[1 + (bi - 3)]));  // attention.py:100
+  }
+  if (lvl >= 6)
+    for (int j = 1; j <= 2 && j < (int)c->in_blocks.size(); ++j) RET_IF(xp_ops(c, c->in_blocks[j], true));
+  return 0;
+}
+
 int engine_finalize(mvd_ctx* c) {
   const std::string U = "model.diffusion_model.";
   const mvd_unet_config& u = c->u;
@@ -608,6 +703,7 @@ int engine_finalize(mvd_ctx* c) {
   };
   if (has_unet) RET_IF(build_unet());
   c->has_unet = has_unet;
+  RET_IF(apply_xp_policy(c));
   // ---------------- Lightning-module step embedding (morphable_diffusion.py:452-458) ----------------
   if (has_step) {
     RET_IF(pack_lin(c, "time_embed.0.weight", "time_embed.0.bias", &c->step_te0));

@@ -38,7 +38,29 @@ __device__ __forceinline__ void igemm_epilogue_store(const IGemm& g, int m, long
     if (g.act == ACT_SILU) v = v / (1.0f + __expf(-v));
   }
   if (g.out_f32) ((float*)g.out)[orow * g.ldc + ncol] = v;
-  else ((half_t*)g.out)[orow * g.ldc + ncol] = (half_t)v;
+  else {
+    const half_t hi = (half_t)v;
+    ((half_t*)g.out)[orow * g.ldc + ncol] = hi;
+    if (g.out_split) {
+      ((half_t*)g.out)[orow * g.ldc + g.out_split + ncol] = (half_t)(v - (float)hi);
+      ((half_t*)g.out)[orow * g.ldc + 2 * g.out_split + ncol] = hi;
+    }
+  }
+}
+
+// fp16 store of 4 consecutive columns; with out_split also the rounding residual and a second copy (IGemm::out_split)
+__device__ __forceinline__ void store_h4_split(const IGemm& g, long o, int n, float4 v) {
+  h4 hv;
+  hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+  half_t* p = (half_t*)g.out + o * g.ldc + n;
+  *(h4*)p = hv;
+  if (g.out_split) {
+    h4 lo;
+    lo[0] = (half_t)(v.x - (float)hv[0]); lo[1] = (half_t)(v.y - (float)hv[1]);
+    lo[2] = (half_t)(v.z - (float)hv[2]); lo[3] = (half_t)(v.w - (float)hv[3]);
+    *(h4*)(p + g.out_split) = lo;
+    *(h4*)(p + 2 * g.out_split) = hv;
+  }
 }
 
 
@@ -86,9 +108,7 @@ __device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int
     if (g.out_f32) {
       *(float4*)((float*)g.out + o * g.ldc + n) = v;
     } else {
-      h4 hv;
-      hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
-      *(h4*)((half_t*)g.out + o * g.ldc + n) = hv;
+      store_h4_split(g, o, n, v);
     }
 }
 
@@ -173,9 +193,7 @@ __device__ __forceinline__ void epilogue_frag_store_pre(const IGemm& g, const f3
     if (g.out_f32) {
       *(float4*)((float*)g.out + orow4[i] * g.ldc + n) = v;
     } else {
-      h4 hv;
-      hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
-      *(h4*)((half_t*)g.out + orow4[i] * g.ldc + n) = hv;
+      store_h4_split(g, orow4[i], n, v);
     }
   }
 }

@@ -14,7 +14,7 @@
 namespace {
 
 __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict__ qk, const half_t* __restrict__ ctxn,
-                                                         half_t* __restrict__ z, int npix, int HW, int D, int Cc) {
+                                                         half_t* __restrict__ z, int npix, int HW, int D, int Cc, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,11 +79,18 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
         a2 += a.z * x;
         a3 += a.w * x;
       }
-      half_t* zr = z + (long)pix * H * Cc + c;
-      zr[0] = (half_t)a0;
-      zr[Cc] = (half_t)a1;
-      zr[2 * Cc] = (half_t)a2;
-      zr[3 * Cc] = (half_t)a3;
+      const int W4 = H * Cc;
+      half_t* zr = z + (long)pix * (split ? 3 * W4 : W4) + c;
+      const float av[4] = {a0, a1, a2, a3};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const half_t hi = (half_t)av[h];
+        zr[h * Cc] = hi;
+        if (split) {  // [hi | lo | hi] rows for the extended-precision output projection
+          zr[W4 + h * Cc] = (half_t)(av[h] - (float)hi);
+          zr[2 * W4 + h * Cc] = hi;
+        }
+      }
     }
   }
 }
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
 }  // namespace
 
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s) {
+                      hipStream_t s, int split) {
   if (heads != 4) return mvd_fail("depth_attn: the reference always uses 4 heads (attention.py:97-115)");
   if (Cc % 8 || D > 64) return mvd_fail("depth_attn: Cc must be a multiple of 8 and D <= 64");
   const int npix = n_cond * HW;
@@ -106,7 +113,7 @@ int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)depth_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(depth_attn_kernel, dim3(cdiv(npix, 4)), dim3(256), lds, s, qk, ctxn, z, npix, HW, D, Cc);
+  hipLaunchKernelGGL(depth_attn_kernel, dim3(cdiv(npix, 4)), dim3(256), lds, s, qk, ctxn, z, npix, HW, D, Cc, split);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

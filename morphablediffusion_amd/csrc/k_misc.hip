@@ -123,10 +123,11 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld, int B,
 // fragment 0 with fragment 1 of a wave.
 // cin_src < Cin zero-pads the channel axis (e.g. the 4-channel latent conv padded to 8).
 __global__ void pack_weight_kernel(const float* __restrict__ src, int N, int Cin, int taps, int transposed, int geglu,
-                                   int cin_src, half_t* __restrict__ dst) {
+                                   int cin_src, half_t* __restrict__ dst, int xp) {
   const long total = (long)taps * N * Cin;
+  const int Cl = xp ? Cin / 3 : Cin;  // extended precision: [w_hi | w_hi | w_lo] against activations [a_hi | a_lo | a_hi]
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % Cin);
+    const int cp = (int)(idx % Cin), seg = cp / Cl, c = cp - seg * Cl;
     const long tn = idx / Cin;
     const int nd = (int)(tn % N), t = (int)(tn / N);
     int n = nd;
@@ -139,7 +140,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int N, int Cin
       continue;
     }
     const long s = transposed ? ((long)c * N + n) * taps + t : ((long)n * cin_src + c) * taps + t;
-    dst[idx] = (half_t)src[s];
+    const float w = src[s];
+    const half_t hi = (half_t)w;
+    dst[idx] = seg < 2 ? hi : (half_t)(w - (float)hi);
   }
 }
 
@@ -156,6 +159,24 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restri
 }
 
 // channels-last rows with stride lda -> dense fp16 rows (C % 4 == 0): operand copy for the LDS-DMA kernels
+__global__ void rows_f32_to_f16_split_kernel(const float* __restrict__ in, int lda, long rows, int C, half_t* __restrict__ out) {
+  const int q = C >> 2;
+  const long total = rows * q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const float4 v = *(const float4*)(in + r * lda + c);
+    h4 hi, lo;
+    hi[0] = (half_t)v.x; hi[1] = (half_t)v.y; hi[2] = (half_t)v.z; hi[3] = (half_t)v.w;
+    lo[0] = (half_t)(v.x - (float)hi[0]); lo[1] = (half_t)(v.y - (float)hi[1]);
+    lo[2] = (half_t)(v.z - (float)hi[2]); lo[3] = (half_t)(v.w - (float)hi[3]);
+    half_t* o = out + r * 3 * C + c;
+    *(h4*)o = hi;
+    *(h4*)(o + C) = lo;
+    *(h4*)(o + 2 * C) = hi;
+  }
+}
+
 __global__ void rows_f32_to_f16_kernel(const float* __restrict__ in, int lda, long rows, int C, half_t* __restrict__ out) {
   const int q = C >> 2;
   const long total = rows * q;
@@ -201,7 +222,7 @@ __global__ void fill_rows_f16_kernel(half_t* __restrict__ out, int ld, int rows,
 
 // W_qk[hn*Cc + j][i] = scale * sum_c Wk[hn*hd + c][j] * Wq[hn*hd + c][i]
 __global__ void fold_qk_kernel(const float* __restrict__ wq, const float* __restrict__ wk, int heads, int hd, int Cc,
-                               int I, float scale, half_t* __restrict__ out) {
+                               int I, float scale, half_t* __restrict__ out, float* __restrict__ out32) {
   const long total = (long)heads * Cc * I;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int i = (int)(idx % I);
@@ -209,13 +230,14 @@ __global__ void fold_qk_kernel(const float* __restrict__ wq, const float* __rest
     const int hn = row / Cc, j = row - hn * Cc;
     double acc = 0.0;
     for (int c = 0; c < hd; ++c) acc += (double)wk[(long)(hn * hd + c) * Cc + j] * (double)wq[(long)(hn * hd + c) * I + i];
-    out[idx] = (half_t)(float)(acc * scale);
+    if (out32) out32[idx] = (float)(acc * scale);
+    else out[idx] = (half_t)(float)(acc * scale);
   }
 }
 
 // W_ov[i][hn*Cc + j] = sum_c Wo[i][hn*hd + c] * Wv[hn*hd + c][j]
 __global__ void fold_ov_kernel(const float* __restrict__ wo, const float* __restrict__ wv, int heads, int hd, int Cc,
-                               int I, half_t* __restrict__ out) {
+                               int I, half_t* __restrict__ out, float* __restrict__ out32) {
   const long total = (long)I * heads * Cc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int col = (int)(idx % (heads * Cc));
@@ -223,14 +245,22 @@ __global__ void fold_ov_kernel(const float* __restrict__ wo, const float* __rest
     const int hn = col / Cc, j = col - hn * Cc;
     double acc = 0.0;
     for (int c = 0; c < hd; ++c) acc += (double)wo[(long)i * I + hn * hd + c] * (double)wv[(long)(hn * hd + c) * Cc + j];
-    out[idx] = (half_t)(float)acc;
+    if (out32) out32[idx] = (float)acc;
+    else out[idx] = (half_t)(float)acc;
   }
 }
 
-__global__ void relu_beta_tile_kernel(const float* __restrict__ beta, int Cc, int heads, half_t* __restrict__ out) {
+__global__ void relu_beta_tile_kernel(const float* __restrict__ beta, int Cc, int heads, half_t* __restrict__ out, int split) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= heads * Cc) return;
-  out[idx] = (half_t)fmaxf(beta[idx % Cc], 0.f);
+  const int W4 = heads * Cc;
+  if (idx >= W4) return;
+  const float v = fmaxf(beta[idx % Cc], 0.f);
+  const half_t hi = (half_t)v;
+  out[idx] = hi;
+  if (split) {
+    out[W4 + idx] = (half_t)(v - (float)hi);
+    out[2 * W4 + idx] = hi;
+  }
 }
 
 // UNetWrapper.predict_with_unconditional_scale (morphable_diffusion.py:148) + denoise_apply_impl (:692-697)
@@ -293,10 +323,11 @@ int launch_nhwc_to_nchw(const float* in, int ld, int B, int C, int HW, float* ou
 }
 
 int launch_pack_weight(const float* src, int N, int Cin, int taps, int transposed, int geglu, half_t* dst,
-                       hipStream_t s, int cin_src) {
-  if (cin_src <= 0) cin_src = Cin;
+                       hipStream_t s, int cin_src, int xp) {
+  if (xp && Cin % 3) return mvd_fail("pack_weight: the extended-precision layout needs Cin = 3 * Cl");
+  if (cin_src <= 0) cin_src = xp ? Cin / 3 : Cin;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)N * Cin * taps)), dim3(256), 0, s, src, N, Cin, taps,
-                     transposed, geglu, cin_src, dst);
+                     transposed, geglu, cin_src, dst, xp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -320,6 +351,13 @@ int launch_rows_f32_to_f16(const float* in, int lda, long rows, int C, half_t* o
   return 0;
 }
 
+int launch_rows_f32_to_f16_split(const float* in, int lda, long rows, int C, half_t* out, hipStream_t s) {
+  if ((C & 3) || (lda & 3)) return mvd_fail("rows_f32_to_f16_split: C and lda must be multiples of 4");
+  hipLaunchKernelGGL(rows_f32_to_f16_split_kernel, dim3(grid_for((size_t)rows * C / 4)), dim3(256), 0, s, in, lda, rows, C, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 int launch_pack_upconv_weight(const float* src, int N, int Cin, half_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(pack_upconv_weight_kernel, dim3(grid_for((size_t)16 * N * Cin)), dim3(256), 0, s, src, N, Cin, dst);
   HIP_CHECK_RET(hipGetLastError());
@@ -333,22 +371,23 @@ int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n
 }
 
 int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
-                   hipStream_t s) {
+                   hipStream_t s, float* out32) {
   hipLaunchKernelGGL(fold_qk_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wq, wk, heads, hd, Cc, I,
-                     scale, out);
+                     scale, out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s) {
+int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s,
+                   float* out32) {
   hipLaunchKernelGGL(fold_ov_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wo, wv, heads, hd, Cc, I,
-                     out);
+                     out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(relu_beta_tile_kernel, dim3(cdiv(heads * Cc, 256)), dim3(256), 0, s, beta, Cc, heads, out);
+int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s, int split) {
+  hipLaunchKernelGGL(relu_beta_tile_kernel, dim3(cdiv(heads * Cc, 256)), dim3(256), 0, s, beta, Cc, heads, out, split);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int G, const float* __restrict__ preadd, int pld,
                                                        const float* __restrict__ partial, int nslabs,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int act, half_t* __restrict__ out, int ldo) {
+                                                       float eps, int act, half_t* __restrict__ out, int ldo, int split) {
   __shared__ float s_mean[32], s_rstd[32];
   __shared__ float s_scale[GN_MAXC], s_shift[GN_MAXC];
   __shared__ double s_pa[256], s_pq[256];
@@ -204,12 +204,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       for (int u = 0; u < GN_UNROLL; ++u) {
         const int ru = r + u * m.row_par;
         if (ru >= r_end) break;
+        const float y0 = act_apply(v[u].x * sc.x + sh.x, act), y1 = act_apply(v[u].y * sc.y + sh.y, act);
+        const float y2 = act_apply(v[u].z * sc.z + sh.z, act), y3 = act_apply(v[u].w * sc.w + sh.w, act);
         h4 o;
-        o[0] = (half_t)act_apply(v[u].x * sc.x + sh.x, act);
-        o[1] = (half_t)act_apply(v[u].y * sc.y + sh.y, act);
-        o[2] = (half_t)act_apply(v[u].z * sc.z + sh.z, act);
-        o[3] = (half_t)act_apply(v[u].w * sc.w + sh.w, act);
-        *(h4*)(ob + (long)ru * ldo + q * 4) = o;
+        o[0] = (half_t)y0; o[1] = (half_t)y1; o[2] = (half_t)y2; o[3] = (half_t)y3;
+        half_t* op = ob + (long)ru * ldo + q * 4;
+        *(h4*)op = o;
+        if (split) {  // [hi | lo | hi]: the operand of an extended-precision consumer
+          h4 lo;
+          lo[0] = (half_t)(y0 - (float)o[0]); lo[1] = (half_t)(y1 - (float)o[1]);
+          lo[2] = (half_t)(y2 - (float)o[2]); lo[3] = (half_t)(y3 - (float)o[3]);
+          *(h4*)(op + C) = lo;
+          *(h4*)(op + 2 * C) = o;
+        }
       }
     }
   }
@@ -237,7 +244,7 @@ template <int NT, int MAXE>
 __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
                                                       const float* __restrict__ preadd, int pld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, int act, half_t* __restrict__ out, int ldo) {
+                                                      float eps, int act, half_t* __restrict__ out, int ldo, int split) {
   __shared__ float s_red[NT / 64];
   const int t = threadIdx.x;
   int wg = blockIdx.x;
@@ -287,10 +294,20 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
     const int e = t + i * NT;
     if (e < n2) {
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
+      const float y0 = act_apply((v[i].x - mean) * rstd * gm[2 * j] + bt[2 * j], act);
+      const float y1 = act_apply((v[i].y - mean) * rstd * gm[2 * j + 1] + bt[2 * j + 1], act);
       h2 o;
-      o[0] = (half_t)act_apply((v[i].x - mean) * rstd * gm[2 * j] + bt[2 * j], act);
-      o[1] = (half_t)act_apply((v[i].y - mean) * rstd * gm[2 * j + 1] + bt[2 * j + 1], act);
-      *(h2*)(ob + (long)row * ldo + 2 * j) = o;
+      o[0] = (half_t)y0;
+      o[1] = (half_t)y1;
+      half_t* op = ob + (long)row * ldo + 2 * j;
+      *(h2*)op = o;
+      if (split) {  // [hi | lo | hi]: the operand of an extended-precision consumer
+        h2 lo;
+        lo[0] = (half_t)(y0 - (float)o[0]);
+        lo[1] = (half_t)(y1 - (float)o[1]);
+        *(h2*)(op + C) = lo;
+        *(h2*)(op + 2 * C) = o;
+      }
     }
   }
 }
@@ -399,14 +416,15 @@ int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, i
 
 int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
-                    half_t* out, int ldo, hipStream_t s) {
+                    half_t* out, int ldo, hipStream_t s, int split) {
   if (C > GN_MAXC || C % 4 || ld % 4 || ldo % 4) return mvd_fail("gn_apply: channel counts must be multiples of 4");
+  if (split && ldo < 3 * C) return mvd_fail("gn_apply: a split output needs ldo >= 3C");
   int blocks = rows_per_sample / 8;
   if (blocks < 1) blocks = 1;
   const int cap = B >= 16 ? 64 : (B >= 4 ? 128 : 512);
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, ld, rows_per_sample, C, G, preadd, pld ? pld : C,
-                     partial, nslabs, gamma, beta, eps, act, out, ldo);
+                     partial, nslabs, gamma, beta, eps, act, out, ldo, split);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -419,11 +437,12 @@ bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo) {
 }
 
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
-                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s) {
+                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split) {
   const int n2 = rows * (C / G) / 2;
+  if (split && ldo < 3 * C) return mvd_fail("gn_group: a split output needs ldo >= 3C");
   const dim3 grid(B * G);
 #define MVD_GN(NT, ME) \
-  hipLaunchKernelGGL((gn_group_kernel<NT, ME>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, out, ldo)
+  hipLaunchKernelGGL((gn_group_kernel<NT, ME>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, out, ldo, split)
   // the smallest register tile that holds the group (unused slots still cost predicated loop iterations), 512-thread
   // workgroups up to 8192 pairs: swept on the UNet's shapes (tools/gn_bench.py), e.g. C=320 @32x32: 35 -> 27 us
   if (n2 <= 256 * 4) MVD_GN(256, 4);

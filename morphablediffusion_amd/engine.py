@@ -23,7 +23,11 @@ MAX_SAMPLE_SLOTS = 8  # per-sample mesh / camera tables kept resident in the con
 
 
 class Engine:
-    def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0):
+    def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0,
+                 precision_level: int = 2):
+        """precision_level: mvd_set_precision_level (0..6): how many of the output-side layers run with split fp16 operands
+        (extended precision); 2 is the default the parity bounds are stated for."""
+        self.precision_level = int(precision_level)
         if not torch.cuda.is_available():
             raise L.MvdError("no MI355X visible: the denoiser has no CPU path")
         self.lib = L.load()
@@ -60,6 +64,7 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.mvd_create(C.byref(uc), C.byref(vc), self.device.index or 0,
                                         C.c_size_t(int(workspace_gb * (1 << 30))), C.byref(self._ctx)))
+        L.check(self.lib.mvd_set_precision_level(self._ctx, self.precision_level))
         self._loaded = False
         self.num_vertices = 0
         self._slot_nv = {}

@@ -46,10 +46,11 @@ class DepthWiseAttention(nn.Module):
     """Drop-in for ldm.models.diffusion.attention.DepthWiseAttention (YAML unet_config.target,
     configs/facescape.yaml:26-42).  forward(x, timesteps, context, source_dict) -> [Bv,4,h,w]."""
 
-    def __init__(self, volume_dims=(5, 16, 32, 64), *args, **kwargs):
+    def __init__(self, volume_dims=(5, 16, 32, 64), *args, precision_level=2, **kwargs):
         super().__init__()
         if args:
             raise TypeError("pass UNet arguments by keyword, as the reference config does")
+        self.precision_level = precision_level  # not a reference kwarg: mvd_set_precision_level of a stand-alone engine
         self.cfg = _unet_cfg(dict(kwargs, volume_dims=tuple(volume_dims)))
         self.cfg.validate()
         self._engine: Optional[Engine] = None
@@ -61,7 +62,7 @@ class DepthWiseAttention(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         """Standalone use: keys as in the reference UNet's own state_dict (no ``model.diffusion_model.`` prefix)."""
         if self._engine is None:
-            self._engine = Engine(self.cfg, VolumeConfig())
+            self._engine = Engine(self.cfg, VolumeConfig(), precision_level=self.precision_level)
             self._owns_engine = True
         from .spec import unet_manifest
         sd = {"model.diffusion_model." + k: v for k, v in state_dict.items()}
@@ -187,7 +188,7 @@ class SyncMultiviewDiffusion(nn.Module):
                  projection="perspective", use_spatial_volume=False, view_num=16, image_size=256, cfg_scale=3.0,
                  output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
                  clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
-                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0):
+                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2):
         super().__init__()
         self.view_num = view_num
         self.viewpoint_dim = 4
@@ -206,7 +207,7 @@ class SyncMultiviewDiffusion(nn.Module):
                                                input_image_size=image_size, projection=projection,
                                                use_spatial_volume=use_spatial_volume)
         self.engine = Engine(self.model.diffusion_model.cfg, self.spatial_volume.cfg, device=device,
-                             workspace_gb=workspace_gb)
+                             workspace_gb=workspace_gb, precision_level=precision_level)
         self.model.diffusion_model.bind(self.engine)
         self.spatial_volume.bind(self.engine)
         self._device = torch.device(device)

@@ -63,9 +63,57 @@ def test_calls_before_weights_and_without_optional_sections_fail_loudly():
         e.vae_decode(torch.zeros(1, 4, 32, 32))
     with pytest.raises(L.MvdError):
         e.clip_encode(torch.zeros(1, 3, 256, 256))
-    with pytest.raises(L.MvdError):  # uploading after finalize is an error, not a silent no-op
-        e.load_state_dict(gi.unet_weights(cfg))
-    assert torch.isfinite(_fwd(e, cfg, 1)).all()
+    # C ABI: uploading into a finalized context is an error, not a silent no-op ...
+    import ctypes as C
+    w = torch.zeros(4)
+    rc = e.lib.mvd_upload_weight(e._ctx, b"model.diffusion_model.out.2.bias", L.ptr(w), (C.c_int64 * 1)(4), 1, 0)
+    assert rc != 0 and b"finalized" in e.lib.mvd_last_error()
+    # ... while the Python surface reloads like nn.Module does (a fresh context behind the same Engine object)
+    ref = _fwd(e, cfg, 1)
+    inc = e.load_state_dict(gi.unet_weights(cfg))
+    assert inc.unexpected_keys == [] and any(k.startswith("spatial_volume.") for k in inc.missing_keys)
+    assert torch.equal(_fwd(e, cfg, 1), ref)
+    e.close()
+
+
+def test_set_mesh_is_transactional_and_sample_slots_keep_their_tables():
+    """A failed mvd_set_mesh (voxel index outside out_sh) leaves the active mesh intact; slots switched with
+    mvd_select_sample keep their own tables (B > 1 does not rebuild them every step)."""
+    from morphablediffusion_amd import synthetic
+    from morphablediffusion_amd.engine import Engine
+    from morphablediffusion_amd.spec import VolumeConfig
+    N = 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    e = Engine(ucfg, vcfg, workspace_gb=2.0)
+    e.load_state_dict(gi.full_weights(ucfg, vcfg))
+    b0 = synthetic.make_batch(N, "perspective", 500, mesh_seed=1)
+    b1 = synthetic.make_batch(N, "perspective", 400, mesh_seed=2, radii=(0.2, 0.25, 0.27))
+    x = torch.randn(N, 4, 32, 32, generator=torch.Generator().manual_seed(0)).cuda()
+    te, ve = torch.zeros(256).cuda(), torch.zeros(N, 4).cuda()
+
+    def vol(b, slot):
+        e.select_sample(slot)
+        return e.volume_from_fused(e.vertex_features(x, te, ve, torch.arange(N)))
+
+    def upload(b, slot):
+        e.select_sample(slot)
+        e.set_mesh(b["vertices"][0], b["coord"][0], b["out_sh"][0], b["bounds"][0])
+        e.set_cameras(b["target_K"][0], b["target_RT"][0])
+
+    upload(b0, 0)
+    v0 = vol(b0, 0)
+    bad = b0["coord"][0].clone()
+    bad[7, 1] = b0["out_sh"][0, 1] + 3
+    with pytest.raises(L.MvdError, match="outside out_sh"):
+        e.set_mesh(b0["vertices"][0], bad, b0["out_sh"][0], b0["bounds"][0])
+    assert torch.equal(vol(b0, 0), v0)  # the old tables are still there and still consistent
+    upload(b1, 1)
+    v1 = vol(b1, 1)
+    assert not torch.equal(v0, v1)
+    assert torch.equal(vol(b0, 0), v0) and torch.equal(vol(b1, 1), v1)  # switching back and forth, no re-upload
+    e.select_sample(5)  # an empty slot has no mesh
+    with pytest.raises(L.MvdError, match="mvd_set_mesh"):
+        e.vertex_features(x, te, ve, torch.arange(N))
     e.close()
 
 
