@@ -146,7 +146,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the 50-step trajectory and the VAE decode reported next to the headline (profiling runs: the "
+                         "process then executes only identical denoising steps)")
     ap.add_argument("--batch-view-num", type=int, default=0, help="views per UNet pass (0 = all local views)")
+    ap.add_argument("--config", default="headline", choices=["headline", "n8", "smplx32"],
+                    help="headline = BASELINE.json's metric configuration (N=16, 256^2: configs[2], the default the driver "
+                         "runs); n8 = configs[1] (N=8, 256^2); smplx32 = configs[4] (SMPL-X-sized mesh, N=32 views, 512^2 -> "
+                         "64^2 latents, orthographic cameras, 4 views per UNet pass).  Only 'headline' is the headline value")
     ap.add_argument("--probe-stride", type=int, default=4,
                     help="bracket 1 in N launches of the dominant kernel family with HIP events inside the timed region")
     ap.add_argument("--simulate-gpus", type=int, default=0,
@@ -183,13 +190,19 @@ def main():
     from morphablediffusion_amd.spec import UNetConfig, VolumeConfig, full_manifest
     from morphablediffusion_amd.weights import seeded_state_dict
 
-    ucfg, vcfg = UNetConfig(), VolumeConfig(num_views=N_VIEWS)
+    global N_VIEWS
+    CFG = {"headline": dict(N=16, size=256, proj="perspective", nverts=5023, radii=(0.22, 0.28, 0.25), bvn=0),
+           "n8": dict(N=8, size=256, proj="perspective", nverts=5023, radii=(0.22, 0.28, 0.25), bvn=0),
+           "smplx32": dict(N=32, size=512, proj="orthographic", nverts=10475, radii=(0.18, 0.45, 0.12), bvn=4)}[args.config]
+    N_VIEWS = CFG["N"]
+    ucfg = UNetConfig(image_size=CFG["size"] // 8)
+    vcfg = VolumeConfig(num_views=N_VIEWS, projection=CFG["proj"], input_image_size=CFG["size"])
     W = seeded_state_dict(full_manifest(ucfg, vcfg), 7)  # random-init weights of the reference architecture
     from morphablediffusion_amd.spec import VaeConfig, vae_decoder_manifest
     W.update(seeded_state_dict(vae_decoder_manifest(VaeConfig()), 7))  # first-stage decoder (reported separately)
     model = SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
-        view_num=N_VIEWS, image_size=256, cfg_scale=2.0, device=dev, workspace_gb=32.0)
+        projection=CFG["proj"], view_num=N_VIEWS, image_size=CFG["size"], cfg_scale=2.0, device=dev, workspace_gb=48.0)
     model.load_state_dict(W)
     sampler = model.sampler
     sampler.shard_views = world > 1
@@ -197,14 +210,16 @@ def main():
         sampler.simulate_world = args.simulate_gpus
     lo, hi = sampler.view_range(N_VIEWS)
     nl = hi - lo
-    bvn = args.batch_view_num or nl
+    bvn = args.batch_view_num or min(nl, CFG["bvn"] or nl)
+    lat = CFG["size"] // 8
 
-    batch = {k: v.to(dev) for k, v in synthetic.make_batch(N_VIEWS, "perspective", 5023, mesh_seed=1).items()}
-    x_T, x_in, clip = [t.to(dev) for t in synthetic.make_latents(N_VIEWS, 32, seed=6033)]
+    batch = {k: v.to(dev) for k, v in synthetic.make_batch(N_VIEWS, CFG["proj"], CFG["nverts"], mesh_seed=1,
+                                                            image_size=CFG["size"], radii=CFG["radii"]).items()}
+    x_T, x_in, clip = [t.to(dev) for t in synthetic.make_latents(N_VIEWS, lat, seed=6033)]
     x = x_T[:, lo:hi].contiguous()
     info = {"x": x_in}
     g = torch.Generator(device=dev).manual_seed(123)
-    noise = torch.randn(1, N_VIEWS, 4, 32, 32, device=dev, generator=g)[:, lo:hi].contiguous()
+    noise = torch.randn(1, N_VIEWS, 4, lat, lat, device=dev, generator=g)[:, lo:hi].contiguous()
     nsteps = len(sampler.ddim_timesteps)
 
     def one_step(i, xx):
@@ -252,6 +267,8 @@ def main():
     # through SyncDDIMSampler.sample, and the first-stage decode of this rank's views
     extras = {"ddim50_wall_s": None, "vae_decode_ms": None}
     try:
+        if args.no_extras:
+            raise RuntimeError("skipped (--no-extras)")
         gen = torch.Generator(device=dev).manual_seed(6033)
         torch.cuda.synchronize()
         if world > 1:
@@ -269,7 +286,7 @@ def main():
         img = model.decode_first_stage(zl)
         torch.cuda.synchronize()
         extras["vae_decode_ms"] = 1e3 * (time.perf_counter() - t1)
-        assert torch.isfinite(img).all() and tuple(img.shape) == (nl, 3, 256, 256)
+        assert torch.isfinite(img).all() and tuple(img.shape) == (nl, 3, CFG["size"], CFG["size"])
     except Exception as exc:  # never lose the headline line to an extra
         print(f"bench extras failed: {exc!r}", file=sys.stderr)
 
@@ -299,13 +316,17 @@ def main():
         dom = roof(max(families, key=lambda f: f["ms"]))
     if rank == 0:
         out = {
-            "metric": "multi-view denoising steps/sec (N=16 views, 256x256, CFG 2.0, DDIM-50 step)",
+            "metric": "multi-view denoising steps/sec (N=16 views, 256x256, CFG 2.0, DDIM-50 step)" if args.config == "headline"
+                      else f"NOT the headline metric: denoising steps/sec of BASELINE config '{args.config}' "
+                           f"(N={N_VIEWS} views, {CFG['size']}x{CFG['size']}, CFG 2.0)",
             "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "FaceScape-FLAME-sized synthetic sample: N=16 target views, 256x256 (latent 32x32), "
-                                   "5023-vertex mesh, full-width UNet (916.9M params, random init), CFG 2.0, "
-                                   "one denoise_apply per step", "views_per_gpu": nl, "batch_view_num": bvn,
+            "config": {"workload": f"synthetic sample ({'FaceScape-FLAME' if CFG['nverts'] == 5023 else 'SMPL-X'}-sized mesh, "
+                                   f"{CFG['nverts']} vertices before voxel de-duplication): N={N_VIEWS} target views, "
+                                   f"{CFG['size']}x{CFG['size']} (latent {lat}x{lat}), {CFG['proj']} cameras, full-width UNet "
+                                   f"(916.9M params, random init), CFG 2.0, one denoise_apply per step",
+                       "name": args.config, "views_per_gpu": nl, "batch_view_num": bvn,
                        "parallelism": f"view-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": None if dom is None else {
                 "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],

@@ -124,6 +124,17 @@ int mvd_set_volume_ready_event(mvd_ctx* ctx, void* event);
  * mvd_frustum_volumes / mvd_denoise_views. */
 int mvd_volume_from_fused(mvd_ctx* ctx, const float* fused, float* volume_out, void* stream);
 
+/* Training-step variants (reference training_step morphable_diffusion.py:520-549).  The Lightning module
+ * is in train mode there, so the sparse CNN's BatchNorm1d layers (network.py:105) normalise with the statistics of the
+ * sample's active rows instead of their running buffers: mvd_volume_from_fused_train is mvd_volume_from_fused with that
+ * behaviour.  mvd_mse_loss: out[0] = mean((a - b)^2) over n device floats (the "loss_simple" of :541-542). */
+int mvd_volume_from_fused_train(mvd_ctx* ctx, const float* fused, float* volume_out, void* stream);
+int mvd_mse_loss(mvd_ctx* ctx, const float* a, const float* b, size_t n, float* out, void* stream);
+/* Puts a volume [64,V,V,V] (reference layout, e.g. one sample of construct_spatial_volume's [B,64,V,V,V] result) back into
+ * the context for mvd_frustum_volumes / mvd_denoise_views: with B > 1 samples per step (training_step) the per-sample
+ * volumes are built first and the frustum stage runs afterwards (morphable_diffusion.py:531-533). */
+int mvd_set_volume(mvd_ctx* ctx, const float* volume, void* stream);
+
 /* SpatialVolumeNet.construct_view_frustum_volume (morphable_diffusion.py:265-320) for TN views of the
  * volume held in the context.  out_l: [TN,C_l,D_l,s_l,s_l] fp32 (reference layout), any may be NULL. */
 int mvd_frustum_volumes(mvd_ctx* ctx, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,

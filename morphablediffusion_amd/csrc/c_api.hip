@@ -257,6 +257,32 @@ int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, voi
   return 0;
 }
 
+int mvd_volume_from_fused_train(mvd_ctx* c, const float* fused, float* volume_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  RET_IF(engine_volume_from_fused(c, fused, S(stream), /*bn_batch_stats=*/true));
+  if (volume_out) {
+    const int V = c->v.spatial_volume_size;
+    RET_IF(launch_nhwc_to_nchw(c->volume, 64, 1, 64, V * V * V, volume_out, S(stream)));
+  }
+  return 0;
+}
+
+int mvd_set_volume(mvd_ctx* c, const float* volume, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !volume) return mvd_fail("mvd_set_volume: null argument");
+  if (!c->volume) return mvd_fail("mvd_set_volume: mvd_set_mesh must be called first");
+  const int V = c->v.spatial_volume_size;
+  c->vol_ready = nullptr;
+  return launch_nchw_to_nhwc(volume, 1, 64, V * V * V, c->volume, 64, 64, S(stream));
+}
+
+int mvd_mse_loss(mvd_ctx* c, const float* a, const float* b, size_t n, float* out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !a || !b || !out || n == 0) return mvd_fail("mvd_mse_loss: bad argument");
+  return launch_mse(a, b, n, out, S(stream));
+}
+
 int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
                         float* out0, float* out1, float* out2, float* out3, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");

@@ -133,6 +133,8 @@ struct SparseLayerW {
   float* w = nullptr;      // [27][Cin][Cout] fp32
   float* scale = nullptr;  // folded eval BatchNorm
   float* shift = nullptr;
+  float* gamma = nullptr;  // BatchNorm weight / bias themselves (train mode: batch statistics, engine_volume_from_fused)
+  float* beta = nullptr;
   int cin = 0, cout = 0;
   bool strided = false;
 };
@@ -273,7 +275,9 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
                            float* vf_out = nullptr);
 int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, hipStream_t s);
-int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s);
+// bn_batch_stats: the sparse CNN's BatchNorm1d layers normalise with the statistics of the active rows (the module in train
+// mode, as during the reference's training_step) instead of the running buffers
+int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats = false);
 struct FrustumOut {
   half_t* lvl0_half = nullptr;  // level 0 in fp16 instead of lvl[0] when engine_frustum(..., half0 = true)
   float* lvl[4];  // channels-last fp32 [TN, D_l, s_l, s_l, C_l]

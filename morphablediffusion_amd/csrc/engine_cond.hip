@@ -323,7 +323,7 @@ int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, fl
 }
 
 // SparseConvNet (network.py:74-96) + latent-code volume gather (morphable_diffusion.py:232-257)
-int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s) {
+int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats) {
   MeshTables& m = c->mesh;
   if (!m.Nv) return mvd_fail("mvd_set_mesh must be called first");
   const float* in = fused;
@@ -341,7 +341,12 @@ int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s) {
       n_out = m.n_sites[lvl];
     }
     float* out = m.feat[pp];
-    RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.scale, L.shift, out, s));
+    if (bn_batch_stats) {  // train mode: raw conv, then BatchNorm1d(eps 1e-3) on the statistics of the active rows + ReLU
+      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, nullptr, nullptr, out, s));
+      RET_IF(launch_bn_rows_relu(out, n_out, L.cout, L.gamma, L.beta, 1e-3f, s));
+    } else {
+      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.scale, L.shift, out, s));
+    }
     in = out;
     pp ^= 1;
   }

@@ -655,10 +655,13 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       // two-way handshake: the side stream starts after everything enqueued on the caller's stream so far, and the caller's
       // stream resumes only once the side stream has passed that point (without the acknowledgement the step
       // was not bit-reproducible in ~5 % of runs)
+      static const bool one_way = getenv("MVD_ONE_WAY_FORK") != nullptr;  // investigation aid (tools/det_fork.sh)
       HIP_CHECK_RET(hipEventRecord(c->ev_fork, s));
       HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-      HIP_CHECK_RET(hipEventRecord(c->ev_join2, c->side));
-      HIP_CHECK_RET(hipStreamWaitEvent(s, c->ev_join2, 0));
+      if (!one_way) {
+        HIP_CHECK_RET(hipEventRecord(c->ev_join2, c->side));
+        HIP_CHECK_RET(hipStreamWaitEvent(s, c->ev_join2, 0));
+      }
       join.side = c->side;
       join.ev = c->ev_join;
       cs = c->side;

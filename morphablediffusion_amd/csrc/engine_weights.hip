@@ -210,6 +210,10 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   HIP_CHECK_RET(hipMemcpy(L->w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
   HIP_CHECK_RET(hipMemcpy(L->scale, sc.data(), cout * 4, hipMemcpyHostToDevice));
   HIP_CHECK_RET(hipMemcpy(L->shift, sh.data(), cout * 4, hipMemcpyHostToDevice));
+  RET_IF(dmalloc(c, (void**)&L->gamma, cout * 4));
+  RET_IF(dmalloc(c, (void**)&L->beta, cout * 4));
+  HIP_CHECK_RET(hipMemcpy(L->gamma, hg.data(), cout * 4, hipMemcpyHostToDevice));
+  HIP_CHECK_RET(hipMemcpy(L->beta, hb.data(), cout * 4, hipMemcpyHostToDevice));
   return 0;
 }
 

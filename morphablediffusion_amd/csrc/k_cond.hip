@@ -139,8 +139,57 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   if (t < Cout) {
     float v = 0.f;
     for (int q = 0; q < P; ++q) v += s_red[q * Cout + t];
-    out[(long)site * Cout + t] = fmaxf(v * scale[t] + shift[t], 0.f);
+    out[(long)site * Cout + t] = scale ? fmaxf(v * scale[t] + shift[t], 0.f) : v;  // scale == null: raw conv output
   }
+}
+
+// one workgroup per channel: mean, then centred second moment over the n rows (fp32, fixed order), then the in-place apply
+__global__ __launch_bounds__(256) void bn_rows_relu_kernel(float* __restrict__ x, int n, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps) {
+  __shared__ float s_red[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int r = t; r < n; r += 256) a += x[(long)r * C + c];
+  s_red[t] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  const float mean = s_red[0] / (float)n;
+  __syncthreads();
+  float q = 0.f;
+  for (int r = t; r < n; r += 256) {
+    const float d = x[(long)r * C + c] - mean;
+    q += d * d;
+  }
+  s_red[t] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  const float rstd = rsqrtf(s_red[0] / (float)n + eps), g = gamma[c], b = beta[c];
+  for (int r = t; r < n; r += 256) x[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
+}
+
+// mean((a - b)^2) of n elements into out[0]: one workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                   float* __restrict__ out) {
+  __shared__ double s_red[1024];
+  const int t = threadIdx.x;
+  double acc = 0.0;
+  for (size_t i = t; i < n; i += 1024) {
+    const double d = (double)a[i] - (double)b[i];
+    acc += d * d;
+  }
+  s_red[t] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[0] = (float)(s_red[0] / (double)n);
 }
 
 // out [V][V][V][C] (z,y,x,c) fp32
@@ -251,6 +300,19 @@ int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int 
   if (Cout > 256 || n_out <= 0) return n_out <= 0 ? 0 : mvd_fail("sparse_conv: Cout > 256");
   hipLaunchKernelGGL(sparse_conv_kernel, dim3(n_out), dim3(256), 0, s, in, nbr, n_out, Cin, Cout, w,
                      scale, shift, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_bn_rows_relu(float* x, int n, int C, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  if (n <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, n, C, gamma, beta, eps);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_mse(const float* a, const float* b, size_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -208,12 +208,24 @@ class Engine:
         h = C.c_void_p(0) if event is None else C.c_void_p(event.cuda_event)
         L.check(self.lib.mvd_set_volume_ready_event(self._ctx, h))
 
-    def volume_from_fused(self, fused, want_output=True):
+    def volume_from_fused(self, fused, want_output=True, train=False):
+        """train: BatchNorm layers of the sparse CNN use batch statistics (the reference's module in train mode)."""
         V = self.vcfg.spatial_volume_size
         out = torch.empty(64, V, V, V, device=self.device, dtype=torch.float32) if want_output else None
         f = _f32(fused, self.device)
-        L.check(self.lib.mvd_volume_from_fused(self._ctx, L.ptr(f), L.ptr(out), _stream()))
+        fn = self.lib.mvd_volume_from_fused_train if train else self.lib.mvd_volume_from_fused
+        L.check(fn(self._ctx, L.ptr(f), L.ptr(out), _stream()))
         return out
+
+    def set_volume(self, volume):
+        v = _f32(volume, self.device)
+        L.check(self.lib.mvd_set_volume(self._ctx, L.ptr(v), _stream()))
+
+    def mse_loss(self, a, b):
+        a, b = _f32(a, self.device), _f32(b, self.device)
+        out = torch.empty(1, device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_mse_loss(self._ctx, L.ptr(a), L.ptr(b), C.c_size_t(a.numel()), L.ptr(out), _stream()))
+        return out[0]
 
     def frustum_volumes(self, t_embed, v_embed, view_idx):
         dev = self.device

@@ -89,14 +89,36 @@ class UNetWrapper(nn.Module):
             raise NotImplementedError  # morphable_diffusion.py:92
         self.diffusion_model = instantiate_from_config(diff_model_config)
         self.drop_conditions = drop_conditions
+        self.drop_scheme = drop_scheme
         self.use_zero_123 = use_zero_123
 
     def get_trainable_parameters(self):
         return self.diffusion_model.get_trainable_parameters()
 
-    def forward(self, x, t, clip_embed, volume_feats, x_concat, is_train=False):
-        if is_train:
-            raise NotImplementedError("training step is out of scope of the inference engine")
+    def drop(self, cond, mask):
+        return mask.view(cond.shape[0], *[1] * (cond.dim() - 1)) * cond
+
+    def get_drop_scheme(self, B, device, random=None):
+        """morphable_diffusion.py:84-93.  ``random``: the uniform draw [B] (default: torch.rand, as the reference)."""
+        if self.drop_scheme != "default":
+            raise NotImplementedError
+        if random is None:
+            random = torch.rand(B, dtype=torch.float32, device=device)
+        random = random.to(device)
+        return ((random > 0.15) & (random <= 0.2), (random > 0.1) & (random <= 0.15), (random > 0.05) & (random <= 0.1),
+                random <= 0.05)
+
+    def forward(self, x, t, clip_embed, volume_feats, x_concat, is_train=False, drop_random=None):
+        """morphable_diffusion.py:95-130.  is_train with drop_conditions: the condition dropout of the training step (the
+        forward pass runs in the engine; see SyncMultiviewDiffusion.training_step for what exists of the backward pass)."""
+        if self.drop_conditions and is_train:
+            B = x.shape[0]
+            drop_clip, drop_volume, drop_concat, drop_all = self.get_drop_scheme(B, x.device, drop_random)
+            clip_embed = self.drop(clip_embed, 1.0 - (drop_clip | drop_all).float())
+            vm = 1.0 - (drop_volume | drop_all).float()
+            for k, v in volume_feats.items():  # in place on the dict, as the reference does (:114-115)
+                volume_feats[k] = self.drop(v, vm)
+            x_concat = self.drop(x_concat, 1.0 - (drop_concat | drop_all).float())
         xc = x_concat * 1.0
         if self.use_zero_123:
             xc[:, :4] = xc[:, :4] / 0.18215
@@ -162,23 +184,30 @@ class SpatialVolumeNet(nn.Module):
             self._slots[slot] = (key, ts)
 
     def construct_spatial_volume(self, x, t_embed, v_embed, batch):
+        """train mode (nn.Module.train(), as Lightning sets it for training_step): the sparse CNN's BatchNorm layers use
+        batch statistics, exactly like the reference's module in train mode."""
         B, N = x.shape[:2]
         vols = []
         for bi in range(B):
             self._set_sample(batch, bi)
             fused = self._engine.vertex_features(x[bi], t_embed[bi], v_embed[bi], torch.arange(N))
-            vols.append(self._engine.volume_from_fused(fused))
+            vols.append(self._engine.volume_from_fused(fused, train=self.training))
         return torch.stack(vols)
 
     def construct_view_frustum_volume(self, spatial_volume, t_embed, v_embed, target_indices, batch):
-        """Uses the volume held by the engine from the last construct_spatial_volume of the same sample."""
+        """B == 1 uses the volume held by the engine from the last construct_spatial_volume of the same sample; B > 1 (the
+        training step: one target view per sample) re-uploads each sample's ``spatial_volume[bi]`` first."""
         B, TN = target_indices.shape
-        if B != 1:
-            raise NotImplementedError("frustum volumes are built one sample at a time")
-        self._set_sample(batch, 0)
-        idx = target_indices[0]
-        out = self._engine.frustum_volumes(t_embed[0], v_embed[0][idx.to(v_embed.device)], idx)
-        return out, None
+        outs = []
+        for bi in range(B):
+            self._set_sample(batch, bi)
+            if B > 1:
+                self._engine.set_volume(spatial_volume[bi])
+            idx = target_indices[bi]
+            outs.append(self._engine.frustum_volumes(t_embed[bi], v_embed[bi][idx.to(v_embed.device)], idx))
+        if B == 1:
+            return outs[0], None
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}, None
 
 
 class SyncMultiviewDiffusion(nn.Module):
@@ -279,6 +308,52 @@ class SyncMultiviewDiffusion(nn.Module):
             with torch.no_grad():
                 clip_embed = self.clip_image_encoder.encode(image_input)
         return None, clip_embed, input_info
+
+    def add_noise(self, x_start, t, noise=None):
+        """morphable_diffusion.py:551-565 (schedule buffers :428-450).  ``noise``: the N(0,1) draw (default: randn_like)."""
+        B = x_start.shape[0]
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        ac = self.sampler.schedule.alphas_cumprod.to(x_start.device)
+        shape = (B,) + (1,) * (x_start.dim() - 1)
+        x_noisy = ac.sqrt()[t].view(shape) * x_start + (1.0 - ac).sqrt()[t].view(shape) * noise
+        return x_noisy, noise
+
+    def training_step(self, batch, prepared=None, time_steps=None, noise=None, target_index=None, drop_random=None):
+        """SyncMultiviewDiffusion.training_step (morphable_diffusion.py:520-549): FORWARD pass and loss in the HIP engine --
+        random time steps, add_noise, one random target view per sample, the 32^3 volume from ALL noisy views (BatchNorm in
+        train mode), one frustum volume per sample, the UNet with condition dropout, MSE against the injected noise.
+        ``prepared`` = (x, clip_embed, input_info) replaces self.prepare(batch); the four random draws may be passed in
+        (parity tests), otherwise they are drawn on the host in the reference's order (randint, randn_like, randint, rand) so
+        that torch.manual_seed reproduces the reference's CPU stream.  Returns the loss (a device scalar, no autograd graph);
+        the prediction is kept in ``self.last_noise_predict``.  Backward pass: SURVEY 8(f) rank 2, see DESIGN.md."""
+        dev = self.device
+        x, clip_embed, input_info = self.prepare(batch) if prepared is None else prepared
+        B, N = x.shape[:2]
+        if time_steps is None:
+            time_steps = torch.randint(0, self.num_timesteps, (B,)).long()
+        if noise is None:
+            noise = torch.randn(x.shape)
+        if target_index is None:
+            target_index = torch.randint(0, N, (B, 1)).long()
+        if drop_random is None and self.model.drop_conditions:
+            drop_random = torch.rand(B, dtype=torch.float32)
+        time_steps, target_index = time_steps.to(dev), target_index.to(dev)
+        x_noisy, noise = self.add_noise(x.to(dev), time_steps, noise.to(dev))
+        was_training = self.training
+        self.train()  # BatchNorm batch statistics in the sparse CNN, as in the reference's training_step
+        try:
+            v_embed = self.get_viewpoint_embedding(batch).to(dev)
+            t_embed = self.embed_time(time_steps)
+            sv = self.spatial_volume.construct_spatial_volume(x_noisy, t_embed, v_embed, batch)
+            clip_, vf, xc = self.get_target_view_feats(input_info["x"].to(dev), sv, clip_embed.to(dev), t_embed, v_embed,
+                                                       target_index, batch)
+        finally:
+            self.train(was_training)
+        ar = torch.arange(B, device=dev)[:, None]
+        pred = self.model(x_noisy[ar, target_index][:, 0], time_steps, clip_, vf, xc, is_train=True, drop_random=drop_random)
+        self.last_noise_predict = pred
+        return self.engine.mse_loss(noise[ar, target_index][:, 0].contiguous(), pred)
 
     def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):
         B, _, H, W = x_input.shape

@@ -346,8 +346,14 @@ def fuse_views(W, feats, p="spatial_volume.smpl_feature_extractor."):
     return y.reshape(B, N, -1, Nv).mean(1).permute(0, 2, 1)
 
 
-def _bn_relu(W, p, x):
-    y = (x - W[p + ".running_mean"]) / torch.sqrt(W[p + ".running_var"] + 1e-3) * W[p + ".weight"] + W[p + ".bias"]
+def _bn_relu(W, p, x, train=False):
+    """BatchNorm1d(eps 1e-3) over the active rows + ReLU.  eval: running statistics; train (the module is in train mode
+    during training_step): statistics of this sample's active rows, biased variance (running buffers are not updated here)."""
+    if train:
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+    else:
+        mean, var = W[p + ".running_mean"], W[p + ".running_var"]
+    y = (x - mean) / torch.sqrt(var + 1e-3) * W[p + ".weight"] + W[p + ".bias"]
     return torch.relu(y)
 
 
@@ -398,7 +404,7 @@ def _strided_conv(feats, coords, shape, weight):
     return out, ocoords, oshape
 
 
-def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net."):
+def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", train=False):
     """SparseConvNet.forward network.py:85-96 (double_conv :109, stride_conv :152, triple_conv :127),
     eval-mode BatchNorm1d(eps 1e-3).  feats [Nv,16], coords [Nv,3] (z,y,x) int; returns the
     dense [1,64,D/4,H/4,W/4] volume.  PARITY UNPINNED (spconv absent) -- see module header.
@@ -424,7 +430,7 @@ def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net."):
                 x, coords, shape = _strided_conv(x, coords, shape, w)
             else:
                 x = _subm_conv(x, coords, shape, w)
-            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x)
+            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x, train)
     dense = torch.zeros([x.shape[1]] + shape)
     dense[:, coords[:, 0], coords[:, 1], coords[:, 2]] = x.t()
     return dense[None]
@@ -442,13 +448,14 @@ def latent_volume(vcfg, feature_volume, bounds_min_xyz, out_sh):
     return sample_zeros_align(feature_volume, g[None]).reshape(1, -1, V, V, V)
 
 
-def construct_spatial_volume(W, vcfg, x_noisy, t_embed, v_embed, batch):
-    """SpatialVolumeNet.construct_spatial_volume, morphable_diffusion.py:182-263 (use_spatial_volume False)."""
+def construct_spatial_volume(W, vcfg, x_noisy, t_embed, v_embed, batch, train=False):
+    """SpatialVolumeNet.construct_spatial_volume, morphable_diffusion.py:182-263 (use_spatial_volume False).
+    train: the sparse CNN's BatchNorm layers use batch statistics (module in train mode)."""
     B = x_noisy.shape[0]
     fused = fuse_views(W, vertex_features(W, vcfg, x_noisy, t_embed, v_embed, batch))  # B,Nv,16
     vols = []
     for bi in range(B):
-        fv = sparse_conv_net(W, fused[bi], batch["coord"][bi], batch["out_sh"][bi])
+        fv = sparse_conv_net(W, fused[bi], batch["coord"][bi], batch["out_sh"][bi], train=train)
         vols.append(latent_volume(vcfg, fv, batch["bounds"][bi, 0], batch["out_sh"][bi])[0])
     return torch.stack(vols)
 
@@ -576,3 +583,50 @@ def sample(W, plan, vcfg, x_input, clip_embed, scale, batch, num_ddim=50, eta=1.
         if index % log_every_t == 0 or index == total - 1:
             inter.append(x)
     return x, inter, eps_all
+
+
+# ------------------------------------------------------------------------------------------ training step
+def drop_masks(drop_random):
+    """UNetWrapper.get_drop_scheme + the masks of UNetWrapper.forward (morphable_diffusion.py:84-115), 'default' scheme:
+    u <= 0.05 drops everything, (0.05, 0.1] the concatenated latent, (0.1, 0.15] the volumes, (0.15, 0.2] the CLIP token.
+    Returns the three keep-masks (clip, volume, concat) as float tensors [B]."""
+    u = drop_random
+    drop_clip = (u > 0.15) & (u <= 0.2)
+    drop_volume = (u > 0.1) & (u <= 0.15)
+    drop_concat = (u > 0.05) & (u <= 0.1)
+    drop_all = u <= 0.05
+    return 1.0 - (drop_clip | drop_all).float(), 1.0 - (drop_volume | drop_all).float(), 1.0 - (drop_concat | drop_all).float()
+
+
+def add_noise(x_start, t, noise, num_ddpm=1000, linear_start=0.00085, linear_end=0.0120):
+    """SyncMultiviewDiffusion.add_noise, morphable_diffusion.py:551-565 (schedule buffers :428-450)."""
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, num_ddpm, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+    return ac.sqrt()[t].view(shape) * x_start + (1.0 - ac).sqrt()[t].view(shape) * noise
+
+
+def training_step(W, plan, vcfg, x0, x_input, clip_embed, batch, time_steps, noise, target_index, drop_random=None):
+    """SyncMultiviewDiffusion.training_step, morphable_diffusion.py:520-549, with the random draws passed in (time_steps [B],
+    noise like x0 [B,N,4,h,w], target_index [B,1], drop_random [B] or None = no condition dropout) and ``prepare`` replaced
+    by its outputs (x0 = target latents, x_input, clip_embed).  Differentiable: tensors of W with requires_grad receive
+    gradients from ``loss.backward()``.  Returns (loss, noise_predict)."""
+    B = x0.shape[0]
+    x_noisy = add_noise(x0, time_steps, noise)
+    v_embed = viewpoint_embedding(batch)
+    t_embed = embed_time(W, time_steps, vcfg.time_dim)
+    sv = construct_spatial_volume(W, vcfg, x_noisy, t_embed, v_embed, batch, train=True)
+    vf = construct_view_frustum_volume(W, vcfg, sv, t_embed, v_embed, target_index, batch)
+    ar = torch.arange(B)[:, None]
+    xs = x_noisy[ar, target_index][:, 0]
+    clip_, xc = clip_embed, x_input
+    if drop_random is not None:
+        mc, mv, mx = drop_masks(drop_random)
+        clip_ = clip_ * mc.view(B, 1, 1)
+        vf = {k: v * mv.view(B, 1, 1, 1, 1) for k, v in vf.items()}
+        xc = xc * mx.view(B, 1, 1, 1)
+    xc = xc.clone()
+    xc[:, :4] = xc[:, :4] / 0.18215
+    pred = unet_forward(W, plan, torch.cat([xs, xc], 1), time_steps, clip_, vf)
+    target = noise[ar, target_index][:, 0]
+    return ((target - pred) ** 2).mean(), pred

@@ -384,3 +384,35 @@ def test_ragged_view_chunks_small():
     print(f"[property] batch_view_num 3 vs 4: relL2={d:.2e}")
     assert torch.isfinite(a).all() and d <= 5e-4
     m.engine.close()
+
+
+@pytest.mark.parametrize("name,N,size,projection,nverts,radii,bvn", [
+    ("configs[1]: N=8, 256^2", 8, 256, "perspective", 5023, (0.22, 0.28, 0.25), 8),
+    ("configs[4]: SMPL-X-sized mesh, N=32, 512^2 (64^2 latents), orthographic, 4 views per pass", 32, 512, "orthographic",
+     10475, (0.18, 0.45, 0.12), 4),
+])
+def test_full_width_config_variants_properties(name, N, size, projection, nverts, radii, bvn):
+    """The other BASELINE.json configurations at FULL UNet width (their parity cases run at reduced width): workspace sizing,
+    and the properties that need no reference -- finite, deterministic (bit-identical repeat), invariant to the view chunking
+    up to fp32 summation order, and different views get different results."""
+    import dataclasses
+    ucfg = dataclasses.replace(gi.FULL_UNET, image_size=size // 8)
+    vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=size)
+    m = make_model(ucfg, vcfg, N, workspace_gb=40.0)
+    batch = to_dev(synthetic.make_batch(N, projection, nverts, mesh_seed=1, image_size=size, radii=radii))
+    x_T, x_in, clip = [t.cuda() for t in synthetic.make_latents(N, size // 8, seed=6033)]
+    noise = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    index = 30
+    ts = torch.full((1,), int(m.sampler.ddim_timesteps[index]), dtype=torch.long, device="cuda")
+    run = lambda b: m.sampler.denoise_apply(x_T, {"x": x_in}, clip, ts, index, 2.0, batch_view_num=b, batch=batch, noise=noise,
+                                            return_eps=True)
+    out, eps = run(bvn)
+    assert torch.isfinite(out).all() and torch.isfinite(eps).all() and eps.std() > 1e-3
+    out2, eps2 = run(bvn)
+    assert torch.equal(out, out2) and torch.equal(eps, eps2), "repeat is not bit-identical"
+    _, eps3 = run(max(1, bvn // 2))
+    d = ((eps3 - eps).norm() / eps.norm()).item()
+    print(f"[property] {name}: batch_view_num {bvn} vs {max(1, bvn // 2)}: eps relL2={d:.2e}")
+    assert d <= 5e-4
+    assert not torch.allclose(eps[0, 0], eps[0, 1])
+    m.engine.close()

@@ -279,3 +279,47 @@ def test_clip_image_embedding(name, kw):
     x = torch.rand(int(g["B"]), 3, 256, 256, generator=gen) * 2.0 - 1.0
     check(CO.preprocess(x, cfg.image), g, "pixels")
     check(CO.encode(W, cfg, x), g, "embed")
+
+
+def _train_inputs(g):
+    B, N = int(g["B"]), int(g["N"])
+    b0 = synthetic.make_batch(N, "perspective", int(g["nverts_in"]), mesh_seed=1)
+    batch = {k: v.repeat(B, *([1] * (v.dim() - 1))).clone() for k, v in b0.items()}
+    for bi in range(B):
+        batch["target_K"][bi] = b0["target_K"][0].roll(bi, 0)
+        batch["target_RT"][bi] = b0["target_RT"][0].roll(bi, 0)
+    gen = torch.Generator().manual_seed(int(g["seed_latents"]))
+    x0 = torch.randn(B, N, 4, 32, 32, generator=gen) * 0.8
+    x_in = torch.randn(B, 4, 32, 32, generator=gen) * 0.18215
+    clip = torch.randn(B, 1, 768, generator=gen)
+    # the reference's stream: randint (time steps), randn_like (noise), randint (target view) on one seeded CPU generator
+    torch.manual_seed(int(g["seed_draws"]))
+    ts = torch.randint(0, 1000, (B,)).long()
+    noise = torch.randn_like(x0)
+    ti = torch.randint(0, N, (B, 1)).long()
+    assert np.array_equal(ts.numpy(), g["time_steps"]) and np.array_equal(ti.numpy(), g["target_index"])
+    return batch, x0, x_in, clip, ts, noise, ti, torch.from_numpy(np.asarray(g["drop_random"]))
+
+
+def test_training_step_loss_and_gradients():
+    """f2: the oracle's training_step (forward, loss, and -- through autograd on the functional restatement -- the gradients
+    of the last DepthTransformer) against the reference's own training_step + loss.backward()."""
+    g = load("train_small.npz")
+    N = int(g["N"])
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    W = gi.full_weights(ucfg, vcfg)
+    batch, x0, x_in, clip, ts, noise, ti, dr = _train_inputs(g)
+    P = "model.diffusion_model.output_conditions.8."
+    names = [str(n) for n in g["grad_names"]]
+    for n in names:
+        W[P + n].requires_grad_(True)
+    loss, pred = O.training_step(W, build_unet_plan(ucfg), vcfg, x0, x_in, clip, batch, ts, noise, ti, dr)
+    pred.retain_grad()
+    loss.backward()
+    check(loss.detach().reshape(1), g, "loss", 1e-5)
+    check(pred.detach(), g, "noise_predict")
+    check(pred.grad, g, "dpred", 1e-5)
+    for n in names:
+        check(W[P + n].grad, g, "grad." + n, 1e-3)
+    m_clip, m_vol, m_cat = O.drop_masks(dr)
+    assert m_clip.tolist() == [0, 1, 1, 1] and m_vol.tolist() == [0, 0, 1, 1] and m_cat.tolist() == [0, 1, 0, 1]

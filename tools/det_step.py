@@ -19,9 +19,10 @@ ctxm = torch.cuda.stream(torch.cuda.Stream()) if os.environ.get("DET_STREAM") el
 ctxm.__enter__()
 ref = step()
 bad = 0
-for i in range(100):
+REPS = int(os.environ.get("DET_REPS", "100"))
+for i in range(REPS):
     o = step()
     if not torch.equal(o, ref):
         bad += 1
         print(i, "diff", (o - ref).abs().max().item(), "of", ref.abs().max().item())
-print("mismatches", bad, "of 100")
+print("mismatches", bad, "of", REPS, "| env:", {k: v for k, v in os.environ.items() if k.startswith(("MVD_", "DET_"))})

@@ -1,7 +1,10 @@
 """Aggregate MVD_LAYER_TIMING lines (stderr of bench.py) of the LAST `denoise` pass: identical GEMM descriptors summed."""
 import re, sys, collections
-lines = [l for l in open(sys.argv[1]) if l.startswith("[gemm]")]
-n = int(sys.argv[2])            # GEMM launches per step
+raw = open(sys.argv[1]).read()
+if "[step-begin]" in raw:       # tools/layer_step.py marks the steps: take the last one
+    raw = raw.rsplit("[step-begin]", 1)[1]
+lines = [l for l in raw.splitlines() if l.startswith("[gemm]")]
+n = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else len(lines)   # GEMM launches per step
 last = lines[-n:]
 agg = collections.OrderedDict()
 for l in last:

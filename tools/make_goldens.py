@@ -346,6 +346,63 @@ def gold_trained(ns, full=True):
         gold_step(ns, "step_full_trained.npz", gi.FULL_UNET, 16, "perspective", 20, True, 5023, 16, style="trained")
 
 
+def gold_train(ns):
+    """f2: the reference's training_step (morphable_diffusion.py:520-549) at reduced width, run with
+    the reference's own methods in the reference's own order -- time steps, add_noise (:551-565), random target view,
+    construct_spatial_volume on all noisy views, one frustum volume per sample, UNetWrapper.forward(is_train=True) with
+    condition dropout (:95-130), MSE -- then loss.backward().  ``prepare`` (VAE / CLIP) is replaced by seeded latents.
+    The random draws are stored so that the HIP path can be fed the same ones; the dropout's uniform draw is INJECTED
+    (torch.rand patched for that one call) so that all four branches of get_drop_scheme (:84-93) occur in a batch of 4.
+    Stored: loss, noise_predict, and the gradients of every parameter of the LAST DepthTransformer (output_conditions.8)
+    plus the gradient w.r.t. the UNet output."""
+    B, N = 4, 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    model, _ = build_full_model(ns, ucfg, vcfg, N)
+    model.model.drop_conditions = True
+    model.train()
+    b0 = synthetic.make_batch(N, "perspective", 500, mesh_seed=1)
+    batch = {k: v.repeat(B, *([1] * (v.dim() - 1))).clone() for k, v in b0.items()}
+    # different cameras per sample: rotate the rig index
+    for bi in range(B):
+        batch["target_K"][bi] = b0["target_K"][0].roll(bi, 0)
+        batch["target_RT"][bi] = b0["target_RT"][0].roll(bi, 0)
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(B, N, 4, 32, 32, generator=g) * 0.8           # target latents (what prepare() returns as x)
+    x_in = torch.randn(B, 4, 32, 32, generator=g) * 0.18215
+    clip = torch.randn(B, 1, 768, generator=g)
+    drop_random = torch.tensor([0.03, 0.12, 0.07, 0.6])            # drop all | drop volume | drop concat | keep everything
+    torch.manual_seed(4242)
+    time_steps = torch.randint(0, model.num_timesteps, (B,)).long()
+    x_noisy, noise = model.add_noise(x0, time_steps)
+    target_index = torch.randint(0, N, (B, 1)).long()
+    v_embed = model.get_viewpoint_embedding(batch)
+    t_embed = model.embed_time(time_steps)
+    sv = model.spatial_volume.construct_spatial_volume(x_noisy, t_embed, v_embed, batch)
+    clip_, vf, xc = model.get_target_view_feats(x_in, sv, clip, t_embed, v_embed, target_index, batch)
+    x_noisy_ = x_noisy[torch.arange(B)[:, None], target_index][:, 0]
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: drop_random.clone()
+    try:
+        pred = model.model(x_noisy_, time_steps, clip_, vf, xc, is_train=True)
+    finally:
+        torch.rand = real_rand
+    pred.retain_grad()
+    noise_target = noise[torch.arange(B)[:, None], target_index][:, 0]
+    loss = torch.nn.functional.mse_loss(noise_target, pred, reduction="none").mean()
+    loss.backward()
+    packs = {"noise_predict": gi.pack(pred), "loss": gi.pack(loss.reshape(1)), "dpred": gi.pack(pred.grad),
+             "x_noisy": gi.pack(x_noisy)}
+    names = []
+    for n_, p_ in model.model.diffusion_model.output_conditions[8].named_parameters():
+        assert p_.grad is not None and p_.grad.abs().max() > 0, n_
+        packs["grad." + n_] = gi.pack(p_.grad, limit=1 << 18)
+        names.append(n_)
+    print("train golden: loss", float(loss), "pred std", float(pred.std()), "grads:", len(names))
+    save("train_small.npz", packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
+                                    "target_index": target_index.numpy(), "drop_random": drop_random.numpy(),
+                                    "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names)})
+
+
 def gold_variants(ns):
     """The other BASELINE.json configs as parity cases, at reduced UNet width:
     config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
@@ -363,6 +420,7 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
+    ap.add_argument("--only-train", action="store_true", help="only the training-step golden (loss + gradients)")
     ap.add_argument("--only-traj", action="store_true", help="only the multi-step trajectory golden")
     ap.add_argument("--only-trained", action="store_true", help="only the goldens on the trained-like weight set")
     ap.add_argument("--only-clip", action="store_true", help="only the CLIP image-embedding goldens (needs transformers, not the reference)")
@@ -382,6 +440,9 @@ def main():
     if args.only_traj:
         gold_traj(ns)
         return
+    if args.only_train:
+        gold_train(ns)
+        return
     if args.only_trained:
         gold_trained(ns, not args.skip_full)
         return
@@ -393,6 +454,7 @@ def main():
         gold_unet_full(ns)
         hot = gold_step(ns, "step_full.npz", gi.FULL_UNET, 16, "perspective", 49, True, 5023, 8, frustum_views=2)
     gold_traj(ns)
+    gold_train(ns)
     gold_variants(ns)
     gold_trained(ns, not args.skip_full)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
