@@ -130,6 +130,20 @@ int mvd_volume_from_fused(mvd_ctx* ctx, const float* fused, float* volume_out, v
  * behaviour.  mvd_mse_loss: out[0] = mean((a - b)^2) over n device floats (the "loss_simple" of :541-542). */
 int mvd_volume_from_fused_train(mvd_ctx* ctx, const float* fused, float* volume_out, void* stream);
 int mvd_mse_loss(mvd_ctx* ctx, const float* a, const float* b, size_t n, float* out, void* stream);
+/* Backward pass, first slice: the gradients of every parameter of the LAST DepthTransformer (output_conditions.<last>,
+ * ldm/models/diffusion/attention.py:49-84 -- the tail of get_trainable_parameters(), :140-142).
+ *   mvd_train_tape(ctx, max_batch)   allocates the tape (max_batch > 0) or releases it (0): while on, mvd_unet_forward keeps the
+ *                                    input of that block and the UNet's final hidden state of the latest call;
+ *   mvd_train_backward_last_condition(ctx, dpred [B,out_channels,s,s] = dL/d(output of the taped forward), ctx0
+ *                                    [B,volume_dims[0],D,s,s] = the finest source_dict volume that forward saw, B, D, stream)
+ *                                    re-computes the block in fp32 from the master weights and back-propagates through the
+ *                                    output head (openaimodel.py:717-721) and the block;
+ *   mvd_train_get_grad(ctx, key, out, numel, stream)   copies the gradient of state_dict entry `key` (reference name, PyTorch
+ *                                    layout) to device memory.
+ * Everything upstream of that block needs the backward of the whole UNet: not part of this slice. */
+int mvd_train_tape(mvd_ctx* ctx, int max_batch);
+int mvd_train_backward_last_condition(mvd_ctx* ctx, const float* dpred, const float* ctx0, int B, int D, void* stream);
+int mvd_train_get_grad(mvd_ctx* ctx, const char* name, float* out, size_t numel, void* stream);
 /* Puts a volume [64,V,V,V] (reference layout, e.g. one sample of construct_spatial_volume's [B,64,V,V,V] result) back into
  * the context for mvd_frustum_volumes / mvd_denoise_views: with B > 1 samples per step (training_step) the per-sample
  * volumes are built first and the frustum stage runs afterwards (morphable_diffusion.py:531-533). */

@@ -101,6 +101,10 @@ void mvd_destroy(mvd_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (auto& kv : c->raw) hipFree(kv.second.d);
+  for (auto& kv : c->train_w) hipFree(kv.second.d);
+  for (auto& kv : c->train_g) hipFree(kv.second.d);
+  hipFree(c->tape_x);
+  hipFree(c->tape_h);
   for (void* p : c->owned) hipFree(p);
   mesh_free(c->mesh);
   hipFree(c->cams);
@@ -277,6 +281,28 @@ int mvd_set_volume(mvd_ctx* c, const float* volume, void* stream) {
   return launch_nchw_to_nhwc(volume, 1, 64, V * V * V, c->volume, 64, 64, S(stream));
 }
 
+int mvd_train_tape(mvd_ctx* c, int max_batch) {
+  if (!c) return mvd_fail("null context");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  return engine_tape_enable(c, max_batch);
+}
+
+int mvd_train_backward_last_condition(mvd_ctx* c, const float* dpred, const float* ctx0, int B, int D, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !dpred || !ctx0 || B <= 0) return mvd_fail("mvd_train_backward_last_condition: bad argument");
+  return engine_train_backward_last_condition(c, dpred, ctx0, B, D, S(stream));
+}
+
+int mvd_train_get_grad(mvd_ctx* c, const char* name, float* out, size_t numel, void* stream) {
+  if (!c || !name || !out) return mvd_fail("mvd_train_get_grad: null argument");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  auto it = c->train_g.find(name);
+  if (it == c->train_g.end() || !it->second.d) return mvd_fail("mvd_train_get_grad: no gradient under that name (run the backward first)");
+  if (it->second.numel != numel) return mvd_fail("mvd_train_get_grad: size mismatch");
+  HIP_CHECK_RET(hipMemcpyAsync(out, it->second.d, numel * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
+  return 0;
+}
+
 int mvd_mse_loss(mvd_ctx* c, const float* a, const float* b, size_t n, float* out, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !a || !b || !out || n == 0) return mvd_fail("mvd_mse_loss: bad argument");
@@ -340,7 +366,39 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)Bv * u.context_dim)), dim3(256), 0, s, clip, TN,
                      u.context_dim, copies, ctx, tt, timestep);
   HIP_CHECK_RET(hipGetLastError());
+  static const bool dbg_vol = getenv("MVD_DEBUG_VOLUME") != nullptr;  // investigation aid: is the volume modified during the UNet?
+  std::vector<float> vol_before;
+  const size_t vol_n = (size_t)c->v.spatial_volume_size * c->v.spatial_volume_size * c->v.spatial_volume_size * 64;
+  if (dbg_vol) {
+    hipDeviceSynchronize();
+    vol_before.resize(vol_n);
+    hipMemcpy(vol_before.data(), c->volume, vol_n * 4, hipMemcpyDeviceToHost);
+  }
   RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s, &produce));
+  if (dbg_vol) {
+    hipDeviceSynchronize();
+    std::vector<float> vol_after(vol_n);
+    hipMemcpy(vol_after.data(), c->volume, vol_n * 4, hipMemcpyDeviceToHost);
+    size_t ndiff = 0, first = 0, last = 0;
+    for (size_t i = 0; i < vol_n; ++i)
+      if (memcmp(&vol_before[i], &vol_after[i], 4)) {
+        if (!ndiff) first = i;
+        last = i;
+        ++ndiff;
+      }
+    fprintf(stderr, "[volume] %zu of %zu floats changed during the UNet call (first %zu, last %zu); volume=%p workspace=[%p, %p)\n", ndiff,
+            vol_n, first, last, (void*)c->volume, (void*)c->ws.base, (void*)(c->ws.base + c->ws.size));
+    if (ndiff) {
+      fprintf(stderr, "[volume] sample:");
+      size_t shown = 0;
+      for (size_t i = first; i <= last && shown < 12; ++i)
+        if (memcmp(&vol_before[i], &vol_after[i], 4)) {
+          fprintf(stderr, " [%zu] %g->%g", i, vol_before[i], vol_after[i]);
+          ++shown;
+        }
+      fprintf(stderr, "\n");
+    }
+  }
   RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));
   const size_t n = (size_t)TN * 4 * HW;
   RET_IF(launch_cfg_ddim(eps_nchw, cfg ? eps_nchw + n : nullptr, cfg_scale, x_noisy, noise, sqrt_one_minus_at, sqrt_at,

@@ -234,6 +234,21 @@ struct mvd_ctx {
   LinW film_t, film_v, enc_t, enc_v;
   int film_total = 0, film_off[9] = {0};
 
+  // training slice (engine_train.hip): fp32 master copies of the parameters it differentiates, their gradients, and the tape
+  // (input of the last DepthTransformer + the UNet's final hidden state of the last forward)
+  std::map<std::string, RawTensor> train_w, train_g;
+  std::string train_prefix;
+  float* tape_x = nullptr;
+  float* tape_h = nullptr;
+  int tape_B = 0, tape_valid = 0;
+
+  struct DbgBuf {
+    std::string name;
+    const void* p;
+    size_t bytes;
+  };
+  std::vector<DbgBuf> dbg;  // MVD_DEBUG_SUM: buffers to checksum at the end of the forward (investigation aid)
+
   Workspace ws;
   // per-sample, step-invariant tables.  `mesh` / `cams` / `n_cams` are the ACTIVE sample's; mvd_select_sample parks them
   // in `slots[cur_slot]` and activates another slot, so a batch of B samples keeps B sets resident across the steps
@@ -270,6 +285,11 @@ struct Ctx5 {  // channels-last context volume of one level for the first n_ctx 
 typedef std::function<int(hipStream_t)> CtxProducer;
 int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
                 int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce = nullptr);
+// engine_train.hip
+int engine_train_keep(mvd_ctx* c);
+int engine_tape_enable(mvd_ctx* c, int max_batch);
+int engine_tape_record(mvd_ctx* c, const float* x, int ldx, const float* h, int ldh, int Bv, hipStream_t s);
+int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, const float* ctx0_ncdhw, int B, int D, hipStream_t s);
 // engine_cond.hip
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,

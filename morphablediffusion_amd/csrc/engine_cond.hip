@@ -395,6 +395,16 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   WS_CHECK(gath && tmp && a && pre && up);
   RET_IF(launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
                                c->v.spatial_volume_length, c->v.projection == 0, gath, s));
+  static const bool dbg_sum = getenv("MVD_DEBUG_SUM") != nullptr;
+  if (dbg_sum) {
+    const int V = c->v.spatial_volume_size;
+    c->dbg.push_back({"volume", c->volume, (size_t)V * V * V * 64 * 4});
+    c->dbg.push_back({"gath", gath, vox(0) * 64 * 2});
+    c->dbg.push_back({"film", pre, (size_t)TN * c->film_total * 4});
+    c->dbg.push_back({"x1", x[1], vox(1) * fd[1] * 4});
+    c->dbg.push_back({"x2", x[2], vox(2) * fd[2] * 4});
+    c->dbg.push_back({"x3", x[3], vox(3) * fd[3] * 4});
+  }
   GemmArgs g;
   g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = x[0]; g.ldc = fd[0];
   RET_IF(run_conv3d(c, g, TN, D0, S0, S0, 1, s));

@@ -667,6 +667,13 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       cs = c->side;
     }
     f.ctx_side = use_side;
+    // investigation aids (tools/det_fork2.sh)
+    static const bool x_sync = getenv("MVD_FORK_SYNC") != nullptr;
+    static const long x_pad = getenv("MVD_FORK_PAD_MB") ? atol(getenv("MVD_FORK_PAD_MB")) : 0;
+    static const long x_side_spin = getenv("MVD_SIDE_SPIN") ? atol(getenv("MVD_SIDE_SPIN")) : 0;
+    if (x_sync) hipStreamSynchronize(s);
+    if (x_pad) WS_CHECK(c->ws.alloc((size_t)x_pad << 20));
+    if (x_side_spin && use_side) RET_IF(launch_spin(x_side_spin, c->side));
     if (produce) {
       // the producer's scratch is freed scope by scope on the host while the side stream may still be using it: keep it
       // allocated until this forward's own scope ends (after the join)
@@ -715,6 +722,13 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
       f.cn_pre[k] = cn;
     }
+    return 0;
+  };
+  auto after_fork = [&]() -> int {  // investigation aids
+    static const long x_pad2 = getenv("MVD_POSTFORK_PAD_MB") ? atol(getenv("MVD_POSTFORK_PAD_MB")) : 0;
+    static const long x_main_spin = getenv("MVD_MAIN_SPIN") ? atol(getenv("MVD_MAIN_SPIN")) : 0;
+    if (x_pad2) WS_CHECK(c->ws.alloc((size_t)x_pad2 << 20));
+    if (x_main_spin) RET_IF(launch_spin(x_main_spin, s));
     return 0;
   };
   if (!produce) RET_IF(fork_ctx());
@@ -796,6 +810,8 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
         int level = 0;
         for (int r = u.image_size; r > H; r >>= 1) ++level;
         RET_IF(do_cond(f, *cond, cur, o, H, W, level, (int)(cond - c->conds.data())));
+        if (c->tape_B && cond == &c->conds.back())  // training tape: input and output of the last DepthTransformer
+          RET_IF(engine_tape_record(c, cur.p, cur.ld, o.p, o.ld, Bv, s));
       } else {
         RET_IF(do_op(f, ops[k], cur, o, H, W));
       }
@@ -817,7 +833,10 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.C = in_ch[j];
     RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
     cur = dst;
-    if (!forked && (H < u.image_size || j == nb - 1)) RET_IF(fork_ctx());
+    if (!forked && (H < u.image_size || j == nb - 1)) {
+      RET_IF(fork_ctx());
+      RET_IF(after_fork());
+    }
   }
   {
     View dst;
@@ -851,6 +870,58 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     GemmArgs g;
     g.a = a; g.lda = mc * wx; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
     RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));
+  }
+  static const bool dbg_sum = getenv("MVD_DEBUG_SUM") != nullptr;  // investigation aid: which buffers differ between repeats?
+  if (dbg_sum) {
+    hipStreamSynchronize(s);
+    if (c->side) hipStreamSynchronize(c->side);
+    unsigned long long* d = ws_alloc<unsigned long long>(c, 1);
+    WS_CHECK(d);
+    auto sum = [&](const void* p, size_t bytes) -> unsigned long long {
+      unsigned long long h = 0;
+      if (!p || launch_bits_checksum(p, bytes, d, s)) return 0;
+      hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+      return h;
+    };
+    static std::vector<unsigned short> gath_ref;  // first call's frustum gather output: where do later calls differ?
+    for (auto& b : c->dbg)
+      if (b.name == "gath") {
+        std::vector<unsigned short> cur(b.bytes / 2);
+        hipMemcpy(cur.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
+        if (gath_ref.empty()) gath_ref = cur;
+        else {
+          size_t nd = 0, first = 0, last = 0, zeros = 0;
+          for (size_t i = 0; i < cur.size(); ++i)
+            if (cur[i] != gath_ref[i]) {
+              if (!nd) first = i;
+              last = i;
+              ++nd;
+              zeros += cur[i] == 0;
+            }
+          fprintf(stderr, "[gath] %zu halfs differ from the first call (first %zu last %zu, %zu now zero)", nd, first, last, zeros);
+          size_t shown = 0;
+          for (size_t i = first; i <= last && nd && shown < 10; ++i)
+            if (cur[i] != gath_ref[i]) {
+              fprintf(stderr, " [%zu:pt %zu ch %zu] %04x->%04x", i, i / 64, i % 64, gath_ref[i], cur[i]);
+              ++shown;
+            }
+          fprintf(stderr, "\n");
+        }
+      }
+    fprintf(stderr, "[sum]");
+    for (auto& b : c->dbg) fprintf(stderr, " %s=%016llx", b.name.c_str(), sum(b.p, b.bytes));
+    c->dbg.clear();
+    for (int l = 0; l < 4 && src && n_ctx > 0; ++l) {
+      const int Dl = depth0 >> l, Sl = u.image_size >> l;
+      const size_t n = (size_t)n_ctx * Dl * Sl * Sl * u.volume_dims[l];
+      fprintf(stderr, " src%d=%016llx", l, sum(src[l].p, n * (src[l].f32 ? 4 : 2)));
+    }
+    for (size_t k2 = 0; k2 < c->conds.size() && k2 < 16; ++k2)
+      if (f.cn_pre[k2]) fprintf(stderr, " cn%zu=%016llx", k2, sum(f.cn_pre[k2], 64));  // first bytes only: cheap marker
+    for (int i = 0; i < nb; ++i)
+      fprintf(stderr, " cat%d=%016llx", i, sum(cat[i], (size_t)Bv * in_res[nb - 1 - i] * in_res[nb - 1 - i] * cat_C[i] * 4));
+    fprintf(stderr, " final=%016llx eps=%016llx\n", sum(final_h, (size_t)Bv * u.image_size * u.image_size * mc * 4),
+            sum(eps_nhwc, (size_t)Bv * u.image_size * u.image_size * u.out_channels * 4));
   }
   return 0;
 }

@@ -708,6 +708,7 @@ int engine_finalize(mvd_ctx* c) {
   if (has_unet) RET_IF(build_unet());
   c->has_unet = has_unet;
   RET_IF(apply_xp_policy(c));
+  RET_IF(engine_train_keep(c));
   // ---------------- Lightning-module step embedding (morphable_diffusion.py:452-458) ----------------
   if (has_step) {
     RET_IF(pack_lin(c, "time_embed.0.weight", "time_embed.0.bias", &c->step_te0));

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
   }
   const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;  // out of range for the resource: the hardware returns zeros, no memory access
 
   // per-lane source offsets: LDS position (row, pos = lane&7) receives source chunk pos ^ ((row>>1)&7)
   unsigned h_off[NH], w_off[NW];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     const int y = (rem / bx_per) * IH + hy - 1, x = (rem % bx_per) * IW + hx - 1;
     const bool ok = hp < HP && b < g.B && y >= 0 && y < H && x >= 0 && x < W;
     const unsigned pix = (unsigned)((b * H + y) * W + x);
-    h_off[i] = ((pix * (unsigned)g.lda + chunk * 8) * 2) | (0u - (unsigned)(!ok));
+    h_off[i] = ok ? (pix * (unsigned)g.lda + chunk * 8) * 2 : 0xFFFFFFFFu;
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     const int chunk = (lane & 7) ^ ((r >> 1) & 7);
     const int n = n0 + r;
     const bool ok = r < BN && n < N;
-    w_off[i] = (((unsigned)n * (unsigned)Cin + chunk * 8) * 2) | (0u - (unsigned)(!ok));
+    w_off[i] = ok ? ((unsigned)n * (unsigned)Cin + chunk * 8) * 2 : 0xFFFFFFFFu;
   }
   const unsigned tap_stride = (unsigned)N * (unsigned)Cin * 2;
 
@@ -110,9 +111,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     for (int i = 0; i < NH; ++i) {
       const int grp = wave + 8 * i;
       if (grp < HG) {
-        const unsigned inval = 0u - (unsigned)(h_off[i] == 0xFFFFFFFFu);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sHalo + buf * HALO_BYTES + grp * 1024), 16,
-                                                 (h_off[i] + cc * 128) | inval, 0, 0, 0);
+        const unsigned off = h_off[i] == 0xFFFFFFFFu ? OOB : h_off[i] + cc * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sHalo + buf * HALO_BYTES + grp * 1024), 16, off, 0, 0, 0);
       }
     }
   };
@@ -121,9 +121,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     for (int i = 0; i < NW; ++i) {
       const int grp = wave + 8 * i;
       if (grp < WGR) {
-        const unsigned inval = 0u - (unsigned)(w_off[i] == 0xFFFFFFFFu);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + stage * W_BYTES + grp * 1024), 16,
-                                                 (w_off[i] + tap * tap_stride + cc * 128) | inval, 0, 0, 0);
+        const unsigned off = w_off[i] == 0xFFFFFFFFu ? OOB : w_off[i] + tap * tap_stride + cc * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + stage * W_BYTES + grp * 1024), 16, off, 0, 0, 0);
       }
     }
   };

@@ -401,6 +401,30 @@ int launch_cfg_ddim(const float* eps_c, const float* eps_u, float scale, const f
   return 0;
 }
 
+// investigation aid (MVD_DEBUG_SUM): order-independent 64-bit checksum of a buffer's bit patterns
+__global__ void bits_checksum_kernel(const unsigned* __restrict__ p, size_t nwords, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+    a += (unsigned long long)p[i] * 0x9E3779B97F4A7C15ull + (i & 0xFFFF);
+  atomicAdd(out, a);
+}
+__global__ void spin_kernel(long cycles, int* sink) {
+  const long t0 = clock64();
+  while (clock64() - t0 < cycles) {}
+  if (sink && threadIdx.x == 9999) *sink = 1;
+}
+int launch_spin(long cycles, hipStream_t s) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, cycles, (int*)nullptr);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
+  hipMemsetAsync(out, 0, 8, s);
+  hipLaunchKernelGGL(bits_checksum_kernel, dim3(512), dim3(256), 0, s, (const unsigned*)p, bytes / 4, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, a, b, n);
   HIP_CHECK_RET(hipGetLastError());

@@ -217,6 +217,21 @@ class Engine:
         L.check(fn(self._ctx, L.ptr(f), L.ptr(out), _stream()))
         return out
 
+    # ---- training slice ---------------------------------------------------------
+    def train_tape(self, max_batch: int):
+        """mvd_train_tape: keep the last DepthTransformer's input and the final hidden state of the next unet_forward calls."""
+        L.check(self.lib.mvd_train_tape(self._ctx, int(max_batch)))
+
+    def backward_last_condition(self, dpred, ctx0):
+        """dpred [B,4,s,s] = dL/d(eps of the taped forward); ctx0 [B,Cc,D,s,s] = source_dict[s] that forward saw."""
+        dp, c0 = _f32(dpred, self.device), _f32(ctx0, self.device)
+        L.check(self.lib.mvd_train_backward_last_condition(self._ctx, L.ptr(dp), L.ptr(c0), dp.shape[0], c0.shape[2], _stream()))
+
+    def get_grad(self, key: str, shape):
+        out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))
+        return out
+
     def set_volume(self, volume):
         v = _f32(volume, self.device)
         L.check(self.lib.mvd_set_volume(self._ctx, L.ptr(v), _stream()))

@@ -55,6 +55,7 @@ class DepthWiseAttention(nn.Module):
         self.cfg.validate()
         self._engine: Optional[Engine] = None
         self._owns_engine = False
+        self._trainable = {}
 
     def bind(self, engine: Engine):
         self._engine = engine
@@ -66,6 +67,7 @@ class DepthWiseAttention(nn.Module):
             self._owns_engine = True
         from .spec import unet_manifest
         sd = {"model.diffusion_model." + k: v for k, v in state_dict.items()}
+        self._keep_trainable(state_dict)
         self._engine.expected_keys = lambda _sd: set(unet_manifest(self.cfg))
         inc = self._engine.load_state_dict(sd, strict=strict)
         n = len("model.diffusion_model.")
@@ -77,7 +79,29 @@ class DepthWiseAttention(nn.Module):
         return self._engine.unet_forward(x, timesteps, context, source_dict)
 
     def get_trainable_parameters(self):
-        return []  # inference engine: the conditioning blocks are not trainable here (training is a next-row item)
+        """attention.py:140-142: the parameters of middle_conditions and output_conditions, in the reference's registration
+        order.  fp32 master copies of the loaded tensors (nn.Parameter); ``backward_last_condition`` fills ``.grad`` of the
+        ones the built backward slice reaches (the last DepthTransformer), the others keep ``grad = None``."""
+        return list(self._trainable.values())
+
+    def _keep_trainable(self, sd, prefix=""):
+        from .spec import unet_manifest
+        self._trainable = {}
+        for k in unet_manifest(self.cfg, prefix=""):
+            if k.startswith(("middle_conditions.", "output_conditions.")) and prefix + k in sd:
+                self._trainable[k] = nn.Parameter(sd[prefix + k].detach().float().clone())
+        for k, p_ in self._trainable.items():
+            self.register_parameter(k.replace(".", "_"), p_)
+
+    def backward_last_condition(self, dpred, ctx0):
+        """Back-propagates dL/d(output of the last forward, run with the tape on) into the last DepthTransformer's parameters."""
+        eng = self._engine
+        eng.backward_last_condition(dpred, ctx0)
+        last = max(int(k.split(".")[1]) for k in self._trainable if k.startswith("output_conditions."))
+        pre = f"output_conditions.{last}."
+        for k, p_ in self._trainable.items():
+            if k.startswith(pre):
+                p_.grad = eng.get_grad("model.diffusion_model." + k, p_.shape).to(p_.device)
 
 
 class UNetWrapper(nn.Module):
@@ -252,6 +276,7 @@ class SyncMultiviewDiffusion(nn.Module):
         """generate_face.py:76 calls this with strict=False on ``ckpt['state_dict']``; returns torch's
         (missing_keys, unexpected_keys) pair w.r.t. the keys the denoising path consumes."""
         self.spatial_volume.invalidate()
+        self.model.diffusion_model._keep_trainable(state_dict, "model.diffusion_model.")
         return self.engine.load_state_dict(state_dict, strict=strict)
 
     def get_viewpoint_embedding(self, batch):
@@ -319,14 +344,17 @@ class SyncMultiviewDiffusion(nn.Module):
         x_noisy = ac.sqrt()[t].view(shape) * x_start + (1.0 - ac).sqrt()[t].view(shape) * noise
         return x_noisy, noise
 
-    def training_step(self, batch, prepared=None, time_steps=None, noise=None, target_index=None, drop_random=None):
+    def training_step(self, batch, prepared=None, time_steps=None, noise=None, target_index=None, drop_random=None,
+                      backward=False):
         """SyncMultiviewDiffusion.training_step (morphable_diffusion.py:520-549): FORWARD pass and loss in the HIP engine --
         random time steps, add_noise, one random target view per sample, the 32^3 volume from ALL noisy views (BatchNorm in
         train mode), one frustum volume per sample, the UNet with condition dropout, MSE against the injected noise.
         ``prepared`` = (x, clip_embed, input_info) replaces self.prepare(batch); the four random draws may be passed in
         (parity tests), otherwise they are drawn on the host in the reference's order (randint, randn_like, randint, rand) so
         that torch.manual_seed reproduces the reference's CPU stream.  Returns the loss (a device scalar, no autograd graph);
-        the prediction is kept in ``self.last_noise_predict``.  Backward pass: SURVEY 8(f) rank 2, see DESIGN.md."""
+        the prediction is kept in ``self.last_noise_predict``.  ``backward=True`` also runs the part of the backward pass that
+        exists (first slice): dL/dpred = 2 (pred - target) / numel through the output head into every
+        parameter of the last DepthTransformer -- ``.grad`` of those entries of get_trainable_parameters() is set."""
         dev = self.device
         x, clip_embed, input_info = self.prepare(batch) if prepared is None else prepared
         B, N = x.shape[:2]
@@ -351,9 +379,16 @@ class SyncMultiviewDiffusion(nn.Module):
         finally:
             self.train(was_training)
         ar = torch.arange(B, device=dev)[:, None]
+        if backward:
+            self.engine.train_tape(B)
         pred = self.model(x_noisy[ar, target_index][:, 0], time_steps, clip_, vf, xc, is_train=True, drop_random=drop_random)
         self.last_noise_predict = pred
-        return self.engine.mse_loss(noise[ar, target_index][:, 0].contiguous(), pred)
+        target = noise[ar, target_index][:, 0].contiguous()
+        loss = self.engine.mse_loss(target, pred)
+        if backward:
+            dpred = (pred - target) * (2.0 / pred.numel())  # d mean((t - p)^2) / dp
+            self.model.diffusion_model.backward_last_condition(dpred, vf[self.image_size // 8])  # vf: after the dropout
+        return loss
 
     def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):
         B, _, H, W = x_input.shape

@@ -413,6 +413,8 @@ def test_full_width_config_variants_properties(name, N, size, projection, nverts
     _, eps3 = run(max(1, bvn // 2))
     d = ((eps3 - eps).norm() / eps.norm()).item()
     print(f"[property] {name}: batch_view_num {bvn} vs {max(1, bvn // 2)}: eps relL2={d:.2e}")
-    assert d <= 5e-4
+    # another UNet batch means other tile / split-K choices (fp32 summation order, and with it a few fp16 operand roundings):
+    # the two runs differ by less than either differs from the reference (parity bound 1e-3)
+    assert d <= REL_L2
     assert not torch.allclose(eps[0, 0], eps[0, 1])
     m.engine.close()
