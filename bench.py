@@ -204,6 +204,7 @@ def main():
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
         projection=CFG["proj"], view_num=N_VIEWS, image_size=CFG["size"], cfg_scale=2.0, device=dev, workspace_gb=48.0)
     model.load_state_dict(W)
+    model.eval()  # generate_face.py:77
     sampler = model.sampler
     sampler.shard_views = world > 1
     if args.simulate_gpus and world == 1:

@@ -376,7 +376,12 @@ class Engine:
         z = _f32(z, self.device)
         B, _, h, w = z.shape
         out = torch.empty(B, 3, 8 * h, 8 * w, device=self.device)
-        L.check(self.lib.mvd_vae_decode(self._ctx, L.ptr(z), B, h, w, L.ptr(out), _stream()))
+        # chunks of at most 16 x 256^2 output pixels: the kernels address an operand with 32-bit byte offsets (4 GiB), and the
+        # widest decoder activation is 128 channels x 4 bytes per pixel
+        per = max(1, (16 * 256 * 256) // (64 * h * w))
+        for i in range(0, B, per):
+            zc = z[i:i + per].contiguous()
+            L.check(self.lib.mvd_vae_decode(self._ctx, L.ptr(zc), zc.shape[0], h, w, L.ptr(out[i:i + per]), _stream()))
         return out
 
     def clip_encode(self, x):

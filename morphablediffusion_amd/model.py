@@ -547,6 +547,9 @@ class SyncDDIMSampler:
         dev = x_local.device
         real = world > 1 and not self.simulate_world
         side = self.overlap and dev.type == "cuda"
+        # nn.Module semantics, as in the reference: in train mode the sparse CNN's BatchNorm layers use batch statistics
+        # (construct_spatial_volume, morphable_diffusion.py:253-254); callers that sample call .eval() (generate_face.py:77)
+        bn_train = bool(getattr(self.model.spatial_volume, "training", False))
         if side and self._comm is None:
             self._comm = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
         NL = x_local.shape[0]
@@ -568,7 +571,7 @@ class SyncDDIMSampler:
                 elif world > 1:  # --simulate-gpus: stand in for the other ranks' slices
                     for r in range(1, world):
                         vf_all[r * NL:(r + 1) * NL].copy_(vf_all[:NL])
-                eng.volume_from_fused(eng.fuse_vertex_features(vf_all, out=fused_buf), want_output=False)
+                eng.volume_from_fused(eng.fuse_vertex_features(vf_all, out=fused_buf), want_output=False, train=bn_train)
         else:
             fused = eng.vertex_features(x_local, t_embed, v_embed_local, local_idx, add_bias=(rank == 0))
             if dev.type == "cuda":  # persistent: the communication stream reads it after this call returns
@@ -577,7 +580,7 @@ class SyncDDIMSampler:
             def tail():
                 if real:
                     dist.all_reduce(fused)  # Nv*16 fp32, latency-bound
-                eng.volume_from_fused(fused, want_output=False)
+                eng.volume_from_fused(fused, want_output=False, train=bn_train)
         if not side:
             if dev.type == "cuda":
                 eng.set_volume_ready_event(None)

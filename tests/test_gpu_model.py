@@ -50,7 +50,7 @@ def make_model(ucfg, vcfg, N, workspace_gb=8.0, extra_weights=None, style="init"
     if extra_weights:
         W.update(extra_weights)
     m.load_state_dict(W)
-    return m
+    return m.eval()  # as generate_face.py:77 / the eval scripts do: BatchNorm running statistics in the sparse CNN
 
 
 def run_step(m, g, x_T, x_in, clip, ts, index, bvn, batch, noise, eps_rel=REL_L2):

@@ -112,7 +112,7 @@ class FakeEngine:
         acc = torch.zeros_like(vf_all[0])
         for v in range(vf_all.shape[0]): acc = acc + vf_all[v]  # fixed view order
         return acc / self.N + 0.5
-    def volume_from_fused(self, fused, want_output=True): self.fused = fused.clone()
+    def volume_from_fused(self, fused, want_output=True, train=False): self.fused = fused.clone()
     def denoise_views(self, x, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg, noise, coef, want_eps=False):
         s = self.fused.sum()
         out = x * coef[2] + s * 1e-3 + view_idx.float().view(-1, 1, 1, 1) * 1e-2

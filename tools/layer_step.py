@@ -19,6 +19,7 @@ W = seeded_state_dict(full_manifest(ucfg, vcfg), 7)
 model = SyncMultiviewDiffusion(unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
                                view_num=N_VIEWS, image_size=256, cfg_scale=2.0, workspace_gb=32.0)
 model.load_state_dict(W)
+model.eval()
 s = model.sampler
 if args.simulate_gpus:
     s.simulate_world = args.simulate_gpus
