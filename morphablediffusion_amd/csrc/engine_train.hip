@@ -117,6 +117,8 @@ int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, co
                           "proj_out.2.weight", "proj_out.3.weight", "proj_out.3.bias", "proj_out.5.weight"};
   for (const char* n : gnames)
     if (!grad_buf(c, P + n)) return mvd_fail("training backward: gradient buffer allocation failed");
+  for (const char* n : {"out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias"})  // the output head (finetune_unet=True)
+    if (!grad_buf(c, U + n)) return mvd_fail("training backward: gradient buffer allocation failed");
   auto G = [&](const char* n) { return c->train_g[P + n].d; };
   WsScope ws_scope(c);
   auto F = [&](size_t n) { return ws_alloc<float>(c, n); };
@@ -174,7 +176,17 @@ int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, co
   RET_IF(launch_nchw_to_nhwc(dpred_nchw, B, oc, HW, dpred, oc, oc, s));
   RET_IF(gemm(dpred, oc, 0, m_out, 9 * dim, 0, dcolo, R, 9 * dim, oc));            // dgrad of the output conv
   RET_IF(train_col2im3(dcolo, B, S, S, dim, da, s));
-  RET_IF(train_gn_bwd(Hh, da, B, HW, dim, 32, g_out, e_out, st_out, ACT_SILU, dh, nullptr, nullptr, t1, t2, s));
+  RET_IF(train_gn_bwd(Hh, da, B, HW, dim, 32, g_out, e_out, st_out, ACT_SILU, dh, c->train_g[U + "out.0.weight"].d,
+                      c->train_g[U + "out.0.bias"].d, t1, t2, s));
+  {  // the output conv's own weight / bias gradient: dW = dpred^T im2col(a), db = column sums of dpred
+    float* colo = dcolo;  // [R][9*dim]: the dgrad columns are consumed, the buffer is free again
+    float* mgo = F((size_t)oc * 9 * dim);
+    WS_CHECK(mgo);
+    RET_IF(train_im2col3(aout, B, S, S, dim, colo, s));
+    RET_IF(gemm(dpred, oc, 1, colo, 9 * dim, 0, mgo, oc, 9 * dim, R));
+    RET_IF(train_perm_w3(mgo, oc, dim, 0, c->train_g[U + "out.2.weight"].d, s));
+    RET_IF(train_colsum(dpred, R, oc, c->train_g[U + "out.2.bias"].d, s));
+  }
   // dh = dL/d(x + proj_out(.)): second conv3x3 of proj_out
   RET_IF(gemm(dh, dim, 1, col2, 9 * I, 0, mg, dim, 9 * I, R));                      // wgrad [dim][9][I]
   RET_IF(train_perm_w3(mg, dim, I, 0, G("proj_out.5.weight"), s));

@@ -81,6 +81,14 @@ def test_training_step_gradients_of_last_depth_transformer_vs_reference():
         upstream = n.startswith(("proj_in.", "proj_context.", "depth_attn.to_q", "depth_attn.to_k"))
         assert rel <= (1.5e-2 if upstream else 1e-2), (n, rel)
     assert all(p.grad is None for k, p in tr.items() if not k.startswith("output_conditions.8."))  # not built yet: stated, not faked
+    # the output head (trainable under finetune_unet=True): out.0 (GroupNorm32) and out.2 (conv) gradients
+    for n in [str(x) for x in g["head_names"]]:
+        want_shape = [int(v) for v in g[f"gradout.{n}.shape"]]
+        got = m.engine.get_grad("model.diffusion_model.out." + n, want_shape).cpu()
+        a, b, _ = gi.unpack_compare(got, g, "gradout." + n)
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        print(f"[parity] grad out.{n}: relL2={rel:.2e}")
+        assert rel <= 1e-2, (n, rel)
     m.engine.close()
 
 

@@ -311,8 +311,11 @@ def test_training_step_loss_and_gradients():
     batch, x0, x_in, clip, ts, noise, ti, dr = _train_inputs(g)
     P = "model.diffusion_model.output_conditions.8."
     names = [str(n) for n in g["grad_names"]]
+    head = [str(n) for n in g["head_names"]]
     for n in names:
         W[P + n].requires_grad_(True)
+    for n in head:
+        W["model.diffusion_model.out." + n].requires_grad_(True)
     loss, pred = O.training_step(W, build_unet_plan(ucfg), vcfg, x0, x_in, clip, batch, ts, noise, ti, dr)
     pred.retain_grad()
     loss.backward()
@@ -321,5 +324,7 @@ def test_training_step_loss_and_gradients():
     check(pred.grad, g, "dpred", 1e-5)
     for n in names:
         check(W[P + n].grad, g, "grad." + n, 1e-3)
+    for n in head:
+        check(W["model.diffusion_model.out." + n].grad, g, "gradout." + n, 1e-3)
     m_clip, m_vol, m_cat = O.drop_masks(dr)
     assert m_clip.tolist() == [0, 1, 1, 1] and m_vol.tolist() == [0, 0, 1, 1] and m_cat.tolist() == [0, 1, 0, 1]

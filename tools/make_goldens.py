@@ -397,10 +397,16 @@ def gold_train(ns):
         assert p_.grad is not None and p_.grad.abs().max() > 0, n_
         packs["grad." + n_] = gi.pack(p_.grad, limit=1 << 18)
         names.append(n_)
-    print("train golden: loss", float(loss), "pred std", float(pred.std()), "grads:", len(names))
+    # the output head (openaimodel.py:717-721): trainable under finetune_unet=True (configs/facescape.yaml:10)
+    head = []
+    for n_, p_ in model.model.diffusion_model.out.named_parameters():
+        packs["gradout." + n_] = gi.pack(p_.grad, limit=1 << 18)
+        head.append(n_)
+    print("train golden: loss", float(loss), "pred std", float(pred.std()), "grads:", len(names), "+ head", head)
     save("train_small.npz", packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
                                     "target_index": target_index.numpy(), "drop_random": drop_random.numpy(),
-                                    "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names)})
+                                    "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names),
+                                    "head_names": np.array(head)})
 
 
 def gold_variants(ns):
