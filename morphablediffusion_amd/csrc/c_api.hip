@@ -366,39 +366,7 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)Bv * u.context_dim)), dim3(256), 0, s, clip, TN,
                      u.context_dim, copies, ctx, tt, timestep);
   HIP_CHECK_RET(hipGetLastError());
-  static const bool dbg_vol = getenv("MVD_DEBUG_VOLUME") != nullptr;  // investigation aid: is the volume modified during the UNet?
-  std::vector<float> vol_before;
-  const size_t vol_n = (size_t)c->v.spatial_volume_size * c->v.spatial_volume_size * c->v.spatial_volume_size * 64;
-  if (dbg_vol) {
-    hipDeviceSynchronize();
-    vol_before.resize(vol_n);
-    hipMemcpy(vol_before.data(), c->volume, vol_n * 4, hipMemcpyDeviceToHost);
-  }
   RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s, &produce));
-  if (dbg_vol) {
-    hipDeviceSynchronize();
-    std::vector<float> vol_after(vol_n);
-    hipMemcpy(vol_after.data(), c->volume, vol_n * 4, hipMemcpyDeviceToHost);
-    size_t ndiff = 0, first = 0, last = 0;
-    for (size_t i = 0; i < vol_n; ++i)
-      if (memcmp(&vol_before[i], &vol_after[i], 4)) {
-        if (!ndiff) first = i;
-        last = i;
-        ++ndiff;
-      }
-    fprintf(stderr, "[volume] %zu of %zu floats changed during the UNet call (first %zu, last %zu); volume=%p workspace=[%p, %p)\n", ndiff,
-            vol_n, first, last, (void*)c->volume, (void*)c->ws.base, (void*)(c->ws.base + c->ws.size));
-    if (ndiff) {
-      fprintf(stderr, "[volume] sample:");
-      size_t shown = 0;
-      for (size_t i = first; i <= last && shown < 12; ++i)
-        if (memcmp(&vol_before[i], &vol_after[i], 4)) {
-          fprintf(stderr, " [%zu] %g->%g", i, vol_before[i], vol_after[i]);
-          ++shown;
-        }
-      fprintf(stderr, "\n");
-    }
-  }
   RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));
   const size_t n = (size_t)TN * 4 * HW;
   RET_IF(launch_cfg_ddim(eps_nchw, cfg ? eps_nchw + n : nullptr, cfg_scale, x_noisy, noise, sqrt_one_minus_at, sqrt_at,

@@ -185,6 +185,5 @@ int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, in
                          const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s);
 int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V,
                           float vol_len, int persp, half_t* out, hipStream_t s);
-int launch_spin(long cycles, hipStream_t s);  // investigation aid: a one-wave kernel that spins for `cycles`
 int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);
 int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s);

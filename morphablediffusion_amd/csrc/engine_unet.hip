@@ -655,7 +655,9 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       // two-way handshake: the side stream starts after everything enqueued on the caller's stream so far, and the caller's
       // stream resumes only once the side stream has passed that point (without the acknowledgement the step
       // was not bit-reproducible in ~5 % of runs)
-      static const bool one_way = getenv("MVD_ONE_WAY_FORK") != nullptr;  // investigation aid (tools/det_fork.sh)
+      // MVD_ONE_WAY_FORK re-creates the round-1 non-determinism on demand (tools/det_fork.sh; the pad /
+      // spin / host-sync variants of that investigation are in the history: commit 88b2973)
+      static const bool one_way = getenv("MVD_ONE_WAY_FORK") != nullptr;
       HIP_CHECK_RET(hipEventRecord(c->ev_fork, s));
       HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_fork, 0));
       if (!one_way) {
@@ -667,13 +669,6 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       cs = c->side;
     }
     f.ctx_side = use_side;
-    // investigation aids (tools/det_fork2.sh)
-    static const bool x_sync = getenv("MVD_FORK_SYNC") != nullptr;
-    static const long x_pad = getenv("MVD_FORK_PAD_MB") ? atol(getenv("MVD_FORK_PAD_MB")) : 0;
-    static const long x_side_spin = getenv("MVD_SIDE_SPIN") ? atol(getenv("MVD_SIDE_SPIN")) : 0;
-    if (x_sync) hipStreamSynchronize(s);
-    if (x_pad) WS_CHECK(c->ws.alloc((size_t)x_pad << 20));
-    if (x_side_spin && use_side) RET_IF(launch_spin(x_side_spin, c->side));
     if (produce) {
       // the producer's scratch is freed scope by scope on the host while the side stream may still be using it: keep it
       // allocated until this forward's own scope ends (after the join)
@@ -722,13 +717,6 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
       f.cn_pre[k] = cn;
     }
-    return 0;
-  };
-  auto after_fork = [&]() -> int {  // investigation aids
-    static const long x_pad2 = getenv("MVD_POSTFORK_PAD_MB") ? atol(getenv("MVD_POSTFORK_PAD_MB")) : 0;
-    static const long x_main_spin = getenv("MVD_MAIN_SPIN") ? atol(getenv("MVD_MAIN_SPIN")) : 0;
-    if (x_pad2) WS_CHECK(c->ws.alloc((size_t)x_pad2 << 20));
-    if (x_main_spin) RET_IF(launch_spin(x_main_spin, s));
     return 0;
   };
   if (!produce) RET_IF(fork_ctx());
@@ -833,10 +821,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.C = in_ch[j];
     RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
     cur = dst;
-    if (!forked && (H < u.image_size || j == nb - 1)) {
-      RET_IF(fork_ctx());
-      RET_IF(after_fork());
-    }
+    if (!forked && (H < u.image_size || j == nb - 1)) RET_IF(fork_ctx());
   }
   {
     View dst;
@@ -883,31 +868,6 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
       return h;
     };
-    static std::vector<unsigned short> gath_ref;  // first call's frustum gather output: where do later calls differ?
-    for (auto& b : c->dbg)
-      if (b.name == "gath") {
-        std::vector<unsigned short> cur(b.bytes / 2);
-        hipMemcpy(cur.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
-        if (gath_ref.empty()) gath_ref = cur;
-        else {
-          size_t nd = 0, first = 0, last = 0, zeros = 0;
-          for (size_t i = 0; i < cur.size(); ++i)
-            if (cur[i] != gath_ref[i]) {
-              if (!nd) first = i;
-              last = i;
-              ++nd;
-              zeros += cur[i] == 0;
-            }
-          fprintf(stderr, "[gath] %zu halfs differ from the first call (first %zu last %zu, %zu now zero)", nd, first, last, zeros);
-          size_t shown = 0;
-          for (size_t i = first; i <= last && nd && shown < 10; ++i)
-            if (cur[i] != gath_ref[i]) {
-              fprintf(stderr, " [%zu:pt %zu ch %zu] %04x->%04x", i, i / 64, i % 64, gath_ref[i], cur[i]);
-              ++shown;
-            }
-          fprintf(stderr, "\n");
-        }
-      }
     fprintf(stderr, "[sum]");
     for (auto& b : c->dbg) fprintf(stderr, " %s=%016llx", b.name.c_str(), sum(b.p, b.bytes));
     c->dbg.clear();

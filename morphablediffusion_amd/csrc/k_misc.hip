@@ -408,16 +408,6 @@ __global__ void bits_checksum_kernel(const unsigned* __restrict__ p, size_t nwor
     a += (unsigned long long)p[i] * 0x9E3779B97F4A7C15ull + (i & 0xFFFF);
   atomicAdd(out, a);
 }
-__global__ void spin_kernel(long cycles, int* sink) {
-  const long t0 = clock64();
-  while (clock64() - t0 < cycles) {}
-  if (sink && threadIdx.x == 9999) *sink = 1;
-}
-int launch_spin(long cycles, hipStream_t s) {
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, cycles, (int*)nullptr);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
 int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
   hipMemsetAsync(out, 0, 8, s);
   hipLaunchKernelGGL(bits_checksum_kernel, dim3(512), dim3(256), 0, s, (const unsigned*)p, bytes / 4, out);

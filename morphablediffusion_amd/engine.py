@@ -81,21 +81,20 @@ class Engine:
             pass
 
     # ---- weights -------------------------------------------------------------------------------
-    def expected_keys(self, sd):
-        """Keys the engine consumes: the hot-path manifest (always) plus the VAE / CLIP groups present in ``sd``."""
-        from .spec import full_manifest
-        return set(full_manifest(self.ucfg, self.vcfg))
-
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False, expected=None):
         """Key-for-key upload of a reference state_dict (generate_face.py:75-76) and packing.  Like nn.Module it may be
         called again (another checkpoint, EMA weights): the context is rebuilt, so every call must carry the complete set.
-        Returns (missing_keys, unexpected_keys) w.r.t. the hot-path manifest; ``strict`` raises on either, as torch does.
+        Returns (missing_keys, unexpected_keys) w.r.t. ``expected`` (default: the hot-path manifest); ``strict`` raises on
+        either, as torch does.
         Keys outside the path (``num_batches_tracked``, schedule buffers, the CLIP text tower, ...) count as unexpected only
         under strict=True, exactly as they would for a module that does not declare them."""
         if self._loaded:  # packed weights are immutable: start from a fresh context
             self.close()
             self._create()
-        want = self.expected_keys(sd)
+        if expected is None:  # the hot-path manifest; a stand-alone UNet passes its own (DepthWiseAttention.load_state_dict)
+            from .spec import full_manifest
+            expected = full_manifest(self.ucfg, self.vcfg)
+        want = set(expected)
         have = {k for k, v in sd.items() if torch.is_tensor(v)}
         missing = sorted(want - have)
         side = ("first_stage_model.", "clip_image_encoder.")

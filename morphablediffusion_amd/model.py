@@ -68,8 +68,7 @@ class DepthWiseAttention(nn.Module):
         from .spec import unet_manifest
         sd = {"model.diffusion_model." + k: v for k, v in state_dict.items()}
         self._keep_trainable(state_dict)
-        self._engine.expected_keys = lambda _sd: set(unet_manifest(self.cfg))
-        inc = self._engine.load_state_dict(sd, strict=strict)
+        inc = self._engine.load_state_dict(sd, strict=strict, expected=unet_manifest(self.cfg))
         n = len("model.diffusion_model.")
         return type(inc)([k[n:] for k in inc.missing_keys], [k[n:] for k in inc.unexpected_keys])
 
@@ -90,8 +89,7 @@ class DepthWiseAttention(nn.Module):
         for k in unet_manifest(self.cfg, prefix=""):
             if k.startswith(("middle_conditions.", "output_conditions.")) and prefix + k in sd:
                 self._trainable[k] = nn.Parameter(sd[prefix + k].detach().float().clone())
-        for k, p_ in self._trainable.items():
-            self.register_parameter(k.replace(".", "_"), p_)
+        # deliberately NOT registered on the module: state_dict() stays what the reference's is (the engine owns the weights)
 
     def backward_last_condition(self, dpred, ctx0):
         """Back-propagates dL/d(output of the last forward, run with the tape on) into the last DepthTransformer's parameters."""
