@@ -81,14 +81,15 @@ __device__ __forceinline__ bool igemm_fast_epi(const IGemm& g) {
 }
 
 // bias / per-sample bias / residual / SiLU / store for 4 consecutive columns n..n+3 of GEMM row m
-__device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int n, float4 v) {
+// bs >= 0: the sample index of row m (for the per-sample bias), already known to the caller
+__device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int n, float4 v, int bs_known = -1) {
     v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
     if (g.bias) {
       const float4 b = *(const float4*)(g.bias + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
     if (g.rowbias) {
-      const int bs = m / (g.Z * g.Y * g.X);
+      const int bs = bs_known >= 0 ? bs_known : m / (g.Z * g.Y * g.X);
       const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
@@ -115,7 +116,7 @@ __device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int
 // rows4[i] / orow4[i]: GEMM row index m and output row of fragment row (lane>>3) + 8 i  (m < 0: skip)
 __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16& acc, float* scratch, int lane,
                                                     const int (&rows4)[4], const long (&orow4)[4], int n_base,
-                                                    float* partial) {
+                                                    float* partial, const int* bs4 = nullptr) {
   // C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[r];
@@ -132,7 +133,7 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
       *(float4*)(partial + (long)m * g.N + n) = v;
       continue;
     }
-    epilogue_vec4(g, m, orow4[i], n, v);
+    epilogue_vec4(g, m, orow4[i], n, v, bs4 ? bs4[i] : -1);
   }
 }
 
@@ -141,7 +142,7 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
 // first LDS transpose, so the residual reads of a 42 MB tensor are in flight together instead of one fragment at a time
 // behind each transpose (the in-situ conv ran ~20 us above its isolated time mostly for that).
 __device__ __forceinline__ void epilogue_prefetch(const IGemm& g, int lane, const int (&rows4)[4], const long (&orow4)[4],
-                                                  int n_base, float4 (&pre)[4]) {
+                                                  int n_base, float4 (&pre)[4], const int* bs4 = nullptr) {
   const int n = n_base + (lane & 7) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void epilogue_prefetch(const IGemm& g, int lane, cons
         p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
       }
       if (g.rowbias) {
-        const int bs = m / (g.Z * g.Y * g.X);
+        const int bs = bs4 ? bs4[i] : m / (g.Z * g.Y * g.X);
         const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
         p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
       }
@@ -218,6 +219,95 @@ __device__ __forceinline__ void epilogue_frag_store_raw(const IGemm& g, const f3
       h4 hv;
       hv[0] = (half_t)x.x; hv[1] = (half_t)x.y; hv[2] = (half_t)x.z; hv[3] = (half_t)x.w;
       *(h4*)((half_t*)g.out + orow4[i] * g.ldc + n) = hv;
+    }
+  }
+}
+
+// ---- fp16 output, linear rows, 8 columns per lane -------------------------------------------------------------
+// The store path is issue-bound (a wave's 8-byte stores move half the bytes per cycle of its 16-byte stores; measured
+// with tools/gemm_timeline.py: 4.7 us for the fp16 epilogue of a 256 x 160 tile, the same as for its fp32 epilogue), so
+// fp16 results leave as 16-byte stores: lane -> rows (lane >> 2) + 16 i (i = 0, 1), columns 8 (lane & 3) .. + 8.
+// m_w: GEMM row of the wave's fragment row 0; rows are output rows (out_linear), the sample of a row is
+// floor((m + 0.5) * inv_rps).  Needs ldc, ldr, rb_ld, out_split and the column count to be multiples of 8.
+__device__ __forceinline__ bool epilogue8_ok(const IGemm& g, int ncols) {
+  return !g.out_f32 && g.out_linear && !((g.ldc | ncols | g.out_split) & 7) && (!g.resid || !(g.ldr & 7)) &&
+         (!g.rowbias || !(g.rb_ld & 7));
+}
+
+__device__ __forceinline__ void frag_to_scratch(const f32x16& acc, float* scratch, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own writes are visible to its own reads
+}
+
+// every global load of one fragment's epilogue (bias + per-sample bias + residual), summed: issued for all fragments
+// of a tile before the first transpose, so they are in flight together
+__device__ __forceinline__ void epilogue8_prefetch(const IGemm& g, int lane, int m_w, int M, int n_base, float inv_rps,
+                                                   float (&pre)[2][8]) {
+  const int n = n_base + (lane & 3) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_w + (lane >> 2) + 16 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pre[i][e] = 0.f;
+    if (m >= M || n >= g.N) continue;
+    if (g.bias) {
+      const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+      pre[i][0] += b0.x; pre[i][1] += b0.y; pre[i][2] += b0.z; pre[i][3] += b0.w;
+      pre[i][4] += b1.x; pre[i][5] += b1.y; pre[i][6] += b1.z; pre[i][7] += b1.w;
+    }
+    if (g.rowbias) {
+      const float* rb = g.rowbias + (long)(int)(((float)m + 0.5f) * inv_rps) * g.rb_ld + n;
+      const float4 b0 = *(const float4*)rb, b1 = *(const float4*)(rb + 4);
+      pre[i][0] += b0.x; pre[i][1] += b0.y; pre[i][2] += b0.z; pre[i][3] += b0.w;
+      pre[i][4] += b1.x; pre[i][5] += b1.y; pre[i][6] += b1.z; pre[i][7] += b1.w;
+    }
+    if (g.resid) {
+      if (g.resid_f32) {
+        const float* rp = (const float*)g.resid + (long)m * g.ldr + n;
+        const float4 q0 = *(const float4*)rp, q1 = *(const float4*)(rp + 4);
+        pre[i][0] += q0.x; pre[i][1] += q0.y; pre[i][2] += q0.z; pre[i][3] += q0.w;
+        pre[i][4] += q1.x; pre[i][5] += q1.y; pre[i][6] += q1.z; pre[i][7] += q1.w;
+      } else {
+        const h8 q = *(const h8*)((const half_t*)g.resid + (long)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[i][e] += (float)q[e];
+      }
+    }
+  }
+}
+
+// RAW: v is final (GEGLU product, folded GroupNorm): plain transposed store into columns ncol_base + [0, 32) < ncols.
+// Otherwise out = act(acc * alpha + pre) with the optional [hi | lo | hi] split.
+template <bool RAW>
+__device__ __forceinline__ void epilogue8_frag_store(const IGemm& g, const f32x16& acc, float* scratch, int lane, int m_w,
+                                                     int M, int ncol_base, int ncols, const float (*pre)[8]) {
+  frag_to_scratch(acc, scratch, lane);
+  const int c8 = (lane & 3) * 8, n = ncol_base + c8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int fr = (lane >> 2) + 16 * i, m = m_w + fr;
+    if (m >= M || n >= ncols) continue;
+    const float4 a = *(const float4*)(scratch + fr * EPI_LD + c8), b = *(const float4*)(scratch + fr * EPI_LD + c8 + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if constexpr (!RAW) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = v[e] * g.alpha + pre[i][e];
+        if (g.act == ACT_SILU) v[e] = v[e] / (1.0f + __expf(-v[e]));
+      }
+    }
+    h8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+    half_t* p = (half_t*)g.out + (long)m * g.ldc + n;
+    *(h8*)p = hv;
+    if (!RAW && g.out_split) {
+      h8 lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = (half_t)(v[e] - (float)hv[e]);
+      *(h8*)(p + g.out_split) = lo;
+      *(h8*)(p + 2 * g.out_split) = hv;
     }
   }
 }

@@ -25,6 +25,21 @@ namespace {
 
 constexpr int GBM = 256, GNT = 512, GST = 3;
 
+#ifdef MVD_TIMELINE
+// investigation build only (make EXTRA=-DMVD_TIMELINE): per-workgroup phase timestamps of the last launch
+__device__ unsigned long long mvd_tl[16 * 4096];
+#define TL(i)                                                                                      \
+  do {                                                                                             \
+    if (tl_rep == MVD_TLREP - 1 && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) \
+      mvd_tl[blockIdx.x * 16 + (i)] = wall_clock64();                                               \
+  } while (0)
+#ifndef MVD_TLREP
+#define MVD_TLREP 1
+#endif
+#else
+#define TL(i)
+#endif
+
 [[maybe_unused]] __device__ __forceinline__ int swzg(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int N>
@@ -37,7 +52,11 @@ __device__ __forceinline__ void wait_vmg() {
 // walks `nch` consecutive tiles of the row-major tile grid, so long-M / short-K shapes stream A through the ring;
 // MODE 1 keeps only (sum, sumsq) of the accumulators per GroupNorm group and 256-row tile (nothing is stored),
 // MODE 2 stores relu(acc * rowscale[b][n] + rowbias[b][n]) in fp16.  Both need rows-per-sample % 256 == 0.
-template <int BN, int MODE = 0>
+// PLAIN (MODE 0 only): one centre tap, unit strides, linear input and output rows (every Linear layer and 1x1 conv): the
+// A offsets are m * lda, so the set-up has no integer division and the first loads go out a few hundred cycles after the
+// workgroup starts (a kernel's first pass over its code runs at instruction-fetch speed, ~0.7 us per KiB: measured
+// with tools/gemm_timeline.py, the general set-up cost 1.8 us per workgroup before the first load was issued).
+template <int BN, int MODE = 0, bool PLAIN = false>
 __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int FN = BN / 32;
@@ -50,6 +69,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MVD_TIMELINE
+#pragma unroll 1
+  for (int tl_rep = 0; tl_rep < MVD_TLREP; ++tl_rep) {
+  if (tl_rep) __syncthreads();
+#endif
+  TL(0);
   const int M = g.B * g.Z * g.Y * g.X, N = g.N, Cin = g.Cin;
   const int tiles_m = (M + GBM - 1) / GBM, tiles_n = (N + BN - 1) / BN;
   constexpr bool WALK = MODE != 0;  // tiles are walked in row-major order across row tiles too
@@ -94,7 +119,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     const int row = (wave + 8 * i) * 8 + (lane >> 3);
     a_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
-    if (m < M) {
+    if constexpr (PLAIN) {
+      ab[i] = az[i] = ay[i] = ax[i] = 0;
+      a_off[i] = (((unsigned)m * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(m >= M));
+    } else if (m < M) {
       const int x = m % g.X;
       int t = m / g.X;
       const int y = t % g.Y;
@@ -116,6 +144,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     w_off[i] = ((unsigned)row * (unsigned)Cin + w_ch[i] * 8) * 2;
   }
   const int cpt = (Cin + 63) / 64;  // k-steps per tap
+  [[maybe_unused]] const float inv_rps = 1.0f / (float)(g.Z * g.Y * g.X);
   unsigned w_slab = 0;              // byte offset of the current tap's weight slab
   auto set_tap = [&](int tap) {
     const int tu = __builtin_amdgcn_readfirstlane(tap);
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         }
         set_for = tmw;
       }
-    } else {
+    } else if constexpr (!PLAIN) {
       tap = ks / cpt;
       cc = ks - tap * cpt;
       if (tap != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
@@ -189,8 +218,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
       ++tn;
     }
   };
+  TL(6);
   if (nsteps > 0) {
     dma_step(p_tn, p_ks, 0);
+    TL(7);
     advance(p_tn, p_ks);
     if (nsteps > 1) {
       dma_step(p_tn, p_ks, 1);
@@ -201,6 +232,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     }
   }
   __builtin_amdgcn_s_barrier();
+  TL(1);
 
   int tn = tn_beg, ks = kbeg, stage = 0;
   h8 af[2], bf[2][FN];
@@ -217,6 +249,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     read_frags(0, af[0], bf[0]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+      if (s == 0 && kk == 1) TL(8);
+      if (s == 0 && kk == 2) TL(9);
+      if (s == 1 && kk == 1) TL(12);
+      if (s == 1 && kk == 2) TL(13);
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
@@ -243,12 +279,19 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
       }
     }
     // step s+1 must have landed before anyone reads it; only this step's own prefetch may stay in flight
+    if (s == 0) TL(10);
+    if (s == 1) TL(14);
     if (pf) wait_vmg<NA + NW_MIN>();
     else wait_vmg<0>();
+    if (s == 0) TL(11);
+    if (s == 1) TL(15);
     __builtin_amdgcn_s_barrier();
 
     const bool tile_done = ks + 1 == kend;
+    if (s == 0) TL(2);
+    if (s == 1) TL(3);
     if (tile_done) {
+      TL(4);
       // ---- epilogue of column tile tn; scratch = the ring slot just consumed (free until the next prefetch) ----
       int n0 = tn * BN;
       if constexpr (WALK) {
@@ -257,13 +300,20 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         n0 = (tn - tmw * tiles_n) * BN;
       }
       float* scratch = (float*)(smem + stage * STAGE + wave * EPI_WAVE_BYTES);
-      int rows4[4];
+      int rows4[4], bs4[4];
       long orow4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wave * 32 + (lane >> 3) + 8 * i;
         rows4[i] = m < M ? m : -1;
-        orow4[i] = m < M ? out_row_off(g, m, ozo, oyo, oxo) : 0;
+        if constexpr (PLAIN) {
+          orow4[i] = m < M ? m : 0;
+          // sample of row m: one float multiply (exact for m < 2^22; launch_gemm_dma checks), not four integer divisions
+          bs4[i] = g.rowbias ? (int)(((float)m + 0.5f) * inv_rps) : 0;
+        } else {
+          orow4[i] = m < M ? out_row_off(g, m, ozo, oyo, oxo) : 0;
+          bs4[i] = -1;
+        }
       }
       if constexpr (MODE == 1) {
         // statistics-only pass: (sum, sumsq) of the accumulators per GroupNorm group of this 256-row tile; nothing is
@@ -328,13 +378,26 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               v[r] = (acc[2 * p][r] * g.alpha + bx) * gelu_erf(acc[2 * p + 1][r] * g.alpha + bg);
-            epilogue_frag_store_raw(g, v, scratch, lane, rows4, orow4, (n0 >> 1) + p * 32, N >> 1);
+            if (PLAIN && epilogue8_ok(g, N >> 1))
+              epilogue8_frag_store<true>(g, v, scratch, lane, m0 + wave * 32, M, (n0 >> 1) + p * 32, N >> 1, nullptr);
+            else
+              epilogue_frag_store_raw(g, v, scratch, lane, rows4, orow4, (n0 >> 1) + p * 32, N >> 1);
           }
         }
       } else {
         float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
+        if (PLAIN && !part && epilogue8_ok(g, N)) {
+          float pre[FN][2][8];
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part);
+          for (int fn = 0; fn < FN; ++fn) epilogue8_prefetch(g, lane, m0 + wave * 32, M, n0 + fn * 32, inv_rps, pre[fn]);
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn)
+            epilogue8_frag_store<false>(g, acc[fn], scratch, lane, m0 + wave * 32, M, n0 + fn * 32, N, pre[fn]);
+        } else {  // (fp32 results: 16-byte stores already; prefetching their residual reads measured no gain)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn)
+            epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part, PLAIN ? bs4 : nullptr);
+        }
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j)
@@ -345,28 +408,43 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     advance(tn, ks);
     if (++stage == GST) stage = 0;
   }
+  TL(5);
+#ifdef MVD_TIMELINE
+  }
+#endif
 #endif
 }
 
-template <int BN, int MODE = 0>
+template <int BN, int MODE = 0, bool PLAIN = false>
 int launch_gd(const IGemm& g, int M, hipStream_t s) {
   constexpr int LDS = GST * (GBM * 128 + BN * 128);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
   bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    HIP_CHECK_RET(
+        hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, MODE, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int nch = g.nch > 0 ? g.nch : 1;
   const int gx = MODE ? cdiv(cdiv(M, GBM) * cdiv(g.N, BN), nch) : cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch);
   dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
-  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE>), grid, dim3(GNT), LDS, s, g);
+  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE, PLAIN>), grid, dim3(GNT), LDS, s, g);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 }  // namespace
+
+#ifdef MVD_TIMELINE
+extern "C" int mvd_debug_timeline(unsigned long long* host_out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mvd_tl), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(mvd_tl)) != hipSuccess) return -1;
+  return hipMemset(p, 0, sizeof(mvd_tl)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // eligibility: fp16 activations with 16-byte aligned rows and a vectorisable epilogue
 bool gemm_dma_eligible(const IGemm& g) {
@@ -423,6 +501,11 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
     if (!g.rowbias || g.out_f32) return mvd_fail("gemm_dma: the apply pass needs scale, shift and an fp16 output");
     return g.bn == 64 ? launch_gd<64, 2>(g, M, s) : launch_gd<128, 2>(g, M, s);
   }
-  const int r = g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
-  return r;  // split-K: the caller (igemm_go) runs launch_splitk_reduce
+  // split-K: the caller (igemm_go) runs launch_splitk_reduce
+  static const bool no_plain = getenv("MVD_NO_PLAIN") != nullptr;
+  const bool plain = !no_plain && g.npar == 0 && g.ntaps == 1 && g.tap[0] == igemm_tap(0, 0, 0, 0) && g.out_linear && g.ups == 0 &&
+                     g.sz == 1 && g.sy == 1 && g.sx == 1 && g.PZ == g.Z && g.PY == g.Y && g.PX == g.X && g.IZ == g.Z &&
+                     g.IY == g.Y && g.IX == g.X && M < (1 << 22);
+  if (plain) return g.bn == 160 ? launch_gd<160, 0, true>(g, M, s) : (g.bn == 64 ? launch_gd<64, 0, true>(g, M, s) : launch_gd<128, 0, true>(g, M, s));
+  return g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
 }
