@@ -108,7 +108,16 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   } else if (dense) {
     int nch = 1, sk2 = 1;
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
-    gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
+    static const bool old_plan = getenv("MVD_OLD_PLAN") != nullptr;
+    const bool plain_gemm = !g.gn_partial && !g.rowscale && g.ntaps == 1;
+    if (plain_gemm && !old_plan) {
+      int bn = 0;
+      gemm_dma_plan_us(M, g.N, ksteps, g.geglu, g.out_f32 ? 4 : (g.out_split ? 6 : 2), g.resid ? (g.resid_f32 ? 4 : 2) : 0, &bn,
+                       &nch, &sk2);
+      g.bn = bn;
+    } else {
+      gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
+    }
     if (g.gn_partial || g.rowscale) {  // folded-GroupNorm passes walk the whole tile grid: one round of workgroups
       if (g.bn == 160) g.bn = 128;
       const int tiles = cdiv(M, 256) * cdiv(g.N, g.bn);
@@ -117,9 +126,21 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
       force_splitk = 1;
     }
     sk = g.geglu ? 1 : (force_splitk > 0 ? force_splitk : sk2);
+    {  // sweeps (tools/gemm_plan_sweep.py): column-tile width and split of the next dense launches
+      static const int tune_bn = getenv("MVD_DENSE_BN") ? atoi(getenv("MVD_DENSE_BN")) : 0;
+      static const int tune_sk = getenv("MVD_DENSE_SK") ? atoi(getenv("MVD_DENSE_SK")) : 0;
+      if (tune_bn && !g.geglu && !g.gn_partial && !g.rowscale) {
+        g.bn = tune_bn;
+        gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
+        if (force_splitk <= 0) sk = sk2;
+      }
+      if (tune_sk && !g.geglu && force_splitk <= 0) sk = tune_sk;
+    }
     if (sk > ksteps) sk = ksteps;
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
     g.nch = sk > 1 ? 1 : nch;
+    static const bool plan_debug = getenv("MVD_PLAN_DEBUG") != nullptr;
+    if (plan_debug) fprintf(stderr, "[plan] M=%d N=%d ksteps=%d -> bn=%d nch=%d sk=%d\n", M, g.N, ksteps, g.bn, g.nch, sk);
   } else {
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);

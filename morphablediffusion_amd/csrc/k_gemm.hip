@@ -487,6 +487,61 @@ void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, in
   *splitk_out = best_sk;
 }
 
+// Column-tile width, column walk and split-K of a plain dense launch from a time model in microseconds, fitted to
+// tools/gemm_timeline.py / tools/gemm_plan_sweep.py (MI355X, one 256-row workgroup per CU):
+//   workgroup = 2.8 (first loads + the cold first k-step) + k-steps * t_step(bn) + tiles * t_epi,
+//   t_epi     = the round's result bytes at ~6 TB/s (every workgroup of a round stores at the same time), >= 2.5,
+//   split-K   = fp32 slabs written by the GEMM and read back by the reduce launch (its own ~5 us of launch and latency).
+// The k-step model above undervalued the slab traffic: e.g. 8192 x 2560 x 640 ran 63 us as 3 splits and 49 us unsplit.
+// out_b / res_b: bytes per result element stored and per residual element read (GEGLU: per paired column).
+void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out) {
+  const int CUS = 256;
+  const int tiles_m = cdiv(M, GBM);
+  double best = 1e30;
+  int best_bn = *bn_io, best_nch = 1, best_sk = 1;
+  const int cand[3] = {64, 128, 160};
+  for (int ci = 0; ci < 3; ++ci) {
+    const int bn = cand[ci];
+    if (geglu ? bn != 128 : (*bn_io < 0 && bn != -*bn_io)) continue;  // bn_io < 0: the caller fixes the width
+    const double t_step = bn == 64 ? 0.70 : (bn == 128 ? 1.05 : 1.25);
+    const int tiles_n = cdiv(N, bn);
+    const double tile_cols = geglu ? bn / 2 : bn;
+    for (int nch = 1; nch <= tiles_n; ++nch) {
+      const int wgs = tiles_m * cdiv(tiles_n, nch), rounds = cdiv(wgs, CUS);
+      const int in_round = wgs < CUS ? wgs : CUS;
+      double t_epi = in_round * 256.0 * tile_cols * (out_b + res_b) / 6e6;
+      if (t_epi < 2.5) t_epi = 2.5;
+      const double t = rounds * (2.8 + (double)nch * ksteps * t_step + nch * t_epi) + 2.0;
+      if (t < best) {
+        best = t;
+        best_bn = bn;
+        best_nch = nch;
+        best_sk = 1;
+      }
+    }
+    if (geglu) continue;
+    for (int sk = 2; sk <= 16 && sk * 2 <= ksteps; ++sk) {
+      const int per = cdiv(ksteps, sk), sk_eff = cdiv(ksteps, per);  // no empty split
+      if (sk_eff != sk) continue;
+      const int wgs = tiles_m * tiles_n * sk, rounds = cdiv(wgs, CUS);
+      const int in_round = wgs < CUS ? wgs : CUS;
+      double t_epi = in_round * 256.0 * bn * 4.0 / 6e6;
+      if (t_epi < 2.5) t_epi = 2.5;
+      const double mn = (double)M * N;
+      const double t = rounds * (2.8 + per * t_step + t_epi) + 2.0 + 5.0 + (sk * mn * 4.0 + mn * (out_b + res_b)) / 6e6;
+      if (t < best) {
+        best = t;
+        best_bn = bn;
+        best_nch = 1;
+        best_sk = sk;
+      }
+    }
+  }
+  *bn_io = best_bn;
+  *nch_out = best_nch;
+  *splitk_out = best_sk;
+}
+
 int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
   if (M <= 0 || g.N <= 0) return 0;
