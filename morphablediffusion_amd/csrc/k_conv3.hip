@@ -82,6 +82,16 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
   constexpr unsigned OOB = 0xFFFFFFFFu;  // out of range for the resource: the hardware returns zeros, no memory access
 
   // per-lane source offsets: LDS position (row, pos = lane&7) receives source chunk pos ^ ((row>>1)&7)
+  // block -> (sample, block row, block column) with a float reciprocal instead of integer divisions (exact far beyond the
+  // block counts that occur; a kernel's first pass over its code runs at instruction-fetch speed, and each runtime
+  // integer division is ~35 instructions of it)
+  const float inv_bpi = 1.0f / (float)bpi, inv_bxp = 1.0f / (float)bx_per;
+  auto block_pos = [&](int gb, int& b, int& by, int& bx) {
+    b = (int)(((float)gb + 0.5f) * inv_bpi);
+    const int rem = gb - b * bpi;
+    by = (int)(((float)rem + 0.5f) * inv_bxp);
+    bx = rem - by * bx_per;
+  };
   unsigned h_off[NH], w_off[NW];
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
@@ -89,9 +99,9 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     const int chunk = (lane & 7) ^ ((hp >> 1) & 7);
     const int j = hp / HPB, hr = hp - j * HPB;
     const int hy = hr / HW_, hx = hr - hy * HW_;
-    const int gb = tm * NI + j;
-    const int b = gb / bpi, rem = gb - b * bpi;
-    const int y = (rem / bx_per) * IH + hy - 1, x = (rem % bx_per) * IW + hx - 1;
+    int b, by, bx;
+    block_pos(tm * NI + j, b, by, bx);
+    const int y = by * IH + hy - 1, x = bx * IW + hx - 1;
     const bool ok = hp < HP && b < g.B && y >= 0 && y < H && x >= 0 && x < W;
     const unsigned pix = (unsigned)((b * H + y) * W + x);
     h_off[i] = ok ? (pix * (unsigned)g.lda + chunk * 8) * 2 : 0xFFFFFFFFu;
@@ -219,17 +229,18 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
   if (igemm_fast_epi(g)) {
     float* scratch = (float*)(smem + (tid >> 6) * EPI_WAVE_BYTES);
     float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
-    int rows4[4];
+    int rows4[4], bs4[4];
     long orow4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pp = (tid >> 6) * 32 + (lane >> 3) + 8 * i;
       const int j = pp / (IW * IH), rr = pp - j * (IW * IH);
-      const int gb = tm * NI + j;
-      const int b = gb / bpi, rem = gb - b * bpi;
-      const int y = (rem / bx_per) * IH + rr / IW, x = (rem % bx_per) * IW + rr % IW;
+      int b, by, bx;
+      block_pos(tm * NI + j, b, by, bx);
+      const int y = by * IH + rr / IW, x = bx * IW + rr % IW;
       rows4[i] = b < g.B ? (b * H + y) * W + x : -1;
       orow4[i] = rows4[i];
+      bs4[i] = b < g.B ? b : 0;
     }
     if (part) {
 #pragma unroll
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     } else {
       float4 pre[FN][4];  // all bias / residual loads of the tile in flight before the first transpose
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) epilogue_prefetch(g, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
+      for (int fn = 0; fn < FN; ++fn) epilogue_prefetch(g, lane, rows4, orow4, n0 + fn * 32, pre[fn], bs4);
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) epilogue_frag_store_pre(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
     }
@@ -248,10 +259,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
   for (int r = 0; r < 16; ++r) {
     const int pp = (tid >> 6) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int j = pp / (IW * IH), rr = pp - j * (IW * IH);
-    const int gb = tm * NI + j;
-    const int b = gb / bpi, rem = gb - b * bpi;
+    int b, by, bx;
+    block_pos(tm * NI + j, b, by, bx);
     if (b >= g.B) continue;
-    const int y = (rem / bx_per) * IH + rr / IW, x = (rem % bx_per) * IW + rr % IW;
+    const int y = by * IH + rr / IW, x = bx * IW + rr % IW;
     const int m = (b * H + y) * W + x;
     if (g.splitk > 1) {
       float* part = g.partial + (long)blockIdx.y * M * N;

@@ -288,16 +288,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
   const int N = g.N;
   const long total = (long)M * N;
   if (igemm_fast_epi(g)) {  // 16-byte path: 4 consecutive columns per thread
-    const long total4 = total >> 2;
-    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
-      const long idx = i4 << 2;
-      const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+    // (row, column quad) advance incrementally (one 32-bit division per thread, none per element); the slabs of a quad are
+    // loaded four at a time before they are added, in slab order (the sum is the same as a serial loop's)
+    const int N4 = N >> 2, total4 = (int)(total >> 2), stride = gridDim.x * blockDim.x;
+    int i4 = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = i4 / N4, q = i4 - m * N4;
+    const int dm = stride / N4, dq = stride - dm * N4;
+    const float inv_rps = 1.0f / (float)(g.Z * g.Y * g.X);
+    const bool fast_bs = M < (1 << 22);
+    for (; i4 < total4; i4 += stride) {
+      const long idx = (long)i4 << 2;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < g.splitk; ++s) {
-        const float4 q = *(const float4*)(g.partial + (long)s * total + idx);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      for (int s0 = 0; s0 < g.splitk; s0 += 4) {
+        float4 qv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sj = min(s0 + j, g.splitk - 1);
+          qv[j] = *(const float4*)(g.partial + (long)sj * total + idx);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (s0 + j < g.splitk) {
+            v.x += qv[j].x; v.y += qv[j].y; v.z += qv[j].z; v.w += qv[j].w;
+          }
       }
-      epilogue_vec4(g, m, out_row(g, m), n, v);
+      epilogue_vec4(g, m, out_row(g, m), q << 2, v, fast_bs ? (int)(((float)m + 0.5f) * inv_rps) : -1);
+      m += dm;
+      q += dq;
+      if (q >= N4) {
+        q -= N4;
+        ++m;
+      }
     }
     return;
   }

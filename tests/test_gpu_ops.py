@@ -154,7 +154,7 @@ def test_group_norm(eng, B, C, HW, G, eps, act):
     close(eng.op_group_norm(x, G, g, b, eps, act), want, f"group_norm C={C} HW={HW} G={G} act={act}")
 
 
-@pytest.mark.parametrize("rows,C", [(257, 320), (64, 1280), (1000, 64)])
+@pytest.mark.parametrize("rows,C", [(257, 320), (64, 1280), (1000, 64), (1030, 640), (33, 1280), (4096, 320)])
 def test_layer_norm(eng, rows, C):
     x = rnd(rows, C) * 3.0 - 0.5
     g, b = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
