@@ -218,6 +218,9 @@ int mvd_probe_report(mvd_ctx* ctx, char* buf, size_t cap);
 /* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,
  * 4 = GEGLU epilogue */
 int mvd_bench_linear(mvd_ctx* ctx, int M, int K, int N, int flags, int iters, float* ms_out, void* stream);
+/* same for GroupNorm(groups) + SiLU of a channels-last fp32 [B, HW, C] tensor -> fp16 (split: the [hi | lo | hi] operand
+ * of an extended-precision consumer); flags: 1 = split output */
+int mvd_bench_group_norm(mvd_ctx* ctx, int B, int C, int HW, int groups, int flags, int iters, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

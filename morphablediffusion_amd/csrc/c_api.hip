@@ -664,4 +664,37 @@ int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, floa
   return 0;
 }
 
+int mvd_bench_group_norm(mvd_ctx* c, int B, int C, int HW, int groups, int flags, int iters, float* ms_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const size_t n = (size_t)B * HW * C;
+  const int split = flags & 1, wo = split ? 3 : 1;
+  float* x = ws_alloc<float>(c, n);
+  half_t* tmp = ws_alloc<half_t>(c, n);
+  half_t* y = ws_alloc<half_t>(c, n * wo);
+  float* gb = ws_alloc<float>(c, (size_t)2 * C);
+  WS_CHECK(x && tmp && y && gb);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(n)), dim3(256), 0, s, tmp, n, 29u);
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(n)), dim3(256), 0, s, tmp, x, n);
+  hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk((size_t)2 * C)), dim3(256), 0, s, tmp, (size_t)2 * C, 5u);
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)2 * C)), dim3(256), 0, s, tmp, gb, (size_t)2 * C);
+  NormW nw;
+  nw.g = gb; nw.b = gb + C; nw.C = C;
+  RET_IF(run_group_norm(c, x, C, B, HW, nw, groups, 1e-5f, ACT_SILU, nullptr, y, C * wo, s, 0, split));  // warm-up
+  hipEvent_t e0, e1;
+  HIP_CHECK_RET(hipEventCreate(&e0));
+  HIP_CHECK_RET(hipEventCreate(&e1));
+  HIP_CHECK_RET(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) RET_IF(run_group_norm(c, x, C, B, HW, nw, groups, 1e-5f, ACT_SILU, nullptr, y, C * wo, s, 0, split));
+  HIP_CHECK_RET(hipEventRecord(e1, s));
+  HIP_CHECK_RET(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_out = ms / (float)iters;
+  return 0;
+}
+
 }  // extern "C"

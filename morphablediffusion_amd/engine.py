@@ -356,6 +356,11 @@ class Engine:
         L.check(self.lib.mvd_bench_linear(self._ctx, M, K, N, flags, iters, C.byref(ms), _stream()))
         return ms.value
 
+    def bench_group_norm(self, B, Cc, HW, groups=32, split=False, iters=20):
+        ms = C.c_float(0)
+        L.check(self.lib.mvd_bench_group_norm(self._ctx, B, Cc, HW, groups, 1 if split else 0, iters, C.byref(ms), _stream()))
+        return ms.value
+
     def probe_config(self, mode, family=None, stride=1):
         """mvd_probe_config: 0 off, 1 every launch of every kernel family, 2 a 1-in-stride sample of ``family``."""
         L.check(self.lib.mvd_probe_config(self._ctx, int(mode), None if family is None else family.encode(), int(stride)))

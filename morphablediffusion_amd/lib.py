@@ -15,7 +15,7 @@ SYMBOLS = [
     "mvd_embed_time", "mvd_select_sample", "mvd_set_mesh", "mvd_set_cameras", "mvd_vertex_features", "mvd_vertex_view_features", "mvd_fuse_vertex_features",
     "mvd_set_volume_ready_event", "mvd_volume_from_fused", "mvd_volume_from_fused_train", "mvd_mse_loss", "mvd_set_volume", "mvd_train_tape", "mvd_train_backward_last_condition", "mvd_train_get_grad",
     "mvd_frustum_volumes", "mvd_denoise_views", "mvd_op_conv", "mvd_op_linear", "mvd_op_group_norm",
-    "mvd_op_layer_norm", "mvd_op_attention", "mvd_op_conv3d", "mvd_bench_conv", "mvd_bench_linear", "mvd_probe_config", "mvd_probe_report", "mvd_vae_decode", "mvd_vae_encode",
+    "mvd_op_layer_norm", "mvd_op_attention", "mvd_op_conv3d", "mvd_bench_conv", "mvd_bench_linear", "mvd_bench_group_norm", "mvd_probe_config", "mvd_probe_report", "mvd_vae_decode", "mvd_vae_encode",
     "mvd_clip_encode", "mvd_clip_embed_dim",
 ]
 
