@@ -162,9 +162,9 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 
   // step stream: (column tile, k) with k = tap * cpt + cc; the ring treats the whole walk as one stream
   int set_for = -1;
-  auto dma_step = [&](int tile, int ks, int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sW = sA + A_BYTES;
+  int d_kb = 0, d_n0 = 0;  // k offset, first column and weight base of the step being loaded
+  unsigned d_wbase = 0;
+  auto dma_prepare = [&](int tile, int ks) {
     int tn = tile, tap = 0, cc = ks;
     if constexpr (WALK) {  // linear rows, one tap: the A offsets follow the row tile
       const int tmw = tile / tiles_n;
@@ -185,23 +185,35 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         set_for = tap;
       }
     }
-    const int kb = cc * 64;
+    d_kb = cc * 64;
+    d_n0 = tn * BN;
+    d_wbase = w_slab + (unsigned)d_n0 * (unsigned)Cin * 2 + d_kb * 2;
+  };
+  // piece p of a stage: p < NA -> 8 A rows, else 8 W rows (one 1 KiB DMA instruction per wave)
+  auto dma_piece = [&](int p, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sW = sA + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const unsigned inval = (0u - (unsigned)(a_off[i] == 0xFFFFFFFFu)) | (0u - (unsigned)(kb + a_ch[i] * 8 >= Cin));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sA + (wave + 8 * i) * 1024), 16, (a_off[i] + kb * 2) | inval, 0,
-                                               0, 0);
-    }
-    const int n0 = tn * BN;
-    const unsigned wbase = w_slab + (unsigned)n0 * (unsigned)Cin * 2 + kb * 2;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int grp = wave + 8 * i;
-      if (grp < WGR) {
-        const unsigned inval = (0u - (unsigned)(n0 + w_row[i] >= N)) | (0u - (unsigned)(kb + w_ch[i] * 8 >= Cin));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + grp * 1024), 16, (w_off[i] + wbase) | inval, 0, 0, 0);
+    for (int i = 0; i < NA; ++i)
+      if (p == i) {
+        const unsigned inval = (0u - (unsigned)(a_off[i] == 0xFFFFFFFFu)) | (0u - (unsigned)(d_kb + a_ch[i] * 8 >= Cin));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sA + (wave + 8 * i) * 1024), 16, (a_off[i] + d_kb * 2) | inval,
+                                                 0, 0, 0);
       }
-    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (p == NA + i) {
+        const int grp = wave + 8 * i;
+        if (grp < WGR) {
+          const unsigned inval = (0u - (unsigned)(d_n0 + w_row[i] >= N)) | (0u - (unsigned)(d_kb + w_ch[i] * 8 >= Cin));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + grp * 1024), 16, (w_off[i] + d_wbase) | inval, 0, 0, 0);
+        }
+      }
+  };
+  auto dma_step = [&](int tile, int ks, int stage) {
+    dma_prepare(tile, ks);
+#pragma unroll
+    for (int p = 0; p < NA + NW; ++p) dma_piece(p, stage);
   };
 
   f32x16 acc[FN];
@@ -268,6 +280,18 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef MVD_DMA_SPREAD
+      if (pf) {  // experiment: the step's DMA instructions spread over the four kk blocks
+        int st2 = stage + 2;
+        if (st2 >= GST) st2 -= GST;
+        constexpr int NP = NA + NW, PER = (NP + 3) / 4;
+        if (kk == 0) dma_prepare(p_tn, p_ks);
+#pragma unroll
+        for (int p = kk * PER; p < (kk + 1) * PER && p < NP; ++p) dma_piece(p, st2);
+        if (kk == 3) advance(p_tn, p_ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       if (kk == 1 && pf) {
         // into the ring slot that was read at step s-1 (all waves passed the barrier that ended it); mid-step, so the
         // DMA address set-up does not delay the first fragment reads of the step (see k_conv3.hip)
@@ -277,6 +301,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         advance(p_tn, p_ks);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
     // step s+1 must have landed before anyone reads it; only this step's own prefetch may stay in flight
     if (s == 0) TL(10);

@@ -28,7 +28,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
+// PLAIN: one centre tap, unit strides, linear input and output rows (Linear layers, 1x1 convs): no integer division in the
+// set-up or the epilogue (see k_gemm.hip: the first pass over a kernel's code runs at instruction-fetch speed).
+template <bool A_F32, int BN, int WAVES_M, int WAVES_N, bool PLAIN = false>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave sub-tile
   constexpr int FM = WM / 32, FN = WN / 32;             // 32x32 fragments per wave
@@ -65,7 +67,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
-    if (m < M) {
+    if constexpr (PLAIN) {
+      ab[i] = m < M ? 0 : -1;
+      az[i] = ay[i] = 0;
+      ax[i] = m;
+    } else if (m < M) {
       int x = m % g.X;
       int t = m / g.X;
       int y = t % g.Y;
@@ -96,6 +102,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     const int wslab = ti >> 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if constexpr (PLAIN) {
+        a_off[i] = (((unsigned)ax[i] * (unsigned)g.lda + chunk * 8) * ESZ) | (0u - (unsigned)(ab[i] < 0));
+        continue;
+      }
       const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
       const bool ok = ab[i] >= 0 && iz >= 0 && iz < g.IZ && iy >= 0 && iy < g.IY && ix >= 0 && ix < g.IX;
       const unsigned pix = (unsigned)(((ab[i] * g.PZ + (iz >> g.ups)) * g.PY + (iy >> g.ups)) * g.PX + (ix >> g.ups));
@@ -206,23 +216,30 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   }
 
   // ---- epilogue ----
+  [[maybe_unused]] const float inv_rps = 1.0f / (float)(g.Z * g.Y * g.X);
   if (igemm_fast_epi(g)) {
     // all tile reads are done (the loop ends on a barrier): reuse the LDS as per-wave transpose scratch
     float* scratch = (float*)(smem + wave * EPI_WAVE_BYTES);
     float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
-      int rows4[4];
+      int rows4[4], bs4[4];
       long orow4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * WM + fm * 32 + (lane >> 3) + 8 * i;
         rows4[i] = m < M ? m : -1;
-        orow4[i] = m < M ? out_row(g, m) : 0;
+        if constexpr (PLAIN) {
+          orow4[i] = m < M ? m : 0;
+          bs4[i] = g.rowbias ? (int)(((float)m + 0.5f) * inv_rps) : 0;  // exact for m < 2^22 (launch_igemm checks)
+        } else {
+          orow4[i] = m < M ? out_row(g, m) : 0;
+          bs4[i] = -1;
+        }
       }
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn)
-        epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part);
+        epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part, PLAIN ? bs4 : nullptr);
     }
     return;
   }
@@ -334,18 +351,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IGemm g) {
   }
 }
 
-template <bool A_F32, int BN, int WAVES_M, int WAVES_N>
+template <bool A_F32, int BN, int WAVES_M, int WAVES_N, bool PLAIN = false>
 int launch_variant(const IGemm& g, int M, hipStream_t s) {
   constexpr int LDS = 2 * (BM * 128 + BN * 128);
   static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
   bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<A_F32, BN, WAVES_M, WAVES_N>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<A_F32, BN, WAVES_M, WAVES_N, PLAIN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   dim3 grid(cdiv(M, BM) * cdiv(g.N, BN), g.splitk > 1 ? g.splitk : 1);
-  hipLaunchKernelGGL((igemm_kernel<A_F32, BN, WAVES_M, WAVES_N>), grid, dim3(NT), LDS, s, g);
+  hipLaunchKernelGGL((igemm_kernel<A_F32, BN, WAVES_M, WAVES_N, PLAIN>), grid, dim3(NT), LDS, s, g);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -393,6 +410,15 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
   }
   const int bn = g.bn ? g.bn : igemm_pick_bn(g.N, g.geglu);
   int r;
+  const bool plain = g.ntaps == 1 && g.tap[0] == igemm_tap(0, 0, 0, 0) && g.out_linear && g.ups == 0 && g.sz == 1 && g.sy == 1 &&
+                     g.sx == 1 && g.PZ == g.Z && g.PY == g.Y && g.PX == g.X && g.IZ == g.Z && g.IY == g.Y && g.IX == g.X &&
+                     M < (1 << 22) && !g.geglu;
+  if (plain) {
+    if (bn == 160) r = g.a_f32 ? launch_variant<true, 160, 4, 1, true>(g, M, s) : launch_variant<false, 160, 4, 1, true>(g, M, s);
+    else if (bn == 64) r = g.a_f32 ? launch_variant<true, 64, 4, 1, true>(g, M, s) : launch_variant<false, 64, 4, 1, true>(g, M, s);
+    else r = g.a_f32 ? launch_variant<true, 128, 2, 2, true>(g, M, s) : launch_variant<false, 128, 2, 2, true>(g, M, s);
+    return r;
+  }
   if (bn == 160) r = g.a_f32 ? launch_variant<true, 160, 4, 1>(g, M, s) : launch_variant<false, 160, 4, 1>(g, M, s);
   else if (bn == 64) r = g.a_f32 ? launch_variant<true, 64, 4, 1>(g, M, s) : launch_variant<false, 64, 4, 1>(g, M, s);
   else r = g.a_f32 ? launch_variant<true, 128, 2, 2>(g, M, s) : launch_variant<false, 128, 2, 2>(g, M, s);

@@ -34,6 +34,8 @@ def family(name):
         a = [x.strip() for x in m.group(2).split(",")]
         if m.group(1) == "igemm_kernel":
             return f"igemm_kernel<{1 if a[0] == 'true' else 0},{a[1]}>"
+        if m.group(1) == "gemm_dma_kernel":
+            a = a[:2]  # <BN, MODE, PLAIN>: the engine books the plain and the general instance under one family
         return f"{m.group(1)}<{','.join(a)}>"
     for key, fam in (("splitk_reduce", "splitk_reduce_kernel"), ("gn_", "group_norm"), ("layernorm", "layernorm"),
                      ("depth_attn", "depth_attn_kernel"), ("attn_kernel", "attn_kernel")):
