@@ -54,8 +54,9 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
   const bool halo = c->use_halo && conv3_halo_eligible(g);
   static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
-  static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 512;
-  // one 256-row workgroup per CU: wins for the Linear layers and wherever weights stream (small M, long K);
+  static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 64;
+  // one 256-row workgroup per CU: wins for the Linear layers and wherever weights stream (small M, long K), down to one
+  // quarter-filled row tile (2-views-per-rank step: 7.08 ms with a 512-row threshold, 6.97 ms with 64);
   // the big shallow 3-D convs keep the 128-row gather kernel (finer tiles, 2 workgroups per CU)
   if (g.npar > 0) {  // parity-batched launch (run_convT3d / run_upconv2d): LDS-DMA kernel, no split-K
     if (!gemm_dma_eligible(g)) return mvd_fail("igemm_go: parity batch needs the LDS-DMA kernel");
