@@ -632,35 +632,55 @@ int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, floa
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
+  const bool cold = flags & 32;  // evict the operands (L2 + memory-side cache) before every timed launch
+  const size_t flush_bytes = cold ? (size_t)768 << 20 : 0;
   half_t* a = ws_alloc<half_t>(c, na);
   half_t* w = ws_alloc<half_t>(c, nw);
   float* o = ws_alloc<float>(c, no);
   float* r = ws_alloc<float>(c, no);
-  WS_CHECK(a && w && o && r);
+  float* bias = ws_alloc<float>(c, (size_t)N + 64 * (size_t)N);
+  char* flush = cold ? ws_alloc<char>(c, flush_bytes) : nullptr;
+  WS_CHECK(a && w && o && r && bias && (!cold || flush));
   hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(na)), dim3(256), 0, s, a, na, 17u);
   hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(nw)), dim3(256), 0, s, w, nw, 91u);
   HIP_CHECK_RET(hipMemsetAsync(r, 0, no * sizeof(float), s));
+  HIP_CHECK_RET(hipMemsetAsync(bias, 0, ((size_t)N + 64 * (size_t)N) * sizeof(float), s));
   ConvW cw;
-  cw.w = w; cw.N = N; cw.Cin = K; cw.taps = 1;
+  cw.w = w; cw.N = N; cw.Cin = K; cw.taps = 1; cw.bias = bias;
   GemmArgs g;
-  g.a = a; g.lda = K; g.w = &cw; g.out = o; g.use_bias = false;
+  g.a = a; g.lda = K; g.w = &cw; g.out = o; g.use_bias = (flags & 8) != 0;
   g.geglu = (flags & 4) ? 1 : 0;
   g.ldc = g.geglu ? N / 2 : N;
   g.out_f32 = (flags & 2) ? 0 : 1;
   if (flags & 1) { g.resid = r; g.resid_f32 = 1; g.ldr = N; }
-  RET_IF(run_linear(c, g, 1, M, s));  // warm-up
+  const int nb = M % 32 == 0 ? 32 : 1;  // samples (per-sample bias rows)
+  if (flags & 16) { g.rowbias = bias + N; g.rb_ld = N; }
+  RET_IF(run_linear(c, g, nb, M, s));  // warm-up
   hipEvent_t e0, e1;
   HIP_CHECK_RET(hipEventCreate(&e0));
   HIP_CHECK_RET(hipEventCreate(&e1));
-  HIP_CHECK_RET(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) RET_IF(run_linear(c, g, 1, M, s));
-  HIP_CHECK_RET(hipEventRecord(e1, s));
-  HIP_CHECK_RET(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+  float total = 0.f;
+  if (cold) {
+    for (int i = 0; i < iters; ++i) {
+      HIP_CHECK_RET(hipMemsetAsync(flush, i & 0xFF, flush_bytes, s));
+      HIP_CHECK_RET(hipEventRecord(e0, s));
+      RET_IF(run_linear(c, g, nb, M, s));
+      HIP_CHECK_RET(hipEventRecord(e1, s));
+      HIP_CHECK_RET(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+      total += ms;
+    }
+  } else {
+    HIP_CHECK_RET(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) RET_IF(run_linear(c, g, nb, M, s));
+    HIP_CHECK_RET(hipEventRecord(e1, s));
+    HIP_CHECK_RET(hipEventSynchronize(e1));
+    HIP_CHECK_RET(hipEventElapsedTime(&total, e0, e1));
+  }
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  *ms_out = ms / (float)iters;
+  *ms_out = total / (float)iters;
   return 0;
 }
 

@@ -82,13 +82,15 @@ __device__ __forceinline__ bool igemm_fast_epi(const IGemm& g) {
 
 // bias / per-sample bias / residual / SiLU / store for 4 consecutive columns n..n+3 of GEMM row m
 // bs >= 0: the sample index of row m (for the per-sample bias), already known to the caller
-__device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int n, float4 v, int bs_known = -1) {
+// skip_bias: bias and per-sample bias are already in the accumulator (gemm_dma_kernel pre-loads them)
+__device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int n, float4 v, int bs_known = -1,
+                                              bool skip_bias = false) {
     v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
-    if (g.bias) {
+    if (g.bias && !skip_bias) {
       const float4 b = *(const float4*)(g.bias + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
-    if (g.rowbias) {
+    if (g.rowbias && !skip_bias) {
       const int bs = bs_known >= 0 ? bs_known : m / (g.Z * g.Y * g.X);
       const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void epilogue_vec4(const IGemm& g, int m, long o, int
 // rows4[i] / orow4[i]: GEMM row index m and output row of fragment row (lane>>3) + 8 i  (m < 0: skip)
 __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16& acc, float* scratch, int lane,
                                                     const int (&rows4)[4], const long (&orow4)[4], int n_base,
-                                                    float* partial, const int* bs4 = nullptr) {
+                                                    float* partial, const int* bs4 = nullptr, bool skip_bias = false) {
   // C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + (lane & 31)] = acc[r];
@@ -133,7 +135,7 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
       *(float4*)(partial + (long)m * g.N + n) = v;
       continue;
     }
-    epilogue_vec4(g, m, orow4[i], n, v, bs4 ? bs4[i] : -1);
+    epilogue_vec4(g, m, orow4[i], n, v, bs4 ? bs4[i] : -1, skip_bias);
   }
 }
 
@@ -243,7 +245,7 @@ __device__ __forceinline__ void frag_to_scratch(const f32x16& acc, float* scratc
 // every global load of one fragment's epilogue (bias + per-sample bias + residual), summed: issued for all fragments
 // of a tile before the first transpose, so they are in flight together
 __device__ __forceinline__ void epilogue8_prefetch(const IGemm& g, int lane, int m_w, int M, int n_base, float inv_rps,
-                                                   float (&pre)[2][8]) {
+                                                   float (&pre)[2][8], bool skip_bias = false) {
   const int n = n_base + (lane & 3) * 8;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -251,12 +253,12 @@ __device__ __forceinline__ void epilogue8_prefetch(const IGemm& g, int lane, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) pre[i][e] = 0.f;
     if (m >= M || n >= g.N) continue;
-    if (g.bias) {
+    if (g.bias && !skip_bias) {
       const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
       pre[i][0] += b0.x; pre[i][1] += b0.y; pre[i][2] += b0.z; pre[i][3] += b0.w;
       pre[i][4] += b1.x; pre[i][5] += b1.y; pre[i][6] += b1.z; pre[i][7] += b1.w;
     }
-    if (g.rowbias) {
+    if (g.rowbias && !skip_bias) {
       const float* rb = g.rowbias + (long)(int)(((float)m + 0.5f) * inv_rps) * g.rb_ld + n;
       const float4 b0 = *(const float4*)rb, b1 = *(const float4*)(rb + 4);
       pre[i][0] += b0.x; pre[i][1] += b0.y; pre[i][2] += b0.z; pre[i][3] += b0.w;

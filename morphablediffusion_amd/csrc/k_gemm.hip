@@ -221,6 +221,27 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   for (int j = 0; j < FN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // Single-tile plain GEMMs start their accumulators at bias[n] + per-sample bias[sample][n] (alpha = 1, the wave's 32-row
+  // band inside one sample): in the C layout a lane owns ONE column of each fragment, so that is two loads per fragment,
+  // issued before the first tile load (hence retired by the first counted wait) instead of 4 x FN dependent 16-byte loads
+  // between the transposes of the epilogue (tools/lin_cold.py: bias + per-sample bias cost the 32768 x 320 x 320 layer
+  // 11 us of 37).
+  [[maybe_unused]] bool folded = false;
+  [[maybe_unused]] float binit[FN], rinit[FN];  // raw loads: summed only after the first tile wait (a use would wait here)
+  if constexpr (PLAIN && MODE == 0) {
+    const int rps = g.Z * g.Y * g.X;
+    folded = !g.geglu && g.splitk <= 1 && nch == 1 && g.alpha == 1.0f && (g.bias || g.rowbias) && tn_beg < tn_end &&
+             (!g.rowbias || (rps & 31) == 0);
+    if (folded) {
+      const int bsu = (int)(((float)min(m0 + wave * 32, M - 1) + 0.5f) * inv_rps);
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = min(tn_beg * BN + fn * 32 + (lane & 31), N - 1);
+        binit[fn] = g.bias ? g.bias[n] : 0.f;
+        rinit[fn] = g.rowbias ? g.rowbias[(long)bsu * g.rb_ld + n] : 0.f;
+      }
+    }
+  }
 
   // prologue: steps 0 and 1 in flight, step 0 landed
   int p_tn = tn_beg, p_ks = kbeg;  // (tile, k) of the next step to prefetch
@@ -245,6 +266,14 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   }
   __builtin_amdgcn_s_barrier();
   TL(1);
+  if constexpr (PLAIN && MODE == 0) {
+    if (folded) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fn][r] = binit[fn] + rinit[fn];
+    }
+  }
 
   int tn = tn_beg, ks = kbeg, stage = 0;
   h8 af[2], bf[2][FN];
@@ -414,14 +443,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
         if (PLAIN && !part && epilogue8_ok(g, N)) {
           float pre[FN][2][8];
 #pragma unroll
-          for (int fn = 0; fn < FN; ++fn) epilogue8_prefetch(g, lane, m0 + wave * 32, M, n0 + fn * 32, inv_rps, pre[fn]);
+          for (int fn = 0; fn < FN; ++fn)
+            epilogue8_prefetch(g, lane, m0 + wave * 32, M, n0 + fn * 32, inv_rps, pre[fn], folded);
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn)
             epilogue8_frag_store<false>(g, acc[fn], scratch, lane, m0 + wave * 32, M, n0 + fn * 32, N, pre[fn]);
         } else {  // (fp32 results: 16-byte stores already; prefetching their residual reads measured no gain)
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn)
-            epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part, PLAIN ? bs4 : nullptr);
+            epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part, PLAIN ? bs4 : nullptr, folded);
         }
       }
 #pragma unroll
