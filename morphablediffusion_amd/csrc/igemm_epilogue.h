@@ -144,18 +144,19 @@ __device__ __forceinline__ void epilogue_frag_store(const IGemm& g, const f32x16
 // first LDS transpose, so the residual reads of a 42 MB tensor are in flight together instead of one fragment at a time
 // behind each transpose (the in-situ conv ran ~20 us above its isolated time mostly for that).
 __device__ __forceinline__ void epilogue_prefetch(const IGemm& g, int lane, const int (&rows4)[4], const long (&orow4)[4],
-                                                  int n_base, float4 (&pre)[4], const int* bs4 = nullptr) {
+                                                  int n_base, float4 (&pre)[4], const int* bs4 = nullptr,
+                                                  bool skip_bias = false) {
   const int n = n_base + (lane & 7) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     const int m = rows4[i];
     if (m >= 0 && n < g.N) {
-      if (g.bias) {
+      if (g.bias && !skip_bias) {
         const float4 b = *(const float4*)(g.bias + n);
         p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
       }
-      if (g.rowbias) {
+      if (g.rowbias && !skip_bias) {
         const int bs = bs4 ? bs4[i] : m / (g.Z * g.Y * g.X);
         const float4 b = *(const float4*)(g.rowbias + (long)bs * g.rb_ld + n);
         p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;

@@ -147,6 +147,25 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+  // bias + per-sample bias as the accumulators' initial value (alpha = 1, no split-K; every block of NI image blocks that
+  // belongs to one sample qualifies -- a lane owns one column per fragment, so two loads per fragment, issued before the
+  // first tile load and summed only after the first counted wait; see k_gemm.hip)
+  bool folded = false;
+  float binit[FN], rinit[FN];
+  {
+    int b_first, b_last, t0, t1;
+    block_pos(tm * NI, b_first, t0, t1);
+    block_pos(min(tm * NI + NI - 1, nblocks - 1), b_last, t0, t1);
+    folded = g.splitk <= 1 && g.alpha == 1.0f && igemm_fast_epi(g) && (g.bias || g.rowbias) && b_first == b_last;
+    if (folded) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = min(n0 + fn * 32 + (lane & 31), N - 1);
+        binit[fn] = g.bias ? g.bias[n] : 0.f;
+        rinit[fn] = g.rowbias ? g.rowbias[(long)b_first * g.rb_ld + n] : 0.f;
+      }
+    }
+  }
   const int nsteps = (cc_end - cc_beg) * 9;
   if (nsteps > 0) {
     dma_halo(cc_beg, 0);
@@ -159,6 +178,12 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     }
   }
   __builtin_amdgcn_s_barrier();
+  if (folded) {
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fn][r] = binit[fn] + rinit[fn];
+  }
   int cc = cc_beg, tap = 0, hbuf = 0, stage = 0;
   h8 af[2], bf[2][FN];
   for (int s = 0; s < nsteps; ++s) {
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     } else {
       float4 pre[FN][4];  // all bias / residual loads of the tile in flight before the first transpose
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) epilogue_prefetch(g, lane, rows4, orow4, n0 + fn * 32, pre[fn], bs4);
+      for (int fn = 0; fn < FN; ++fn) epilogue_prefetch(g, lane, rows4, orow4, n0 + fn * 32, pre[fn], bs4, folded);
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) epilogue_frag_store_pre(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
     }

@@ -177,6 +177,28 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // bias (and, for plain GEMMs whose 32-row bands lie inside one sample, the per-sample bias) as the accumulators' initial
+  // value: one load per fragment column here instead of dependent 16-byte loads between the epilogue's transposes
+  bool folded = false;
+  if (g.splitk <= 1 && g.alpha == 1.0f && !g.geglu && igemm_fast_epi(g) && (g.bias || (PLAIN && g.rowbias))) {
+    const int rps = g.Z * g.Y * g.X;
+    const bool rb_ok = PLAIN && g.rowbias && (rps & 31) == 0;
+    if (!g.rowbias || rb_ok) {
+      folded = true;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int bsu = rb_ok ? (int)(((float)min(m0 + wm * WM + i * 32, M - 1) + 0.5f) / (float)rps) : 0;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = min(n0 + wn * WN + j * 32 + (lane & 31), N - 1);
+          const float b = (g.bias ? g.bias[n] : 0.f) + (rb_ok ? g.rowbias[(long)bsu * g.rb_ld + n] : 0.f);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+        }
+      }
+    }
+  }
+
   if (kbeg < kend) {
     load_tiles();
     store_tiles(0);
@@ -239,7 +261,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       }
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn)
-        epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part, PLAIN ? bs4 : nullptr);
+        epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part, PLAIN ? bs4 : nullptr,
+                            folded);
     }
     return;
   }
