@@ -448,7 +448,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn)
             epilogue8_frag_store<false>(g, acc[fn], scratch, lane, m0 + wave * 32, M, n0 + fn * 32, N, pre[fn]);
-        } else {  // (fp32 results: 16-byte stores already; prefetching their residual reads measured no gain)
+        } else {  // (fp32 results: 16-byte stores already; prefetching their residual reads measured no gain, warm or cold)
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn)
             epilogue_frag_store(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, part, PLAIN ? bs4 : nullptr, folded);
