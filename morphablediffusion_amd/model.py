@@ -511,7 +511,13 @@ class SyncDDIMSampler:
             noise = torch.randn_like(x_target_noisy)
         out = torch.empty_like(x_target_noisy)
         eps_out = torch.empty_like(x_target_noisy) if return_eps else None
-        local_idx = torch.arange(lo, lo + NL)
+        # view indices of this rank, resident on the device (a host tensor here would be a pageable host-to-device copy per
+        # engine call: a host synchronisation on the step path, and not capturable in a hipGraph)
+        key = (lo, NL, str(x_target_noisy.device))
+        if getattr(self, "_idx_key", None) != key:
+            self._idx_key = key
+            self._idx_dev = torch.arange(lo, lo + NL, dtype=torch.int32, device=x_target_noisy.device)
+        local_idx = self._idx_dev
         if host_steps is None:  # one read for the whole call (none at all when the caller passes host_steps)
             host_steps = [int(v) for v in time_steps.tolist()]
         for bi in range(B):
