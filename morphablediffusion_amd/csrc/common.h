@@ -110,6 +110,8 @@ int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
 bool gemm_dma_eligible(const IGemm& g);
 void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, int* splitk_out);
+int launch_target_encoder(const float* x, const float* pre, int n_views, const half_t* const* w, const float* const* bias,
+                          const int* cin, const float* const* gamma, const float* const* beta, float* feats, hipStream_t s);
 void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out);
 int launch_gemm_dma(const IGemm& g, hipStream_t s);
 

@@ -277,6 +277,41 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   // vf_out: the per-view vertex features themselves [n_local][Nv][16] (the all-gather variant of the view exchange)
   float* vf = vf_out ? vf_out : ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
   WS_CHECK(x8 && h && h2 && r1 && a && pre && tpart && feats && vf);
+  // x + time_embed(t) + view_embed(v) of all three blocks in two launches (the step embedding is shared by
+  // all views of the sample): pre[v][16*i + c]
+  RET_IF(launch_small_linear(t_embed, td, -n_local, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre, 48, 0, s));
+  RET_IF(launch_small_linear(v_embed, vd, n_local, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre, 48, 1, s));
+  static const bool no_fused_enc = getenv("MVD_NO_FUSED_ENC") != nullptr;
+  bool fused_enc = !no_fused_enc && S == 32 && c->enc_init.Cin == 8 && c->enc_init.N == 16 && c->enc_init.taps == 9 &&
+                   !c->enc_init.xp && c->enc_final.N == 16 && c->enc_final.Cin == 16 && !c->enc_final.xp;
+  for (int i = 0; i < 3 && fused_enc; ++i)
+    fused_enc = c->enc_blocks[i].c1.Cin == 16 && c->enc_blocks[i].c1.N == 16 && !c->enc_blocks[i].c1.xp &&
+                c->enc_blocks[i].c2.Cin == 16 && c->enc_blocks[i].c2.N == 16 && !c->enc_blocks[i].c2.xp;
+  if (fused_enc) {  // the whole encoder in one launch, one workgroup per view (k_enc.hip)
+    const half_t* w[8];
+    const float *bias[8], *gamma[7], *beta[7];
+    int cin[8];
+    const ConvW* cw[8] = {&c->enc_init, &c->enc_blocks[0].c1, &c->enc_blocks[0].c2, &c->enc_blocks[1].c1, &c->enc_blocks[1].c2,
+                          &c->enc_blocks[2].c1, &c->enc_blocks[2].c2, &c->enc_final};
+    const NormW* nw[7] = {&c->enc_blocks[0].n1, &c->enc_blocks[0].n2, &c->enc_blocks[1].n1, &c->enc_blocks[1].n2,
+                          &c->enc_blocks[2].n1, &c->enc_blocks[2].n2, &c->enc_final_norm};
+    for (int i = 0; i < 8; ++i) {
+      w[i] = cw[i]->w;
+      bias[i] = cw[i]->bias;
+      cin[i] = cw[i]->Cin;
+    }
+    for (int i = 0; i < 7; ++i) {
+      gamma[i] = nw[i]->g;
+      beta[i] = nw[i]->b;
+    }
+    RET_IF(launch_target_encoder(x_noisy, pre, n_local, w, bias, cin, gamma, beta, feats, s));
+    RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
+                                c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
+    if (fused_out)
+      RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
+                               0, s));
+    return 0;
+  }
   RET_IF(launch_nchw_to_nhwc(x_noisy, n_local, 4, HW, x8, 8, 8, s));
   GemmArgs g;
   // no split-K anywhere in the encoder: a view's features must not depend on how many views share the launch (the sharded
@@ -285,10 +320,6 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
   float* cur = h;
   float* nxt = h2;
-  // x + time_embed(t) + view_embed(v) of all three blocks in two launches (the step embedding is shared by
-  // all views of the sample): pre[v][16*i + c]
-  RET_IF(launch_small_linear(t_embed, td, -n_local, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre, 48, 0, s));
-  RET_IF(launch_small_linear(v_embed, vd, n_local, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre, 48, 1, s));
   for (int i = 0; i < 3; ++i) {
     const EncBlockW& e = c->enc_blocks[i];
     RET_IF(run_group_norm(c, cur, 16, n_local, HW, e.n1, 8, 1e-5f, ACT_SILU, pre + 16 * i, a, 16, s, 48));
