@@ -55,40 +55,58 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  if (live && lane < H) {
+  if (live) {
+    // softmax over d for the four heads, all 64 lanes: lane = (part, h), part strides d by 16; the maximum and the sum are
+    // xor-shuffle reductions over the 16 parts (a 4-lane serial scan over D cost ~7 us per pixel at D = 48)
+    const int h = lane & 3, part = lane >> 2;
     float mx = -INFINITY;
-    for (int d = 0; d < D; ++d) mx = fmaxf(mx, sA[d * H + lane]);
+    for (int d = part; d < D; d += 16) mx = fmaxf(mx, sA[d * H + h]);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
-    for (int d = 0; d < D; ++d) {
-      const float e = __expf(sA[d * H + lane] - mx);
-      sA[d * H + lane] = e;
+    for (int d = part; d < D; d += 16) {
+      const float e = __expf(sA[d * H + h] - mx);
+      sA[d * H + h] = e;
       sum += e;
     }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
-    for (int d = 0; d < D; ++d) sA[d * H + lane] *= inv;
+    for (int d = part; d < D; d += 16) sA[d * H + h] *= inv;
   }
   __syncthreads();
   if (live) {
-    for (int c = lane; c < Cc; c += 64) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int d = 0; d < D; ++d) {
-        const float x = (float)sX[d * xld + c];
-        const float4 a = *(const float4*)(sA + d * H);
-        a0 += a.x * x;
-        a1 += a.y * x;
-        a2 += a.z * x;
-        a3 += a.w * x;
-      }
-      const int W4 = H * Cc;
-      half_t* zr = z + (long)pix * (split ? 3 * W4 : W4) + c;
-      const float av[4] = {a0, a1, a2, a3};
+    // z[h][c] = sum_d a[h][d] x[d][c]: an item is (d-part, head, channel octet) -- 16-byte LDS reads of the staged column,
+    // 16-byte fp16 stores; with fewer than 64 (head, octet) pairs the depth range is split over P lane groups and the
+    // partial sums meet through xor shuffles
+    const int cpr = Cc / 8, pairs = H * cpr;
+    const int P = (pairs < 64 && (pairs & (pairs - 1)) == 0) ? 64 / pairs : 1;  // Cc = 64, 128, 256, 512: 32 ... 256 pairs
+    const int W4 = H * Cc;
+    for (int it = lane; it < pairs * P; it += 64) {
+      const int part = it / pairs, rem = it - part * pairs, h = rem / cpr, oct = rem - h * cpr;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int d = part; d < D; d += P) {
+        const h8 xv = *(const h8*)(sX + d * xld + oct * 8);
+        const float a = sA[d * H + h];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const half_t hi = (half_t)av[h];
-        zr[h * Cc] = hi;
+        for (int k = 0; k < 8; ++k) acc[k] += a * (float)xv[k];
+      }
+      for (int o = pairs; o < 64; o <<= 1) {  // P > 1: lanes it, it + pairs, ... hold the same (head, octet)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], o);
+      }
+      if (part == 0) {
+        h8 hi;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hi[k] = (half_t)acc[k];
+        half_t* zr = z + (long)pix * (split ? 3 * W4 : W4) + h * Cc + oct * 8;
+        *(h8*)zr = hi;
         if (split) {  // [hi | lo | hi] rows for the extended-precision output projection
-          zr[W4 + h * Cc] = (half_t)(av[h] - (float)hi);
-          zr[2 * W4 + h * Cc] = hi;
+          h8 lo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) lo[k] = (half_t)(acc[k] - (float)hi[k]);
+          *(h8*)(zr + W4) = lo;
+          *(h8*)(zr + 2 * W4) = hi;
         }
       }
     }
@@ -101,6 +119,7 @@ int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond
                       hipStream_t s, int split) {
   if (heads != 4) return mvd_fail("depth_attn: the reference always uses 4 heads (attention.py:97-115)");
   if (Cc % 8 || D > 64) return mvd_fail("depth_attn: Cc must be a multiple of 8 and D <= 64");
+  if (((uintptr_t)z & 15)) return mvd_fail("depth_attn: output must be 16-byte aligned");
   const int npix = n_cond * HW;
   if (npix == 0) return 0;
   const int x_bytes = ((D * (Cc + 8) * 2 + 15) / 16) * 16;
