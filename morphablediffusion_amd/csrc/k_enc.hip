@@ -1,7 +1,7 @@
 // NoisyTargetViewEncoder (network.py:181-207) as ONE kernel: the 2-D encoder of the conditioner is eight 3x3 convs
 // (4 -> 16 -> ... -> 16 channels) and seven GroupNorm(8)+SiLU over a 32 x 32 image per view -- 75 MFLOP per conv for 16
 // views, which as separate launches (1 layout pass + 8 implicit GEMMs + 7 norms, each 10-22 us of launch, set-up and drain)
-// cost ~0.3 ms of every step, on its critical path.  Here one workgroup (4 waves) owns one view:
+// cost ~0.3 ms of every step, on its critical path.  Here one workgroup (16 waves) owns one view:
 //   * the activations that a conv reads live in LDS as a zero-bordered 34 x 34 x 16 fp16 tile (the same fp16 operand
 //     rounding as the implicit-GEMM path: GroupNorm / SiLU in fp32, one rounding to fp16, fp32 accumulation);
 //   * a conv is 64 output tiles of 16 pixels x 16 channels, 5 x v_mfma_f32_16x16x32_f16 each (k = tap * 16 + channel,
@@ -9,14 +9,14 @@
 //     weights of the implicit GEMM -- sit in registers for the whole conv);
 //   * the residual stream h and the block-internal tensor stay in registers in the MFMA C layout (lane = channel
 //     n = lane & 15, four pixels per tile), so GroupNorm's per-group sums are in-lane sums + three xor shuffles + one
-//     4-wave exchange through LDS.
+//     exchange between the waves through LDS.
 // Output: feats [views * 1024][16] fp32, the operand of the vertex gather.
 #include "common.h"
 
 namespace {
 
 [[maybe_unused]] constexpr int ES = 32, EPX = ES * ES, ETS = ES + 2, EPS = 16;  // image side, pixels, halo tile side, halfs per tile pixel
-[[maybe_unused]] constexpr int ENT = 256, ETILES = EPX / 16 / (ENT / 64);        // 16 output tiles of 16 pixels per wave
+[[maybe_unused]] constexpr int ENT = 1024, ETILES = EPX / 16 / (ENT / 64);       // 4 output tiles of 16 pixels per wave
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
