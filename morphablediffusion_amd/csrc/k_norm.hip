@@ -13,6 +13,7 @@ constexpr int GN_MAX_SLABS = 64;
 constexpr int GN_MAXC = 2560;
 constexpr int GN_NQ = 3;  // channel quads per thread when C/4 > 256 (C <= 3072)
 constexpr int GN_UNROLL = 4;
+constexpr int GN_GROUP_MAXC = 256;  // channels per group the single-pass kernel keeps in LDS (gn_group_eligible)
 
 struct GnMap {
   int Q, lanes_q, row_par, nq;
@@ -240,13 +241,28 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
   return t;
 }
 
+#ifdef MVD_TIMELINE
+__device__ unsigned long long mvd_gn_tl[8 * 4096];
+#define GTL(i)                                                                          \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) mvd_gn_tl[blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define GTL(i)
+#endif
+// (register tiles of up to 10 pairs are held to 64 VGPRs = 2048 resident threads per CU: the 1024-thread variant compiled to
+// 70, i.e. one workgroup per CU and four rounds for the 1024 slices of a 32-sample batch)
 template <int NT, int MAXE>
-__global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
+__global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
                                                       const float* __restrict__ preadd, int pld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, int act, half_t* __restrict__ out, int ldo, int split) {
   __shared__ float s_red[NT / 64];
+  // the group's gain, bias and pre-add in LDS: as global loads inside the store loop (4 loads per 4-byte store, each
+  // iteration waiting on its own) they made "normalise + store" 9 of the workgroup's 13.7 us (tools/gn_timeline.py)
+  __shared__ __attribute__((aligned(8))) float s_par[3][GN_GROUP_MAXC];
   const int t = threadIdx.x;
+  GTL(0);
   int wg = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, slot = wg >> 3;
@@ -257,7 +273,11 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
   const float inv_h = 1.0f / (float)h;
   const float* xb = x + (long)b * rows * ld + g * cpg;
   half_t* ob = out + (long)b * rows * ldo + g * cpg;
-  const float* pre = preadd ? preadd + (long)b * pld + g * cpg : nullptr;
+  if (t < cpg) {
+    s_par[0][t] = gamma[g * cpg + t];
+    s_par[1][t] = beta[g * cpg + t];
+    s_par[2][t] = preadd ? preadd[(long)b * pld + g * cpg + t] : 0.f;
+  }
   float2 v[MAXE];
   float s = 0.f;
 #pragma unroll
@@ -267,16 +287,27 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
     if (e < n2) {
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
       v[i] = *(const float2*)(xb + (long)row * ld + 2 * j);
-      if (pre) {
-        v[i].x += pre[2 * j];
-        v[i].y += pre[2 * j + 1];
+    }
+  }
+  if (preadd) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int e = t + i * NT;
+      if (e < n2) {
+        const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
+        const float2 p = *(const float2*)(&s_par[2][2 * j]);
+        v[i].x += p.x;
+        v[i].y += p.y;
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) s += v[i].x + v[i].y;
   const float n = (float)rows * (float)cpg;
+  GTL(1);
   const float mean = block_sum<NT>(s, s_red) / n;
+  GTL(2);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) {
@@ -287,15 +318,18 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
     }
   }
   const float rstd = rsqrtf(block_sum<NT>(q, s_red) / n + eps);
-  const float* gm = gamma + g * cpg;
-  const float* bt = beta + g * cpg;
+  GTL(3);
+  // (the block reductions above synchronised the workgroup after s_par was written)
+  int t2 = t;
+  asm volatile("" : "+v"(t2));  // re-derive (row, j) here instead of keeping MAXE pairs of them live across the reductions
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) {
-    const int e = t + i * NT;
+    const int e = t2 + i * NT;
     if (e < n2) {
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
-      const float y0 = act_apply((v[i].x - mean) * rstd * gm[2 * j] + bt[2 * j], act);
-      const float y1 = act_apply((v[i].y - mean) * rstd * gm[2 * j + 1] + bt[2 * j + 1], act);
+      const float2 gm = *(const float2*)(&s_par[0][2 * j]), bt = *(const float2*)(&s_par[1][2 * j]);
+      const float y0 = act_apply((v[i].x - mean) * rstd * gm.x + bt.x, act);
+      const float y1 = act_apply((v[i].y - mean) * rstd * gm.y + bt.y, act);
       h2 o;
       o[0] = (half_t)y0;
       o[1] = (half_t)y1;
@@ -310,7 +344,18 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const float* __restrict__ 
       }
     }
   }
+  GTL(4);
 }
+
+#ifdef MVD_TIMELINE
+extern "C" int mvd_debug_gn_timeline(unsigned long long* host_out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mvd_gn_tl), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(mvd_gn_tl)) != hipSuccess) return -1;
+  return hipMemset(p, 0, sizeof(mvd_gn_tl)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // tile / slab partials [B][nslabs][G][2] -> per-sample scale[c] = rstd*gamma[c], shift[c] = beta[c] - mean*rstd*gamma[c]
 // in global memory: a GroupNorm folded into the epilogue of the GEMM that re-computes its input (engine_unet: do_cond)
@@ -487,7 +532,8 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
 bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo) {
   if (C % G) return false;
   const int cpg = C / G;
-  return (cpg % 2) == 0 && (ld % 2) == 0 && (ldo % 2) == 0 && (pld % 2) == 0 && (long)rows * cpg <= 32768 && rows < (1 << 22);
+  return (cpg % 2) == 0 && cpg <= GN_GROUP_MAXC && (ld % 2) == 0 && (ldo % 2) == 0 && (pld % 2) == 0 &&
+         (long)rows * cpg <= 32768 && rows < (1 << 22);
 }
 
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
