@@ -447,6 +447,13 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, half_t* __restrict__ out) {
   constexpr int RPW = 64 / L;  // rows per wave
+  // gain and bias through LDS (loaded once per workgroup while the rows are in flight): as global loads inside the store
+  // loop every iteration waited on its own
+  __shared__ __attribute__((aligned(16))) float s_gb[2][8 * L * NO];
+  for (int i = threadIdx.x; i < C; i += 256) {
+    s_gb[0][i] = gamma[i];
+    s_gb[1][i] = beta[i];
+  }
   const int lane = threadIdx.x & 63, sub = lane & (L - 1);
   const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / L;
   const bool ok = row < rows;
@@ -477,13 +484,14 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 #pragma unroll
   for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = rsqrtf(q / (float)C + eps);
+  __syncthreads();
   if (!ok) return;
   half_t* orow = out + (long)row * C;
 #pragma unroll
   for (int i = 0; i < NO; ++i) {
     const int c = (sub + L * i) * 8;
-    const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
-    const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+    const float4 g0 = *(const float4*)(&s_gb[0][c]), g1 = *(const float4*)(&s_gb[0][c + 4]);
+    const float4 b0 = *(const float4*)(&s_gb[1][c]), b1 = *(const float4*)(&s_gb[1][c + 4]);
     const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     h8 o;
 #pragma unroll
