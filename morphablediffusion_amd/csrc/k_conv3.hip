@@ -24,6 +24,17 @@ namespace {
 
 constexpr int BMP = 256, NT3 = 512;
 
+#ifdef MVD_TIMELINE
+// investigation build only (make EXTRA=-DMVD_TIMELINE): per-workgroup phase timestamps of the last launch
+__device__ unsigned long long mvd_c3_tl[8 * 4096];
+#define TL3(i)                                                                                              \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) mvd_c3_tl[blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define TL3(i)
+#endif
+
 [[maybe_unused]] __device__ __forceinline__ int swz3(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -58,6 +69,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TL3(0);
   const int H = g.Y, W = g.X, N = g.N, Cin = g.Cin;
   const int bx_per = W / IW, by_per = H / IH, bpi = bx_per * by_per;
   const int nblocks = g.B * bpi;
@@ -167,6 +179,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     }
   }
   const int nsteps = (cc_end - cc_beg) * 9;
+  TL3(6);
   if (nsteps > 0) {
     dma_halo(cc_beg, 0);
     dma_w(0, cc_beg, 0);
@@ -178,6 +191,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     }
   }
   __builtin_amdgcn_s_barrier();
+  TL3(1);
   if (folded) {
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
@@ -242,6 +256,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
       wait_vm<0>();
     }
     __builtin_amdgcn_s_barrier();
+    if (s == 0) TL3(2);
+    if (s == 1) TL3(3);
     if (++tap == 9) {
       tap = 0;
       ++cc;
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
     if (++stage == WST) stage = 0;
   }
 
+  TL3(4);
   const int M = g.B * H * W;
   if (igemm_fast_epi(g)) {
     float* scratch = (float*)(smem + (tid >> 6) * EPI_WAVE_BYTES);
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) epilogue_frag_store_pre(g, acc[fn], scratch, lane, rows4, orow4, n0 + fn * 32, pre[fn]);
     }
+    TL3(5);
     return;
   }
   const int ncol0 = n0 + (lane & 31);
@@ -327,6 +345,16 @@ int launch_c3_dma(const IGemm& g, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MVD_TIMELINE
+extern "C" int mvd_debug_conv3_timeline(unsigned long long* host_out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mvd_c3_tl), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(mvd_c3_tl)) != hipSuccess) return -1;
+  return hipMemset(p, 0, sizeof(mvd_c3_tl)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // eligibility: fp16 channels-last input, 3x3 stride 1 pad 1, no fused upsample, Cin % 64 == 0,
 // square-ish power-of-two images of side >= 8
