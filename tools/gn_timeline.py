@@ -23,3 +23,6 @@ for (B, Cc, hw) in ((32, 320, 32), (32, 640, 32), (32, 640, 16), (32, 1280, 16),
     print(f"B={B} C={Cc} {hw}x{hw}: {ms*1e3:.1f} us back-to-back, {len(t)} workgroups | start spread {r[:,0].max():.2f} (median start {med(r[:,0]):.2f}) | "
           f"loads+sum {med(r[:,1]-r[:,0]):.2f} | reduce1 {med(r[:,2]-r[:,1]):.2f} | var+reduce2 {med(r[:,3]-r[:,2]):.2f} | normalise+store {med(r[:,4]-r[:,3]):.2f} | "
           f"block total {med(r[:,4]-r[:,0]):.2f} | kernel span {r[:,4].max():.2f}")
+    st = np.sort(r[:, 0])
+    print("   start-time percentiles (us): " + " ".join(f"p{p}={st[int(len(st) * p / 100) - (p == 100)]:.2f}" for p in (10, 25, 50, 60, 70, 75, 80, 90, 100))
+          + f" | late starters (> 2 us): {(st > 2.0).sum()} of {len(st)}")
