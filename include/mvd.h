@@ -217,7 +217,7 @@ int mvd_probe_config(mvd_ctx* ctx, int mode, const char* family, int stride);
 int mvd_probe_report(mvd_ctx* ctx, char* buf, size_t cap);
 /* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,
  * 4 = GEGLU epilogue, 8 = bias, 16 = per-sample bias (32 samples), 32 = cold operands (a 768 MiB memset evicts the caches
- * before every launch and each launch is timed on its own) */
+ * before every launch and each launch is timed on its own), 64 = fp32 activations */
 int mvd_bench_linear(mvd_ctx* ctx, int M, int K, int N, int flags, int iters, float* ms_out, void* stream);
 /* same for GroupNorm(groups) + SiLU of a channels-last fp32 [B, HW, C] tensor -> fp16 (split: the [hi | lo | hi] operand
  * of an extended-precision consumer); flags: 1 = split output */

@@ -640,8 +640,10 @@ int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, floa
   float* r = ws_alloc<float>(c, no);
   float* bias = ws_alloc<float>(c, (size_t)N + 64 * (size_t)N);
   char* flush = cold ? ws_alloc<char>(c, flush_bytes) : nullptr;
-  WS_CHECK(a && w && o && r && bias && (!cold || flush));
+  float* a32 = (flags & 64) ? ws_alloc<float>(c, na) : nullptr;  // fp32 activations (converted while staged)
+  WS_CHECK(a && w && o && r && bias && (!cold || flush) && (!(flags & 64) || a32));
   hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(na)), dim3(256), 0, s, a, na, 17u);
+  if (a32) hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(na)), dim3(256), 0, s, a, a32, na);
   hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(nw)), dim3(256), 0, s, w, nw, 91u);
   HIP_CHECK_RET(hipMemsetAsync(r, 0, no * sizeof(float), s));
   HIP_CHECK_RET(hipMemsetAsync(bias, 0, ((size_t)N + 64 * (size_t)N) * sizeof(float), s));
@@ -649,6 +651,7 @@ int mvd_bench_linear(mvd_ctx* c, int M, int K, int N, int flags, int iters, floa
   cw.w = w; cw.N = N; cw.Cin = K; cw.taps = 1; cw.bias = bias;
   GemmArgs g;
   g.a = a; g.lda = K; g.w = &cw; g.out = o; g.use_bias = (flags & 8) != 0;
+  if (a32) { g.a = a32; g.a_f32 = 1; }
   g.geglu = (flags & 4) ? 1 : 0;
   g.ldc = g.geglu ? N / 2 : N;
   g.out_f32 = (flags & 2) ? 0 : 1;

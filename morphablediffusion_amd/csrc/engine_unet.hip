@@ -51,7 +51,10 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
 int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   const int M = g.B * g.Z * g.Y * g.X;
   g.bn = igemm_pick_bn(g.N, g.geglu);
-  if (g.a_f32 && g.bn == 160) g.bn = 128;  // the fp32-source variant keeps to the 128-wide tile (register budget)
+  // (fp32 sources keep the 160-wide tile too: 32768 x 960 x 320 runs 48 us as 3 x 128 columns -- 768 workgroups, one and
+  //  a half rounds, A read three times -- and 37 us as 2 x 160; MVD_IGEMM_F32_BN128=1 restores the old choice)
+  static const bool f32_bn128 = getenv("MVD_IGEMM_F32_BN128") != nullptr;
+  if (g.a_f32 && g.bn == 160 && f32_bn128) g.bn = 128;
   const bool halo = c->use_halo && conv3_halo_eligible(g);
   static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
   static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 64;

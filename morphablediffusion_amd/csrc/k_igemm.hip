@@ -24,6 +24,17 @@
 namespace {
 
 constexpr int BM = 128, BK = 64, NT = 256;
+
+#ifdef MVD_TIMELINE
+// investigation build only (make EXTRA=-DMVD_TIMELINE): per-workgroup phase timestamps of the last launch
+__device__ unsigned long long mvd_ig_tl[8 * 8192];
+#define TLI(i)                                                                                               \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) mvd_ig_tl[blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define TLI(i)
+#endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -38,6 +49,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TLI(0);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int M = g.B * g.Z * g.Y * g.X;
   const int N = g.N;
@@ -177,6 +189,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  TLI(6);
+  if (kbeg < kend) load_tiles();  // the first tile's loads go out before the bias loads below are waited for
   // bias (and, for plain GEMMs whose 32-row bands lie inside one sample, the per-sample bias) as the accumulators' initial
   // value: one load per fragment column here instead of dependent 16-byte loads between the epilogue's transposes
   bool folded = false;
@@ -199,11 +213,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     }
   }
 
-  if (kbeg < kend) {
-    load_tiles();
-    store_tiles(0);
-  }
+  if (kbeg < kend) store_tiles(0);
   __syncthreads();
+  TLI(1);
   int cur = 0;
   for (int ks = kbeg; ks < kend; ++ks) {
     const bool more = ks + 1 < kend;
@@ -235,7 +247,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+    if (ks == kbeg) TLI(2);
+    if (ks == kbeg + 1) TLI(3);
   }
+  TLI(4);
 
   // ---- epilogue ----
   [[maybe_unused]] const float inv_rps = 1.0f / (float)(g.Z * g.Y * g.X);
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
         epilogue_frag_store(g, acc[fm][fn], scratch, lane, rows4, orow4, n0 + wn * WN + fn * 32, part, PLAIN ? bs4 : nullptr,
                             folded);
     }
+    TLI(5);
     return;
   }
   if constexpr (FN == 2 && WN == 64) {
@@ -391,6 +407,16 @@ int launch_variant(const IGemm& g, int M, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MVD_TIMELINE
+extern "C" int mvd_debug_igemm_timeline(unsigned long long* host_out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mvd_ig_tl), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(mvd_ig_tl)) != hipSuccess) return -1;
+  return hipMemset(p, 0, sizeof(mvd_ig_tl)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_splitk_reduce(const IGemm& g, hipStream_t s) {
   const long total = (long)g.B * g.Z * g.Y * g.X * g.N;

@@ -350,10 +350,11 @@ class Engine:
         L.check(self.lib.mvd_bench_conv(self._ctx, B, Cc, H, W, Cout, iters, C.byref(ms), _stream()))
         return ms.value
 
-    def bench_linear(self, M, K, N, resid=False, out_half=False, geglu=False, iters=20, bias=False, rowbias=False, cold=False):
+    def bench_linear(self, M, K, N, resid=False, out_half=False, geglu=False, iters=20, bias=False, rowbias=False, cold=False,
+                     a_f32=False):
         ms = C.c_float(0)
         flags = ((1 if resid else 0) | (2 if out_half else 0) | (4 if geglu else 0) | (8 if bias else 0) | (16 if rowbias else 0) |
-                 (32 if cold else 0))
+                 (32 if cold else 0) | (64 if a_f32 else 0))
         L.check(self.lib.mvd_bench_linear(self._ctx, M, K, N, flags, iters, C.byref(ms), _stream()))
         return ms.value
 
