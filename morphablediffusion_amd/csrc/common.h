@@ -143,7 +143,7 @@ int launch_clip_tokens(const float* pe, const float* cls, const float* pos, int 
 int launch_scale_copy(const float* src, size_t n, float k, float* dst, hipStream_t s);
 int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st);
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s, int split = 0);
+                      hipStream_t s, int split = 0, int nfill = 0, const half_t* fill_row = nullptr);
 int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,
                         int act_in, float* out, int ldo, int accumulate, hipStream_t s);
 int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipStream_t s);

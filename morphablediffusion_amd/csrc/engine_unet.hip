@@ -585,11 +585,13 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
     {
       ProbeScope ps(c, f.s, "depth_attn_kernel", 4.0 * crow * (double)D * 4 * Cc,
                     (double)crow * D * Cc * 2.0 + (double)crow * 4 * Cc * 6.0);
-      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo));
+      // the rows of the unconditional samples (all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every
+      // head) are filled by the same launch
+      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo, rows - crow, d.relu_beta));
     }
-  }
-  if (f.Bv > f.n_ctx)  // all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every head
+  } else if (f.Bv > f.n_ctx) {
     RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc * wz, 4 * Cc * wz, rows - crow, d.relu_beta, 4 * Cc * wz, f.s));
+  }
   g = GemmArgs();
   g.a = z; g.lda = 4 * Cc * wz; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));

@@ -14,7 +14,8 @@
 namespace {
 
 __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict__ qk, const half_t* __restrict__ ctxn,
-                                                         half_t* __restrict__ z, int npix, int HW, int D, int Cc, int split) {
+                                                         half_t* __restrict__ z, int npix, int HW, int D, int Cc, int split,
+                                                         int nfill, const half_t* __restrict__ fill_row) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,6 +28,14 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
   float* sA = sQ + H * Cc;  // [d][h] scores then probabilities, D <= 64
   const int pix = blockIdx.x * 4 + wave;
   const bool live = pix < npix;
+  // rows npix .. npix + nfill - 1 (the CFG-unconditional samples: all-zero context -> uniform softmax -> z = relu(beta)
+  // for every head) are written from fill_row by the surplus waves of the same launch
+  if (!live && pix < npix + nfill) {
+    const int rowlen = (split ? 3 : 1) * H * Cc;
+    const h8* src = (const h8*)fill_row;
+    h8* dst = (h8*)(z + (long)pix * rowlen);
+    for (int i = lane; i < rowlen / 8; i += 64) dst[i] = src[i];
+  }
   const int b = live ? pix / HW : 0, p = live ? pix - b * HW : 0;
 
   if (live) {
@@ -116,12 +125,13 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
 }  // namespace
 
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s, int split) {
+                      hipStream_t s, int split, int nfill, const half_t* fill_row) {
   if (heads != 4) return mvd_fail("depth_attn: the reference always uses 4 heads (attention.py:97-115)");
   if (Cc % 8 || D > 64) return mvd_fail("depth_attn: Cc must be a multiple of 8 and D <= 64");
   if (((uintptr_t)z & 15)) return mvd_fail("depth_attn: output must be 16-byte aligned");
   const int npix = n_cond * HW;
-  if (npix == 0) return 0;
+  if (nfill < 0 || (nfill > 0 && (!fill_row || ((uintptr_t)fill_row & 15)))) return mvd_fail("depth_attn: bad fill row");
+  if (npix + nfill == 0) return 0;
   const int x_bytes = ((D * (Cc + 8) * 2 + 15) / 16) * 16;
   const int per_wave = x_bytes + 4 * Cc * 4 + 64 * 4 * 4;
   const int lds = per_wave * 4;
@@ -132,7 +142,8 @@ int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)depth_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(depth_attn_kernel, dim3(cdiv(npix, 4)), dim3(256), lds, s, qk, ctxn, z, npix, HW, D, Cc, split);
+  hipLaunchKernelGGL(depth_attn_kernel, dim3(cdiv(npix + nfill, 4)), dim3(256), lds, s, qk, ctxn, z, npix, HW, D, Cc, split,
+                     nfill, fill_row);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
