@@ -328,6 +328,13 @@ struct GemmArgs {
   bool use_bias = true;
   int force_splitk = 0;
   int out_split = 0;  // fp16 output as [hi | lo | hi] of this logical width (IGemm::out_split)
+  // Deferred split-K reduction (run_conv2d): when the plan splits K and the fp32 slabs [sk][rows][N] fit in `slabs`
+  // (capacity slabs_cap floats), the GEMM writes them there, NO reduce pass runs and *sk_used = sk; the consumer adds the
+  // slabs, the bias and the per-sample bias itself (run_group_norm with nslab > 1).  Otherwise *sk_used = 1 and `out` holds
+  // the finished result as usual.
+  float* slabs = nullptr;
+  size_t slabs_cap = 0;
+  int* sk_used = nullptr;
 };
 // plain GEMM / 1x1 conv over `rows` rows grouped in `B` samples (rows % B == 0)
 int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s);
@@ -341,8 +348,11 @@ int run_conv3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, int s
 int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipStream_t s);
 // GroupNorm(+act) -> fp16
 // split: out rows are [hi | lo | hi] (3 * n.C halfs), the operand of an extended-precision consumer
+// nslab > 1 (single-pass form only, nslab <= 4): x is nslab split-K slabs `slab_stride` floats apart whose sum, plus bias2[c]
+// and the pre-add, is the tensor to normalise (GemmArgs::slabs)
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0, int split = 0);
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0, int split = 0,
+                   int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr);
 // restores the workspace bump pointer when the scope is left, on the error returns too (a failed call must not leak
 // workspace into the calls that follow it)
 struct WsScope {

@@ -48,7 +48,7 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.out_split = ga.out_split;
 }
 
-int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
+int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmArgs* defer = nullptr) {
   const int M = g.B * g.Z * g.Y * g.X;
   g.bn = igemm_pick_bn(g.N, g.geglu);
   // (fp32 sources keep the 160-wide tile too: 32768 x 960 x 320 runs 48 us as 3 x 128 columns -- 768 workgroups, one and
@@ -154,10 +154,18 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
   WsScope ws_scope(c);
   g.splitk = sk;
   g.partial = nullptr;
+  bool deferred = false;  // the caller's consumer adds the slabs (GemmArgs::slabs): no reduce pass
   if (sk > 1) {
-    g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
-    if (!g.partial) g.splitk = 1;  // not enough scratch: single pass
+    if (defer && defer->slabs && defer->sk_used && sk <= 4 && (size_t)sk * M * g.N <= defer->slabs_cap && !g.geglu && !g.resid &&
+        g.act == 0 && g.alpha == 1.0f) {
+      g.partial = defer->slabs;
+      deferred = true;
+    } else {
+      g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
+      if (!g.partial) g.splitk = 1;  // not enough scratch: single pass
+    }
   }
+  if (defer && defer->sk_used) *defer->sk_used = deferred ? sk : 1;
   static const bool timing = getenv("MVD_LAYER_TIMING") != nullptr;  // debugging aid: per-GEMM time on stderr
   static hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (timing) {
@@ -192,7 +200,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s) {
     ProbeScope ps(c, s, fam, flops, bytes);
     r = launch_igemm(g, s);
   }
-  if (!r && g.splitk > 1) {  // the slabs are written once and read once: 2 x splitk x M x N x 4 bytes that no roofline needs
+  if (!r && g.splitk > 1 && !deferred) {  // the slabs are written once and read once: 2 x splitk x M x N x 4 bytes that no roofline needs
     ProbeScope ps(c, s, "splitk_reduce_kernel", 0.0, (double)M * g.N * 4.0 * (g.splitk + 1));
     r = launch_splitk_reduce(g, s);
   }
@@ -243,7 +251,7 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
   } else {
     return mvd_fail("run_conv2d: kernel must be 1x1 or 3x3");
   }
-  return igemm_go(c, g, ga.force_splitk, s);
+  return igemm_go(c, g, ga.force_splitk, s, &ga);
 }
 
 int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStream_t s) {
@@ -382,13 +390,15 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 }
 
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
-                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld, int split) {
+                   int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld, int split, int nslab,
+                   size_t slab_stride, const float* bias2) {
   // algorithmic: x read once (fp32), fp16 result written once
   ProbeScope ps(c, s, "group_norm", 0.0, (double)B * rows_per_sample * n.C * 6.0);
   static const bool two_pass = getenv("MVD_GN_TWO_PASS") != nullptr;
   if (!two_pass && gn_group_eligible(ld, rows_per_sample, n.C, groups, preadd ? (preadd_ld ? preadd_ld : n.C) : 0, ldo))
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
-                           ldo, s, split);
+                           ldo, s, split, nslab, slab_stride, bias2);
+  if (nslab > 1) return mvd_fail("run_group_norm: slab input needs the single-pass form");
   WsScope ws_scope(c);
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
@@ -435,8 +445,22 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   GemmArgs g1;
   g1.a = a1; g1.lda = r.cin * w1; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
   g1.rowbias = f.emb_all + r.emb_off; g1.rb_ld = c->emb_total;
+  // conv1's result only feeds GroupNorm 2: when the conv splits K, the norm adds the slabs (+ bias + emb) itself and the
+  // reduce pass (a launch, a write and a read of h1) disappears
+  static const bool no_defer = getenv("MVD_NO_DEFER_REDUCE") != nullptr || getenv("MVD_GN_TWO_PASS") != nullptr;
+  int sk1 = 1;
+  const size_t slab_elems = (size_t)rows * r.cout;
+  if (!no_defer && gn_group_eligible(r.cout, H * W, r.cout, 32, c->emb_total, r.cout * w2)) {
+    g1.slabs = ws_alloc<float>(c, 4 * slab_elems);
+    g1.slabs_cap = g1.slabs ? 4 * slab_elems : 0;
+    g1.sk_used = &sk1;
+  }
   RET_IF(run_conv2d(c, g1, f.Bv, H, W, 1, 0, f.s));
-  RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout * w2, f.s, 0, r.c2.xp));
+  if (sk1 > 1)
+    RET_IF(run_group_norm(c, g1.slabs, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, g1.rowbias, a2, r.cout * w2, f.s, g1.rb_ld,
+                          r.c2.xp, sk1, slab_elems, r.c1.bias));
+  else
+    RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout * w2, f.s, 0, r.c2.xp));
   const float* resid = in.p;
   int ldr = in.ld;
   if (r.has_skip) {

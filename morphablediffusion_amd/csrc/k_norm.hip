@@ -252,11 +252,14 @@ __device__ unsigned long long mvd_gn_tl[8 * 4096];
 #endif
 // (register tiles of up to 10 pairs are held to 64 VGPRs = 2048 resident threads per CU: the 1024-thread variant compiled to
 // 70, i.e. one workgroup per CU and four rounds for the 1024 slices of a 32-sample batch)
-template <int NT, int MAXE>
+// NS > 1: x is NS split-K slabs (slab_stride floats apart) of the producing conv; their sum + bias2[c] + the pre-add is the
+// tensor to normalise (the conv's reduce pass never runs: GemmArgs::slabs)
+template <int NT, int MAXE, int NS>
 __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
                                                       const float* __restrict__ preadd, int pld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, int act, half_t* __restrict__ out, int ldo, int split) {
+                                                      float eps, int act, half_t* __restrict__ out, int ldo, int split,
+                                                      long slab_stride, const float* __restrict__ bias2) {
   __shared__ float s_red[NT / 64];
   // the group's gain, bias and pre-add in LDS: as global loads inside the store loop (4 loads per 4-byte store, each
   // iteration waiting on its own) they made "normalise + store" 9 of the workgroup's 13.7 us (tools/gn_timeline.py)
@@ -276,8 +279,9 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
   if (t < cpg) {
     s_par[0][t] = gamma[g * cpg + t];
     s_par[1][t] = beta[g * cpg + t];
-    s_par[2][t] = preadd ? preadd[(long)b * pld + g * cpg + t] : 0.f;
+    s_par[2][t] = (preadd ? preadd[(long)b * pld + g * cpg + t] : 0.f) + (bias2 ? bias2[g * cpg + t] : 0.f);
   }
+  const bool has_pre = preadd || bias2;
   float2 v[MAXE];
   float s = 0.f;
 #pragma unroll
@@ -287,9 +291,15 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
     if (e < n2) {
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
       v[i] = *(const float2*)(xb + (long)row * ld + 2 * j);
+#pragma unroll
+      for (int sl = 1; sl < NS; ++sl) {
+        const float2 q2 = *(const float2*)(xb + sl * slab_stride + (long)row * ld + 2 * j);
+        v[i].x += q2.x;
+        v[i].y += q2.y;
+      }
     }
   }
-  if (preadd) {
+  if (has_pre) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
@@ -545,12 +555,22 @@ bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo) {
 }
 
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
-                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split) {
+                    const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split, int nslab,
+                    size_t slab_stride, const float* bias2) {
   const int n2 = rows * (C / G) / 2;
   if (split && ldo < 3 * C) return mvd_fail("gn_group: a split output needs ldo >= 3C");
+  if (nslab < 1 || nslab > 4) return mvd_fail("gn_group: 1 to 4 slabs");
   const dim3 grid(B * G);
-#define MVD_GN(NT, ME) \
-  hipLaunchKernelGGL((gn_group_kernel<NT, ME>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, out, ldo, split)
+#define MVD_GN1(NT, ME, NS_)                                                                                                     \
+  hipLaunchKernelGGL((gn_group_kernel<NT, ME, NS_>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, \
+                     out, ldo, split, (long)slab_stride, bias2)
+#define MVD_GN(NT, ME)                      \
+  do {                                      \
+    if (nslab == 1) MVD_GN1(NT, ME, 1);     \
+    else if (nslab == 2) MVD_GN1(NT, ME, 2); \
+    else if (nslab == 3) MVD_GN1(NT, ME, 3); \
+    else MVD_GN1(NT, ME, 4);                \
+  } while (0)
   // the smallest register tile that holds the group (unused slots still cost predicated loop iterations), 512-thread
   // workgroups up to 8192 pairs: swept on the UNet's shapes (tools/gn_bench.py), e.g. C=320 @32x32: 35 -> 27 us
   if (n2 <= 256 * 4) MVD_GN(256, 4);
@@ -560,6 +580,7 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
   else if (n2 <= 1024 * 10) MVD_GN(1024, 10);
   else MVD_GN(1024, 16);
 #undef MVD_GN
+#undef MVD_GN1
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
