@@ -333,10 +333,10 @@ def main():
                 "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                 "frac": dom["achieved"] / dom["peak"],
                 # HBM-side bytes per launch of this family from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 per the
-                # gfx950 correction + WRITE_SIZE; profiles/r02_a_pmc_hbm_traffic.txt), known for the headline workload only
-                "traffic": 92.4e6 if (dominant == "gemm_dma_kernel<128,0>" and args.config == "headline" and world == 1
+                # gfx950 correction + WRITE_SIZE; profiles/r02_b_pmc_hbm_traffic.txt), known for the headline workload only
+                "traffic": 109.5e6 if (dominant == "gemm_dma_kernel<128,0>" and args.config == "headline" and world == 1
                                       and not args.simulate_gpus) else None,
-                "traffic_unit": "bytes per launch, family average (algorithmic: 41.7e6)",
+                "traffic_unit": "bytes per launch, family average (algorithmic: 52.2e6)",
                 "kernel": dominant,
                 "how": f"HIP events on the launch stream around a deterministic 1-in-{args.probe_stride} sample of this "
                        f"family's launches INSIDE the timed region ({dom['launches_bracketed']} of {dom['launches']} launches, "
