@@ -17,6 +17,10 @@
 //     previous one runs), and the A rows are re-read from L2;
 //   * zero-fills M / N / K tails in hardware (out-of-range buffer offsets), epilogue as in the implicit GEMM
 //     (bias, per-sample bias, residual, SiLU, GEGLU pairing, fp16/fp32 store, split-K partials).
+//   * keeps what a workgroup executes before its first load and after its last MFMA short (most launches are ONE tile per
+//     workgroup, and a kernel's first pass over its code runs at instruction-fetch speed): plain layers take a PLAIN
+//     instantiation without integer divisions, biases enter as the accumulators' initial value, fp16 results leave as
+//     16-byte stores (measured phase by phase with tools/gemm_timeline.py).
 // LDS rows are 128 B (64 halfs) with the 16-byte chunk XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128.
 #include "common.h"
 #include "igemm_epilogue.h"
