@@ -113,6 +113,16 @@ int mvd_vertex_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed
 int mvd_vertex_view_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed,
                              const int32_t* view_idx, int n_local, float* vf_out, void* stream);
 int mvd_fuse_vertex_features(mvd_ctx* ctx, const float* vf_all, int n_views, float* fused_out, void* stream);
+/* Stage probes for the parity tests (each stage of the conditioner on its own, in the reference's layouts):
+ *   mvd_stage_target_encoder   NoisyTargetViewEncoder.forward (ldm/models/diffusion/network.py:181-207) for n_local views of one
+ *                              sample: x_noisy [n_local,4,s,s], t_embed [time_dim], v_embed [n_local,view_dim] -> feats [n_local,16,s,s];
+ *   mvd_stage_sparse_dense     SparseConvNet.forward(...) (network.py:74-96, the xyzc_net call of morphable_diffusion.py:253-254):
+ *                              fused [Nv,16] -> dense [C,d,h,w] of the coarsest level (spconv's .dense(), batch 1); train_mode != 0
+ *                              uses batch statistics in the BatchNorm1d layers.  shape_out (may be NULL) receives {C,d,h,w};
+ *                              dense_out == NULL only queries the shape. */
+int mvd_stage_target_encoder(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local,
+                             float* feats, void* stream);
+int mvd_stage_sparse_dense(mvd_ctx* ctx, const float* fused, int train_mode, float* dense_out, int32_t* shape_out, void* stream);
 /* Cross-stream hand-over of the volume.  The exchange + mvd_fuse_vertex_features + mvd_volume_from_fused may run on a
  * communication stream of the caller while `stream` of mvd_denoise_views already executes the UNet's input blocks (which
  * need none of it): record a hipEvent_t after mvd_volume_from_fused on that stream and register it here; every later reader

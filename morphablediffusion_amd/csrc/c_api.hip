@@ -244,6 +244,34 @@ int mvd_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float
   return engine_fuse_vertex_features(c, vf_all, n_views, fused_out, S(stream));
 }
 
+int mvd_stage_target_encoder(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local,
+                             float* feats_nchw, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !x_noisy || !t_embed || !v_embed || !feats_nchw || n_local <= 0) return mvd_fail("mvd_stage_target_encoder: bad argument");
+  WsScope ws_scope(c);
+  const int HW = c->u.image_size * c->u.image_size;
+  float* feats = ws_alloc<float>(c, (size_t)n_local * HW * 16);
+  WS_CHECK(feats);
+  RET_IF(engine_target_encoder(c, x_noisy, t_embed, v_embed, n_local, feats, S(stream)));
+  return launch_nhwc_to_nchw(feats, 16, n_local, 16, HW, feats_nchw, S(stream));
+}
+
+int mvd_stage_sparse_dense(mvd_ctx* c, const float* fused, int train_mode, float* dense_out, int32_t* shape_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->mesh.Nv) return mvd_fail("mvd_set_mesh must be called first");
+  const MeshTables& m = c->mesh;
+  if (shape_out) {
+    shape_out[0] = c->sparse[8].cout;
+    for (int a = 0; a < 3; ++a) shape_out[1 + a] = m.shape[2][a];
+  }
+  if (!dense_out) return 0;  // shape query
+  if (!fused) return mvd_fail("mvd_stage_sparse_dense: null argument");
+  const float* rows = nullptr;
+  RET_IF(engine_sparse_net(c, fused, S(stream), train_mode != 0, &rows));
+  return launch_sparse_densify(rows, m.grid2, (long)m.shape[2][0] * m.shape[2][1] * m.shape[2][2], c->sparse[8].cout, dense_out, S(stream));
+}
+
 int mvd_set_volume_ready_event(mvd_ctx* c, void* event) {
   if (!c) return mvd_fail("null context");
   c->vol_ready = (hipEvent_t)event;
@@ -253,6 +281,7 @@ int mvd_set_volume_ready_event(mvd_ctx* c, void* event) {
 int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  c->vol_ready = nullptr;  // a registered hand-over event guarded the PREVIOUS volume (the caller registers a new one after this call)
   RET_IF(engine_volume_from_fused(c, fused, S(stream)));
   if (volume_out) {
     const int V = c->v.spatial_volume_size;
@@ -264,6 +293,7 @@ int mvd_volume_from_fused(mvd_ctx* c, const float* fused, float* volume_out, voi
 int mvd_volume_from_fused_train(mvd_ctx* c, const float* fused, float* volume_out, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  c->vol_ready = nullptr;
   RET_IF(engine_volume_from_fused(c, fused, S(stream), /*bn_batch_stats=*/true));
   if (volume_out) {
     const int V = c->v.spatial_volume_size;

@@ -187,6 +187,7 @@ int launch_bn_rows_relu(float* x, int n, int C, const float* gamma, const float*
 int launch_mse(const float* a, const float* b, size_t n, float* out, hipStream_t s);
 int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
                          const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s);
+int launch_sparse_densify(const float* feats, const int* grid, long nvox, int C, float* out, hipStream_t s);
 int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V,
                           float vol_len, int persp, half_t* out, hipStream_t s);
 int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);

@@ -294,6 +294,11 @@ int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, co
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
                            float* vf_out = nullptr);
+// NoisyTargetViewEncoder alone: x_noisy [n_local,4,S,S] -> feats channels-last [n_local*S*S][16]
+int engine_target_encoder(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local, float* feats,
+                          hipStream_t s);
+// the sparse voxel CNN alone: *rows_out = feature rows [n_sites[2]][64] of the coarsest level (mesh ping-pong buffer)
+int engine_sparse_net(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats, const float** rows_out);
 int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, hipStream_t s);
 // bn_batch_stats: the sparse CNN's BatchNorm1d layers normalise with the statistics of the active rows (the module in train
 // mode, as during the reference's training_step) instead of the running buffers

@@ -259,11 +259,9 @@ int engine_select_sample(mvd_ctx* c, int slot) {
 // ----------------------------------------------------------------------------------------------------
 // NoisyTargetViewEncoder (network.py:181-207) for n_local views + fused unprojection/vertex gather + this
 // rank's share of the view mean (morphable_diffusion.py:203-231).
-int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
-                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
-                           float* vf_out) {
+int engine_target_encoder(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local, float* feats,
+                          hipStream_t s) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
-  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
   WsScope ws_scope(c);
   const int S = c->u.image_size, HW = S * S, rows = n_local * HW, td = c->v.time_dim, vd = c->v.view_dim;
   float* x8 = ws_alloc<float>(c, (size_t)rows * 8);
@@ -272,11 +270,7 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   float* r1 = ws_alloc<float>(c, (size_t)rows * 16);
   half_t* a = ws_alloc<half_t>(c, (size_t)rows * 16);
   float* pre = ws_alloc<float>(c, (size_t)n_local * 48);
-  float* tpart = ws_alloc<float>(c, 16);
-  float* feats = ws_alloc<float>(c, (size_t)rows * 16);
-  // vf_out: the per-view vertex features themselves [n_local][Nv][16] (the all-gather variant of the view exchange)
-  float* vf = vf_out ? vf_out : ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
-  WS_CHECK(x8 && h && h2 && r1 && a && pre && tpart && feats && vf);
+  WS_CHECK(x8 && h && h2 && r1 && a && pre);
   // x + time_embed(t) + view_embed(v) of all three blocks in two launches (the step embedding is shared by
   // all views of the sample): pre[v][16*i + c]
   RET_IF(launch_small_linear(t_embed, td, -n_local, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre, 48, 0, s));
@@ -304,13 +298,7 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
       gamma[i] = nw[i]->g;
       beta[i] = nw[i]->b;
     }
-    RET_IF(launch_target_encoder(x_noisy, pre, n_local, w, bias, cin, gamma, beta, feats, s));
-    RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
-                                c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
-    if (fused_out)
-      RET_IF(launch_fuse_views(vf, n_local, c->mesh.Nv, c->v.num_views, c->fuse_w, add_bias ? c->fuse_b : nullptr, fused_out,
-                               0, s));
-    return 0;
+    return launch_target_encoder(x_noisy, pre, n_local, w, bias, cin, gamma, beta, feats, s);
   }
   RET_IF(launch_nchw_to_nhwc(x_noisy, n_local, 4, HW, x8, 8, 8, s));
   GemmArgs g;
@@ -335,7 +323,21 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   RET_IF(run_group_norm(c, cur, 16, n_local, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, a, 16, s));
   g = GemmArgs();
   g.a = a; g.lda = 16; g.w = &c->enc_final; g.out = feats; g.ldc = 16; g.force_splitk = 1;
-  RET_IF(run_conv2d(c, g, n_local, S, S, 1, 0, s));
+  return run_conv2d(c, g, n_local, S, S, 1, 0, s);
+}
+
+int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
+                           const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
+                           float* vf_out) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
+  WsScope ws_scope(c);
+  const int S = c->u.image_size, rows = n_local * S * S;
+  float* feats = ws_alloc<float>(c, (size_t)rows * 16);
+  // vf_out: the per-view vertex features themselves [n_local][Nv][16] (the all-gather variant of the view exchange)
+  float* vf = vf_out ? vf_out : ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
+  WS_CHECK(feats && vf);
+  RET_IF(engine_target_encoder(c, x_noisy, t_embed, v_embed, n_local, feats, s));
   RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
                               c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
   if (fused_out)
@@ -353,8 +355,9 @@ int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, fl
   return launch_fuse_views(vf_all, n_views, c->mesh.Nv, c->v.num_views, c->fuse_w, c->fuse_b, fused_out, 0, s);
 }
 
-// SparseConvNet (network.py:74-96) + latent-code volume gather (morphable_diffusion.py:232-257)
-int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats) {
+// SparseConvNet (network.py:74-96): fused [Nv,16] -> feature rows of the coarsest level's active sites [n_sites[2]][64]
+// (*rows_out points into the mesh's ping-pong buffers)
+int engine_sparse_net(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats, const float** rows_out) {
   MeshTables& m = c->mesh;
   if (!m.Nv) return mvd_fail("mvd_set_mesh must be called first");
   const float* in = fused;
@@ -381,6 +384,15 @@ int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool
     in = out;
     pp ^= 1;
   }
+  *rows_out = in;
+  return 0;
+}
+
+// + latent-code volume gather (morphable_diffusion.py:232-257)
+int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats) {
+  MeshTables& m = c->mesh;
+  const float* in = nullptr;
+  RET_IF(engine_sparse_net(c, fused, s, bn_batch_stats, &in));
   RET_IF(launch_latent_gather(in, m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh,
                               c->v.voxel_size, c->v.spatial_volume_size, c->v.spatial_volume_length, c->volume, s));
   return 0;

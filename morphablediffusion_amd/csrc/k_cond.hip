@@ -226,6 +226,18 @@ __global__ void latent_gather_kernel(const float* __restrict__ feats, const int*
   }
 }
 
+// rows [n][C] of the active sites -> dense [C][gd][gh][gw] (spconv's .dense(): zero where no site is active)
+__global__ void sparse_densify_kernel(const float* __restrict__ feats, const int* __restrict__ grid, long nvox, int C,
+                                      float* __restrict__ out) {
+  const long total = nvox * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long vox = idx % nvox;
+    const int c = (int)(idx / nvox);
+    const int row = grid[vox];
+    out[idx] = row < 0 ? 0.f : feats[(long)row * C + c];
+  }
+}
+
 // vol [V][V][V][C] fp32 -> out [TN][D][S][S][C] fp16 ; 16 threads per point, C/16 channels each (C = 64 -> 4)
 __global__ __launch_bounds__(256) void frustum_gather_kernel(const float* __restrict__ vol, const ViewCam* __restrict__ cams,
                                                              const int* __restrict__ view_idx, int TN, int D, int S, int V,
@@ -317,6 +329,13 @@ int launch_mse(const float* a, const float* b, size_t n, float* out, hipStream_t
   return 0;
 }
 
+int launch_sparse_densify(const float* feats, const int* grid, long nvox, int C, float* out, hipStream_t s) {
+  const long total = nvox * C;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(sparse_densify_kernel, dim3(blocks), dim3(256), 0, s, feats, grid, nvox, C, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
                          const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s) {
   // min_xyz / out_sh are HOST pointers (step-invariant mesh metadata); out_sh is (d,h,w) = (z,y,x)

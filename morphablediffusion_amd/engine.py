@@ -202,6 +202,24 @@ class Engine:
         L.check(self.lib.mvd_fuse_vertex_features(self._ctx, L.ptr(vf), vf.shape[0], L.ptr(out), _stream()))
         return out
 
+    def stage_target_encoder(self, x_noisy, t_embed, v_embed):
+        """NoisyTargetViewEncoder alone (network.py:181-207): x_noisy [n,4,s,s], t_embed [time_dim], v_embed [n,view_dim] ->
+        [n,16,s,s].  Parity probe."""
+        dev = self.device
+        x, te, ve = _f32(x_noisy, dev), _f32(t_embed, dev), _f32(v_embed, dev)
+        out = torch.empty(x.shape[0], 16, x.shape[2], x.shape[3], device=dev, dtype=torch.float32)
+        L.check(self.lib.mvd_stage_target_encoder(self._ctx, L.ptr(x), L.ptr(te), L.ptr(ve), x.shape[0], L.ptr(out), _stream()))
+        return out
+
+    def stage_sparse_dense(self, fused, train=False):
+        """The sparse voxel CNN alone (network.py:74-96): fused [Nv,16] -> dense [C,d,h,w] of the coarsest level.  Parity probe."""
+        shp = (C.c_int32 * 4)()
+        L.check(self.lib.mvd_stage_sparse_dense(self._ctx, None, 0, None, shp, _stream()))
+        f = _f32(fused, self.device)
+        out = torch.empty(*[int(v) for v in shp], device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_stage_sparse_dense(self._ctx, L.ptr(f), 1 if train else 0, L.ptr(out), shp, _stream()))
+        return out
+
     def set_volume_ready_event(self, event):
         """event: torch.cuda.Event recorded after volume_from_fused on another stream (kept alive by the caller), or None."""
         h = C.c_void_p(0) if event is None else C.c_void_p(event.cuda_event)

@@ -191,6 +191,17 @@ def test_stages_and_step_small_vs_golden(name, projection):
     t_embed = m.embed_time(ts)
     compare(t_embed, g, "t_embed")
     v_embed = m.get_viewpoint_embedding(batch)
+    # every stage of the conditioner on its own against the reference's stage goldens (a6-a11), not only the composite
+    # volume: 2-D encoder (fp16 MFMA operands), unprojection + vertex gather, view fusion, sparse voxel CNN (fp32)
+    eng = m.engine
+    m.spatial_volume._set_sample(batch, 0)
+    enc = eng.stage_target_encoder(x_T[0], t_embed[0], v_embed[0])
+    compare(enc[:1], g, "enc_view0")
+    vf = eng.vertex_view_features(x_T[0], t_embed[0], v_embed[0], torch.arange(N))      # [N,Nv,16]
+    compare(vf.permute(0, 2, 1)[None], g, "vertex_feats")                                # reference layout [1,N,16,Nv]
+    fused = eng.fuse_vertex_features(vf)                                                 # [Nv,16]
+    compare(fused[None], g, "fused")
+    compare(eng.stage_sparse_dense(fused)[None], g, "sparse_dense", rel=1e-4, mx=1e-3)   # fp32 kernels
     sv = m.spatial_volume.construct_spatial_volume(x_T, t_embed, v_embed, batch)
     compare(sv, g, "spatial_volume", rel=1e-4, mx=1e-3)  # fp32 path end to end
     fd, _ = m.spatial_volume.construct_view_frustum_volume(sv, t_embed, v_embed, torch.arange(0, 2)[None], batch)

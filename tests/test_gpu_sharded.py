@@ -79,8 +79,10 @@ def test_two_rank_sharded_step_matches_single():
     assert torch.equal(parts[0]["fused"], fused) and torch.equal(parts[1]["fused"], fused)
     assert torch.isfinite(sharded).all()
     rel = ((sharded - ref).norm() / ref.norm()).item()
-    print(f"[property] 2-rank sharded vs single: relL2={rel:.2e}")
-    # the UNet half is not bit-identical: the per-rank batch changes tile / split-K choices, i.e. the fp32 summation order
+    print(f"[property] 2-rank sharded vs single: relL2={rel:.2e} bit-identical={torch.equal(sharded, ref)}")
+    # What is ASSERTED bit for bit is the exchange (the fused features above).  x_prev is bounded, not required to be equal:
+    # here both runs use 2 views per UNet pass, so it normally comes out identical too, but two processes sharing one GPU
+    # interleave their kernels and a different per-rank batch would change tile / split-K choices (fp32 summation order).
     assert rel <= 5e-4
 
 
