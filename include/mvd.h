@@ -140,20 +140,53 @@ int mvd_volume_from_fused(mvd_ctx* ctx, const float* fused, float* volume_out, v
  * behaviour.  mvd_mse_loss: out[0] = mean((a - b)^2) over n device floats (the "loss_simple" of :541-542). */
 int mvd_volume_from_fused_train(mvd_ctx* ctx, const float* fused, float* volume_out, void* stream);
 int mvd_mse_loss(mvd_ctx* ctx, const float* a, const float* b, size_t n, float* out, void* stream);
-/* Backward pass, first slice: the gradients of every parameter of the LAST DepthTransformer (output_conditions.<last>,
- * ldm/models/diffusion/attention.py:49-84 -- the tail of get_trainable_parameters(), :140-142).
- *   mvd_train_tape(ctx, max_batch)   allocates the tape (max_batch > 0) or releases it (0): while on, mvd_unet_forward keeps the
- *                                    input of that block and the UNet's final hidden state of the latest call;
- *   mvd_train_backward_last_condition(ctx, dpred [B,out_channels,s,s] = dL/d(output of the taped forward), ctx0
- *                                    [B,volume_dims[0],D,s,s] = the finest source_dict volume that forward saw, B, D, stream)
- *                                    re-computes the block in fp32 from the master weights and back-propagates through the
- *                                    output head (openaimodel.py:717-721) and the block;
- *   mvd_train_get_grad(ctx, key, out, numel, stream)   copies the gradient of state_dict entry `key` (reference name, PyTorch
- *                                    layout) to device memory.
- * Everything upstream of that block needs the backward of the whole UNet: not part of this slice. */
-int mvd_train_tape(mvd_ctx* ctx, int max_batch);
-int mvd_train_backward_last_condition(mvd_ctx* ctx, const float* dpred, const float* ctx0, int B, int D, void* stream);
+/* Training step of the UNet (reference training_step morphable_diffusion.py:520-549 from `self.model(...)`
+ * on, loss.backward(), configure_optimizers :627-646).
+ *   mvd_train_enable(ctx, 1)        BEFORE mvd_finalize_weights: the uploaded fp32 tensors of model.diffusion_model.* /
+ *                                   spatial_volume.* / time_embed.* are kept as master parameters in ONE flat arena (sorted by
+ *                                   key, each tensor aligned to 64 floats); gradients and Adam moments use the same layout.
+ *   mvd_train_param_count / _info   enumerate the parameters: name (state_dict key), offset and numel in the arena (floats),
+ *                                   shape (up to 8 dims) -- what nn.Module.named_parameters() is to the reference.
+ *   mvd_train_arena_size            floats per arena.
+ *   mvd_train_adopt_arena(which, ptr, numel)   moves arena `which` (0 parameters, 1 gradients, 2 / 3 Adam moments) into
+ *                                   caller-owned device memory of the same size (its content is copied over, a not yet
+ *                                   existing arena is zeroed): the caller's tensor framework then sees parameters / gradients
+ *                                   as views of ONE buffer (one RCCL all-reduce for the DDP gradient averaging of
+ *                                   train_morphable_diffusion.py:302-303).  The memory must outlive the context.
+ *   mvd_train_zero_grad             optimizer.zero_grad().
+ *   mvd_train_unet_step             x [B,in_channels,s,s], timesteps [B], context [B,1,context_dim], src{0..3} the
+ *                                   source_dict volumes [B,C_l,D_l,s_l,s_l] (after the condition dropout), target [B,out,s,s]:
+ *                                   pred = UNet(x, ...), loss = mean((target - pred)^2) (morphable_diffusion.py:541-542), then
+ *                                   dL/dpred * loss_scale is back-propagated through every block; parameter gradients are
+ *                                   ACCUMULATED (x loss_scale) into the gradient arena.  dsrc{0..3} (each may be NULL) receive
+ *                                   the gradient w.r.t. the volumes (x loss_scale).  recompute != 0: activation checkpointing
+ *                                   per block (ldm/modules/diffusionmodules/util.py:102-148 -- only block inputs are kept, a
+ *                                   block is re-run before its backward); 0 keeps every intermediate of the forward pass.
+ *                                   fp16 MFMA operands, fp32 accumulation / master weights; pick loss_scale so that the scaled
+ *                                   gradients stay inside the fp16 range (mvd_train_adamw_step reports overflow).
+ *   mvd_train_get_grad              copy of one parameter's gradient (PyTorch layout), still multiplied by the loss scale(s).
+ *   mvd_train_adamw_step            torch.optim.AdamW on the arena: the UNet group (all of model.diffusion_model.* when
+ *                                   finetune_unet != 0, else the DepthTransformers of attention.py:140-142) at `lr`,
+ *                                   time_embed.* and spatial_volume.* at `lr_aux` (the reference: 10 lr); gradients are
+ *                                   multiplied by inv_scale first.  `step` counts from 1.  If any gradient is inf / nan the
+ *                                   whole update is skipped (*skipped_out = 1; reading it back synchronises the stream; NULL
+ *                                   = no read-back).
+ *   mvd_train_repack                after the parameters changed: re-derive every packed fp16 weight in place. */
+int mvd_train_enable(mvd_ctx* ctx, int on);
+int mvd_train_param_count(mvd_ctx* ctx);
+int mvd_train_param_info(mvd_ctx* ctx, int index, char* name, size_t name_cap, int64_t* offset, int64_t* numel, int64_t* shape,
+                         int* ndim);
+int64_t mvd_train_arena_size(mvd_ctx* ctx);
+int mvd_train_adopt_arena(mvd_ctx* ctx, int which, float* ptr, int64_t numel);
+int mvd_train_zero_grad(mvd_ctx* ctx, void* stream);
+int mvd_train_unet_step(mvd_ctx* ctx, const float* x, const int64_t* timesteps, const float* context, int B, const float* src0,
+                        const float* src1, const float* src2, const float* src3, int depth0, const float* target, float loss_scale,
+                        int recompute, float* pred_out, float* loss_out, float* dsrc0, float* dsrc1, float* dsrc2, float* dsrc3,
+                        void* stream);
 int mvd_train_get_grad(mvd_ctx* ctx, const char* name, float* out, size_t numel, void* stream);
+int mvd_train_adamw_step(mvd_ctx* ctx, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float inv_scale, int finetune_unet, int* skipped_out, void* stream);
+int mvd_train_repack(mvd_ctx* ctx);
 /* Puts a volume [64,V,V,V] (reference layout, e.g. one sample of construct_spatial_volume's [B,64,V,V,V] result) back into
  * the context for mvd_frustum_volumes / mvd_denoise_views: with B > 1 samples per step (training_step) the per-sample
  * volumes are built first and the frustum stage runs afterwards (morphable_diffusion.py:531-533). */
@@ -191,6 +224,15 @@ int mvd_op_attention(mvd_ctx* ctx, const float* q, const float* k, const float* 
                      float* out, void* stream);
 int mvd_op_conv3d(mvd_ctx* ctx, const float* x_ncdhw, int B, int Cin, int D, int H, int W, const float* w,
                   const float* bias, int Cout, int stride, int transposed, const float* resid, float* out, void* stream);
+/* backward-kernel hooks used by tests/test_gpu_train_ops.py (each is compared with torch.autograd of the same op):
+ * self-attention backward (q, k, v, d_out, dq, dk, dv: [B,T,heads*d] fp32; the kernels themselves work on fp16), GroupNorm
+ * (+ SiLU / ReLU) backward and LayerNorm backward on channels-last fp32 ([B,rows,C] / [rows,C]). */
+int mvd_op_attention_bwd(mvd_ctx* ctx, const float* q, const float* k, const float* v, const float* d_out, int B, int T, int heads,
+                         int d, float* dq, float* dk, float* dv, void* stream);
+int mvd_op_group_norm_bwd(mvd_ctx* ctx, const float* x, const float* dy, int B, int rows, int C, int groups, const float* gamma,
+                          const float* beta, float eps, int act, float* dx, float* dgamma, float* dbeta, void* stream);
+int mvd_op_layer_norm_bwd(mvd_ctx* ctx, const float* x, const float* dy, int rows, int C, const float* gamma, float* dx,
+                          float* dgamma, float* dbeta, void* stream);
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);

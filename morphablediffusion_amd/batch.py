@@ -168,6 +168,13 @@ def views_to_uint8(x_sample: torch.Tensor, input_image: torch.Tensor) -> np.ndar
     return np.concatenate(list(rows), 0)
 
 
+def save_image_grid(x_sample: torch.Tensor, batch, path: str):
+    """SyncMultiviewDiffusion.log_image (morphable_diffusion.py:589-599): per sample the input view followed by the N
+    generated views, samples stacked vertically, written as one image file."""
+    from PIL import Image
+    Image.fromarray(views_to_uint8(x_sample, batch["input_image"])).save(path)
+
+
 def neus2_transform(Ks: torch.Tensor, RTs: torch.Tensor, image_size: int = 256) -> Dict:
     """The ``transform.json`` dictionary of generate_face.py:145-154,173-186 (NeuS2 input): per view the camera-to-world
     matrix with the y and z axes flipped (OpenCV -> OpenGL camera) and the 3x3 intrinsics."""

@@ -72,6 +72,20 @@ inline int nblk(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 4096 ? 
 
 }  // namespace
 
+int bwd_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step,
+              float inv_scale, const int* skip, hipStream_t s);
+int bwd_finite_check(const float* g, size_t n, int* flag, hipStream_t s);
+
+int bwd_attention(const half_t* qkv, int ld3, const half_t* o, const half_t* dO, int ldo, half_t* dqkv, int ldd, float* lse, float* delta,
+                  int B, int T, int heads, int d, hipStream_t s);
+int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                   const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
+                   float* db_part, float* dpre_part, hipStream_t s);
+int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s);
+int bwd_ln_max_blocks();
+int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
+                   long lddx, int accum, float* part, int* nblk, hipStream_t s);
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s);
 extern "C" {
 
 const char* mvd_last_error(void) { return g_err.c_str(); }
@@ -100,11 +114,12 @@ void mvd_destroy(mvd_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
-  for (auto& kv : c->raw) hipFree(kv.second.d);
-  for (auto& kv : c->train_w) hipFree(kv.second.d);
-  for (auto& kv : c->train_g) hipFree(kv.second.d);
-  hipFree(c->tape_x);
-  hipFree(c->tape_h);
+  for (auto& kv : c->raw)
+    if (!c->param_index.count(kv.first)) hipFree(kv.second.d);  // master parameters live in the arena
+  float* arenas[4] = {c->arena_p, c->arena_g, c->arena_m, c->arena_v};
+  for (int i = 0; i < 4; ++i)
+    if (arenas[i] && c->arena_owned[i]) hipFree(arenas[i]);
+  hipFree(c->found_inf);
   for (void* p : c->owned) hipFree(p);
   mesh_free(c->mesh);
   hipFree(c->cams);
@@ -311,26 +326,164 @@ int mvd_set_volume(mvd_ctx* c, const float* volume, void* stream) {
   return launch_nchw_to_nhwc(volume, 1, 64, V * V * V, c->volume, 64, 64, S(stream));
 }
 
-int mvd_train_tape(mvd_ctx* c, int max_batch) {
+int mvd_train_enable(mvd_ctx* c, int on) {
   if (!c) return mvd_fail("null context");
-  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
-  return engine_tape_enable(c, max_batch);
+  if (c->finalized) return mvd_fail("mvd_train_enable: call it before mvd_finalize_weights");
+  c->train_mode = on != 0;
+  return 0;
 }
 
-int mvd_train_backward_last_condition(mvd_ctx* c, const float* dpred, const float* ctx0, int B, int D, void* stream) {
+int mvd_train_param_count(mvd_ctx* c) { return (c && c->train_mode && c->finalized) ? (int)c->params.size() : 0; }
+
+int mvd_train_param_info(mvd_ctx* c, int i, char* name, size_t cap, int64_t* offset, int64_t* numel, int64_t* shape, int* ndim) {
+  if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_param_info: context not finalized in training mode");
+  if (i < 0 || i >= (int)c->params.size()) return mvd_fail("mvd_train_param_info: index out of range");
+  const mvd_ctx::ParamRec& r = c->params[i];
+  if (name) {
+    if (r.key.size() + 1 > cap) return mvd_fail("mvd_train_param_info: name buffer too small");
+    memcpy(name, r.key.c_str(), r.key.size() + 1);
+  }
+  if (offset) *offset = (int64_t)r.off;
+  if (numel) *numel = (int64_t)r.numel;
+  if (ndim) *ndim = (int)r.shape.size();
+  if (shape)
+    for (size_t k = 0; k < r.shape.size() && k < 8; ++k) shape[k] = r.shape[k];
+  return 0;
+}
+
+int64_t mvd_train_arena_size(mvd_ctx* c) { return (c && c->train_mode && c->finalized) ? (int64_t)c->arena_n : 0; }
+
+int mvd_train_adopt_arena(mvd_ctx* c, int which, float* ptr, int64_t numel) {
+  if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_adopt_arena: context not finalized in training mode");
+  if (which < 0 || which > 3 || !ptr || numel != (int64_t)c->arena_n) return mvd_fail("mvd_train_adopt_arena: bad argument");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  float** slot[4] = {&c->arena_p, &c->arena_g, &c->arena_m, &c->arena_v};
+  float* old = *slot[which];
+  if (old == ptr) return 0;
+  if (old) HIP_CHECK_RET(hipMemcpy(ptr, old, c->arena_n * sizeof(float), hipMemcpyDeviceToDevice));
+  else HIP_CHECK_RET(hipMemset(ptr, 0, c->arena_n * sizeof(float)));
+  if (old && c->arena_owned[which]) hipFree(old);
+  *slot[which] = ptr;
+  c->arena_owned[which] = false;
+  if (which == 0)
+    for (auto& r : c->params) c->raw[r.key].d = ptr + r.off;
+  return 0;
+}
+
+int mvd_train_zero_grad(mvd_ctx* c, void* stream) {
+  if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_zero_grad: context not finalized in training mode");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  HIP_CHECK_RET(hipMemsetAsync(c->arena_g, 0, c->arena_n * sizeof(float), S(stream)));
+  return 0;
+}
+
+int mvd_train_unet_step(mvd_ctx* c, const float* x, const int64_t* timesteps, const float* context, int B, const float* src0,
+                        const float* src1, const float* src2, const float* src3, int depth0, const float* target, float loss_scale,
+                        int recompute, float* pred_out, float* loss_out, float* dsrc0, float* dsrc1, float* dsrc2, float* dsrc3,
+                        void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
-  if (!c || !dpred || !ctx0 || B <= 0) return mvd_fail("mvd_train_backward_last_condition: bad argument");
-  return engine_train_backward_last_condition(c, dpred, ctx0, B, D, S(stream));
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (!x || !timesteps || !context || !target || !pred_out || B <= 0) return mvd_fail("mvd_train_unet_step: bad argument");
+  hipStream_t s = S(stream);
+  const mvd_unet_config& u = c->u;
+  WsScope ws_scope(c);
+  const int HW = u.image_size * u.image_size, cin = u.in_channels, oc = u.out_channels;
+  if (cin % 8) return mvd_fail("in_channels must be a multiple of 8");
+  float* xn = ws_alloc<float>(c, (size_t)B * HW * cin);
+  float* eps = ws_alloc<float>(c, (size_t)B * HW * oc);
+  float* tgt = ws_alloc<float>(c, (size_t)B * HW * oc);
+  WS_CHECK(xn && eps && tgt);
+  RET_IF(launch_nchw_to_nhwc(x, B, cin, HW, xn, cin, cin, s));
+  RET_IF(launch_nchw_to_nhwc(target, B, oc, HW, tgt, oc, oc, s));
+  const float* srcs[4] = {src0, src1, src2, src3};
+  float* douts[4] = {dsrc0, dsrc1, dsrc2, dsrc3};
+  Ctx5 cl[4];
+  float* dcl[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t nvol[4];
+  for (int l = 0; l < 4; ++l) {
+    if (!srcs[l]) return mvd_fail("mvd_train_unet_step: missing source_dict level");
+    const int sl = u.image_size >> l, Dl = depth0 >> l, C = u.volume_dims[l];
+    nvol[l] = (size_t)B * Dl * sl * sl * C;
+    float* t = ws_alloc<float>(c, nvol[l]);
+    WS_CHECK(t);
+    RET_IF(launch_nchw_to_nhwc(srcs[l], B, C, Dl * sl * sl, t, C, C, s));
+    cl[l].p = t;
+    cl[l].f32 = 1;
+    if (douts[l]) {
+      dcl[l] = ws_alloc<float>(c, nvol[l]);
+      WS_CHECK(dcl[l]);
+      HIP_CHECK_RET(hipMemsetAsync(dcl[l], 0, nvol[l] * sizeof(float), s));
+    }
+  }
+  RET_IF(engine_train_step(c, xn, cin, timesteps, context, B, depth0, cl, tgt, loss_scale, recompute, eps, loss_out, dcl, s));
+  RET_IF(launch_nhwc_to_nchw(eps, oc, B, oc, HW, pred_out, s));
+  for (int l = 0; l < 4; ++l)
+    if (douts[l]) {
+      const int sl = u.image_size >> l, Dl = depth0 >> l, C = u.volume_dims[l];
+      RET_IF(launch_nhwc_to_nchw(dcl[l], C, B, C, Dl * sl * sl, douts[l], s));
+    }
+  return 0;
 }
 
 int mvd_train_get_grad(mvd_ctx* c, const char* name, float* out, size_t numel, void* stream) {
   if (!c || !name || !out) return mvd_fail("mvd_train_get_grad: null argument");
   if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
-  auto it = c->train_g.find(name);
-  if (it == c->train_g.end() || !it->second.d) return mvd_fail("mvd_train_get_grad: no gradient under that name (run the backward first)");
-  if (it->second.numel != numel) return mvd_fail("mvd_train_get_grad: size mismatch");
-  HIP_CHECK_RET(hipMemcpyAsync(out, it->second.d, numel * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
+  auto it = c->param_index.find(name);
+  if (it == c->param_index.end()) return mvd_fail("mvd_train_get_grad: not a parameter of this context (training mode off?)");
+  const mvd_ctx::ParamRec& r = c->params[it->second];
+  if (r.numel != numel) return mvd_fail("mvd_train_get_grad: size mismatch");
+  HIP_CHECK_RET(hipMemcpyAsync(out, c->arena_g + r.off, numel * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
   return 0;
+}
+
+int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float inv_scale, int finetune_unet, int* skipped_out, void* stream) {
+  if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_adamw_step: context not finalized in training mode");
+  if (step < 1) return mvd_fail("mvd_train_adamw_step: step counts from 1");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  hipStream_t s = S(stream);
+  for (float** a : {&c->arena_m, &c->arena_v})
+    if (!*a) {
+      HIP_CHECK_RET(hipMalloc((void**)a, c->arena_n * sizeof(float)));
+      HIP_CHECK_RET(hipMemset(*a, 0, c->arena_n * sizeof(float)));
+      c->arena_owned[a == &c->arena_m ? 2 : 3] = true;
+    }
+  HIP_CHECK_RET(hipMemsetAsync(c->found_inf, 0, sizeof(int), s));
+  RET_IF(bwd_finite_check(c->arena_g, c->arena_n, c->found_inf, s));
+  // the reference's parameter groups (morphable_diffusion.py:627-646): the UNet (all of it with finetune_unet, else the
+  // DepthTransformers: attention.py:140-142) at lr; time_embed and spatial_volume at 10 lr (passed in as lr_aux).
+  // Consecutive parameters of one group are updated by one launch.
+  const std::string U = "model.diffusion_model.";
+  auto group_of = [&](const std::string& k) -> int {
+    if (k.rfind(U, 0) == 0) {
+      if (finetune_unet) return 1;
+      return (k.rfind(U + "middle_conditions.", 0) == 0 || k.rfind(U + "output_conditions.", 0) == 0) ? 1 : 0;
+    }
+    return 2;
+  };
+  size_t i = 0;
+  while (i < c->params.size()) {
+    const int grp = group_of(c->params[i].key);
+    size_t j = i;
+    while (j + 1 < c->params.size() && group_of(c->params[j + 1].key) == grp) ++j;
+    if (grp) {
+      const size_t off = c->params[i].off, end = c->params[j].off + ((c->params[j].numel + 63) & ~(size_t)63);
+      RET_IF(bwd_adamw(c->arena_p + off, c->arena_g + off, c->arena_m + off, c->arena_v + off, end - off, grp == 1 ? lr : lr_aux, beta1,
+                       beta2, eps, weight_decay, step, inv_scale, c->found_inf, s));
+    }
+    i = j + 1;
+  }
+  if (skipped_out) {
+    HIP_CHECK_RET(hipMemcpyAsync(skipped_out, c->found_inf, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+int mvd_train_repack(mvd_ctx* c) {
+  if (!c) return mvd_fail("null context");
+  return engine_repack(c);
 }
 
 int mvd_mse_loss(mvd_ctx* c, const float* a, const float* b, size_t n, float* out, void* stream) {
@@ -559,6 +712,63 @@ int mvd_op_attention(mvd_ctx* c, const float* q, const float* k, const float* v,
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, o, out, (size_t)rows * C);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+
+// backward-kernel hooks (tests/test_gpu_train_ops.py): each against torch.autograd of the same op
+int mvd_op_attention_bwd(mvd_ctx* c, const float* q, const float* k, const float* v, const float* d_out, int B, int T, int heads, int d,
+                         float* dq, float* dk, float* dv, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c) return mvd_fail("null context");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const int C = heads * d, rows = B * T;
+  half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
+  half_t* o = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* do16 = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* dqkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
+  float* lse = ws_alloc<float>(c, (size_t)B * heads * T);
+  float* delta = ws_alloc<float>(c, (size_t)B * heads * T);
+  float* tmp = ws_alloc<float>(c, (size_t)rows * 3 * C);
+  WS_CHECK(qkv && o && do16 && dqkv && lse && delta && tmp);
+  hipLaunchKernelGGL(pack_qkv_rows_kernel, dim3(nblk((size_t)rows * C)), dim3(256), 0, s, q, k, v, rows, C, qkv);
+  RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, o, C, B, T, heads, d, s));
+  RET_IF(bwd_cast_rows(d_out, C, rows, C, C, do16, s));
+  RET_IF(bwd_attention(qkv, 3 * C, o, do16, C, dqkv, 3 * C, lse, delta, B, T, heads, d, s));
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk((size_t)rows * 3 * C)), dim3(256), 0, s, dqkv, tmp, (size_t)rows * 3 * C);
+  HIP_CHECK_RET(hipGetLastError());
+  float* outs[3] = {dq, dk, dv};
+  for (int i = 0; i < 3; ++i)
+    HIP_CHECK_RET(hipMemcpy2DAsync(outs[i], (size_t)C * 4, tmp + (size_t)i * C, (size_t)3 * C * 4, (size_t)C * 4, rows, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// x, dy, dx: [B, rows, C] channels-last
+int mvd_op_group_norm_bwd(mvd_ctx* c, const float* x, const float* dy, int B, int rows, int C, int groups, const float* gamma,
+                          const float* beta, float eps, int act, float* dx, float* dgamma, float* dbeta, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c) return mvd_fail("null context");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  float* dg = ws_alloc<float>(c, (size_t)B * C);
+  float* db = ws_alloc<float>(c, (size_t)B * C);
+  WS_CHECK(dg && db);
+  RET_IF(bwd_group_norm(x, C, nullptr, 0, dy, C, B, rows, C, groups, gamma, beta, eps, act, dx, C, 0, dg, db, nullptr, s));
+  RET_IF(bwd_sum_rows_add(dg, B, C, C, dgamma, 0, s));
+  return bwd_sum_rows_add(db, B, C, C, dbeta, 0, s);
+}
+
+int mvd_op_layer_norm_bwd(mvd_ctx* c, const float* x, const float* dy, int rows, int C, const float* gamma, float* dx, float* dgamma,
+                          float* dbeta, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c) return mvd_fail("null context");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  float* part = ws_alloc<float>(c, (size_t)bwd_ln_max_blocks() * 2 * C);
+  WS_CHECK(part);
+  int nb = 0;
+  RET_IF(bwd_layer_norm(x, C, dy, C, rows, C, gamma, 1e-5f, dx, C, 0, part, &nb, s));
+  RET_IF(bwd_sum_rows_add(part, nb, C, 2 * C, dgamma, 0, s));
+  return bwd_sum_rows_add(part + C, nb, C, 2 * C, dbeta, 0, s);
 }
 
 int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream) {

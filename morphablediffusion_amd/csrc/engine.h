@@ -29,11 +29,18 @@ struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
   half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
   float* bias = nullptr;
   int N = 0, Cin = 0, taps = 1;
+  // training mode only (engine_train.hip: build_dgrad): the adjoint's weights, fp16 [taps, flipped][cin_l][Np] with Np = N padded
+  // to a multiple of 8 -- the same packed layout with the roles of N and Cin swapped, so dgrad runs on the forward kernels
+  half_t* wT = nullptr;
+  int Np = 0;
+  std::string key;   // state_dict key of the weight tensor (gradient bookkeeping); empty for stacked / folded weights
+  std::string bkey;  // ... of the bias
 };
 struct NormW {
   float* g = nullptr;
   float* b = nullptr;
   int C = 0;
+  std::string key;  // state_dict prefix ("....norm"): <key>.weight / <key>.bias
 };
 struct LinW {  // small per-sample linear: fp16 [N][K]
   half_t* w = nullptr;
@@ -147,8 +154,14 @@ struct EncBlockW {
 struct Workspace {
   char* base = nullptr;
   size_t size = 0, off = 0, peak = 0;
-  int hold = 0;  // > 0: scopes that end now keep their allocations (work enqueued on the side stream is still using them);
-                 // the enclosing scope opened before the hold releases everything
+  // 0: every scope releases its allocations when it ends.
+  // 1: none does (work enqueued on the side stream is still using them); the enclosing scope opened before the hold releases
+  //    everything.
+  // 2: training forward, keep-all: scratch scopes (WS_TEMP: split-K slabs, operand copies) release, everything a block
+  //    computes stays for the backward pass.
+  // 3: training forward with per-block recompute: block scopes (WS_BLOCK) release too, only the chain level (block inputs /
+  //    outputs) stays.
+  int hold = 0;
   void* alloc(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
     if (o + bytes > size) return nullptr;
@@ -234,13 +247,25 @@ struct mvd_ctx {
   LinW film_t, film_v, enc_t, enc_v;
   int film_total = 0, film_off[9] = {0};
 
-  // training slice (engine_train.hip): fp32 master copies of the parameters it differentiates, their gradients, and the tape
-  // (input of the last DepthTransformer + the UNet's final hidden state of the last forward)
-  std::map<std::string, RawTensor> train_w, train_g;
-  std::string train_prefix;
-  float* tape_x = nullptr;
-  float* tape_h = nullptr;
-  int tape_B = 0, tape_valid = 0;
+  // training (engine_train.hip).  With train_mode set before finalize the uploaded fp32 tensors of the hot path
+  // (model.diffusion_model.* | spatial_volume.* | time_embed.*) are kept as the MASTER parameters in one flat arena (sorted by
+  // key, so the reference's optimiser groups are contiguous ranges); `raw` keeps pointing into it, gradients / Adam moments
+  // live in arenas of the same layout, and engine_repack re-derives every packed fp16 weight from the masters in place.
+  bool train_mode = false;
+  bool repacking = false;
+  size_t repack_cursor = 0, sec_begin = 0, sec_end = 0;  // the `owned` allocations [sec_begin, sec_end) belong to the re-packable sections
+  std::vector<size_t> owned_bytes;
+  struct ParamRec {
+    std::string key;
+    size_t off = 0, numel = 0;
+    std::vector<int64_t> shape;
+  };
+  std::vector<ParamRec> params;
+  std::map<std::string, size_t> param_index;
+  size_t arena_n = 0;
+  float *arena_p = nullptr, *arena_g = nullptr, *arena_m = nullptr, *arena_v = nullptr;
+  bool arena_owned[4] = {false, false, false, false};  // hipMalloc'ed here (true) or adopted from the caller (mvd_train_adopt_arena)
+  int* found_inf = nullptr;  // device flag of the last gradient finite-check
 
   struct DbgBuf {
     std::string name;
@@ -280,16 +305,85 @@ struct Ctx5 {  // channels-last context volume of one level for the first n_ctx 
   const void* p = nullptr;
   int f32 = 1;
 };
+// ---- training tape (engine_train.hip): what the forward pass leaves behind for the backward pass -------------------------
+struct View {
+  float* p = nullptr;
+  int ld = 0, C = 0;
+};
+struct ResSaved {  // ResBlock._forward intermediates
+  const half_t* a1 = nullptr;  // silu(GN1(x)) [rows][ld1] (first cin columns; [hi | lo | hi] when the conv is extended-precision)
+  const half_t* a2 = nullptr;  // silu(GN2(h1))
+  const float* h1 = nullptr;   // conv1(a1) + bias + emb: the input of GN2
+  int ld1 = 0, ld2 = 0;
+};
+struct STSaved {  // SpatialTransformer / BasicTransformerBlock intermediates
+  const half_t *n0 = nullptr, *l1 = nullptr, *qkv = nullptr, *ao = nullptr, *l3 = nullptr, *gg = nullptr, *t3 = nullptr;
+  const float *t0 = nullptr, *t2 = nullptr;
+  int ldn0 = 0, ldt3 = 0;
+};
+enum { OP_COND = 5 };
+struct StageRec {
+  int kind = 0, idx = 0, chain = 0;  // chain: 0..nb-1 input blocks, nb middle, nb+1+i output block i
+  View in, out;
+  int H = 0, W = 0, level = 0;       // input resolution
+  bool have_saved = false;
+  ResSaved rs;
+  STSaved ss;
+};
+struct TrainTape {
+  bool recompute = false;  // true: only block inputs / outputs are kept, each block is re-run before its backward
+  std::vector<StageRec> stages;  // forward order
+  const float *e0 = nullptr, *e1 = nullptr, *e2 = nullptr, *ea = nullptr, *a2 = nullptr, *context = nullptr;
+  float* final_h = nullptr;
+  const half_t* head_a = nullptr;
+  int head_ld = 0;
+  std::vector<float*> cat;
+  std::vector<int> cat_C, h_ch, in_ch, in_res;
+  int Bv = 0, depth0 = 0;
+  const struct Ctx5* src = nullptr;
+};
 // produce (optional): fills src[] by enqueueing the context-volume producer (the frustum network) on the stream it is given;
 // engine_unet calls it after its full-resolution input blocks, on the side stream (see engine_unet.hip)
 typedef std::function<int(hipStream_t)> CtxProducer;
 int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
-                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce = nullptr);
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce = nullptr,
+                TrainTape* tape = nullptr);
+// executor state of one UNet forward (engine_unet.hip); the block functions are shared with the backward pass, which re-runs
+// single blocks (TrainTape::recompute)
+struct Fwd {
+  mvd_ctx* c;
+  hipStream_t s;
+  int Bv, n_ctx, depth0;
+  const float* emb_all;  // [Bv][emb_total]
+  const float* context;  // [Bv][context_dim]
+  const float* a2_all;   // [Bv][a2_total] folded attn2 output per SpatialTransformer
+  const Ctx5* src;
+  const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
+  // relu(GroupNorm(proj_context(volume))) of every DepthTransformer, produced on the side stream (nullptr: inline)
+  const half_t* cn_pre[16] = {nullptr};
+  bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
+  bool train = false;     // training forward: no deferred split-K slabs, LN1 / LN3 outputs in separate buffers
+};
+int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv = nullptr);
+int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv = nullptr);
+int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1);
+int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec = nullptr);
+// engine_weights.hip: re-derive the packed weights of the UNet / step embedding / conditioner from the master parameters
+int engine_repack(mvd_ctx* c);
 // engine_train.hip
-int engine_train_keep(mvd_ctx* c);
-int engine_tape_enable(mvd_ctx* c, int max_batch);
-int engine_tape_record(mvd_ctx* c, const float* x, int ldx, const float* h, int ldh, int Bv, hipStream_t s);
-int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, const float* ctx0_ncdhw, int B, int D, hipStream_t s);
+int engine_train_setup(mvd_ctx* c);     // finalize, train mode: masters into the arena
+bool engine_hot_key(const std::string& k);  // a key of the re-packable sections (UNet / conditioner / step embedding)
+int engine_build_dgrad(mvd_ctx* c);     // adjoint weights of every UNet GEMM (ConvW::wT)
+float* engine_grad(mvd_ctx* c, const std::string& key);         // gradient / master of a state_dict entry (nullptr: not a parameter)
+const float* engine_master(mvd_ctx* c, const std::string& key);
+int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes);         // owned allocation; replays the recorded one while re-packing
+// One training step of the UNet (training_step morphable_diffusion.py:520-549 from `self.model(...)` on + loss.backward()):
+// forward with the tape, loss = mean((pred - target)^2), dL/dpred * loss_scale back through every block; parameter gradients
+// are ACCUMULATED into the gradient arena (x loss_scale).  dsrc[l] (may be null): gradient w.r.t. the context volumes,
+// channels-last like src[l].  recompute: keep only block inputs and re-run each block before its backward.
+int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,
+                      const Ctx5 src[4], const float* target_nhwc, float loss_scale, int recompute, float* pred_nhwc, float* loss_out,
+                      float* const dsrc[4], hipStream_t s);
 // engine_cond.hip
 int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                            const int32_t* view_idx_dev, int n_local, int add_bias, float* fused_out, hipStream_t s,
@@ -360,12 +454,14 @@ int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sampl
                    int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr);
 // restores the workspace bump pointer when the scope is left, on the error returns too (a failed call must not leak
 // workspace into the calls that follow it)
+enum { WS_CHAIN = 0, WS_BLOCK = 1, WS_TEMP = 2 };
 struct WsScope {
   Workspace& w;
   const size_t mark;
-  explicit WsScope(mvd_ctx* c) : w(c->ws), mark(c->ws.off) {}
+  const int kind;
+  explicit WsScope(mvd_ctx* c, int kind_ = WS_CHAIN) : w(c->ws), mark(c->ws.off), kind(kind_) {}
   ~WsScope() {
-    if (!w.hold) w.off = mark;
+    if (!w.hold || (kind == WS_TEMP && w.hold >= 2) || (kind == WS_BLOCK && w.hold == 3)) w.off = mark;
   }
   WsScope(const WsScope&) = delete;
   WsScope& operator=(const WsScope&) = delete;

@@ -1,222 +1,870 @@
-// Training-step backward, first slice: gradients of every parameter of the LAST DepthTransformer
-// (output_conditions.<last>, attention.py:49-84) of the loss of training_step (morphable_diffusion.py:520-549).
-// The UNet forward runs in the inference engine with the tape on: the input of that DepthTransformer and the UNet's final
-// hidden state are kept (fp32).  From those, the block's forward is re-computed in fp32 from the master weights (kept as
-// uploaded) with every intermediate saved, and the loss gradient is propagated
-//     dL/dpred -> out conv (dgrad) -> SiLU / GroupNorm32 -> [x + proj_out(.)] -> conv3x3, ReLU, GN8, conv3x3, ReLU, GN8
-//              -> to_out -> depth attention -> to_q / to_k / to_v -> proj_in (conv1x1, GN8, SiLU) / proj_context (conv1x1x1,
-//                 GN8, ReLU)
-// with the weight / bias / gain gradients collected on the way.  Everything upstream (the other DepthTransformers, the UNet's
-// own blocks, the conditioner) needs the backward of the whole UNet and is not built yet.
+// Training step of the multi-view UNet: forward with a tape, MSE loss, and the backward pass through
+// EVERY block of DepthWiseAttention (reference: training_step morphable_diffusion.py:520-549 from `self.model(...)` on, then
+// loss.backward(); blocks openaimodel.py:256-276 (ResBlock), modules/attention.py:265-336 (SpatialTransformer /
+// BasicTransformerBlock), attention.py:49-84 (DepthTransformer), openaimodel.py:110-160 (Up / Downsample), :717-721 (head)).
+//
+// * dgrad runs on the forward MFMA kernels with the adjoint weights ConvW::wT (transposed, tap-flipped fp16 packs derived
+//   from the forward packs at finalize / repack time);
+// * wgrad is a plain MFMA GEMM dW[Cout][Cin*taps] += dY^T col(X) whose operands are made K-contiguous by transposing casts
+//   (k_bwd.hip: tcast / im2colT); its output layout IS the reference's parameter layout, accumulated straight into the
+//   gradient arena;
+// * norms / GEGLU / softmax / reductions are the fp32 kernels of k_bwd.hip;
+// * the DepthTransformers are differentiated in their UNFOLDED form (to_q / to_k / to_v / to_out separately, as the
+//   reference's parameters are), re-computed from the block input with the master weights; their GEMMs go through `tgemm`
+//   (fp32 in HBM -> fp16 operands -> MFMA);
+// * master parameters, gradients and Adam moments are flat fp32 arenas with one layout (sorted by state_dict key): the
+//   reference's two optimiser groups (morphable_diffusion.py:627-646) are two contiguous ranges, the DDP gradient
+//   all-reduce (train_morphable_diffusion.py:302-303) is ONE collective on one buffer.
+// Activation gradients carry the caller's loss scale (fp16 MFMA operands); nothing here un-scales -- the optimiser does.
 #include <string.h>
+
+#include <algorithm>
 
 #include "engine.h"
 
-int train_sgemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int M, int N, int K, float* scratch,
-                size_t scratch_floats, hipStream_t s);
+// k_bwd.hip
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s);
+int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int C, int stride, int ups, half_t* dst, int Rp, hipStream_t s);
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s);
+int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s);
+int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                   const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
+                   float* db_part, float* dpre_part, hipStream_t s);
+int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s);
+int bwd_colsum_samples(const void* v, int v_f32, long ld, int B, int rows, int C, float* out, long ldo, hipStream_t s);
+int bwd_ln_max_blocks();
+int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
+                   long lddx, int accum, float* part, int* nblk, hipStream_t s);
+int bwd_geglu(const half_t* pre, const float* dgg, long ldg, long rows, int N, half_t* dpre, hipStream_t s);
+int bwd_geglu_unpermute_add(const float* src, int N, int C, float* dst, hipStream_t s);
+int bwd_add_views(float* out, long ldo, const float* a, long lda, const float* b, long ldb, long rows, int C, int accum, hipStream_t s);
+int bwd_upsample2(const float* dup, int B, int H, int W, int C, float* dx, long lddx, int accum, hipStream_t s);
+int bwd_col2im3(const float* dcol, int B, int H, int W, int C, int stride, float* dx, long lddx, int accum, hipStream_t s);
+int bwd_silu_inplace(float* g, const float* u, size_t n, hipStream_t s);
+int bwd_attention(const half_t* qkv, int ld3, const half_t* o, const half_t* dO, int ldo, half_t* dqkv, int ldd, float* lse, float* delta,
+                  int B, int T, int heads, int d, hipStream_t s);
+// k_train.hip
 int train_im2col3(const float* X, int B, int H, int W, int C, float* col, hipStream_t s);
 int train_col2im3(const float* dcol, int B, int H, int W, int C, float* dX, hipStream_t s);
 int train_perm_w3(const float* src, int N, int C, int to_mat, float* dst, hipStream_t s);
 int train_gn_fwd(const float* x, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act, float* y,
                  float* stats, hipStream_t s);
-int train_gn_bwd(const float* x, const float* dy, int B, int rows, int C, int G, const float* gamma, const float* beta,
-                 const float* stats, int act, float* dx, float* dgamma, float* dbeta, float* tmp1, float* tmp2, hipStream_t s);
-int train_colsum(const float* v, long R, int C, float* out, hipStream_t s);
 int train_depth_fwd(const float* q, const float* k, const float* v, int R, int HW, int D, int hn, int hd, float scale, float* attn,
                     float* z, hipStream_t s);
 int train_depth_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dz, int R, int HW, int D, int hn,
                     int hd, float scale, float* dq, float* dk, float* dv, hipStream_t s);
+int train_scale_sub(const float* a, const float* b, float k, size_t n, float* out, hipStream_t s);
 int train_add_inplace(float* a, const float* b, size_t n, hipStream_t s);
 int train_copy_rows(const float* src, int ld, long rows, int C, float* dst, hipStream_t s);
 int train_add_bias_rows(float* x, long rows, int C, const float* bias, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------------------------------
+// arenas
+// ---------------------------------------------------------------------------------------------------------------------
+bool engine_hot_key(const std::string& k) {
+  return k.rfind("model.diffusion_model.", 0) == 0 || k.rfind("spatial_volume.", 0) == 0 || k.rfind("time_embed.", 0) == 0;
+}
 namespace {
-const float* TW(mvd_ctx* c, const std::string& k) {
-  auto it = c->train_w.find(k);
-  return it == c->train_w.end() ? nullptr : it->second.d;
-}
-float* grad_buf(mvd_ctx* c, const std::string& k) {
-  auto it = c->train_w.find(k);
-  if (it == c->train_w.end()) return nullptr;
-  RawTensor& g = c->train_g[k];
-  if (!g.d) {
-    if (hipMalloc((void**)&g.d, it->second.numel * sizeof(float)) != hipSuccess) return nullptr;
-    g.numel = it->second.numel;
-    g.shape = it->second.shape;
-  }
-  return g.d;
-}
+inline bool hot_key(const std::string& k) { return engine_hot_key(k); }
+inline int up8(int n) { return (n + 7) & ~7; }
+inline int up64(int n) { return (n + 63) & ~63; }
 }  // namespace
 
-// keeps fp32 copies of the parameters this slice differentiates (called from engine_finalize while the raw tensors exist)
-int engine_train_keep(mvd_ctx* c) {
-  if (!c->has_unet || c->conds.empty()) return 0;
-  const std::string U = "model.diffusion_model.";
-  c->train_prefix = c->conds.back().key + ".";
+// finalize in training mode: the uploaded fp32 tensors of the hot path become the master parameters, laid out back to back
+// (each aligned to 64 floats) in key order
+int engine_train_setup(mvd_ctx* c) {
+  c->params.clear();
+  c->param_index.clear();
+  size_t off = 0;
   for (auto& kv : c->raw) {
+    if (!hot_key(kv.first)) continue;
+    // BatchNorm running statistics are buffers, not parameters: they stay outside the arena (and outside the optimiser)
     const std::string& k = kv.first;
-    if (k.rfind(c->train_prefix, 0) != 0 && k.rfind(U + "out.", 0) != 0) continue;
-    RawTensor t = kv.second;
-    t.d = nullptr;
-    HIP_CHECK_RET(hipMalloc((void**)&t.d, std::max<size_t>(t.numel, 1) * sizeof(float)));
-    HIP_CHECK_RET(hipMemcpy(t.d, kv.second.d, t.numel * sizeof(float), hipMemcpyDeviceToDevice));
-    c->train_w[k] = t;
+    const bool buffer = k.size() > 13 && (k.compare(k.size() - 13, 13, ".running_mean") == 0 || k.compare(k.size() - 12, 12, ".running_var") == 0);
+    if (buffer) continue;
+    mvd_ctx::ParamRec r;
+    r.key = k;
+    r.off = off;
+    r.numel = kv.second.numel;
+    r.shape = kv.second.shape;
+    c->param_index[k] = c->params.size();
+    c->params.push_back(r);
+    off += (kv.second.numel + 63) & ~(size_t)63;
+  }
+  c->arena_n = off;
+  if (!off) return mvd_fail("training mode: no trainable tensors were uploaded");
+  HIP_CHECK_RET(hipMalloc((void**)&c->arena_p, off * sizeof(float)));
+  HIP_CHECK_RET(hipMalloc((void**)&c->arena_g, off * sizeof(float)));
+  c->arena_owned[0] = c->arena_owned[1] = true;
+  HIP_CHECK_RET(hipMemset(c->arena_p, 0, off * sizeof(float)));
+  HIP_CHECK_RET(hipMemset(c->arena_g, 0, off * sizeof(float)));
+  HIP_CHECK_RET(hipMalloc((void**)&c->found_inf, sizeof(int)));
+  HIP_CHECK_RET(hipMemset(c->found_inf, 0, sizeof(int)));
+  for (auto& r : c->params) {
+    RawTensor& t = c->raw[r.key];
+    HIP_CHECK_RET(hipMemcpy(c->arena_p + r.off, t.d, r.numel * sizeof(float), hipMemcpyDeviceToDevice));
+    hipFree(t.d);
+    t.d = c->arena_p + r.off;
   }
   return 0;
 }
 
-int engine_tape_enable(mvd_ctx* c, int max_batch) {
-  for (float** p : {&c->tape_x, &c->tape_h}) {
-    if (*p) hipFree(*p);
-    *p = nullptr;
+float* engine_grad(mvd_ctx* c, const std::string& key) {
+  auto it = c->param_index.find(key);
+  return it == c->param_index.end() ? nullptr : c->arena_g + c->params[it->second].off;
+}
+const float* engine_master(mvd_ctx* c, const std::string& key) {
+  auto it = c->param_index.find(key);
+  return it == c->param_index.end() ? nullptr : c->arena_p + c->params[it->second].off;
+}
+
+// adjoint weights of every GEMM of the UNet trunk (ResBlocks, SpatialTransformers, conv_in / down / up, the output conv)
+namespace {
+int make_wT(mvd_ctx* c, ConvW& w) {
+  if (!w.w) return 0;
+  const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
+  w.Np = up8(w.N);
+  RET_IF(engine_dmalloc(c, (void**)&w.wT, (size_t)w.taps * Cl * w.Np * sizeof(half_t)));
+  return bwd_pack_dgrad(w.w, w.taps, w.N, w.Cin, Cl, w.Np, w.wT, 0);
+}
+}  // namespace
+int engine_build_dgrad(mvd_ctx* c) {
+  for (auto& r : c->res) {
+    RET_IF(make_wT(c, r.c1));
+    RET_IF(make_wT(c, r.c2));
+    if (r.has_skip) RET_IF(make_wT(c, r.skip));
   }
-  c->tape_B = 0;
-  c->tape_valid = 0;
-  if (max_batch <= 0) return 0;
-  const size_t n = (size_t)max_batch * c->u.image_size * c->u.image_size * c->u.model_channels * c->u.channel_mult[0];
-  HIP_CHECK_RET(hipMalloc((void**)&c->tape_x, n * sizeof(float)));
-  HIP_CHECK_RET(hipMalloc((void**)&c->tape_h, n * sizeof(float)));
-  c->tape_B = max_batch;
+  for (auto& t : c->st)
+    for (ConvW* w : {&t.proj_in, &t.qkv, &t.attn_out, &t.ff1, &t.ff2, &t.proj_out}) RET_IF(make_wT(c, *w));
+  for (auto& w : c->convs) RET_IF(make_wT(c, w));
+  RET_IF(make_wT(c, c->out_conv));
   return 0;
 }
 
-// called by engine_unet around the last DepthTransformer when the tape is on
-int engine_tape_record(mvd_ctx* c, const float* x, int ldx, const float* h, int ldh, int Bv, hipStream_t s) {
-  if (!c->tape_B) return 0;
-  if (Bv > c->tape_B) return mvd_fail("training tape: batch larger than mvd_train_tape(max_batch)");
-  const int S = c->u.image_size, dim = c->u.model_channels * c->u.channel_mult[0];
-  RET_IF(train_copy_rows(x, ldx, (long)Bv * S * S, dim, c->tape_x, s));
-  RET_IF(train_copy_rows(h, ldh, (long)Bv * S * S, dim, c->tape_h, s));
-  c->tape_valid = Bv;
+// ---------------------------------------------------------------------------------------------------------------------
+// backward machinery
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Bwd {
+  mvd_ctx* c;
+  hipStream_t s;
+  int B;
+  Fwd* f;
+  TrainTape* tape;
+  float* demb = nullptr;  // [B][emb_total]: dL/d(emb_layers output) of every ResBlock
+  float* da2 = nullptr;   // [B][a2_total]: dL/d(attn2 output) of every SpatialTransformer
+  float* dsrc[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct Opnd {  // a GEMM operand in HBM
+  const void* p;
+  int f32;   // 1 fp32, 0 fp16
+  long ld;
+  int trans;  // A: 0 = [M][K], 1 = stored [K][M];  B: 1 = stored [N][K] (weight layout), 0 = stored [K][N]
+};
+
+// fp16 [rows][Kp] image of an operand: `stored_rows` = the operand is stored [rows][K] (row-major, stride ld), otherwise
+// [K][rows].  A row-major fp16 operand is used in place (need_dense: only when its rows are back to back).
+int operand16(mvd_ctx* c, const Opnd& o, int rows, int K, int Kp, bool stored_rows, bool need_dense, const half_t** out, int* ld,
+              hipStream_t s) {
+  if (stored_rows && !o.f32) {
+    if (o.ld % 8 || K != Kp || (((uintptr_t)o.p) & 15) || (need_dense && o.ld != Kp))
+      return mvd_fail("tgemm: a row-major fp16 operand needs K % 8 == 0, ld % 8 == 0 (dense for the weight side)");
+    *out = (const half_t*)o.p;
+    *ld = (int)o.ld;
+    return 0;
+  }
+  half_t* d = ws_alloc<half_t>(c, (size_t)rows * Kp);
+  WS_CHECK(d);
+  if (stored_rows) RET_IF(bwd_cast_rows((const float*)o.p, o.ld, rows, K, Kp, d, s));
+  else RET_IF(bwd_tcast(o.p, o.f32, o.ld, K, rows, d, Kp, s));  // stored [K][rows] -> [rows][Kp]
+  *out = d;
+  *ld = Kp;
   return 0;
 }
 
-// dpred [B,oc,S,S] (NCHW) = dL/d(UNet output); ctx0 [B,Cc,D,S,S] (NCDHW) = the finest source_dict volume the forward saw
-int engine_train_backward_last_condition(mvd_ctx* c, const float* dpred_nchw, const float* ctx0_ncdhw, int B, int D, hipStream_t s) {
-  if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
-  if (c->tape_valid != B) return mvd_fail("training backward: run the UNet forward with the tape on (same batch) first");
-  const std::string U = "model.diffusion_model.", P = c->train_prefix;
-  const CondW& cd = c->conds.back();
-  const int S = c->u.image_size, HW = S * S, R = B * HW, dim = cd.dim, I = cd.I, Cc = cd.Cc, hn = 4, hd = Cc / 2, oc = c->u.out_channels;
-  if (D != (48 * S) / 32 && D <= 0) return mvd_fail("training backward: bad depth");
-  const long RC = (long)B * D * HW;  // context rows
+// C[M][N] (ldc) (+)= op(A)[M][K] op(B)[K][N] on the MFMA GEMM kernels.  A.trans: stored [K][M]; B.trans: stored [N][K]
+// (the weight layout), otherwise [K][N].
+int tgemm(mvd_ctx* c, Opnd A, Opnd Bm, float* C, int ldc, int M, int N, int K, bool accum, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return mvd_fail("tgemm: empty problem");
+  WsScope scope(c, WS_TEMP);
+  const int Kp = up8(K);
+  const half_t *a16, *b16;
+  int lda, ldb;
+  RET_IF(operand16(c, A, M, K, Kp, !A.trans, false, &a16, &lda, s));
+  RET_IF(operand16(c, Bm, N, K, Kp, Bm.trans != 0, true, &b16, &ldb, s));
+  ConvW w;
+  w.w = const_cast<half_t*>(b16);
+  w.N = N;
+  w.Cin = Kp;
+  w.taps = 1;
+  GemmArgs g;
+  g.a = a16; g.lda = lda; g.w = &w; g.out = C; g.ldc = ldc; g.use_bias = false;
+  if (accum) {
+    g.resid = C;
+    g.ldr = ldc;
+  }
+  return run_linear(c, g, 1, M, s);
+}
+inline Opnd F32(const float* p, long ld, int trans) { return Opnd{p, 1, ld, trans}; }
+inline Opnd F16(const half_t* p, long ld, int trans) { return Opnd{p, 0, ld, trans}; }
+
+// dense fp16 [rows][up8(C)] copy of an fp32 gradient (the A operand of a dgrad GEMM)
+int grad16(mvd_ctx* c, const float* g, long ld, long rows, int C, half_t** out, hipStream_t s) {
+  half_t* d = ws_alloc<half_t>(c, (size_t)rows * up8(C));
+  WS_CHECK(d);
+  RET_IF(bwd_cast_rows(g, ld, rows, C, up8(C), d, s));
+  *out = d;
+  return 0;
+}
+
+// dX[rows][cin] (lddx) (+)= dY16[rows][Np] wT   (Linear / 1x1 conv adjoint on the forward GEMM kernels)
+int dgrad_linear(Bwd& b, const ConvW& w, const half_t* dy16, int ld16, void* dx, int lddx, int out_f32, int rows, bool accum) {
+  if (!w.wT) return mvd_fail("training backward: adjoint weights missing (context not finalized in training mode)");
+  ConvW t;
+  t.w = w.wT;
+  t.N = w.cin_l > 0 ? w.cin_l : w.Cin;
+  t.Cin = w.Np;
+  t.taps = 1;
+  GemmArgs g;
+  g.a = dy16; g.lda = ld16; g.w = &t; g.out = dx; g.out_f32 = out_f32; g.ldc = lddx; g.use_bias = false;
+  if (accum) {
+    g.resid = dx;
+    g.resid_f32 = out_f32;
+    g.ldr = lddx;
+  }
+  return run_linear(b.c, g, b.B, rows, b.s);
+}
+// 3x3 / stride 1 conv adjoint: the forward conv kernels on the tap-flipped transposed weights
+int dgrad_conv3(Bwd& b, const ConvW& w, const half_t* dy16, float* dx, int lddx, int H, int W, bool accum) {
+  if (!w.wT || w.taps != 9) return mvd_fail("training backward: 3x3 adjoint weights missing");
+  ConvW t;
+  t.w = w.wT;
+  t.N = w.cin_l > 0 ? w.cin_l : w.Cin;
+  t.Cin = w.Np;
+  t.taps = 9;
+  GemmArgs g;
+  g.a = dy16; g.lda = w.Np; g.w = &t; g.out = dx; g.ldc = lddx; g.use_bias = false;
+  if (accum) {
+    g.resid = dx;
+    g.ldr = lddx;
+  }
+  return run_conv2d(b.c, g, b.B, H, W, 1, 0, b.s);
+}
+// G[N][K2] += dyT[N][Rp] colT[K2][Rp]^T
+int wgrad_gemm(Bwd& b, const half_t* dyT, int N, const half_t* colT, int K2, int Rp, float* G, bool accum = true) {
+  if (!G) return 0;  // not a parameter of this run
+  ConvW t;
+  t.w = const_cast<half_t*>(colT);
+  t.N = K2;
+  t.Cin = Rp;
+  t.taps = 1;
+  GemmArgs g;
+  g.a = dyT; g.lda = Rp; g.w = &t; g.out = G; g.ldc = K2; g.use_bias = false;
+  if (accum) {
+    g.resid = G;
+    g.ldr = K2;
+  }
+  return run_linear(b.c, g, 1, N, b.s);
+}
+// weight + bias gradient of a Linear / 1x1 conv: dy fp32 [rows][N] (ld), x [rows][K] (fp16 or fp32)
+int wgrad_linear(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int rows, int K) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  const int Rp = up64(rows), N = w.N;
+  if (float* G = engine_grad(c, w.key)) {
+    half_t* dyT = ws_alloc<half_t>(c, (size_t)N * Rp);
+    half_t* xT = ws_alloc<half_t>(c, (size_t)K * Rp);
+    WS_CHECK(dyT && xT);
+    RET_IF(bwd_tcast(dy, 1, ldy, rows, N, dyT, Rp, b.s));
+    RET_IF(bwd_tcast(x, x_f32, ldx, rows, K, xT, Rp, b.s));
+    RET_IF(wgrad_gemm(b, dyT, N, xT, K, Rp, G));
+  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
+    float* part = ws_alloc<float>(c, (size_t)b.B * N);
+    WS_CHECK(part);
+    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, rows / b.B, N, part, N, b.s));
+    RET_IF(bwd_sum_rows_add(part, b.B, N, N, Gb, 1, b.s));
+  }
+  return 0;
+}
+// weight + bias gradient of a 3x3 conv (stride / nearest-upsampled input as in the forward): x [B,H,W,K] physical
+int wgrad_conv3(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int H, int W, int K, int stride,
+                int ups) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  const int Ho = ((H << ups) - 1) / stride + 1, Wo = ((W << ups) - 1) / stride + 1;
+  const int rows = b.B * Ho * Wo, Rp = up64(rows), N = w.N;
+  if (float* G = engine_grad(c, w.key)) {
+    half_t* dyT = ws_alloc<half_t>(c, (size_t)N * Rp);
+    half_t* colT = ws_alloc<half_t>(c, (size_t)K * 9 * Rp);
+    WS_CHECK(dyT && colT);
+    RET_IF(bwd_tcast(dy, 1, ldy, rows, N, dyT, Rp, b.s));
+    RET_IF(bwd_im2colT(x, x_f32, ldx, b.B, H, W, K, stride, ups, colT, Rp, b.s));
+    RET_IF(wgrad_gemm(b, dyT, N, colT, K * 9, Rp, G));
+  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
+    float* part = ws_alloc<float>(c, (size_t)b.B * N);
+    WS_CHECK(part);
+    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, Ho * Wo, N, part, N, b.s));
+    RET_IF(bwd_sum_rows_add(part, b.B, N, N, Gb, 1, b.s));
+  }
+  return 0;
+}
+// GroupNorm backward incl. its gain / bias gradients
+int gn_backward(Bwd& b, const NormW& n, int groups, float eps, int act, const float* x, long ld, const float* dy, long ldy, int rows_ps,
+                float* dx, long lddx, bool accum) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  float* dg = ws_alloc<float>(c, (size_t)b.B * n.C);
+  float* db = ws_alloc<float>(c, (size_t)b.B * n.C);
+  WS_CHECK(dg && db);
+  RET_IF(bwd_group_norm(x, ld, nullptr, 0, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, dg, db,
+                        nullptr, b.s));
+  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(dg, b.B, n.C, n.C, G, 1, b.s));
+  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(db, b.B, n.C, n.C, G, 1, b.s));
+  return 0;
+}
+int ln_backward(Bwd& b, const NormW& n, const float* x, long ld, const float* dy, long ldy, int rows, float* dx, long lddx, bool accum) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  float* part = ws_alloc<float>(c, (size_t)bwd_ln_max_blocks() * 2 * n.C);
+  WS_CHECK(part);
+  int nblk = 0;
+  RET_IF(bwd_layer_norm(x, ld, dy, ldy, rows, n.C, n.g, 1e-5f, dx, lddx, accum ? 1 : 0, part, &nblk, b.s));
+  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(part, nblk, n.C, 2 * n.C, G, 1, b.s));
+  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(part + n.C, nblk, n.C, 2 * n.C, G, 1, b.s));
+  return 0;
+}
+
+// ---- ResBlock (openaimodel.py:256-276) ------------------------------------------------------------------------------
+int bwd_res(Bwd& b, const ResW& r, const ResSaved& sv, View in, View dout, View din, bool accum, int H, int W) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  const int HW = H * W, rows = b.B * HW, cin = r.cin, cout = r.cout;
+  float* d_a2 = ws_alloc<float>(c, (size_t)rows * cout);
+  float* d_h1 = ws_alloc<float>(c, (size_t)rows * cout);
+  float* d_a1 = ws_alloc<float>(c, (size_t)rows * cin);
+  WS_CHECK(d_a2 && d_h1 && d_a1);
+  half_t* dy16;
+  RET_IF(grad16(c, dout.p, dout.ld, rows, cout, &dy16, b.s));
+  // out = conv2(a2) + b2 + skip(x)
+  RET_IF(dgrad_conv3(b, r.c2, dy16, d_a2, cout, H, W, false));
+  RET_IF(wgrad_conv3(b, r.c2, dout.p, dout.ld, sv.a2, 0, sv.ld2, H, W, cout, 1, 0));
+  // a2 = silu(GN2(h1))
+  RET_IF(gn_backward(b, r.n2, 32, 1e-5f, ACT_SILU, sv.h1, cout, d_a2, cout, HW, d_h1, cout, false));
+  // h1 = conv1(a1) + b1 + emb[b]: the per-sample sums of d_h1 are the gradient of this block's slice of the stacked emb
+  // projection, their sum over the samples the conv bias gradient
+  RET_IF(bwd_colsum_samples(d_h1, 1, cout, b.B, HW, cout, b.demb + r.emb_off, c->emb_total, b.s));
+  if (float* Gb = engine_grad(c, r.c1.bkey)) RET_IF(bwd_sum_rows_add(b.demb + r.emb_off, b.B, cout, c->emb_total, Gb, 1, b.s));
+  half_t* dh16;
+  RET_IF(grad16(c, d_h1, cout, rows, cout, &dh16, b.s));
+  RET_IF(dgrad_conv3(b, r.c1, dh16, d_a1, cin, H, W, false));
+  {
+    ConvW w1 = r.c1;
+    w1.bkey.clear();  // the bias gradient was taken from the emb sums above
+    RET_IF(wgrad_conv3(b, w1, d_h1, cout, sv.a1, 0, sv.ld1, H, W, cin, 1, 0));
+  }
+  // a1 = silu(GN1(x))
+  RET_IF(gn_backward(b, r.n1, 32, 1e-5f, ACT_SILU, in.p, in.ld, d_a1, cin, HW, din.p, din.ld, accum));
+  if (r.has_skip) {
+    RET_IF(dgrad_linear(b, r.skip, dy16, up8(cout), din.p, din.ld, 1, rows, true));
+    RET_IF(wgrad_linear(b, r.skip, dout.p, dout.ld, in.p, 1, in.ld, rows, cin));
+  } else {
+    RET_IF(bwd_add_views(din.p, din.ld, dout.p, dout.ld, nullptr, 0, rows, cout, 1, b.s));
+  }
+  return 0;
+}
+
+// ---- SpatialTransformer (modules/attention.py:325-336, BasicTransformerBlock._forward :265-269) ----------------------
+int bwd_st(Bwd& b, const STW& t, const STSaved& sv, View in, View dout, View din, bool accum, int H, int W) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  const int C = t.C, T = H * W, rows = b.B * T;
+  float* d_t = ws_alloc<float>(c, (size_t)rows * C);       // dL/d t3, then + LN3 path = dL/d t2, then + LN1 path = dL/d t0
+  float* d_gg = ws_alloc<float>(c, (size_t)rows * 4 * C);
+  half_t* pre16 = ws_alloc<half_t>(c, (size_t)rows * 8 * C);
+  half_t* dpre16 = ws_alloc<half_t>(c, (size_t)rows * 8 * C);
+  float* d_l = ws_alloc<float>(c, (size_t)rows * C);       // dL/d l3, later dL/d l1, later dL/d n0
+  half_t* d_ao16 = ws_alloc<half_t>(c, (size_t)rows * C);
+  half_t* dqkv16 = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
+  float* lse = ws_alloc<float>(c, (size_t)b.B * t.heads * T);
+  float* delta = ws_alloc<float>(c, (size_t)b.B * t.heads * T);
+  float* tmpW = ws_alloc<float>(c, (size_t)8 * C * C);
+  float* part = ws_alloc<float>(c, (size_t)b.B * 8 * C);
+  WS_CHECK(d_t && d_gg && pre16 && dpre16 && d_l && d_ao16 && dqkv16 && lse && delta && tmpW && part);
+  const std::string tb = t.key + ".transformer_blocks.0";
+  half_t* g16;
+  // out = proj_out(t3) + x
+  RET_IF(grad16(c, dout.p, dout.ld, rows, C, &g16, b.s));
+  RET_IF(dgrad_linear(b, t.proj_out, g16, C, d_t, C, 1, rows, false));
+  RET_IF(wgrad_linear(b, t.proj_out, dout.p, dout.ld, sv.t3, 0, sv.ldt3, rows, C));
+  // t3 = t2 + ff2(gg)
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(dgrad_linear(b, t.ff2, g16, C, d_gg, 4 * C, 1, rows, false));
+  RET_IF(wgrad_linear(b, t.ff2, d_t, C, sv.gg, 0, 4 * C, rows, 4 * C));
+  // gg = GEGLU(ff1(l3)): the pre-activations are re-computed (packed column order), never stored by the forward pass
+  {
+    GemmArgs g;
+    g.a = sv.l3; g.lda = C; g.w = &t.ff1; g.out = pre16; g.out_f32 = 0; g.ldc = 8 * C;
+    RET_IF(run_linear(c, g, b.B, rows, b.s));
+  }
+  RET_IF(bwd_geglu(pre16, d_gg, 4 * C, rows, 8 * C, dpre16, b.s));
+  RET_IF(dgrad_linear(b, t.ff1, dpre16, 8 * C, d_l, C, 1, rows, false));
+  {  // FF1 weight / bias gradient: computed in the packed row order, un-permuted into the reference's [value | gate] rows
+    WsScope sc2(c, WS_TEMP);
+    const int Rp = up64(rows);
+    half_t* dyT = ws_alloc<half_t>(c, (size_t)8 * C * Rp);
+    half_t* xT = ws_alloc<half_t>(c, (size_t)C * Rp);
+    WS_CHECK(dyT && xT);
+    if (float* G = engine_grad(c, t.ff1.key)) {
+      RET_IF(bwd_tcast(dpre16, 0, 8 * C, rows, 8 * C, dyT, Rp, b.s));
+      RET_IF(bwd_tcast(sv.l3, 0, C, rows, C, xT, Rp, b.s));
+      RET_IF(wgrad_gemm(b, dyT, 8 * C, xT, C, Rp, tmpW, false));
+      RET_IF(bwd_geglu_unpermute_add(tmpW, 8 * C, C, G, b.s));
+    }
+    if (float* Gb = engine_grad(c, t.ff1.bkey)) {
+      RET_IF(bwd_colsum_samples(dpre16, 0, 8 * C, b.B, T, 8 * C, part, 8 * C, b.s));
+      RET_IF(bwd_sum_rows_add(part, b.B, 8 * C, 8 * C, tmpW, 0, b.s));
+      RET_IF(bwd_geglu_unpermute_add(tmpW, 8 * C, 1, Gb, b.s));
+    }
+  }
+  // l3 = LN3(t2)
+  RET_IF(ln_backward(b, t.ln3, sv.t2, C, d_l, C, rows, d_t, C, true));
+  // t2 = t0 + to_out(ao) + b_o + attn2[b]
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(dgrad_linear(b, t.attn_out, g16, C, d_ao16, C, 0, rows, false));
+  {
+    ConvW wo = t.attn_out;
+    wo.bkey.clear();
+    RET_IF(wgrad_linear(b, wo, d_t, C, sv.ao, 0, C, rows, C));
+    // per-sample token sums of d_t2: gradient of the attn2 output (a per-sample constant) and, summed, of attn1's output bias
+    RET_IF(bwd_colsum_samples(d_t, 1, C, b.B, T, C, b.da2 + t.a2_off, c->a2_total, b.s));
+    if (float* Gb = engine_grad(c, t.attn_out.bkey)) RET_IF(bwd_sum_rows_add(b.da2 + t.a2_off, b.B, C, c->a2_total, Gb, 1, b.s));
+  }
+  // self-attention
+  RET_IF(bwd_attention(sv.qkv, 3 * C, sv.ao, d_ao16, C, dqkv16, 3 * C, lse, delta, b.B, T, t.heads, C / t.heads, b.s));
+  RET_IF(dgrad_linear(b, t.qkv, dqkv16, 3 * C, d_l, C, 1, rows, false));
+  {
+    WsScope sc2(c, WS_TEMP);
+    const int Rp = up64(rows);
+    half_t* dyT = ws_alloc<half_t>(c, (size_t)3 * C * Rp);
+    half_t* xT = ws_alloc<half_t>(c, (size_t)C * Rp);
+    WS_CHECK(dyT && xT);
+    RET_IF(bwd_tcast(dqkv16, 0, 3 * C, rows, 3 * C, dyT, Rp, b.s));
+    RET_IF(bwd_tcast(sv.l1, 0, C, rows, C, xT, Rp, b.s));
+    RET_IF(wgrad_gemm(b, dyT, 3 * C, xT, C, Rp, tmpW, false));
+    const char* names[3] = {".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight"};
+    for (int i = 0; i < 3; ++i)
+      if (float* G = engine_grad(c, tb + names[i]))
+        RET_IF(bwd_add_views(G, C, tmpW + (size_t)i * C * C, C, nullptr, 0, C, C, 1, b.s));
+  }
+  // l1 = LN1(t0)
+  RET_IF(ln_backward(b, t.ln1, sv.t0, C, d_l, C, rows, d_t, C, true));
+  // t0 = proj_in(n0) + b
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(dgrad_linear(b, t.proj_in, g16, C, d_l, C, 1, rows, false));
+  RET_IF(wgrad_linear(b, t.proj_in, d_t, C, sv.n0, 0, sv.ldn0, rows, C));
+  // n0 = GN(x) (eps 1e-6, no activation); out also carries x itself
+  RET_IF(gn_backward(b, t.norm, 32, 1e-6f, ACT_NONE, in.p, in.ld, d_l, C, T, din.p, din.ld, accum));
+  RET_IF(bwd_add_views(din.p, din.ld, dout.p, dout.ld, nullptr, 0, rows, C, 1, b.s));
+  return 0;
+}
+
+// ---- conv_in / Downsample / Upsample (openaimodel.py:110-160) --------------------------------------------------------
+int bwd_conv(Bwd& b, int kind, const ConvW& w, View in, View dout, View din, bool accum, bool need_din, int H, int W) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  const int stride = kind == OP_DOWN ? 2 : 1, ups = kind == OP_UP ? 1 : 0;
+  const int Ho = ((H << ups) - 1) / stride + 1, Wo = ((W << ups) - 1) / stride + 1, rows_o = b.B * Ho * Wo;
+  const int cin = w.cin_l > 0 ? w.cin_l : w.Cin, cout = w.N;
+  RET_IF(wgrad_conv3(b, w, dout.p, dout.ld, in.p, 1, in.ld, H, W, cin, stride, ups));
+  if (!need_din) return 0;
+  half_t* dy16;
+  RET_IF(grad16(c, dout.p, dout.ld, rows_o, cout, &dy16, b.s));
+  if (kind == OP_UP) {
+    float* d_up = ws_alloc<float>(c, (size_t)rows_o * cin);
+    WS_CHECK(d_up);
+    RET_IF(dgrad_conv3(b, w, dy16, d_up, cin, Ho, Wo, false));
+    return bwd_upsample2(d_up, b.B, H, W, cin, din.p, din.ld, accum ? 1 : 0, b.s);
+  }
+  if (kind == OP_DOWN) {
+    // dcol[r][t2 * cin + ci] = sum_co dy[r][co] wT[t2][ci][co]: one plain GEMM against the adjoint pack read as [9 cin][Np]
+    float* dcol = ws_alloc<float>(c, (size_t)rows_o * 9 * cin);
+    WS_CHECK(dcol);
+    ConvW t;
+    t.w = w.wT;
+    t.N = 9 * cin;
+    t.Cin = w.Np;
+    t.taps = 1;
+    GemmArgs g;
+    g.a = dy16; g.lda = w.Np; g.w = &t; g.out = dcol; g.ldc = 9 * cin; g.use_bias = false;
+    RET_IF(run_linear(c, g, b.B, rows_o, b.s));
+    return bwd_col2im3(dcol, b.B, H, W, cin, 2, din.p, din.ld, accum ? 1 : 0, b.s);
+  }
+  return dgrad_conv3(b, w, dy16, din.p, din.ld, H, W, accum);
+}
+
+// ---- DepthTransformer (attention.py:49-84), unfolded, from the block input -----------------------------------------
+int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, int H, int W, int level) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  hipStream_t s = b.s;
+  const int B = b.B, HW = H * W, R = B * HW, dim = cd.dim, I = cd.I, Cc = cd.Cc, hn = 4, hd = Cc / 2;
+  const int D = b.tape->depth0 >> level;
+  const long RC = (long)B * D * HW;
   const float scale = 1.0f / sqrtf((float)hd);
-  auto W = [&](const char* n) { return TW(c, P + n); };
-  const float *w_pi = W("proj_in.0.weight"), *b_pi = W("proj_in.0.bias"), *g_pi = W("proj_in.1.weight"), *e_pi = W("proj_in.1.bias");
-  const float *w_pc = W("proj_context.0.weight"), *g_pc = W("proj_context.1.weight"), *e_pc = W("proj_context.1.bias");
-  const float *w_q = W("depth_attn.to_q.weight"), *w_k = W("depth_attn.to_k.weight"), *w_v = W("depth_attn.to_v.weight"),
-              *w_o = W("depth_attn.to_out.weight");
-  const float *g_o0 = W("proj_out.0.weight"), *e_o0 = W("proj_out.0.bias"), *w_c1 = W("proj_out.2.weight");
-  const float *g_o3 = W("proj_out.3.weight"), *e_o3 = W("proj_out.3.bias"), *w_c2 = W("proj_out.5.weight");
-  const float *g_out = TW(c, U + "out.0.weight"), *e_out = TW(c, U + "out.0.bias"), *w_out = TW(c, U + "out.2.weight");
-  for (const float* q_ : {w_pi, b_pi, g_pi, e_pi, w_pc, g_pc, e_pc, w_q, w_k, w_v, w_o, g_o0, e_o0, w_c1, g_o3, e_o3, w_c2, g_out, e_out, w_out})
-    if (!q_) return mvd_fail("training backward: master weights of the last DepthTransformer / output head were not kept");
-  const char* gnames[] = {"proj_in.0.weight", "proj_in.0.bias", "proj_in.1.weight", "proj_in.1.bias", "proj_context.0.weight",
-                          "proj_context.1.weight", "proj_context.1.bias", "depth_attn.to_q.weight", "depth_attn.to_k.weight",
-                          "depth_attn.to_v.weight", "depth_attn.to_out.weight", "proj_out.0.weight", "proj_out.0.bias",
-                          "proj_out.2.weight", "proj_out.3.weight", "proj_out.3.bias", "proj_out.5.weight"};
-  for (const char* n : gnames)
-    if (!grad_buf(c, P + n)) return mvd_fail("training backward: gradient buffer allocation failed");
-  for (const char* n : {"out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias"})  // the output head (finetune_unet=True)
-    if (!grad_buf(c, U + n)) return mvd_fail("training backward: gradient buffer allocation failed");
-  auto G = [&](const char* n) { return c->train_g[P + n].d; };
-  WsScope ws_scope(c);
+  const std::string P = cd.key + ".";
+  auto Wm = [&](const char* n) { return engine_master(c, P + n); };
+  auto G = [&](const char* n) { return engine_grad(c, P + n); };
+  const float *w_pi = Wm("proj_in.0.weight"), *b_pi = Wm("proj_in.0.bias"), *g_pi = Wm("proj_in.1.weight"), *e_pi = Wm("proj_in.1.bias");
+  const float *w_pc = Wm("proj_context.0.weight"), *g_pc = Wm("proj_context.1.weight"), *e_pc = Wm("proj_context.1.bias");
+  const float *w_q = Wm("depth_attn.to_q.weight"), *w_k = Wm("depth_attn.to_k.weight"), *w_v = Wm("depth_attn.to_v.weight"),
+              *w_o = Wm("depth_attn.to_out.weight");
+  const float *g_o0 = Wm("proj_out.0.weight"), *e_o0 = Wm("proj_out.0.bias"), *w_c1 = Wm("proj_out.2.weight");
+  const float *g_o3 = Wm("proj_out.3.weight"), *e_o3 = Wm("proj_out.3.bias"), *w_c2 = Wm("proj_out.5.weight");
+  for (const float* q_ : {w_pi, b_pi, g_pi, e_pi, w_pc, g_pc, e_pc, w_q, w_k, w_v, w_o, g_o0, e_o0, w_c1, g_o3, e_o3, w_c2})
+    if (!q_) return mvd_fail("training backward: DepthTransformer master weights missing");
+  if (!b.tape->src || !b.tape->src[level].p || !b.tape->src[level].f32) return mvd_fail("training backward: fp32 context volume missing");
+  const float* C0 = (const float*)b.tape->src[level].p;  // channels-last [B][D][HW][Cc]
   auto F = [&](size_t n) { return ws_alloc<float>(c, n); };
-  // ---------------- forward recompute, fp32, every intermediate kept ----------------
-  const float *X = c->tape_x, *Hh = c->tape_h;
-  float* C0 = F((size_t)RC * Cc);
-  float *p = F((size_t)R * I), *pn = F((size_t)R * I), *st_pi = F(B * 8 * 2);
-  float *pc = F((size_t)RC * Cc), *cn = F((size_t)RC * Cc), *st_pc = F(B * 8 * 2);
+  // ---------------- forward recompute, every intermediate kept (fp32 in HBM, fp16 MFMA operands) ----------------
+  float* X = F((size_t)R * dim);
+  float *p = F((size_t)R * I), *pn = F((size_t)R * I);
+  float *pc = F((size_t)RC * Cc), *cn = F((size_t)RC * Cc);
   float *q = F((size_t)R * I), *k = F((size_t)RC * I), *v = F((size_t)RC * I);
   float *attn = F((size_t)R * hn * D), *z = F((size_t)R * I), *o = F((size_t)R * I);
-  float *a1 = F((size_t)R * I), *st_o0 = F(B * 8 * 2), *col1 = F((size_t)R * 9 * I), *o2 = F((size_t)R * I);
-  float *a2 = F((size_t)R * I), *st_o3 = F(B * 8 * 2), *col2 = F((size_t)R * 9 * I);
-  float *aout = F((size_t)R * dim), *st_out = F(B * 32 * 2);
-  float *m_c1 = F((size_t)I * 9 * I), *m_c2 = F((size_t)dim * 9 * I), *m_out = F((size_t)oc * 9 * dim);
-  const size_t scr_n = (size_t)64 << 20;  // floats: split-reduction scratch of the GEMMs
-  float* scr = F(scr_n);
-  // backward buffers
-  float *dpred = F((size_t)R * oc), *dcolo = F((size_t)R * 9 * dim), *da = F((size_t)R * dim), *dh = F((size_t)R * dim);
-  float *t1 = F((size_t)RC * Cc > (size_t)R * dim ? (size_t)RC * Cc : (size_t)R * dim), *t2 = F((size_t)RC * Cc > (size_t)R * dim ? (size_t)RC * Cc : (size_t)R * dim);
+  float *a1 = F((size_t)R * I), *col1 = F((size_t)R * 9 * I), *o2 = F((size_t)R * I);
+  float *a2 = F((size_t)R * I), *col2 = F((size_t)R * 9 * I);
+  float *m_c1 = F((size_t)I * 9 * I), *m_c2 = F((size_t)dim * 9 * I);
   float *dcol = F((size_t)R * 9 * I), *dI1 = F((size_t)R * I), *dI2 = F((size_t)R * I), *mg = F((size_t)dim * 9 * I);
   float *dk = F((size_t)RC * I), *dv = F((size_t)RC * I), *dcn = F((size_t)RC * Cc), *dpc = F((size_t)RC * Cc);
-  WS_CHECK(C0 && p && pn && st_pi && pc && cn && st_pc && q && k && v && attn && z && o && a1 && st_o0 && col1 && o2 && a2 && st_o3 &&
-           col2 && aout && st_out && m_c1 && m_c2 && m_out && scr && dpred && dcolo && da && dh && t1 && t2 && dcol && dI1 && dI2 &&
-           mg && dk && dv && dcn && dpc);
-  auto gemm = [&](const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* Cm, int M, int N, int K) {
-    return train_sgemm(A, lda, ta, Bm, ldb, tb, Cm, M, N, K, scr, scr_n, s);
-  };
-  RET_IF(launch_nchw_to_nhwc(ctx0_ncdhw, B, Cc, D * HW, C0, Cc, Cc, s));
+  float* dh = F((size_t)R * dim);
+  float* mgp = F((size_t)dim * 9 * I);
+  WS_CHECK(mgp);
+  WS_CHECK(X && p && pn && pc && cn && q && k && v && attn && z && o && a1 && col1 && o2 && a2 && col2 && m_c1 && m_c2 && dcol && dI1 &&
+           dI2 && mg && dk && dv && dcn && dpc && dh);
+  RET_IF(train_copy_rows(in.p, in.ld, R, dim, X, s));
+  RET_IF(train_copy_rows(dout.p, dout.ld, R, dim, dh, s));
   RET_IF(train_perm_w3(w_c1, I, I, 1, m_c1, s));
   RET_IF(train_perm_w3(w_c2, dim, I, 1, m_c2, s));
-  RET_IF(train_perm_w3(w_out, oc, dim, 1, m_out, s));
   // proj_in: conv1x1 + bias, GN8, SiLU        (attention.py:52-56)
-  RET_IF(gemm(X, dim, 0, w_pi, dim, 1, p, R, I, dim));
+  RET_IF(tgemm(c, F32(X, dim, 0), F32(w_pi, dim, 1), p, I, R, I, dim, false, s));
   RET_IF(train_add_bias_rows(p, R, I, b_pi, s));
-  RET_IF(train_gn_fwd(p, B, HW, I, 8, g_pi, e_pi, 1e-5f, ACT_SILU, pn, st_pi, s));
+  RET_IF(train_gn_fwd(p, B, HW, I, 8, g_pi, e_pi, 1e-5f, ACT_SILU, pn, nullptr, s));
   // proj_context: conv1x1x1 (no bias), GN8, ReLU   (:57-61)
-  RET_IF(gemm(C0, Cc, 0, w_pc, Cc, 1, pc, (int)RC, Cc, Cc));
-  RET_IF(train_gn_fwd(pc, B, D * HW, Cc, 8, g_pc, e_pc, 1e-5f, ACT_RELU, cn, st_pc, s));
+  RET_IF(tgemm(c, F32(C0, Cc, 0), F32(w_pc, Cc, 1), pc, Cc, (int)RC, Cc, Cc, false, s));
+  RET_IF(train_gn_fwd(pc, B, D * HW, Cc, 8, g_pc, e_pc, 1e-5f, ACT_RELU, cn, nullptr, s));
   // depth attention   (:26-47)
-  RET_IF(gemm(pn, I, 0, w_q, I, 1, q, R, I, I));
-  RET_IF(gemm(cn, Cc, 0, w_k, Cc, 1, k, (int)RC, I, Cc));
-  RET_IF(gemm(cn, Cc, 0, w_v, Cc, 1, v, (int)RC, I, Cc));
+  RET_IF(tgemm(c, F32(pn, I, 0), F32(w_q, I, 1), q, I, R, I, I, false, s));
+  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_k, Cc, 1), k, I, (int)RC, I, Cc, false, s));
+  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_v, Cc, 1), v, I, (int)RC, I, Cc, false, s));
   RET_IF(train_depth_fwd(q, k, v, R, HW, D, hn, hd, scale, attn, z, s));
-  RET_IF(gemm(z, I, 0, w_o, I, 1, o, R, I, I));
+  RET_IF(tgemm(c, F32(z, I, 0), F32(w_o, I, 1), o, I, R, I, I, false, s));
   // proj_out: GN8, ReLU, conv3x3, GN8, ReLU, conv3x3   (:63-70)
-  RET_IF(train_gn_fwd(o, B, HW, I, 8, g_o0, e_o0, 1e-5f, ACT_RELU, a1, st_o0, s));
-  RET_IF(train_im2col3(a1, B, S, S, I, col1, s));
-  RET_IF(gemm(col1, 9 * I, 0, m_c1, 9 * I, 1, o2, R, I, 9 * I));
-  RET_IF(train_gn_fwd(o2, B, HW, I, 8, g_o3, e_o3, 1e-5f, ACT_RELU, a2, st_o3, s));
-  RET_IF(train_im2col3(a2, B, S, S, I, col2, s));
-  // (the block's output x + conv(a2) is the taped final hidden state Hh)
-  // output head: GN32, SiLU (openaimodel.py:717-719); its conv's input is only needed for the (frozen) conv's own wgrad
-  RET_IF(train_gn_fwd(Hh, B, HW, dim, 32, g_out, e_out, 1e-5f, ACT_SILU, aout, st_out, s));
-  // ---------------- backward ----------------
-  RET_IF(launch_nchw_to_nhwc(dpred_nchw, B, oc, HW, dpred, oc, oc, s));
-  RET_IF(gemm(dpred, oc, 0, m_out, 9 * dim, 0, dcolo, R, 9 * dim, oc));            // dgrad of the output conv
-  RET_IF(train_col2im3(dcolo, B, S, S, dim, da, s));
-  RET_IF(train_gn_bwd(Hh, da, B, HW, dim, 32, g_out, e_out, st_out, ACT_SILU, dh, c->train_g[U + "out.0.weight"].d,
-                      c->train_g[U + "out.0.bias"].d, t1, t2, s));
-  {  // the output conv's own weight / bias gradient: dW = dpred^T im2col(a), db = column sums of dpred
-    float* colo = dcolo;  // [R][9*dim]: the dgrad columns are consumed, the buffer is free again
-    float* mgo = F((size_t)oc * 9 * dim);
-    WS_CHECK(mgo);
-    RET_IF(train_im2col3(aout, B, S, S, dim, colo, s));
-    RET_IF(gemm(dpred, oc, 1, colo, 9 * dim, 0, mgo, oc, 9 * dim, R));
-    RET_IF(train_perm_w3(mgo, oc, dim, 0, c->train_g[U + "out.2.weight"].d, s));
-    RET_IF(train_colsum(dpred, R, oc, c->train_g[U + "out.2.bias"].d, s));
+  RET_IF(train_gn_fwd(o, B, HW, I, 8, g_o0, e_o0, 1e-5f, ACT_RELU, a1, nullptr, s));
+  RET_IF(train_im2col3(a1, B, H, W, I, col1, s));
+  RET_IF(tgemm(c, F32(col1, 9 * I, 0), F32(m_c1, 9 * I, 1), o2, I, R, I, 9 * I, false, s));
+  RET_IF(train_gn_fwd(o2, B, HW, I, 8, g_o3, e_o3, 1e-5f, ACT_RELU, a2, nullptr, s));
+  RET_IF(train_im2col3(a2, B, H, W, I, col2, s));
+  // ---------------- backward: dh = dL/d(x + proj_out(.)) ----------------
+  // second conv3x3 of proj_out
+  RET_IF(tgemm(c, F32(dh, dim, 1), F32(col2, 9 * I, 0), mg, 9 * I, dim, 9 * I, R, false, s));      // wgrad [dim][9][I]
+  if (float* g_ = G("proj_out.5.weight")) {
+    RET_IF(train_perm_w3(mg, dim, I, 0, mgp, s));  // [dim][9][I] -> the reference's [dim][I][3][3]
+    RET_IF(train_add_inplace(g_, mgp, (size_t)dim * 9 * I, s));
   }
-  // dh = dL/d(x + proj_out(.)): second conv3x3 of proj_out
-  RET_IF(gemm(dh, dim, 1, col2, 9 * I, 0, mg, dim, 9 * I, R));                      // wgrad [dim][9][I]
-  RET_IF(train_perm_w3(mg, dim, I, 0, G("proj_out.5.weight"), s));
-  RET_IF(gemm(dh, dim, 0, m_c2, 9 * I, 0, dcol, R, 9 * I, dim));
-  RET_IF(train_col2im3(dcol, B, S, S, I, dI1, s));                                  // d a2
-  RET_IF(train_gn_bwd(o2, dI1, B, HW, I, 8, g_o3, e_o3, st_o3, ACT_RELU, dI2, G("proj_out.3.weight"), G("proj_out.3.bias"), t1, t2, s));
-  RET_IF(gemm(dI2, I, 1, col1, 9 * I, 0, mg, I, 9 * I, R));                         // first conv3x3
-  RET_IF(train_perm_w3(mg, I, I, 0, G("proj_out.2.weight"), s));
-  RET_IF(gemm(dI2, I, 0, m_c1, 9 * I, 0, dcol, R, 9 * I, I));
-  RET_IF(train_col2im3(dcol, B, S, S, I, dI1, s));                                  // d a1
-  RET_IF(train_gn_bwd(o, dI1, B, HW, I, 8, g_o0, e_o0, st_o0, ACT_RELU, dI2, G("proj_out.0.weight"), G("proj_out.0.bias"), t1, t2, s));
+  RET_IF(tgemm(c, F32(dh, dim, 0), F32(m_c2, 9 * I, 0), dcol, 9 * I, R, 9 * I, dim, false, s));
+  RET_IF(train_col2im3(dcol, B, H, W, I, dI1, s));                                                   // d a2
+  {
+    NormW n;
+    n.g = const_cast<float*>(g_o3); n.b = const_cast<float*>(e_o3); n.C = I; n.key = P + "proj_out.3";
+    RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, o2, I, dI1, I, HW, dI2, I, false));
+  }
+  RET_IF(tgemm(c, F32(dI2, I, 1), F32(col1, 9 * I, 0), mg, 9 * I, I, 9 * I, R, false, s));         // first conv3x3
+  if (float* g_ = G("proj_out.2.weight")) {
+    RET_IF(train_perm_w3(mg, I, I, 0, mgp, s));
+    RET_IF(train_add_inplace(g_, mgp, (size_t)I * 9 * I, s));
+  }
+  RET_IF(tgemm(c, F32(dI2, I, 0), F32(m_c1, 9 * I, 0), dcol, 9 * I, R, 9 * I, I, false, s));
+  RET_IF(train_col2im3(dcol, B, H, W, I, dI1, s));                                                   // d a1
+  {
+    NormW n;
+    n.g = const_cast<float*>(g_o0); n.b = const_cast<float*>(e_o0); n.C = I; n.key = P + "proj_out.0";
+    RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, o, I, dI1, I, HW, dI2, I, false));
+  }
   // to_out (1x1, no bias): dI2 = d o
-  RET_IF(gemm(dI2, I, 1, z, I, 0, G("depth_attn.to_out.weight"), I, I, R));
-  RET_IF(gemm(dI2, I, 0, w_o, I, 0, dI1, R, I, I));                                 // d z
+  if (float* g_ = G("depth_attn.to_out.weight")) RET_IF(tgemm(c, F32(dI2, I, 1), F32(z, I, 0), g_, I, I, I, R, true, s));
+  RET_IF(tgemm(c, F32(dI2, I, 0), F32(w_o, I, 0), dI1, I, R, I, I, false, s));                      // d z
   float* dq = dI2;
   RET_IF(train_depth_bwd(q, k, v, attn, dI1, R, HW, D, hn, hd, scale, dq, dk, dv, s));
-  RET_IF(gemm(dq, I, 1, pn, I, 0, G("depth_attn.to_q.weight"), I, I, R));
-  RET_IF(gemm(dk, I, 1, cn, Cc, 0, G("depth_attn.to_k.weight"), I, Cc, (int)RC));
-  RET_IF(gemm(dv, I, 1, cn, Cc, 0, G("depth_attn.to_v.weight"), I, Cc, (int)RC));
+  if (float* g_ = G("depth_attn.to_q.weight")) RET_IF(tgemm(c, F32(dq, I, 1), F32(pn, I, 0), g_, I, I, I, R, true, s));
+  if (float* g_ = G("depth_attn.to_k.weight")) RET_IF(tgemm(c, F32(dk, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s));
+  if (float* g_ = G("depth_attn.to_v.weight")) RET_IF(tgemm(c, F32(dv, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s));
   // d cn = dk W_k + dv W_v ; proj_context backward
-  RET_IF(gemm(dk, I, 0, w_k, Cc, 0, dcn, (int)RC, Cc, I));
-  RET_IF(gemm(dv, I, 0, w_v, Cc, 0, dpc, (int)RC, Cc, I));
-  RET_IF(train_add_inplace(dcn, dpc, (size_t)RC * Cc, s));
-  RET_IF(train_gn_bwd(pc, dcn, B, D * HW, Cc, 8, g_pc, e_pc, st_pc, ACT_RELU, dpc, G("proj_context.1.weight"), G("proj_context.1.bias"), t1, t2, s));
-  RET_IF(gemm(dpc, Cc, 1, C0, Cc, 0, G("proj_context.0.weight"), Cc, Cc, (int)RC));
+  RET_IF(tgemm(c, F32(dk, I, 0), F32(w_k, Cc, 0), dcn, Cc, (int)RC, Cc, I, false, s));
+  RET_IF(tgemm(c, F32(dv, I, 0), F32(w_v, Cc, 0), dcn, Cc, (int)RC, Cc, I, true, s));
+  {
+    NormW n;
+    n.g = const_cast<float*>(g_pc); n.b = const_cast<float*>(e_pc); n.C = Cc; n.key = P + "proj_context.1";
+    RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, pc, Cc, dcn, Cc, D * HW, dpc, Cc, false));
+  }
+  if (float* g_ = G("proj_context.0.weight")) RET_IF(tgemm(c, F32(dpc, Cc, 1), F32(C0, Cc, 0), g_, Cc, Cc, Cc, (int)RC, true, s));
+  if (b.dsrc[level])  // gradient w.r.t. the context volume (several DepthTransformers share a level: accumulated)
+    RET_IF(tgemm(c, F32(dpc, Cc, 0), F32(w_pc, Cc, 0), b.dsrc[level], Cc, (int)RC, Cc, Cc, true, s));
   // d pn = dq W_q ; proj_in backward
-  RET_IF(gemm(dq, I, 0, w_q, I, 0, dI1, R, I, I));
+  RET_IF(tgemm(c, F32(dq, I, 0), F32(w_q, I, 0), dI1, I, R, I, I, false, s));
   float* dp = dcol;  // [R][I] fits
-  RET_IF(train_gn_bwd(p, dI1, B, HW, I, 8, g_pi, e_pi, st_pi, ACT_SILU, dp, G("proj_in.1.weight"), G("proj_in.1.bias"), t1, t2, s));
-  RET_IF(gemm(dp, I, 1, X, dim, 0, G("proj_in.0.weight"), I, dim, R));
-  RET_IF(train_colsum(dp, R, I, G("proj_in.0.bias"), s));
+  {
+    NormW n;
+    n.g = const_cast<float*>(g_pi); n.b = const_cast<float*>(e_pi); n.C = I; n.key = P + "proj_in.1";
+    RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_SILU, p, I, dI1, I, HW, dp, I, false));
+  }
+  if (float* g_ = G("proj_in.0.weight")) RET_IF(tgemm(c, F32(dp, I, 1), F32(X, dim, 0), g_, dim, I, dim, R, true, s));
+  if (float* g_ = G("proj_in.0.bias")) {
+    float* part = F((size_t)B * I);
+    WS_CHECK(part);
+    RET_IF(bwd_colsum_samples(dp, 1, I, B, HW, I, part, I, s));
+    RET_IF(bwd_sum_rows_add(part, B, I, I, g_, 1, s));
+  }
+  // d x = dh (residual) + dp W_pi
+  RET_IF(tgemm(c, F32(dp, I, 0), F32(w_pi, dim, 0), din.p, din.ld, R, dim, I, accum, s));
+  RET_IF(bwd_add_views(din.p, din.ld, dh, dim, nullptr, 0, R, dim, 1, s));
+  return 0;
+}
+
+// ---- output head (openaimodel.py:717-721) ---------------------------------------------------------------------------
+int bwd_head(Bwd& b, const float* dpred /* [rows][oc] channels-last */, float* d_final) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  const int S = c->u.image_size, mc = c->u.model_channels, oc = c->u.out_channels, rows = b.B * S * S;
+  float* d_a = ws_alloc<float>(c, (size_t)rows * mc);
+  WS_CHECK(d_a);
+  half_t* dy16;
+  RET_IF(grad16(c, dpred, oc, rows, oc, &dy16, b.s));
+  RET_IF(dgrad_conv3(b, c->out_conv, dy16, d_a, mc, S, S, false));
+  RET_IF(wgrad_conv3(b, c->out_conv, dpred, oc, b.tape->head_a, 0, b.tape->head_ld, S, S, mc, 1, 0));
+  return gn_backward(b, c->out_norm, 32, 1e-5f, ACT_SILU, b.tape->final_h, mc, d_a, mc, S * S, d_final, mc, false);
+}
+
+// ---- time embedding MLP + the stacked ResBlock emb projections (openaimodel.py:527-532, :219-225) --------------------
+int bwd_emb(Bwd& b) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  hipStream_t s = b.s;
+  const int B = b.B, mc = c->u.model_channels, temb = 4 * mc, ET = c->emb_total;
+  const std::string U = "model.diffusion_model.";
+  float* u1 = ws_alloc<float>(c, (size_t)B * temb);
+  float* u2 = ws_alloc<float>(c, (size_t)B * temb);
+  float* d_e2 = ws_alloc<float>(c, (size_t)B * temb);
+  float* d_e1 = ws_alloc<float>(c, (size_t)B * temb);
+  WS_CHECK(u1 && u2 && d_e2 && d_e1);
+  // every ResBlock's emb_layers.1: weight [cout][temb] += demb_slice^T silu(emb), bias += column sums (taken in bwd_res);
+  // d silu(emb) = demb W_all
+  for (auto& r : c->res) {
+    if (float* G = engine_grad(c, r.key + ".emb_layers.1.weight"))
+      RET_IF(tgemm(c, F32(b.demb + r.emb_off, ET, 1), F32(b.tape->e2, temb, 0), G, temb, r.cout, temb, B, true, s));
+    if (float* G = engine_grad(c, r.key + ".emb_layers.1.bias")) RET_IF(bwd_sum_rows_add(b.demb + r.emb_off, B, r.cout, ET, G, 1, s));
+  }
+  RET_IF(tgemm(c, F32(b.demb, ET, 0), F16(c->emb_all.w, temb, 0), d_e2, temb, B, temb, ET, false, s));
+  // pre-activations of the two SiLUs (time_embed.0 / .2), re-computed with the forward kernels
+  {
+    ConvW w0, w2;
+    w0.w = c->te0.w; w0.bias = c->te0.bias; w0.N = temb; w0.Cin = mc;
+    w2.w = c->te2.w; w2.bias = c->te2.bias; w2.N = temb; w2.Cin = temb;
+    GemmArgs g;
+    g.a = b.tape->e0; g.a_f32 = 1; g.lda = mc; g.w = &w0; g.out = u1; g.ldc = temb;
+    RET_IF(run_linear(c, g, B, B, s));
+    g = GemmArgs();
+    g.a = b.tape->e1; g.a_f32 = 1; g.lda = temb; g.w = &w2; g.out = u2; g.ldc = temb;
+    RET_IF(run_linear(c, g, B, B, s));
+  }
+  RET_IF(bwd_silu_inplace(d_e2, u2, (size_t)B * temb, s));  // d u2
+  if (float* G = engine_grad(c, U + "time_embed.2.weight")) RET_IF(tgemm(c, F32(d_e2, temb, 1), F32(b.tape->e1, temb, 0), G, temb, temb, temb, B, true, s));
+  if (float* G = engine_grad(c, U + "time_embed.2.bias")) RET_IF(bwd_sum_rows_add(d_e2, B, temb, temb, G, 1, s));
+  RET_IF(tgemm(c, F32(d_e2, temb, 0), F16(c->te2.w, temb, 0), d_e1, temb, B, temb, temb, false, s));
+  RET_IF(bwd_silu_inplace(d_e1, u1, (size_t)B * temb, s));  // d u1
+  if (float* G = engine_grad(c, U + "time_embed.0.weight")) RET_IF(tgemm(c, F32(d_e1, temb, 1), F32(b.tape->e0, mc, 0), G, mc, temb, mc, B, true, s));
+  if (float* G = engine_grad(c, U + "time_embed.0.bias")) RET_IF(bwd_sum_rows_add(d_e1, B, temb, temb, G, 1, s));
+  return 0;
+}
+
+// ---- attn2 of every SpatialTransformer: a single context token, i.e. out = to_out(to_v(ctx)) (modules/attention.py:187-203
+// with one key: softmax == 1, so to_q / to_k / norm2 receive exactly zero gradient) ------------------------------------
+int bwd_attn2(Bwd& b) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_BLOCK);
+  hipStream_t s = b.s;
+  const int B = b.B, cd = c->u.context_dim, AT = c->a2_total;
+  for (auto& t : c->st) {
+    WsScope sc2(c, WS_TEMP);
+    const int C = t.C;
+    const std::string a = t.key + ".transformer_blocks.0.attn2.";
+    const float *wv = engine_master(c, a + "to_v.weight"), *wo = engine_master(c, a + "to_out.0.weight");
+    if (!wv || !wo) return mvd_fail("training backward: attn2 master weights missing");
+    float* u = ws_alloc<float>(c, (size_t)B * C);
+    float* du = ws_alloc<float>(c, (size_t)B * C);
+    WS_CHECK(u && du);
+    const float* d = b.da2 + t.a2_off;
+    RET_IF(tgemm(c, F32(b.tape->context, cd, 0), F32(wv, cd, 1), u, C, B, C, cd, false, s));
+    if (float* G = engine_grad(c, a + "to_out.0.bias")) RET_IF(bwd_sum_rows_add(d, B, C, AT, G, 1, s));
+    if (float* G = engine_grad(c, a + "to_out.0.weight")) RET_IF(tgemm(c, F32(d, AT, 1), F32(u, C, 0), G, C, C, C, B, true, s));
+    RET_IF(tgemm(c, F32(d, AT, 0), F32(wo, C, 0), du, C, B, C, C, false, s));
+    if (float* G = engine_grad(c, a + "to_v.weight")) RET_IF(tgemm(c, F32(du, C, 1), F32(b.tape->context, cd, 0), G, cd, C, cd, B, true, s));
+  }
+  return 0;
+}
+
+__global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, float k, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = k * (pred[i] - target[i]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,
+                      const Ctx5 src[4], const float* target_nhwc, float loss_scale, int recompute, float* pred_nhwc, float* loss_out,
+                      float* const dsrc[4], hipStream_t s) {
+  if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
+  if (!c->train_mode) return mvd_fail("training step: enable training mode (mvd_train_enable) before mvd_finalize_weights");
+  const mvd_unet_config& u = c->u;
+  const int S = u.image_size, oc = u.out_channels, mc = u.model_channels;
+  const size_t npred = (size_t)B * S * S * oc;
+  WsScope scope(c);  // the whole step: tape + backward scratch
+  TrainTape tape;
+  tape.recompute = recompute != 0;
+  // ---------------- forward ----------------
+  c->ws.hold = recompute ? 3 : 2;
+  int r = engine_unet(c, x_nhwc, x_ld, t, context, B, B, depth0, src, pred_nhwc, s, nullptr, &tape);
+  c->ws.hold = 0;
+  RET_IF(r);
+  const size_t fwd_top = c->ws.off;
+  (void)fwd_top;
+  float* dpred = ws_alloc<float>(c, npred);
+  WS_CHECK(dpred);
+  if (loss_out) RET_IF(launch_mse(target_nhwc, pred_nhwc, npred, loss_out, s));
+  {  // d mean((pred - target)^2) / d pred, times the loss scale
+    const float k = 2.0f * loss_scale / (float)npred;
+    const int blocks = (int)std::min<size_t>((npred + 255) / 256, 4096);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(blocks), dim3(256), 0, s, pred_nhwc, target_nhwc, k, npred, dpred);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  // ---------------- backward ----------------
+  Fwd f{c, s, B, B, depth0, tape.ea, context, tape.a2, src, {nullptr, nullptr, nullptr, nullptr}};
+  f.train = true;
+  for (int l = 0; l < 4; ++l) f.src16[l] = nullptr;
+  Bwd b{c, s, B, &f, &tape};
+  for (int l = 0; l < 4; ++l) b.dsrc[l] = dsrc ? dsrc[l] : nullptr;
+  b.demb = ws_alloc<float>(c, (size_t)B * c->emb_total);
+  b.da2 = ws_alloc<float>(c, (size_t)B * c->a2_total);
+  WS_CHECK(b.demb && b.da2);
+  HIP_CHECK_RET(hipMemsetAsync(b.demb, 0, (size_t)B * c->emb_total * sizeof(float), s));
+  HIP_CHECK_RET(hipMemsetAsync(b.da2, 0, (size_t)B * c->a2_total * sizeof(float), s));
+  const int nb = (int)c->in_blocks.size();
+  // gradient buffers shaped like the concat buffers (see engine_unet: block j's output lives in the skip slice of cat[nb-1-j])
+  std::vector<float*> dcat(nb);
+  for (int i = 0; i < nb; ++i) {
+    const int res = tape.in_res[nb - 1 - i];
+    dcat[i] = ws_alloc<float>(c, (size_t)B * res * res * tape.cat_C[i]);
+    WS_CHECK(dcat[i]);
+  }
+  float* d_final = ws_alloc<float>(c, (size_t)B * S * S * mc);
+  WS_CHECK(d_final);
+  RET_IF(bwd_head(b, dpred, d_final));
+  // stages grouped by chain, in forward order
+  std::vector<std::vector<int>> chains(2 * nb + 1);
+  for (int i = 0; i < (int)tape.stages.size(); ++i) chains[tape.stages[i].chain].push_back(i);
+  // a fp16 view of the context volumes is only needed when blocks are re-run (recompute): engine_unet made one per forward
+  auto run_chain_bwd = [&](int chain, View d_out, View d_in, bool accum_in, bool need_din) -> int {
+    WsScope ch_scope(c, WS_CHAIN);
+    const std::vector<int>& ids = chains[chain];
+    View g_out = d_out;
+    for (int k = (int)ids.size() - 1; k >= 0; --k) {
+      StageRec& st = tape.stages[ids[k]];
+      const bool first = k == 0;
+      View g_in;
+      bool acc = false;
+      if (first) {
+        g_in = d_in;
+        acc = accum_in;
+      } else {
+        g_in.p = ws_alloc<float>(c, (size_t)B * st.H * st.W * st.in.C);
+        WS_CHECK(g_in.p);
+        g_in.ld = st.in.C;
+        g_in.C = st.in.C;
+      }
+      const size_t mark = c->ws.off;
+      if (tape.recompute && (st.kind == OP_RES || st.kind == OP_ST)) {  // re-run the block, keeping its intermediates
+        c->ws.hold = 2;
+        int H = st.H, W = st.W;
+        // the re-run writes the block's output again (same values): into scratch, the taped output may feed other readers
+        View tmp_out;
+        tmp_out.p = ws_alloc<float>(c, (size_t)B * st.H * st.W * st.out.C);
+        tmp_out.ld = st.out.C;
+        tmp_out.C = st.out.C;
+        int rr = tmp_out.p ? 0 : mvd_fail("workspace exhausted: create the context with a larger workspace_bytes");
+        if (!rr) {
+          UOp op{st.kind, st.idx, st.in.C, st.out.C};
+          rr = unet_do_op(f, op, st.in, tmp_out, H, W, &st);
+        }
+        c->ws.hold = 0;
+        if (rr) {
+          c->ws.off = mark;
+          return rr;
+        }
+      }
+      int rr = 0;
+      switch (st.kind) {
+        case OP_RES: rr = bwd_res(b, c->res[st.idx], st.rs, st.in, g_out, g_in, acc, st.H, st.W); break;
+        case OP_ST: rr = bwd_st(b, c->st[st.idx], st.ss, st.in, g_out, g_in, acc, st.H, st.W); break;
+        case OP_COND: rr = bwd_cond(b, c->conds[st.idx], st.in, g_out, g_in, acc, st.H, st.W, st.level); break;
+        default: rr = bwd_conv(b, st.kind, c->convs[st.idx], st.in, g_out, g_in, acc, !(first && !need_din), st.H, st.W); break;
+      }
+      c->ws.off = mark;  // the re-run's intermediates (and nothing else: the block functions release their own scratch)
+      RET_IF(rr);
+      g_out = g_in;
+    }
+    return 0;
+  };
+  auto skip_view = [&](int i) {  // gradient of input block (nb-1-i)'s output
+    View v;
+    v.p = dcat[i] + tape.h_ch[i];
+    v.ld = tape.cat_C[i];
+    v.C = tape.in_ch[nb - 1 - i];
+    return v;
+  };
+  for (int i = nb - 1; i >= 0; --i) {  // output blocks
+    View d_out;
+    if (i + 1 < nb) {
+      d_out.p = dcat[i + 1];
+      d_out.ld = tape.cat_C[i + 1];
+      d_out.C = tape.h_ch[i + 1];
+    } else {
+      d_out.p = d_final;
+      d_out.ld = mc;
+      d_out.C = mc;
+    }
+    View d_in;
+    d_in.p = dcat[i];
+    d_in.ld = tape.cat_C[i];
+    d_in.C = tape.cat_C[i];
+    RET_IF(run_chain_bwd(nb + 1 + i, d_out, d_in, false, true));
+  }
+  {  // middle block: reads input block nb-1's output (skip slice of cat[0]), whose gradient already holds output block 0's share
+    View d_out;
+    d_out.p = dcat[0];
+    d_out.ld = tape.cat_C[0];
+    d_out.C = tape.h_ch[0];
+    RET_IF(run_chain_bwd(nb, d_out, skip_view(0), true, true));
+  }
+  for (int j = nb - 1; j >= 0; --j) {  // input blocks
+    View d_out = skip_view(nb - 1 - j);
+    View d_in;
+    if (j > 0) d_in = skip_view(nb - j);
+    RET_IF(run_chain_bwd(j, d_out, d_in, true, j > 0));
+  }
+  RET_IF(bwd_emb(b));
+  RET_IF(bwd_attn2(b));
   return 0;
 }

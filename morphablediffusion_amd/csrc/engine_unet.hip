@@ -151,7 +151,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     if (sk > ksteps) sk = ksteps;
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
   }
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_TEMP);
   g.splitk = sk;
   g.partial = nullptr;
   bool deferred = false;  // the caller's consumer adds the slabs (GemmArgs::slabs): no reduce pass
@@ -256,7 +256,7 @@ int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, 
 
 int run_upconv2d(mvd_ctx* c, const GemmArgs& ga_in, int B, int H, int W, hipStream_t s) {
   if (!ga_in.w->w_up) return mvd_fail("run_upconv2d: weights were not folded");
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_TEMP);
   GemmArgs ga = ga_in;
   ConvW cw = *ga_in.w;
   cw.w = cw.w_up;
@@ -399,7 +399,7 @@ int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sampl
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
                            ldo, s, split, nslab, slab_stride, bias2);
   if (nslab > 1) return mvd_fail("run_group_norm: slab input needs the single-pass form");
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_TEMP);
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
   int nslabs = 0;
@@ -411,29 +411,12 @@ int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sampl
 
 namespace {
 
-struct View {
-  float* p = nullptr;
-  int ld = 0, C = 0;
-};
-
-struct Fwd {
-  mvd_ctx* c;
-  hipStream_t s;
-  int Bv, n_ctx, depth0;
-  const float* emb_all;  // [Bv][emb_total]
-  const float* context;  // [Bv][context_dim]
-  const float* a2_all;   // [Bv][a2_total] folded attn2 output per SpatialTransformer
-  const Ctx5* src;
-  const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
-  // relu(GroupNorm(proj_context(volume))) of every DepthTransformer, produced on the side stream (nullptr: inline)
-  const half_t* cn_pre[16] = {nullptr};
-  bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
-};
+}  // namespace
 
 // ResBlock._forward, openaimodel.py:256-276
-int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
+int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv) {
   mvd_ctx* c = f.c;
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_BLOCK);
   const int rows = f.Bv * H * W;
   // extended-precision layers (ConvW::xp) read [hi | lo | hi] operands: three times the logical width
   const int w1 = r.c1.xp ? 3 : 1, w2 = r.c2.xp ? 3 : 1;
@@ -450,7 +433,7 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   static const bool no_defer = getenv("MVD_NO_DEFER_REDUCE") != nullptr || getenv("MVD_GN_TWO_PASS") != nullptr;
   int sk1 = 1;
   const size_t slab_elems = (size_t)rows * r.cout;
-  if (!no_defer && gn_group_eligible(r.cout, H * W, r.cout, 32, c->emb_total, r.cout * w2)) {
+  if (!no_defer && !f.train && gn_group_eligible(r.cout, H * W, r.cout, 32, c->emb_total, r.cout * w2)) {
     g1.slabs = ws_alloc<float>(c, 4 * slab_elems);
     g1.slabs_cap = g1.slabs ? 4 * slab_elems : 0;
     g1.sk_used = &sk1;
@@ -481,13 +464,16 @@ int do_res(Fwd& f, const ResW& r, View in, View out, int H, int W) {
   GemmArgs g2;
   g2.a = a2; g2.lda = r.cout * w2; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
   RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));
+  if (sv) {
+    sv->a1 = a1; sv->ld1 = r.cin * w1; sv->h1 = h1; sv->a2 = a2; sv->ld2 = r.cout * w2;
+  }
   return 0;
 }
 
 // SpatialTransformer.forward modules/attention.py:325-336, BasicTransformerBlock._forward :265-269
-int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
+int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv) {
   mvd_ctx* c = f.c;
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_BLOCK);
   const int C = t.C, T = H * W, rows = f.Bv * T;
   const int wi = t.proj_in.xp ? 3 : 1, wo = t.proj_out.xp ? 3 : 1;  // extended precision: [hi | lo | hi] operands
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C * wi);
@@ -498,7 +484,8 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   float* t2 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
   half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
-  WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3);
+  half_t* l3 = f.train ? ws_alloc<half_t>(c, (size_t)rows * C) : l1;  // the backward pass needs both LayerNorm outputs
+  WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3 && l3);
   RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
   g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
@@ -523,10 +510,10 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
     ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
-    RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l1, f.s));
+    RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l3, f.s));
   }
   g = GemmArgs();
-  g.a = l1; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
+  g.a = l3; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
   g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C * wo; g.resid = t2; g.ldr = C;
@@ -535,9 +522,14 @@ int do_st(Fwd& f, const STW& t, View in, View out, int H, int W) {
   g = GemmArgs();
   g.a = t3; g.lda = C * wo; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  if (sv) {
+    sv->n0 = n0; sv->ldn0 = C * wi; sv->t0 = t0; sv->l1 = l1; sv->qkv = qkv; sv->ao = ao; sv->t2 = t2; sv->l3 = l3; sv->gg = gg;
+    sv->t3 = t3; sv->ldt3 = C * wo;
+  }
   return 0;
 }
 
+namespace {
 // DepthTransformer._forward attention.py:78-84 with DepthAttention folded (see k_depth.hip)
 // GroupNorm(proj_context(ctx)) without materialising the projection: pass 1 re-computes the 1x1x1 conv tile by tile and keeps
 // only (sum, sumsq) per group, pass 2 re-computes it and applies scale/shift + ReLU in the epilogue.  Depends on the context
@@ -565,9 +557,11 @@ int ctx_fold(Fwd& f, const CondW& d, int HW, int D, int level, half_t* cn, hipSt
   return run_linear(c, g, f.n_ctx, crow * D, s);
 }
 
-int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1) {
+}  // namespace
+
+int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx) {
   mvd_ctx* c = f.c;
-  WsScope ws_scope(c);
+  WsScope ws_scope(c, WS_BLOCK);
   const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
   const int crow = f.n_ctx * HW;
   // extended precision (ConvW::xp): operands are [hi | lo | hi]
@@ -630,18 +624,20 @@ int do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, 
   return 0;
 }
 
-int do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W) {
+int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec) {
   mvd_ctx* c = f.c;
+  const bool keep = rec && c->ws.hold == 2;  // keep-all tape: the block's intermediates stay valid
+  if (rec) rec->have_saved = keep;
   switch (op.kind) {
-    case OP_RES: return do_res(f, c->res[op.idx], in, out, H, W);
-    case OP_ST: return do_st(f, c->st[op.idx], in, out, H, W);
+    case OP_RES: return unet_do_res(f, c->res[op.idx], in, out, H, W, keep ? &rec->rs : nullptr);
+    case OP_ST: return unet_do_st(f, c->st[op.idx], in, out, H, W, keep ? &rec->ss : nullptr);
     case OP_CONV_IN:
     case OP_DOWN:
     case OP_UP: {
       GemmArgs g;
       g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &c->convs[op.idx]; g.out = out.p; g.ldc = out.ld;
       const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
-      WsScope ws_scope(c);
+      WsScope ws_scope(c, WS_BLOCK);
       if (c->convs[op.idx].xp) {  // extended precision (conv_in): fp32 source -> [hi | lo | hi] copy
         const int Cl = c->convs[op.idx].cin_l;
         half_t* as = ws_alloc<half_t>(c, (size_t)f.Bv * H * W * 3 * Cl);
@@ -660,6 +656,7 @@ int do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W) {
   return mvd_fail("unknown op");
 }
 
+namespace {
 int out_res_of(const std::vector<UOp>& ops, int H) {
   for (auto& o : ops) {
     if (o.kind == OP_DOWN) H = (H - 1) / 2 + 1;
@@ -680,12 +677,14 @@ int engine_side_init(mvd_ctx* c) {
 }
 
 int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int Bv, int n_ctx,
-                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce) {
+                int depth0, const Ctx5 src[4], float* eps_nhwc, hipStream_t s, const CtxProducer* produce, TrainTape* tape) {
   if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
+  if (tape && (produce || n_ctx != Bv)) return mvd_fail("engine_unet: the training forward takes every sample's context volumes");
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels, temb = 4 * mc;
   WsScope ws_scope0(c);
   Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
+  f.train = tape != nullptr;
   // The context volumes (frustum network) and the context half of every DepthTransformer feed nothing before the middle
   // block.  Issued on the side stream they run beside the trunk (which leaves CUs idle at the lower resolutions and whenever
   // a rank holds few views); each DepthTransformer waits for its own event just before its depth attention.  The guard joins
@@ -693,7 +692,8 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   // still be running.
   SideJoin join(s);
   static const bool side_off = getenv("MVD_NO_SIDE_STREAM") != nullptr;
-  const bool use_side = !side_off && n_ctx > 0 && src && c->conds.size() <= 16;
+  // (the training forward stays on one stream: its intermediates are the tape, ordered with the backward pass that follows)
+  const bool use_side = !side_off && !tape && n_ctx > 0 && src && c->conds.size() <= 16;
   bool forked = false;
   // fork_ctx: everything that produces or only reads the context volumes.  With a producer (the frustum network of
   // mvd_denoise_views) it is called after the full-resolution input blocks, so the side stream shares the CUs with the
@@ -794,6 +794,10 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     RET_IF(run_linear(c, g, Bv, Bv, s));
   }
   f.emb_all = ea;
+  if (tape) {
+    tape->e0 = e0; tape->e1 = e1; tape->e2 = e2; tape->ea = ea; tape->context = context;
+    tape->Bv = Bv; tape->depth0 = depth0; tape->src = src;
+  }
   {
     float* a2 = ws_alloc<float>(c, (size_t)Bv * c->a2_total);
     WS_CHECK(a2);
@@ -801,6 +805,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     g.a = context; g.a_f32 = 1; g.lda = u.context_dim; g.w = &c->a2_all; g.out = a2; g.ldc = c->a2_total;
     RET_IF(run_linear(c, g, Bv, Bv, s));
     f.a2_all = a2;
+    if (tape) tape->a2 = a2;
   }
 
   // shapes of the concat buffers
@@ -826,6 +831,10 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   }
   float* final_h = ws_alloc<float>(c, (size_t)Bv * u.image_size * u.image_size * mc);
   WS_CHECK(final_h);
+  if (tape) {
+    tape->cat = cat; tape->cat_C = cat_C; tape->h_ch = h_ch; tape->in_ch = in_ch; tape->in_res = in_res; tape->final_h = final_h;
+  }
+  int chain_id = 0;
 
   auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W) -> int {
     WsScope ws_scope(c);
@@ -845,15 +854,24 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
         o.ld = cout;
       }
       o.C = cout;
+      StageRec rec;
+      rec.chain = chain_id;
+      rec.in = cur;
+      rec.out = o;
+      rec.H = H;
+      rec.W = W;
+      for (int r = u.image_size; r > H; r >>= 1) ++rec.level;
       if (is_cond) {
-        int level = 0;
-        for (int r = u.image_size; r > H; r >>= 1) ++level;
-        RET_IF(do_cond(f, *cond, cur, o, H, W, level, (int)(cond - c->conds.data())));
-        if (c->tape_B && cond == &c->conds.back())  // training tape: input and output of the last DepthTransformer
-          RET_IF(engine_tape_record(c, cur.p, cur.ld, o.p, o.ld, Bv, s));
+        rec.kind = OP_COND;
+        rec.idx = (int)(cond - c->conds.data());
+        RET_IF(unet_do_cond(f, *cond, cur, o, H, W, rec.level, rec.idx));
       } else {
-        RET_IF(do_op(f, ops[k], cur, o, H, W));
+        rec.kind = ops[k].kind;
+        rec.idx = ops[k].idx;
+        rec.in.C = ops[k].cin;
+        RET_IF(unet_do_op(f, ops[k], cur, o, H, W, tape ? &rec : nullptr));
       }
+      if (tape) tape->stages.push_back(rec);
       cur = o;
     }
     return 0;
@@ -870,6 +888,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.p = cat[i] + h_ch[i];
     dst.ld = cat_C[i];
     dst.C = in_ch[j];
+    chain_id = j;
     RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
     cur = dst;
     if (!forked && (H < u.image_size || j == nb - 1)) RET_IF(fork_ctx());
@@ -878,6 +897,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     View dst;
     dst.p = cat[0];
     dst.ld = cat_C[0];
+    chain_id = nb;
     RET_IF(run_chain(c->mid_block, &c->conds[0], cur, dst, H, W));
   }
   for (int i = 0; i < nb; ++i) {
@@ -894,6 +914,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       dst.ld = mc;
     }
     const CondW* cond = i >= 3 ? &c->conds[1 + (i - 3)] : nullptr;  // attention.py:100
+    chain_id = nb + 1 + i;
     RET_IF(run_chain(c->out_blocks[i], cond, in, dst, H, W));
   }
   // out: GroupNorm32 + SiLU + zero-init conv (openaimodel.py:717-721)
@@ -903,6 +924,10 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     half_t* a = ws_alloc<half_t>(c, (size_t)rows * mc * wx);
     WS_CHECK(a);
     RET_IF(run_group_norm(c, final_h, mc, Bv, H * W, c->out_norm, 32, 1e-5f, ACT_SILU, nullptr, a, mc * wx, s, 0, c->out_conv.xp));
+    if (tape) {
+      tape->head_a = a;
+      tape->head_ld = mc * wx;
+    }
     GemmArgs g;
     g.a = a; g.lda = mc * wx; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
     RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));

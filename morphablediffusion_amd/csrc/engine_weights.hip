@@ -6,14 +6,25 @@
 
 #include "engine.h"
 
-namespace {
-
-int dmalloc(mvd_ctx* c, void** p, size_t bytes) {
+// Owned device allocation.  While re-packing (engine_repack) the build functions run again in the same order and get the
+// allocations of the first run back, so every pointer the executors hold stays valid and no memory is allocated.
+int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes) {
   if (bytes == 0) bytes = 16;
+  if (c->repacking) {
+    if (c->repack_cursor >= c->sec_end || c->owned_bytes[c->repack_cursor] != bytes)
+      return mvd_fail("engine_repack: allocation sequence differs from the first build");
+    *p = c->owned[c->repack_cursor++];
+    return 0;
+  }
   HIP_CHECK_RET(hipMalloc(p, bytes));
   c->owned.push_back(*p);
+  c->owned_bytes.push_back(bytes);
   return 0;
 }
+
+namespace {
+
+int dmalloc(mvd_ctx* c, void** p, size_t bytes) { return engine_dmalloc(c, p, bytes); }
 
 int get_raw(mvd_ctx* c, const std::string& k, RawTensor** out) {
   auto it = c->raw.find(k);
@@ -36,6 +47,7 @@ int copy_f32(mvd_ctx* c, const std::string& k, float** out, int* n = nullptr) {
 }
 
 int load_norm(mvd_ctx* c, const std::string& p, NormW* n) {
+  n->key = p;
   RET_IF(copy_f32(c, p + ".weight", &n->g, &n->C));
   RET_IF(copy_f32(c, p + ".bias", &n->b));
   return 0;
@@ -58,6 +70,8 @@ int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool
   o->xp = xp ? 1 : 0;
   o->cin_l = Cl;
   o->taps = taps;
+  o->key = wkey;
+  o->bkey = bkey;
   RET_IF(dmalloc(c, (void**)&o->w, (size_t)taps * N * Cin * sizeof(half_t)));
   RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, 0, cin_src, xp ? 1 : 0));
   if (!bkey.empty()) {
@@ -115,6 +129,7 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(get_raw(c, t + ".attn1.to_v.weight", &v));
   s->qkv.N = 3 * C;
   s->qkv.Cin = C;
+  s->qkv.cin_l = C;
   s->qkv.taps = 1;
   RET_IF(dmalloc(c, (void**)&s->qkv.w, (size_t)3 * C * C * sizeof(half_t)));
   RET_IF(launch_f32_to_f16(q->d, s->qkv.w, (size_t)C * C, 0));
@@ -464,6 +479,7 @@ int repack_xp(mvd_ctx* c, const std::string& wkey, ConvW* o, int cin_pad = 0) {
   ConvW n;
   RET_IF(pack_conv(c, wkey, "", false, false, &n, cin_pad, true));
   n.bias = o->bias;
+  n.bkey = o->bkey;
   n.w_up = nullptr;
   *o = n;
   return 0;
@@ -539,26 +555,23 @@ int apply_xp_policy(mvd_ctx* c) {
   return 0;
 }
 
-int engine_finalize(mvd_ctx* c) {
+namespace {
+
+// ---------------- UNet plan (openaimodel.py:535-720) ----------------
+int build_unet_section(mvd_ctx* c) {
   const std::string U = "model.diffusion_model.";
   const mvd_unet_config& u = c->u;
   const int mc = u.model_channels;
   const int temb = 4 * mc;
-  HIP_CHECK_RET(hipSetDevice(c->device));
-  // sections are optional: a stand-alone UNet (YAML unet_config.target) uploads only its own keys
-  const bool has_unet = c->raw.count(U + "time_embed.0.weight") > 0;
-  const bool has_cond = c->raw.count("spatial_volume.target_encoder.init_conv.weight") > 0;
-  const bool has_step = c->raw.count("time_embed.0.weight") > 0;
-  const bool has_vae = c->raw.count("first_stage_model.decoder.conv_in.weight") > 0;
-  const bool has_vae_enc = c->raw.count("first_stage_model.encoder.conv_in.weight") > 0;
-  const bool has_clip = c->raw.count("clip_image_encoder.model.visual.conv1.weight") > 0;
-  if (!has_unet && !has_cond && !has_vae && !has_vae_enc && !has_clip)
-    return mvd_fail("finalize: no UNet, spatial_volume, first-stage or CLIP weights were uploaded");
-  if (has_clip) RET_IF(build_clip(c));
-  if (has_vae) RET_IF(build_vae(c));
-  if (has_vae_enc) RET_IF(build_vae_encoder(c));
-  // ---------------- UNet plan (openaimodel.py:535-720) ----------------
-  auto build_unet = [&]() -> int {
+  c->res.clear();
+  c->st.clear();
+  c->convs.clear();
+  c->conds.clear();
+  c->in_blocks.clear();
+  c->out_blocks.clear();
+  c->mid_block.clear();
+  c->emb_total = 0;
+  c->a2_total = 0;
   RET_IF(pack_lin(c, U + "time_embed.0.weight", U + "time_embed.0.bias", &c->te0));
   RET_IF(pack_lin(c, U + "time_embed.2.weight", U + "time_embed.2.bias", &c->te2));
   struct EmbPiece {
@@ -704,20 +717,17 @@ int engine_finalize(mvd_ctx* c) {
       RET_IF(build_cond(c, U + "output_conditions." + std::to_string(k), dims[k + 1], ccs[k + 1], &c->conds[k + 1]));
   }
   return 0;
-  };
-  if (has_unet) RET_IF(build_unet());
-  c->has_unet = has_unet;
-  RET_IF(apply_xp_policy(c));
-  RET_IF(engine_train_keep(c));
-  // ---------------- Lightning-module step embedding (morphable_diffusion.py:452-458) ----------------
-  if (has_step) {
-    RET_IF(pack_lin(c, "time_embed.0.weight", "time_embed.0.bias", &c->step_te0));
-    RET_IF(pack_lin(c, "time_embed.2.weight", "time_embed.2.bias", &c->step_te2));
-  }
-  c->has_step = has_step;
-  c->has_cond = has_cond;
-  // ---------------- mesh conditioner ----------------
-  auto build_cond = [&]() -> int {
+}
+
+// ---------------- Lightning-module step embedding (morphable_diffusion.py:452-458) ----------------
+int build_step_section(mvd_ctx* c) {
+  RET_IF(pack_lin(c, "time_embed.0.weight", "time_embed.0.bias", &c->step_te0));
+  RET_IF(pack_lin(c, "time_embed.2.weight", "time_embed.2.bias", &c->step_te2));
+  return 0;
+}
+
+// ---------------- mesh conditioner ----------------
+int build_condnet_section(mvd_ctx* c) {
   const std::string S = "spatial_volume.";
   RET_IF(pack_conv(c, S + "target_encoder.init_conv.weight", S + "target_encoder.init_conv.bias", false, false,
                    &c->enc_init, 8));
@@ -788,12 +798,73 @@ int engine_finalize(mvd_ctx* c) {
     RET_IF(stack(ep, "view_embed", &c->enc_v, c->v.view_dim));
   }
   return 0;
-  };
-  if (has_cond) RET_IF(build_cond());
+}
+
+// everything that engine_repack re-derives, in a fixed order (the allocation replay depends on it)
+int build_hot_sections(mvd_ctx* c) {
+  if (c->has_unet) {
+    RET_IF(build_unet_section(c));
+    RET_IF(apply_xp_policy(c));
+    if (c->train_mode) RET_IF(engine_build_dgrad(c));
+  }
+  if (c->has_step) RET_IF(build_step_section(c));
+  if (c->has_cond) RET_IF(build_condnet_section(c));
+  return 0;
+}
+
+}  // namespace
+
+int engine_finalize(mvd_ctx* c) {
+  const std::string U = "model.diffusion_model.";
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  // sections are optional: a stand-alone UNet (YAML unet_config.target) uploads only its own keys
+  const bool has_unet = c->raw.count(U + "time_embed.0.weight") > 0;
+  const bool has_cond = c->raw.count("spatial_volume.target_encoder.init_conv.weight") > 0;
+  const bool has_step = c->raw.count("time_embed.0.weight") > 0;
+  const bool has_vae = c->raw.count("first_stage_model.decoder.conv_in.weight") > 0;
+  const bool has_vae_enc = c->raw.count("first_stage_model.encoder.conv_in.weight") > 0;
+  const bool has_clip = c->raw.count("clip_image_encoder.model.visual.conv1.weight") > 0;
+  if (!has_unet && !has_cond && !has_vae && !has_vae_enc && !has_clip)
+    return mvd_fail("finalize: no UNet, spatial_volume, first-stage or CLIP weights were uploaded");
+  if (has_clip) RET_IF(build_clip(c));
+  if (has_vae) RET_IF(build_vae(c));
+  if (has_vae_enc) RET_IF(build_vae_encoder(c));
+  c->has_unet = has_unet;
+  c->has_step = has_step;
+  c->has_cond = has_cond;
+  if (c->train_mode) RET_IF(engine_train_setup(c));  // masters into the arena first: the packs below read them from there
+  c->sec_begin = c->owned.size();
+  RET_IF(build_hot_sections(c));
+  c->sec_end = c->owned.size();
   HIP_CHECK_RET(hipDeviceSynchronize());
-  for (auto& kv : c->raw) hipFree(kv.second.d);
-  c->raw.clear();
+  // training mode keeps the hot-path tensors: parameters live in the arena, buffers (BatchNorm running statistics) as they were
+  // uploaded -- engine_repack reads both
+  for (auto it = c->raw.begin(); it != c->raw.end();) {
+    if (c->train_mode && engine_hot_key(it->first)) {
+      ++it;
+      continue;
+    }
+    hipFree(it->second.d);
+    it = c->raw.erase(it);
+  }
   if (c->has_unet) RET_IF(engine_side_init(c));  // side stream + events now, so that nothing is created on the step path
   c->finalized = true;
+  return 0;
+}
+
+// After an optimiser step changed the master parameters: every packed / folded / stacked fp16 weight of the UNet, the step
+// embedding and the conditioner is re-derived IN PLACE (same allocations, same pointers).
+int engine_repack(mvd_ctx* c) {
+  if (!c->finalized || !c->train_mode) return mvd_fail("engine_repack: the context was not finalized in training mode");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  c->repacking = true;
+  c->repack_cursor = c->sec_begin;
+  const int r = build_hot_sections(c);
+  const bool complete = c->repack_cursor == c->sec_end;
+  c->repacking = false;
+  RET_IF(r);
+  if (!complete) return mvd_fail("engine_repack: allocation sequence shorter than the first build");
+  HIP_CHECK_RET(hipDeviceSynchronize());
   return 0;
 }

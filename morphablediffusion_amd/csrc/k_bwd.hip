@@ -1,0 +1,863 @@
+// Backward-pass kernels of the training step (reference training_step morphable_diffusion.py:520-549 +
+// loss.backward()).  The matrix products of the backward pass run on the SAME MFMA kernels as the forward pass:
+//   dgrad  = the forward implicit GEMM on transposed (and, for 3x3, tap-flipped) packed weights (pack_dgrad_weight),
+//   wgrad  = a plain GEMM  dW[Cout][Cin*taps] = dY^T [Cout][R] x col(X)^T [Cin*taps][R]^T  whose two operands are made
+//            K-contiguous (K = pixel rows) by the transposing casts below (tcast / im2colT).
+// What is left for this file is the bandwidth-bound part: transposing casts, GroupNorm / LayerNorm / GEGLU backward, the
+// reductions for bias / gain gradients, the flash-style self-attention backward (MFMA, same transposed formulation as
+// k_attn.hip), nearest-upsample / strided-conv scatter-free adjoints, AdamW.
+// Everything is deterministic: fixed summation orders, no atomics.  Activation gradients are fp32 in HBM (carrying the
+// caller's loss scale), MFMA operands fp16.
+#include "common.h"
+
+namespace {
+
+inline int gridn(size_t n, int cap = 8192) {
+  size_t g = (n + 255) / 256;
+  return (int)(g > (size_t)cap ? (size_t)cap : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const half_t* p) { return (float)*p; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dst[c][r] = fp16(src[r][c]) for c < C, r < Rp (zero for r >= R): the K-contiguous operand of a wgrad GEMM.
+// 64 x 64 tiles through LDS; reads are coalesced along c, writes along r.
+template <typename T>
+__global__ __launch_bounds__(256) void tcast_kernel(const T* __restrict__ src, long ld, int R, int C, half_t* __restrict__ dst, int Rp) {
+  __shared__ half_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    tile[rr][cc] = (r < R && c < C) ? (half_t)ldf(src + (long)r * ld + c) : (half_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cc = i >> 6, rr = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    if (c < C && r < Rp) dst[(long)c * Rp + r] = tile[rr][cc];
+  }
+}
+
+// dst[(ci * 9 + tap)][r] = fp16(X[b, (yo*s + ky - 1) >> ups, (xo*s + kx - 1) >> ups, ci])  (zero outside the virtual image of
+// (H << ups) x (W << ups) and for r >= R); r = (b*Ho + yo)*Wo + xo.  The row order ci*9 + tap makes the wgrad GEMM's
+// output [Cout][Cin*9] the reference's conv weight layout [Cout][Cin][3][3] itself.
+template <typename T>
+__global__ __launch_bounds__(256) void im2colT_kernel(const T* __restrict__ src, long ld, int B, int H, int W, int C, int stride, int ups,
+                                                      int Ho, int Wo, half_t* __restrict__ dst, int Rp) {
+  __shared__ half_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+  const int R = B * Ho * Wo, IY = H << ups, IX = W << ups;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    half_t v = (half_t)0;
+    if (r < R && c < C) {
+      const int xo = r % Wo, yo = (r / Wo) % Ho, b = r / (Wo * Ho);
+      const int y = yo * stride + ky, x = xo * stride + kx;
+      if (y >= 0 && y < IY && x >= 0 && x < IX) v = (half_t)ldf(src + (((long)b * H + (y >> ups)) * W + (x >> ups)) * ld + c);
+    }
+    tile[rr][cc] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cc = i >> 6, rr = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    if (c < C && r < Rp) dst[((long)c * 9 + tap) * Rp + r] = tile[rr][cc];
+  }
+}
+
+// fp32 rows (stride ld) -> dense fp16 rows of width Cp >= C (zero padded), scaled
+__global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long rows, int C, int Cp, half_t* __restrict__ dst) {
+  const long total = rows * Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    const long r = i / Cp;
+    dst[i] = c < C ? (half_t)src[r * ld + c] : (half_t)0;
+  }
+}
+
+// packed forward weight fp16 [taps][N][ldw] (first Cl columns of each row are w_hi) -> dgrad weight [taps][Cl][Np]:
+// wT[taps-1-t][ci][co] = w[t][co][ci]  (the tap flip turns the forward cross-correlation into its adjoint; Np >= N zero padded)
+__global__ void pack_dgrad_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np, half_t* __restrict__ wT) {
+  const long total = (long)taps * Cl * Np;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Np);
+    const long tc = i / Np;
+    const int ci = (int)(tc % Cl), t2 = (int)(tc / Cl);
+    const int t = taps - 1 - t2;
+    wT[i] = co < N ? w[((long)t * N + co) * ldw + ci] : (half_t)0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_f(float u, int act) { return act == ACT_SILU ? u / (1.f + __expf(-u)) : (act == ACT_RELU ? fmaxf(u, 0.f) : u); }
+__device__ __forceinline__ float act_d(float u, int act) {
+  if (act == ACT_SILU) {
+    const float s = 1.f / (1.f + __expf(-u));
+    return s * (1.f + u * (1.f - s));
+  }
+  return act == ACT_RELU ? (u > 0.f ? 1.f : 0.f) : 1.f;
+}
+
+__device__ float block_sum256(float v, float* s_red) {
+  const int t = threadIdx.x;
+  s_red[t] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  const float r = s_red[0];
+  __syncthreads();
+  return r;
+}
+
+// GroupNorm (+ activation) backward, one workgroup per (sample, group).  x [B][rows][ld] fp32 is the norm's INPUT (before the
+// optional per-sample pre-add `pre` [B][pld]); dy the gradient w.r.t. act(gamma xhat + beta).
+//   du = dy act'(u),  dxhat = du gamma,  dx = rstd (dxhat - mean_g(dxhat) - xhat mean_g(dxhat xhat))
+// dx is written (accum = 0) or added.  Per-sample channel sums of du xhat / du / dx go to dg_part / db_part / dpre_part
+// [B][C] (any may be null) -- summed over the samples by sum_rows_add.  Thread t owns channel t % cpg of the group and the rows
+// t / cpg, + rpi, ...: every reduction runs in a fixed order.
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ x, long ld, const float* __restrict__ pre, int pld,
+                                                     const float* __restrict__ dy, long ldy, int rows, int C, int G,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                                     float* __restrict__ dx, long lddx, int accum, float* __restrict__ dg_part,
+                                                     float* __restrict__ db_part, float* __restrict__ dpre_part) {
+  __shared__ float s_red[256], s_a[256], s_b[256];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+  const int rpi = 256 / cpg, t = threadIdx.x;
+  const bool active = t < rpi * cpg;
+  const int c = t % cpg, r0 = t / cpg, ch = g * cpg + c;
+  const float n = (float)rows * (float)cpg;
+  const float* xb = x + (long)b * rows * ld + ch;
+  const float* dyb = dy + (long)b * rows * ldy + ch;
+  const float pv = (pre && active) ? pre[(long)b * pld + ch] : 0.f;
+  float a = 0.f;
+  if (active)
+    for (int r = r0; r < rows; r += rpi) a += xb[(long)r * ld] + pv;
+  const float mean = block_sum256(a, s_red) / n;
+  float q = 0.f;
+  if (active)
+    for (int r = r0; r < rows; r += rpi) {
+      const float d = xb[(long)r * ld] + pv - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(block_sum256(q, s_red) / n + eps);
+  const float gm = active ? gamma[ch] : 0.f, bt = active ? beta[ch] : 0.f;
+  float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
+  if (active)
+    for (int r = r0; r < rows; r += rpi) {
+      const float xh = (xb[(long)r * ld] + pv - mean) * rstd;
+      const float du = dyb[(long)r * ldy] * act_d(gm * xh + bt, act);
+      const float dxh = du * gm;
+      s1 += dxh;
+      s2 += dxh * xh;
+      dg += du * xh;
+      db += du;
+    }
+  const float m1 = block_sum256(s1, s_red) / n, m2 = block_sum256(s2, s_red) / n;
+  float dsum = 0.f;
+  if (active) {
+    float* dxb = dx + (long)b * rows * lddx + ch;
+    for (int r = r0; r < rows; r += rpi) {
+      const float xh = (xb[(long)r * ld] + pv - mean) * rstd;
+      const float du = dyb[(long)r * ldy] * act_d(gm * xh + bt, act);
+      const float v = rstd * (du * gm - m1 - xh * m2);
+      dsum += v;
+      dxb[(long)r * lddx] = accum ? dxb[(long)r * lddx] + v : v;
+    }
+  }
+  // per-channel sums over the row lanes, in row-lane order
+  s_a[t] = dg;
+  s_b[t] = db;
+  s_red[t] = dsum;
+  __syncthreads();
+  if (t < cpg) {
+    float ag = 0.f, ab = 0.f, ad = 0.f;
+    for (int k = 0; k < rpi; ++k) {
+      ag += s_a[k * cpg + t];
+      ab += s_b[k * cpg + t];
+      ad += s_red[k * cpg + t];
+    }
+    const long o = (long)b * C + g * cpg + t;
+    if (dg_part) dg_part[o] = ag;
+    if (db_part) db_part[o] = ab;
+    if (dpre_part) dpre_part[o] = ad;
+  }
+}
+
+// out[c] (+)= sum_r part[r][c] (fixed order), r < R small (samples / workgroup partials)
+__global__ void sum_rows_add_kernel(const float* __restrict__ part, int R, int C, long ldp, float* __restrict__ out, int accum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int r = 0; r < R; ++r) a += part[(long)r * ldp + c];
+  out[c] = accum ? out[c] + a : a;
+}
+
+// out[b][c] = sum over the rows of sample b of v[b*rows + r][c] (ld): one workgroup per (sample, 64-channel slab); 4 row
+// lanes x 64 channels, fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_samples_kernel(const T* __restrict__ v, long ld, int rows, int C, float* __restrict__ out,
+                                                             long ldo) {
+  __shared__ float s[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) a += ldf(v + ((long)b * rows + r) * ld + c);
+  s[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && c < C) out[(long)b * ldo + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// LayerNorm backward over rows of C <= 64 * LN_NC channels: one wave per row, lanes own columns lane + 64 k.
+// dx[r][c] (+)= rstd (dy gamma - mean(dy gamma) - xhat mean(dy gamma xhat)); per-workgroup partial sums of dy xhat / dy go
+// to part[blockIdx][2][C] (summed by sum_rows_add).
+constexpr int LN_NC = 20;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long ld, const float* __restrict__ dy, long ldy, int rows,
+                                                     int C, const float* __restrict__ gamma, float eps, float* __restrict__ dx, long lddx,
+                                                     int accum, float* __restrict__ part) {
+  __shared__ float s_g[4][64 * LN_NC / 4];  // reused per quarter below (see the reduction)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[LN_NC], db[LN_NC];
+#pragma unroll
+  for (int k = 0; k < LN_NC; ++k) dg[k] = db[k] = 0.f;
+  const float invC = 1.f / (float)C;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const float* xr = x + (long)r * ld;
+    const float* dr = dy + (long)r * ldy;
+    float xv[LN_NC], dv[LN_NC];
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_NC; ++k) {
+      const int c = lane + 64 * k;
+      xv[k] = c < C ? xr[c] : 0.f;
+      dv[k] = c < C ? dr[c] : 0.f;
+      a += xv[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    const float mean = a * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_NC; ++k) {
+      const int c = lane + 64 * k;
+      const float d = c < C ? xv[k] - mean : 0.f;
+      q += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * invC + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) {
+        const float xh = (xv[k] - mean) * rstd, dxh = dv[k] * gamma[c];
+        s1 += dxh;
+        s2 += dxh * xh;
+        dg[k] += dv[k] * xh;
+        db[k] += dv[k];
+        xv[k] = xh;
+        dv[k] = dxh;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 * invC, m2 = s2 * invC;
+    float* dxr = dx + (long)r * lddx;
+#pragma unroll
+    for (int k = 0; k < LN_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) {
+        const float v = rstd * (dv[k] - m1 - xv[k] * m2);
+        dxr[c] = accum ? dxr[c] + v : v;
+      }
+    }
+  }
+  // the four waves' partials, added in wave order, one quarter of the columns at a time (LDS budget)
+  float* pg = part + (long)blockIdx.x * 2 * C;
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int k0 = 0; k0 < LN_NC; k0 += LN_NC / 4) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < LN_NC / 4; ++k) s_g[wave][k * 64 + lane] = which ? db[k0 + k] : dg[k0 + k];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < LN_NC / 4; ++k) {
+          const int c = lane + 64 * (k0 + k);
+          if (c < C) pg[(long)which * C + c] = (s_g[0][k * 64 + lane] + s_g[1][k * 64 + lane]) + (s_g[2][k * 64 + lane] + s_g[3][k * 64 + lane]);
+        }
+      }
+    }
+  }
+}
+
+// GEGLU backward (modules/attention.py:37-45, exact-erf GELU).  pre [rows][N] fp16 = the FF1 pre-activations in the PACKED
+// column order of the forward GEMM (64-column blocks: 32 value columns, then their 32 gate columns); dgg [rows][N/2] fp32 =
+// dL/d(value * gelu(gate)).  dpre [rows][N] fp16 in the same packed order.
+__global__ void geglu_bwd_kernel(const half_t* __restrict__ pre, const float* __restrict__ dgg, long ldg, long rows, int N,
+                                 half_t* __restrict__ dpre) {
+  const int Nh = N / 2;
+  const long total = rows * Nh;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Nh);
+    const long r = i / Nh;
+    const int blk = j >> 5, wi = j & 31;
+    const long pv = r * N + blk * 64 + wi, pg = pv + 32;
+    const float v = (float)pre[pv], g = (float)pre[pg], d = dgg[r * ldg + j];
+    const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * g * g);
+    dpre[pv] = (half_t)(d * g * cdf);
+    dpre[pg] = (half_t)(d * v * (cdf + g * pdf));
+  }
+}
+
+// dst[perm(p)][c] += src[p][c]: un-does the GEGLU row interleave for the FF1 weight ([N][C]) / bias ([N][1]) gradients
+__global__ void geglu_unpermute_add_kernel(const float* __restrict__ src, int N, int C, float* __restrict__ dst) {
+  const long total = (long)N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C), nd = (int)(i / C);
+    const int j = nd >> 6, wi = nd & 63;
+    const int n = wi < 32 ? 32 * j + wi : N / 2 + 32 * j + (wi - 32);
+    dst[(long)n * C + c] += src[i];
+  }
+}
+
+// out[r][c] = (accum ? out : 0) + a[r][c] (+ b[r][c]); row strides in elements
+__global__ void add_views_kernel(float* __restrict__ out, long ldo, const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                 long ldb, long rows, int C, int accum) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    float v = a[r * lda + c];
+    if (b) v += b[r * ldb + c];
+    if (accum) v += out[r * ldo + c];
+    out[r * ldo + c] = v;
+  }
+}
+
+// adjoint of nearest x2 upsampling: dx[b,y,x,c] (+)= sum of the 2x2 block of dup [B,2H,2W,C]
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dup, int B, int H, int W, int C, float* __restrict__ dx, long lddx, int accum) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    const float* q = dup + (((long)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+    const float v = (q[0] + q[C]) + (q[(long)2 * W * C] + q[(long)2 * W * C + C]);
+    dx[p * lddx + c] = accum ? dx[p * lddx + c] + v : v;
+  }
+}
+
+// adjoint of the 3x3 / stride s / pad 1 gather: dcol [R_out][9 * C] (column block t2 holds the contribution of weight tap
+// 8 - t2: the dgrad weights are stored tap-flipped) -> dx[b,y,x,c] (+)= sum over taps (ky,kx) and outputs with yo*s + ky - 1 == y
+__global__ void col2im3_bwd_kernel(const float* __restrict__ dcol, int B, int H, int W, int C, int stride, int Ho, int Wo,
+                                   float* __restrict__ dx, long lddx, int accum) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    float a = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ny = y + 1 - tap / 3, nx = x + 1 - tap % 3;
+      if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+      const int yo = ny / stride, xo = nx / stride;
+      if (yo >= Ho || xo >= Wo) continue;
+      a += dcol[(((long)b * Ho + yo) * Wo + xo) * 9 * C + (8 - tap) * C + c];
+    }
+    dx[p * lddx + c] = accum ? dx[p * lddx + c] + a : a;
+  }
+}
+
+// silu'(u) applied to a gradient in place: g *= silu'(u)
+__global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ u, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= act_d(u[i], ACT_SILU);
+}
+
+// d timestep_embedding is not needed (the time steps are data); the sinusoid itself is recomputed by the forward kernels.
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics, the reference's optimiser: morphable_diffusion.py:627-646) on one contiguous range of
+// the flat parameter arena.  g carries the loss scale: inv_scale un-does it.  `skip` (device flag, non-zero when a gradient
+// was non-finite) leaves everything untouched.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                             float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float inv_scale,
+                             const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * inv_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+// flag[0] = 1 if any element is inf / nan (flag must be zeroed first); sumsq[blockIdx] = partial sum of squares (may be null)
+__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ g, size_t n, int* __restrict__ flag) {
+  int bad = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = g[i];
+    if (!(fabsf(x) <= 3.0e38f)) bad = 1;
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) *flag = 1;  // benign race: every writer stores 1
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-attention backward (CrossAttention.forward modules/attention.py:170-203, self-attention case), flash style on the
+// matrix cores, in the transposed formulation of k_attn.hip (one query -- or, in the dK/dV kernel, one key -- per lane):
+//   kernel 1 (per 128 queries):  lse_q, delta_q = dO_q . O_q;   dQ^T = K^T dS^T  with  dS^T = P^T o (V dO^T - delta)
+//   kernel 2 (per 128 keys):     dV^T = dO^T P,   dK^T = Q^T dS   with  P = exp2(S scale - lse),  dS = P o (dO V^T - delta)
+// qkv: [token][q | k | v] fp16 (row stride ld3, each block C = heads * D wide); o / dO: [token][C] fp16.
+// dqkv: [token][dq | dk | dv] fp16.  lse / delta: [B][heads][T] fp32 scratch written by kernel 1, read by kernel 2.
+template <int D>
+struct AttnBwdCfg {
+  static constexpr int KS = (D + 15) / 16, DK = KS * 16, DVF = (D + 31) / 32, DVP = DVF * 32;
+  static constexpr int KLD = DK + 8, VLD = 64 + 8;
+  static constexpr int ROWS_BYTES = 64 * KLD * 2, IMG_BYTES = DVP * VLD * 2;
+};
+
+// stage a 64-row tile of [token][D] (row stride ld, column offset col) as rows [64][KLD] and, optionally, as the transposed
+// image [DVP][VLD]; rows >= T and columns >= D are zero
+template <int D>
+__device__ __forceinline__ void stage_tile(const half_t* __restrict__ base, long ld, int col, long tok0, int r0, int T, half_t* rowsL,
+                                           half_t* imgL) {
+  using Cf = AttnBwdCfg<D>;
+  const int tid = threadIdx.x;
+  constexpr int CH = Cf::DK / 8;
+  for (int idx = tid; idx < 64 * CH; idx += 256) {
+    const int key = idx / CH, ch = idx - key * CH;
+    h8 v = (h8)(half_t)0;
+    if (r0 + key < T && ch * 8 < D) v = *(const h8*)(base + (tok0 + r0 + key) * ld + col + ch * 8);
+    if (rowsL) *(h8*)(rowsL + key * Cf::KLD + ch * 8) = v;
+    if (imgL && ch * 8 < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) imgL[(ch * 8 + e) * Cf::VLD + key] = v[e];
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const half_t* __restrict__ qkv, int ld3, const half_t* __restrict__ o,
+                                                          const half_t* __restrict__ dO, int ldo, half_t* __restrict__ dqkv, int ldd,
+                                                          float* __restrict__ lse, float* __restrict__ delta, int T, int heads,
+                                                          float scale_l2, float scale_nat) {
+  using Cf = AttnBwdCfg<D>;
+  constexpr int KS = Cf::KS, DVF = Cf::DVF, KLD = Cf::KLD, VLD = Cf::VLD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* sK = (half_t*)smem;
+  half_t* sV = (half_t*)(smem + Cf::ROWS_BYTES);
+  half_t* sKT = (half_t*)(smem + 2 * Cf::ROWS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, lq = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = heads * D;
+  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
+  const long tok0 = (long)b * T;
+  h8 qf[KS], dof[KS];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = ks * 16 + hh * 8;
+    qf[ks] = (h8)(half_t)0;
+    dof[ks] = (h8)(half_t)0;
+    if (q_row < T && d0 < D) {
+      qf[ks] = *(const h8*)(qkv + (tok0 + q_row) * ld3 + head * D + d0);
+      dof[ks] = *(const h8*)(dO + (tok0 + q_row) * ldo + head * D + d0);
+      const h8 ov = *(const h8*)(o + (tok0 + q_row) * ldo + head * D + d0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ov[e];
+    }
+  }
+  dl += __shfl_xor(dl, 32);
+  // pass A: softmax statistics of the query's row (online max / sum over the key tiles)
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    __syncthreads();
+    stage_tile<D>(qkv, ld3, C + head * D, tok0, k0, T, sK, nullptr);
+    __syncthreads();
+    float mx = -INFINITY;
+    f32x16 s[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= T) s[f][r] = -INFINITY;
+        mx = fmaxf(mx, s[f][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * scale_l2);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], scale_l2, -m_new));
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + psum;
+    m_run = m_new;
+  }
+  const float lse_q = m_run + __builtin_amdgcn_logf(l_run);  // v_log_f32 is log2
+  if (q_row < T && hh == 0) {
+    lse[((long)b * heads + head) * T + q_row] = lse_q;
+    delta[((long)b * heads + head) * T + q_row] = dl;
+  }
+  // pass B
+  f32x16 acc[DVF];
+#pragma unroll
+  for (int f = 0; f < DVF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  for (int idx = tid; idx < (Cf::DVP - D) * 64; idx += 256) sKT[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    __syncthreads();
+    stage_tile<D>(qkv, ld3, C + head * D, tok0, k0, T, sK, sKT);
+    stage_tile<D>(qkv, ld3, 2 * C + head * D, tok0, k0, T, sV, nullptr);
+    __syncthreads();
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f][r] = dp[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+        const h8 vf = *(const h8*)(sV + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float p = key < T ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], scale_l2, -lse_q)) : 0.f;
+        s[f][r] = p * (dp[f][r] - dl);  // dS^T
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      h8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (half_t)s[kk >> 1][8 * (kk & 1) + j];
+#pragma unroll
+      for (int f = 0; f < DVF; ++f) {
+        const half_t* row = sKT + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
+        const h4 v0 = *(const h4*)(row);
+        const h4 v1 = *(const h4*)(row + 8);
+        h8 va;
+        va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
+        va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, acc[f], 0, 0, 0);
+      }
+    }
+  }
+  if (q_row < T) {
+    half_t* orow = dqkv + (tok0 + q_row) * ldd + head * D;
+#pragma unroll
+    for (int f = 0; f < DVF; ++f)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int dv = f * 32 + 8 * rg + 4 * hh;
+        if (dv < D) {
+          h4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (half_t)(acc[f][rg * 4 + j] * scale_nat);
+          *(h4*)(orow + dv) = v;
+        }
+      }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const half_t* __restrict__ qkv, int ld3, const half_t* __restrict__ dO, int ldo,
+                                                           half_t* __restrict__ dqkv, int ldd, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, int T, int heads, float scale_l2,
+                                                           float scale_nat) {
+  using Cf = AttnBwdCfg<D>;
+  constexpr int KS = Cf::KS, DVF = Cf::DVF, KLD = Cf::KLD, VLD = Cf::VLD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* sQ = (half_t*)smem;
+  half_t* sdO = (half_t*)(smem + Cf::ROWS_BYTES);
+  half_t* sQT = (half_t*)(smem + 2 * Cf::ROWS_BYTES);
+  half_t* sdOT = (half_t*)(smem + 2 * Cf::ROWS_BYTES + Cf::IMG_BYTES);
+  float* s_lse = (float*)(smem + 2 * Cf::ROWS_BYTES + 2 * Cf::IMG_BYTES);
+  float* s_dl = s_lse + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, lq = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = heads * D;
+  const int key = blockIdx.x * 128 + wave * 32 + lq;
+  const long tok0 = (long)b * T;
+  h8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = ks * 16 + hh * 8;
+    kf[ks] = (h8)(half_t)0;
+    vf[ks] = (h8)(half_t)0;
+    if (key < T && d0 < D) {
+      kf[ks] = *(const h8*)(qkv + (tok0 + key) * ld3 + C + head * D + d0);
+      vf[ks] = *(const h8*)(qkv + (tok0 + key) * ld3 + 2 * C + head * D + d0);
+    }
+  }
+  f32x16 dk[DVF], dv[DVF];
+#pragma unroll
+  for (int f = 0; f < DVF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[f][r] = dv[f][r] = 0.f;
+  for (int idx = tid; idx < (Cf::DVP - D) * 64; idx += 256) {
+    sQT[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
+    sdOT[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
+  }
+  const float* lse_b = lse + ((long)b * heads + head) * T;
+  const float* dl_b = delta + ((long)b * heads + head) * T;
+  for (int q0 = 0; q0 < T; q0 += 64) {
+    __syncthreads();
+    stage_tile<D>(qkv, ld3, head * D, tok0, q0, T, sQ, sQT);
+    stage_tile<D>(dO, ldo, head * D, tok0, q0, T, sdO, sdOT);
+    if (tid < 64) {
+      s_lse[tid] = q0 + tid < T ? lse_b[q0 + tid] : 0.f;
+      s_dl[tid] = q0 + tid < T ? dl_b[q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f][r] = dp[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const h8 qa = *(const h8*)(sQ + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s[f], 0, 0, 0);
+        const h8 da = *(const h8*)(sdO + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
+        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float p = q0 + qi < T ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], scale_l2, -s_lse[qi])) : 0.f;
+        s[f][r] = p;                              // P
+        dp[f][r] = p * (dp[f][r] - s_dl[qi]);     // dS
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      h8 pb, sb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[j] = (half_t)s[kk >> 1][8 * (kk & 1) + j];
+        sb[j] = (half_t)dp[kk >> 1][8 * (kk & 1) + j];
+      }
+#pragma unroll
+      for (int f = 0; f < DVF; ++f) {
+        const half_t* r1 = sdOT + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
+        const h4 a0 = *(const h4*)(r1);
+        const h4 a1 = *(const h4*)(r1 + 8);
+        h8 va;
+        va[0] = a0[0]; va[1] = a0[1]; va[2] = a0[2]; va[3] = a0[3];
+        va[4] = a1[0]; va[5] = a1[1]; va[6] = a1[2]; va[7] = a1[3];
+        dv[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, dv[f], 0, 0, 0);
+        const half_t* r2 = sQT + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
+        const h4 b0 = *(const h4*)(r2);
+        const h4 b1 = *(const h4*)(r2 + 8);
+        h8 vb;
+        vb[0] = b0[0]; vb[1] = b0[1]; vb[2] = b0[2]; vb[3] = b0[3];
+        vb[4] = b1[0]; vb[5] = b1[1]; vb[6] = b1[2]; vb[7] = b1[3];
+        dk[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, sb, dk[f], 0, 0, 0);
+      }
+    }
+  }
+  if (key < T) {
+    half_t* krow = dqkv + (tok0 + key) * ldd + C + head * D;
+    half_t* vrow = dqkv + (tok0 + key) * ldd + 2 * C + head * D;
+#pragma unroll
+    for (int f = 0; f < DVF; ++f)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = f * 32 + 8 * rg + 4 * hh;
+        if (d0 < D) {
+          h4 a, c2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a[j] = (half_t)(dk[f][rg * 4 + j] * scale_nat);
+            c2[j] = (half_t)dv[f][rg * 4 + j];
+          }
+          *(h4*)(krow + d0) = a;
+          *(h4*)(vrow + d0) = c2;
+        }
+      }
+  }
+}
+
+template <int D>
+int launch_attn_bwd_t(const half_t* qkv, int ld3, const half_t* o, const half_t* dO, int ldo, half_t* dqkv, int ldd, float* lse,
+                      float* delta, int B, int T, int heads, hipStream_t s) {
+  using Cf = AttnBwdCfg<D>;
+  constexpr int LDS1 = 2 * Cf::ROWS_BYTES + Cf::IMG_BYTES, LDS2 = 2 * Cf::ROWS_BYTES + 2 * Cf::IMG_BYTES + 512;
+  static_assert(LDS2 <= 160 * 1024, "LDS budget");
+  static bool attr_done[MVD_MAX_DEVICES] = {false};
+  bool& attr_set = attr_done[mvd_current_device()];
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+    attr_set = true;
+  }
+  const float scale_nat = 1.0f / sqrtf((float)D), scale_l2 = 1.4426950408889634f * scale_nat;
+  dim3 grid(cdiv(T, 128), heads, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), LDS1, s, qkv, ld3, o, dO, ldo, dqkv, ldd, lse, delta, T, heads, scale_l2,
+                     scale_nat);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(256), LDS2, s, qkv, ld3, dO, ldo, dqkv, ldd, lse, delta, T, heads, scale_l2,
+                     scale_nat);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s) {
+  if (R <= 0 || C <= 0 || Rp < R) return mvd_fail("bwd_tcast: bad shape");
+  dim3 grid(cdiv(Rp, 64), cdiv(C, 64));
+  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp);
+  else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int C, int stride, int ups, half_t* dst, int Rp, hipStream_t s) {
+  const int Ho = ((H << ups) - 1) / stride + 1, Wo = ((W << ups) - 1) / stride + 1;
+  if (Rp < B * Ho * Wo) return mvd_fail("bwd_im2colT: bad shape");
+  dim3 grid(cdiv(Rp, 64), cdiv(C, 64), 9);
+  if (src_f32) hipLaunchKernelGGL(im2colT_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
+  else hipLaunchKernelGGL(im2colT_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(cast_rows_kernel, dim3(gridn((size_t)rows * Cp)), dim3(256), 0, s, src, ld, rows, C, Cp, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s) {
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(gridn((size_t)taps * Cl * Np)), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                   const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
+                   float* db_part, float* dpre_part, hipStream_t s) {
+  if (C % G || C / G > 256) return mvd_fail("bwd_group_norm: channels per group must divide C and be <= 256");
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, ld, pre, pld, dy, ldy, rows, C, G, gamma, beta, eps, act, dx, lddx,
+                     accum, dg_part, db_part, dpre_part);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, R, C, ldp, out, accum);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_colsum_samples(const void* v, int v_f32, long ld, int B, int rows, int C, float* out, long ldo, hipStream_t s) {
+  if (v_f32) hipLaunchKernelGGL(colsum_samples_kernel<float>, dim3(cdiv(C, 64), B), dim3(256), 0, s, (const float*)v, ld, rows, C, out, ldo);
+  else hipLaunchKernelGGL(colsum_samples_kernel<half_t>, dim3(cdiv(C, 64), B), dim3(256), 0, s, (const half_t*)v, ld, rows, C, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_ln_max_blocks() { return 256; }
+// part: [min(256, ceil(rows/4))][2][C] floats; returns the number of partial rows through *nblk
+int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
+                   long lddx, int accum, float* part, int* nblk, hipStream_t s) {
+  if (C > 64 * LN_NC) return mvd_fail("bwd_layer_norm: C too large");
+  int nb = cdiv(rows, 4);
+  if (nb > bwd_ln_max_blocks()) nb = bwd_ln_max_blocks();
+  *nblk = nb;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, s, x, ld, dy, ldy, rows, C, gamma, eps, dx, lddx, accum, part);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_geglu(const half_t* pre, const float* dgg, long ldg, long rows, int N, half_t* dpre, hipStream_t s) {
+  if (N % 64) return mvd_fail("bwd_geglu: N must be a multiple of 64");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(gridn((size_t)rows * N / 2)), dim3(256), 0, s, pre, dgg, ldg, rows, N, dpre);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_geglu_unpermute_add(const float* src, int N, int C, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(geglu_unpermute_add_kernel, dim3(gridn((size_t)N * C)), dim3(256), 0, s, src, N, C, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_add_views(float* out, long ldo, const float* a, long lda, const float* b, long ldb, long rows, int C, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(add_views_kernel, dim3(gridn((size_t)rows * C)), dim3(256), 0, s, out, ldo, a, lda, b, ldb, rows, C, accum);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_upsample2(const float* dup, int B, int H, int W, int C, float* dx, long lddx, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(gridn((size_t)B * H * W * C)), dim3(256), 0, s, dup, B, H, W, C, dx, lddx, accum);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_col2im3(const float* dcol, int B, int H, int W, int C, int stride, float* dx, long lddx, int accum, hipStream_t s) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  hipLaunchKernelGGL(col2im3_bwd_kernel, dim3(gridn((size_t)B * H * W * C)), dim3(256), 0, s, dcol, B, H, W, C, stride, Ho, Wo, dx, lddx, accum);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_silu_inplace(float* g, const float* u, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(gridn(n)), dim3(256), 0, s, g, u, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step,
+              float inv_scale, const int* skip, hipStream_t s) {
+  if (!n) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(gridn(n, 16384)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2),
+                     inv_scale, skip);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_finite_check(const float* g, size_t n, int* flag, hipStream_t s) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(finite_check_kernel, dim3(gridn(n, 4096)), dim3(256), 0, s, g, n, flag);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// qkv [B*T][3C] (ld3), o / dO [B*T][C] (ldo) fp16 -> dqkv [B*T][3C] (ldd) fp16; lse / delta: [B*heads*T] floats scratch each
+int bwd_attention(const half_t* qkv, int ld3, const half_t* o, const half_t* dO, int ldo, half_t* dqkv, int ldd, float* lse, float* delta,
+                  int B, int T, int heads, int d, hipStream_t s) {
+  if (ld3 % 8 || ldo % 8 || ldd % 4 || d % 8 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)dO & 15) || ((uintptr_t)dqkv & 7))
+    return mvd_fail("bwd_attention: alignment");
+#define MVD_ATTN_B(DD) \
+  case DD: return launch_attn_bwd_t<DD>(qkv, ld3, o, dO, ldo, dqkv, ldd, lse, delta, B, T, heads, s);
+  switch (d) {
+    MVD_ATTN_B(8)
+    MVD_ATTN_B(16)
+    MVD_ATTN_B(32)
+    MVD_ATTN_B(40)
+    MVD_ATTN_B(64)
+    MVD_ATTN_B(80)
+    MVD_ATTN_B(160)
+    default: return mvd_fail("bwd_attention: unsupported head dim");
+  }
+#undef MVD_ATTN_B
+}

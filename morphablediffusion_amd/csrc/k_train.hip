@@ -1,68 +1,10 @@
-// Training-step backward kernels (first slice): everything needed to back-propagate the MSE loss of the
-// reference's training_step (morphable_diffusion.py:520-549) from the UNet output through the output head
-// (openaimodel.py:717-721) into the LAST DepthTransformer (attention.py:49-84, output_conditions.8) and to produce the
-// gradient of each of its parameters.  fp32 throughout, channels-last rows, deterministic (fixed summation orders, no
-// atomics).  These are correctness-first kernels: a tiled fp32 GEMM with a two-stage split over the reduction axis, gather-form
-// im2col / col2im, GroupNorm forward / backward with SiLU / ReLU, the depth attention forward / backward.
+// Training-step helper kernels: the fp32 pieces of the DepthTransformer backward (attention.py:49-84) that
+// are bandwidth-bound and stay off the matrix cores -- gather-form im2col / col2im for its two 3x3 convs (their GEMMs run on
+// the MFMA kernels through engine_train.hip: tgemm), GroupNorm forward in fp32, the depth attention forward / backward, row
+// utilities.  Deterministic (fixed summation orders, no atomics).
 #include "common.h"
 
 namespace {
-
-constexpr int TS = 64, TK = 16;  // 64 x 64 output tile, 16-deep k slab, 256 threads x (4 x 4) outputs
-
-// C[M,N] (+)= op(A) op(B);  A is [M,K] (ta = 0, row-major, lda) or [K,M] (ta = 1);  B is [K,N] (tb = 0) or [N,K] (tb = 1).
-// grid.z splits K into equal slabs; with gridDim.z > 1 the partial products go to C + z * M * ldc (reduced by sum_slabs).
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int lda, int ta, const float* __restrict__ B, int ldb,
-                                                    int tb, float* __restrict__ C, int ldc, int M, int N, int K, int kper) {
-  __shared__ float sA[TK][TS + 1], sB[TK][TS + 1];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-  const int kb = blockIdx.z * kper, ke = min(K, kb + kper);
-  float acc[4][4] = {};
-  for (int k0 = kb; k0 < ke; k0 += TK) {
-    for (int i = threadIdx.x; i < TS * TK; i += 256) {
-      int kk, mm;
-      if (ta) { mm = i % TS; kk = i / TS; } else { kk = i % TK; mm = i / TK; }
-      const int m = m0 + mm, k = k0 + kk;
-      sA[kk][mm] = (m < M && k < ke) ? (ta ? A[(long)k * lda + m] : A[(long)m * lda + k]) : 0.f;
-      int kn, nn;
-      if (tb) { kn = i % TK; nn = i / TK; } else { nn = i % TS; kn = i / TS; }
-      const int n = n0 + nn, k2 = k0 + kn;
-      sB[kn][nn] = (n < N && k2 < ke) ? (tb ? B[(long)n * ldb + k2] : B[(long)k2 * ldb + n]) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
-    }
-    __syncthreads();
-  }
-  float* Cz = C + (long)blockIdx.z * M * ldc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-      if (m < M && n < N) Cz[(long)m * ldc + n] = acc[i][j];
-    }
-}
-
-// out[i] = bias? + sum_s part[s][i]  (fixed order)
-__global__ void sum_slabs_kernel(const float* __restrict__ part, int S, long n, float* __restrict__ out) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(long)s * n + i];
-    out[i] = a;
-  }
-}
 
 // col[r][tap * C + c] = X[b, y + dy, x + dx, c] (zero outside), tap = (dy+1)*3 + (dx+1)
 __global__ void im2col3_kernel(const float* __restrict__ X, int B, int H, int W, int C, float* __restrict__ col) {
@@ -143,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x
     q += d * d;
   }
   const float rstd = rsqrtf(block_sum256(q, s_red) / (float)n + eps);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && stats) {
     stats[(b * G + g) * 2] = mean;
     stats[(b * G + g) * 2 + 1] = rstd;
   }
@@ -152,38 +94,6 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x
     const int c = e % cpg;
     const long o = (long)(e / cpg) * C + c;
     yb[o] = act_f((xb[o] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c], act);
-  }
-}
-
-// GroupNorm (+ activation) backward, one block per (b, g):  du = dy act'(u);  dxhat = du gamma;
-// dx = rstd (dxhat - mean_g(dxhat) - xhat mean_g(dxhat xhat)).  Also writes du xhat and du per element (dg_el, db_el may alias
-// scratch) for the per-channel parameter reductions.
-__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int C, int G,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ stats, int act, float* __restrict__ dx,
-                                                     float* __restrict__ dg_el, float* __restrict__ db_el) {
-  __shared__ float s_red[256];
-  const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, n = rows * cpg;
-  const long base = (long)b * rows * C + g * cpg;
-  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-  float s1 = 0.f, s2 = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int c = e % cpg;
-    const long o = base + (long)(e / cpg) * C + c;
-    const float xh = (x[o] - mean) * rstd, u = gamma[g * cpg + c] * xh + beta[g * cpg + c];
-    const float du = dy[o] * act_d(u, act), dxh = du * gamma[g * cpg + c];
-    s1 += dxh;
-    s2 += dxh * xh;
-    dg_el[o] = du * xh;
-    db_el[o] = du;
-  }
-  const float m1 = block_sum256(s1, s_red) / (float)n, m2 = block_sum256(s2, s_red) / (float)n;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int c = e % cpg;
-    const long o = base + (long)(e / cpg) * C + c;
-    const float xh = (x[o] - mean) * rstd;
-    const float dxh = db_el[o] * gamma[g * cpg + c];
-    dx[o] = rstd * (dxh - m1 - xh * m2);
   }
 }
 
@@ -197,83 +107,89 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ v
   if (threadIdx.x == 0) out[c] = s;
 }
 
-// DepthAttention.forward (attention.py:26-47) per pixel; q [R][hn*hd], k / v [B*D*HW][hn*hd] (row = (b*D + d)*HW + p).
-// One block of 128 threads per pixel (thread = head * hd + c, hn * hd <= 128, D <= 64): attn [R][hn][D], z [R][hn*hd].
-__global__ __launch_bounds__(128) void depth_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+// DepthAttention.forward (attention.py:26-47) per pixel; q [R][I], k / v [B*D*HW][I] (row = (b*D + d)*HW + p), I = hn * hd.
+// One workgroup of 256 threads per pixel: the hn * D scores are wave-parallel dot products of length hd, the softmax over the
+// D depth samples is done by one thread per head, z / dq / dk / dv are thread-per-channel.  attn [R][hn][D], z [R][I].
+constexpr int DEPTH_MAX_I = 1024, DEPTH_MAX_D = 64, DEPTH_MAX_H = 4;
+__global__ __launch_bounds__(256) void depth_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                         int HW, int D, int hn, int hd, float scale, float* __restrict__ attn,
                                                         float* __restrict__ z) {
-  __shared__ float s_q[128], s_sim[4 * 64];
-  const int r = blockIdx.x, b = r / HW, p = r % HW, t = threadIdx.x, I = hn * hd;
-  if (t < I) s_q[t] = q[(long)r * I + t];
+  __shared__ float s_q[DEPTH_MAX_I], s_sim[DEPTH_MAX_H * DEPTH_MAX_D];
+  const int r = blockIdx.x, b = r / HW, p = r % HW, t = threadIdx.x, I = hn * hd, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < I; i += 256) s_q[i] = q[(long)r * I + i];
   __syncthreads();
-  for (int e = t; e < hn * D; e += 128) {
+  for (int e = wave; e < hn * D; e += 4) {
     const int h = e / D, d = e % D;
     const float* kr = k + (((long)b * D + d) * HW + p) * I + h * hd;
     float a = 0.f;
-    for (int c = 0; c < hd; ++c) a += s_q[h * hd + c] * kr[c];
-    s_sim[h * 64 + d] = a * scale;
+    for (int c = lane; c < hd; c += 64) a += s_q[h * hd + c] * kr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) s_sim[h * DEPTH_MAX_D + d] = a * scale;
   }
   __syncthreads();
   if (t < hn) {
     float mx = -INFINITY;
-    for (int d = 0; d < D; ++d) mx = fmaxf(mx, s_sim[t * 64 + d]);
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, s_sim[t * DEPTH_MAX_D + d]);
     float sum = 0.f;
     for (int d = 0; d < D; ++d) {
-      const float e = __expf(s_sim[t * 64 + d] - mx);
-      s_sim[t * 64 + d] = e;
+      const float e = __expf(s_sim[t * DEPTH_MAX_D + d] - mx);
+      s_sim[t * DEPTH_MAX_D + d] = e;
       sum += e;
     }
     for (int d = 0; d < D; ++d) {
-      s_sim[t * 64 + d] /= sum;
-      attn[((long)r * hn + t) * D + d] = s_sim[t * 64 + d];
+      s_sim[t * DEPTH_MAX_D + d] /= sum;
+      attn[((long)r * hn + t) * D + d] = s_sim[t * DEPTH_MAX_D + d];
     }
   }
   __syncthreads();
-  if (t < I) {
-    const int h = t / hd;
+  for (int i = t; i < I; i += 256) {
+    const int h = i / hd;
     float a = 0.f;
-    for (int d = 0; d < D; ++d) a += s_sim[h * 64 + d] * v[(((long)b * D + d) * HW + p) * I + t];
-    z[(long)r * I + t] = a;
+    for (int d = 0; d < D; ++d) a += s_sim[h * DEPTH_MAX_D + d] * v[(((long)b * D + d) * HW + p) * I + i];
+    z[(long)r * I + i] = a;
   }
 }
 
 // backward of the above: dq [R][I], dk / dv [B*D*HW][I]
-__global__ __launch_bounds__(128) void depth_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+__global__ __launch_bounds__(256) void depth_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                         const float* __restrict__ attn, const float* __restrict__ dz, int HW, int D,
                                                         int hn, int hd, float scale, float* __restrict__ dq, float* __restrict__ dk,
                                                         float* __restrict__ dv) {
-  __shared__ float s_q[128], s_dz[128], s_a[4 * 64], s_ds[4 * 64];
-  const int r = blockIdx.x, b = r / HW, p = r % HW, t = threadIdx.x, I = hn * hd;
-  if (t < I) {
-    s_q[t] = q[(long)r * I + t];
-    s_dz[t] = dz[(long)r * I + t];
+  __shared__ float s_q[DEPTH_MAX_I], s_dz[DEPTH_MAX_I], s_a[DEPTH_MAX_H * DEPTH_MAX_D], s_ds[DEPTH_MAX_H * DEPTH_MAX_D];
+  const int r = blockIdx.x, b = r / HW, p = r % HW, t = threadIdx.x, I = hn * hd, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < I; i += 256) {
+    s_q[i] = q[(long)r * I + i];
+    s_dz[i] = dz[(long)r * I + i];
   }
-  for (int e = t; e < hn * D; e += 128) s_a[(e / D) * 64 + e % D] = attn[((long)r * hn + e / D) * D + e % D];
+  for (int e = t; e < hn * D; e += 256) s_a[(e / D) * DEPTH_MAX_D + e % D] = attn[((long)r * hn + e / D) * D + e % D];
   __syncthreads();
-  for (int e = t; e < hn * D; e += 128) {  // dattn[h][d] = sum_c dz[h,c] v[d,h,c]
+  for (int e = wave; e < hn * D; e += 4) {  // dattn[h][d] = sum_c dz[h,c] v[d,h,c]
     const int h = e / D, d = e % D;
     const float* vr = v + (((long)b * D + d) * HW + p) * I + h * hd;
     float a = 0.f;
-    for (int c = 0; c < hd; ++c) a += s_dz[h * hd + c] * vr[c];
-    s_ds[h * 64 + d] = a;
+    for (int c = lane; c < hd; c += 64) a += s_dz[h * hd + c] * vr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) s_ds[h * DEPTH_MAX_D + d] = a;
   }
   __syncthreads();
   if (t < hn) {  // softmax backward: dsim = attn (dattn - sum attn dattn)
     float dot = 0.f;
-    for (int d = 0; d < D; ++d) dot += s_a[t * 64 + d] * s_ds[t * 64 + d];
-    for (int d = 0; d < D; ++d) s_ds[t * 64 + d] = s_a[t * 64 + d] * (s_ds[t * 64 + d] - dot);
+    for (int d = 0; d < D; ++d) dot += s_a[t * DEPTH_MAX_D + d] * s_ds[t * DEPTH_MAX_D + d];
+    for (int d = 0; d < D; ++d) s_ds[t * DEPTH_MAX_D + d] = s_a[t * DEPTH_MAX_D + d] * (s_ds[t * DEPTH_MAX_D + d] - dot);
   }
   __syncthreads();
-  if (t < I) {
-    const int h = t / hd;
+  for (int i = t; i < I; i += 256) {
+    const int h = i / hd;
     float a = 0.f;
     for (int d = 0; d < D; ++d) {
-      const long o = (((long)b * D + d) * HW + p) * I + t;
-      a += s_ds[h * 64 + d] * k[o];
-      dk[o] = scale * s_ds[h * 64 + d] * s_q[t];
-      dv[o] = s_a[h * 64 + d] * s_dz[t];
+      const long o = (((long)b * D + d) * HW + p) * I + i;
+      a += s_ds[h * DEPTH_MAX_D + d] * k[o];
+      dk[o] = scale * s_ds[h * DEPTH_MAX_D + d] * s_q[i];
+      dv[o] = s_a[h * DEPTH_MAX_D + d] * s_dz[i];
     }
-    dq[(long)r * I + t] = scale * a;
+    dq[(long)r * I + i] = scale * a;
   }
 }
 
@@ -301,26 +217,6 @@ inline int gridn(size_t n) {
 
 }  // namespace
 
-// C[M,N] = op(A) op(B); `scratch` (>= splits * M * N floats) is needed when the reduction axis is split (K > 4096)
-int train_sgemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int M, int N, int K, float* scratch,
-                size_t scratch_floats, hipStream_t s) {
-  if (M <= 0 || N <= 0 || K <= 0) return mvd_fail("train_sgemm: empty problem");
-  int splits = 1;
-  const int tiles = cdiv(M, TS) * cdiv(N, TS);
-  if (K > 4096 && tiles < 512) {
-    splits = cdiv(1024, tiles);
-    if (splits > cdiv(K, 512)) splits = cdiv(K, 512);
-    if (splits > 256) splits = 256;
-  }
-  int kper = cdiv(cdiv(K, splits), TK) * TK;
-  splits = cdiv(K, kper);
-  if (splits > 1 && (size_t)splits * M * N > scratch_floats) return mvd_fail("train_sgemm: scratch too small for the split reduction");
-  float* dst = splits > 1 ? scratch : C;
-  hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, TS), cdiv(M, TS), splits), dim3(256), 0, s, A, lda, ta, B, ldb, tb, dst, N, M, N, K, kper);
-  if (splits > 1) hipLaunchKernelGGL(sum_slabs_kernel, dim3(gridn((size_t)M * N)), dim3(256), 0, s, scratch, splits, (long)M * N, C);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
 int train_im2col3(const float* X, int B, int H, int W, int C, float* col, hipStream_t s) {
   hipLaunchKernelGGL(im2col3_kernel, dim3(gridn((size_t)B * H * W * 9 * C)), dim3(256), 0, s, X, B, H, W, C, col);
   HIP_CHECK_RET(hipGetLastError());
@@ -342,15 +238,6 @@ int train_gn_fwd(const float* x, int B, int rows, int C, int G, const float* gam
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-// dx; dgamma / dbeta [C] (tmp1, tmp2: [B*rows*C] scratch each)
-int train_gn_bwd(const float* x, const float* dy, int B, int rows, int C, int G, const float* gamma, const float* beta,
-                 const float* stats, int act, float* dx, float* dgamma, float* dbeta, float* tmp1, float* tmp2, hipStream_t s) {
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, dy, rows, C, G, gamma, beta, stats, act, dx, tmp1, tmp2);
-  if (dgamma) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, s, tmp1, (long)B * rows, C, dgamma);
-  if (dbeta) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, s, tmp2, (long)B * rows, C, dbeta);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
 int train_colsum(const float* v, long R, int C, float* out, hipStream_t s) {
   hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, s, v, R, C, out);
   HIP_CHECK_RET(hipGetLastError());
@@ -358,14 +245,15 @@ int train_colsum(const float* v, long R, int C, float* out, hipStream_t s) {
 }
 int train_depth_fwd(const float* q, const float* k, const float* v, int R, int HW, int D, int hn, int hd, float scale, float* attn,
                     float* z, hipStream_t s) {
-  if (hn > 4 || hn * hd > 128 || D > 64) return mvd_fail("train_depth: needs heads <= 4, heads*dim_head <= 128, D <= 64");
-  hipLaunchKernelGGL(depth_fwd_kernel, dim3(R), dim3(128), 0, s, q, k, v, HW, D, hn, hd, scale, attn, z);
+  if (hn > DEPTH_MAX_H || hn * hd > DEPTH_MAX_I || D > DEPTH_MAX_D) return mvd_fail("train_depth: needs heads <= 4, heads*dim_head <= 1024, D <= 64");
+  hipLaunchKernelGGL(depth_fwd_kernel, dim3(R), dim3(256), 0, s, q, k, v, HW, D, hn, hd, scale, attn, z);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 int train_depth_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dz, int R, int HW, int D, int hn,
                     int hd, float scale, float* dq, float* dk, float* dv, hipStream_t s) {
-  hipLaunchKernelGGL(depth_bwd_kernel, dim3(R), dim3(128), 0, s, q, k, v, attn, dz, HW, D, hn, hd, scale, dq, dk, dv);
+  if (hn > DEPTH_MAX_H || hn * hd > DEPTH_MAX_I || D > DEPTH_MAX_D) return mvd_fail("train_depth: needs heads <= 4, heads*dim_head <= 1024, D <= 64");
+  hipLaunchKernelGGL(depth_bwd_kernel, dim3(R), dim3(256), 0, s, q, k, v, attn, dz, HW, D, hn, hd, scale, dq, dk, dv);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -24,10 +24,11 @@ MAX_SAMPLE_SLOTS = 8  # per-sample mesh / camera tables kept resident in the con
 
 class Engine:
     def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0,
-                 precision_level: int = 2):
+                 precision_level: int = 2, train: bool = False):
         """precision_level: mvd_set_precision_level (0..6): how many of the output-side layers run with split fp16 operands
         (extended precision); 2 is the default the parity bounds are stated for."""
         self.precision_level = int(precision_level)
+        self.train_mode = bool(train)  # mvd_train_enable: master parameters / gradients kept in flat arenas (training step)
         if not torch.cuda.is_available():
             raise L.MvdError("no MI355X visible: the denoiser has no CPU path")
         self.lib = L.load()
@@ -65,7 +66,10 @@ class Engine:
             L.check(self.lib.mvd_create(C.byref(uc), C.byref(vc), self.device.index or 0,
                                         C.c_size_t(int(workspace_gb * (1 << 30))), C.byref(self._ctx)))
         L.check(self.lib.mvd_set_precision_level(self._ctx, self.precision_level))
+        L.check(self.lib.mvd_train_enable(self._ctx, 1 if self.train_mode else 0))
         self._loaded = False
+        self.flat_params = self.flat_grads = self.flat_m = self.flat_v = None
+        self.param_table = {}
         self.num_vertices = 0
         self._slot_nv = {}
 
@@ -114,6 +118,8 @@ class Engine:
             L.check(self.lib.mvd_upload_weight(self._ctx, k.encode(), L.ptr(t), shape, t.dim(), on_dev))
         L.check(self.lib.mvd_finalize_weights(self._ctx))
         self._loaded = True
+        if self.train_mode:
+            self._adopt_arenas()
         return IncompatibleKeys(missing, unexpected)
 
     # ---- stages --------------------------------------------------------------------------------
@@ -234,20 +240,84 @@ class Engine:
         L.check(fn(self._ctx, L.ptr(f), L.ptr(out), _stream()))
         return out
 
-    # ---- training slice ---------------------------------------------------------
-    def train_tape(self, max_batch: int):
-        """mvd_train_tape: keep the last DepthTransformer's input and the final hidden state of the next unet_forward calls."""
-        L.check(self.lib.mvd_train_tape(self._ctx, int(max_batch)))
+    # ---- training -----------------------------------------------------------------
+    def _adopt_arenas(self):
+        """The engine's master-parameter and gradient arenas move into torch-owned memory, so that parameters / gradients are
+        VIEWS of two flat tensors (one collective for the DDP gradient averaging, torch optimisers work on them too)."""
+        n = int(self.lib.mvd_train_arena_size(self._ctx))
+        self.flat_params = torch.empty(n, device=self.device, dtype=torch.float32)
+        self.flat_grads = torch.empty(n, device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_train_adopt_arena(self._ctx, 0, L.ptr(self.flat_params), C.c_int64(n)))
+        L.check(self.lib.mvd_train_adopt_arena(self._ctx, 1, L.ptr(self.flat_grads), C.c_int64(n)))
+        self.flat_m = self.flat_v = None
+        self.param_table = {}
+        name = C.create_string_buffer(512)
+        off, numel, nd = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        shape = (C.c_int64 * 8)()
+        for i in range(int(self.lib.mvd_train_param_count(self._ctx))):
+            L.check(self.lib.mvd_train_param_info(self._ctx, i, name, C.c_size_t(len(name)), C.byref(off), C.byref(numel), shape,
+                                                  C.byref(nd)))
+            self.param_table[name.value.decode()] = (off.value, numel.value, tuple(int(shape[k]) for k in range(nd.value)))
 
-    def backward_last_condition(self, dpred, ctx0):
-        """dpred [B,4,s,s] = dL/d(eps of the taped forward); ctx0 [B,Cc,D,s,s] = source_dict[s] that forward saw."""
-        dp, c0 = _f32(dpred, self.device), _f32(ctx0, self.device)
-        L.check(self.lib.mvd_train_backward_last_condition(self._ctx, L.ptr(dp), L.ptr(c0), dp.shape[0], c0.shape[2], _stream()))
+    def param_view(self, key, grad=False):
+        """View of one master parameter (or its gradient) inside the flat arena, in the reference's layout."""
+        off, numel, shape = self.param_table[key]
+        return (self.flat_grads if grad else self.flat_params)[off:off + numel].view(shape)
+
+    def zero_grad(self):
+        L.check(self.lib.mvd_train_zero_grad(self._ctx, _stream()))
+
+    def train_unet_step(self, x, timesteps, context, source_dict, target, loss_scale=1.0, recompute=False, want_dsrc=False):
+        """mvd_train_unet_step: forward + MSE loss + backward through every UNet block.  Returns (pred, loss[, dsrc dict]);
+        parameter gradients (x loss_scale) are accumulated into ``flat_grads``."""
+        if not self.train_mode:
+            raise L.MvdError("the engine was not created with train=True")
+        dev = self.device
+        B = x.shape[0]
+        s = self.ucfg.image_size
+        x = _f32(x, dev)
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        ctx = _f32(context, dev)
+        tgt = _f32(target, dev)
+        srcs = [_f32(source_dict[s >> lvl], dev) for lvl in range(4)]
+        depth0 = srcs[0].shape[2]
+        pred = torch.empty(B, self.ucfg.out_channels, s, s, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        dsrc = [torch.empty_like(v) for v in srcs] if want_dsrc else [None] * 4
+        L.check(self.lib.mvd_train_unet_step(self._ctx, L.ptr(x), L.ptr(t), L.ptr(ctx), B, L.ptr(srcs[0]), L.ptr(srcs[1]),
+                                             L.ptr(srcs[2]), L.ptr(srcs[3]), depth0, L.ptr(tgt), C.c_float(loss_scale),
+                                             1 if recompute else 0, L.ptr(pred), L.ptr(loss), L.ptr(dsrc[0]), L.ptr(dsrc[1]),
+                                             L.ptr(dsrc[2]), L.ptr(dsrc[3]), _stream()))
+        if want_dsrc:
+            return pred, loss[0], {s >> lvl: dsrc[lvl] for lvl in range(4)}
+        return pred, loss[0]
 
     def get_grad(self, key: str, shape):
         out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
         L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))
         return out
+
+    def adamw_step(self, lr, lr_aux, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, inv_scale=1.0, finetune_unet=True,
+                   check=True):
+        """torch.optim.AdamW on the arena (two learning-rate groups, morphable_diffusion.py:627-646) + in-place re-pack of the
+        fp16 weights.  Returns True when the update was skipped because a gradient was inf / nan (check=False: not read back)."""
+        if self.flat_m is None:
+            self.flat_m = torch.zeros_like(self.flat_params)
+            self.flat_v = torch.zeros_like(self.flat_params)
+            n = self.flat_params.numel()
+            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 2, L.ptr(self.flat_m), C.c_int64(n)))
+            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 3, L.ptr(self.flat_v), C.c_int64(n)))
+        skipped = C.c_int(0)
+        L.check(self.lib.mvd_train_adamw_step(self._ctx, C.c_float(lr), C.c_float(lr_aux), C.c_float(betas[0]),
+                                              C.c_float(betas[1]), C.c_float(eps), C.c_float(weight_decay), int(step),
+                                              C.c_float(inv_scale), 1 if finetune_unet else 0,
+                                              C.byref(skipped) if check else None, _stream()))
+        self.repack()
+        return bool(skipped.value)
+
+    def repack(self):
+        """Re-derive every packed fp16 weight from the master parameters (after they changed), in place."""
+        L.check(self.lib.mvd_train_repack(self._ctx))
 
     def set_volume(self, volume):
         v = _f32(volume, self.device)
@@ -362,6 +432,33 @@ class Engine:
         L.check(self.lib.mvd_op_attention(self._ctx, L.ptr(q), L.ptr(k), L.ptr(v), B, T, heads, Cc // heads, L.ptr(out),
                                           _stream()))
         return out
+
+    def op_attention_bwd(self, q, k, v, d_out, heads):
+        dev = self.device
+        q, k, v, d_out = _f32(q, dev), _f32(k, dev), _f32(v, dev), _f32(d_out, dev)
+        B, T, Cc = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        L.check(self.lib.mvd_op_attention_bwd(self._ctx, L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_out), B, T, heads, Cc // heads,
+                                              L.ptr(dq), L.ptr(dk), L.ptr(dv), _stream()))
+        return dq, dk, dv
+
+    def op_group_norm_bwd(self, x, dy, groups, gamma, beta, eps, act=0):
+        """x, dy [B, rows, C] channels-last -> (dx, dgamma, dbeta)"""
+        dev = self.device
+        x, dy, g, b = _f32(x, dev), _f32(dy, dev), _f32(gamma, dev), _f32(beta, dev)
+        B, rows, Cc = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
+        L.check(self.lib.mvd_op_group_norm_bwd(self._ctx, L.ptr(x), L.ptr(dy), B, rows, Cc, groups, L.ptr(g), L.ptr(b), C.c_float(eps),
+                                               act, L.ptr(dx), L.ptr(dg), L.ptr(db), _stream()))
+        return dx, dg, db
+
+    def op_layer_norm_bwd(self, x, dy, gamma):
+        dev = self.device
+        x, dy, g = _f32(x, dev), _f32(dy, dev), _f32(gamma, dev)
+        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
+        L.check(self.lib.mvd_op_layer_norm_bwd(self._ctx, L.ptr(x), L.ptr(dy), x.shape[0], x.shape[1], L.ptr(g), L.ptr(dx), L.ptr(dg),
+                                               L.ptr(db), _stream()))
+        return dx, dg, db
 
     def bench_conv(self, B, Cc, H, W, Cout, iters=20):
         ms = C.c_float(0)

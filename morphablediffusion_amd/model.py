@@ -46,11 +46,12 @@ class DepthWiseAttention(nn.Module):
     """Drop-in for ldm.models.diffusion.attention.DepthWiseAttention (YAML unet_config.target,
     configs/facescape.yaml:26-42).  forward(x, timesteps, context, source_dict) -> [Bv,4,h,w]."""
 
-    def __init__(self, volume_dims=(5, 16, 32, 64), *args, precision_level=2, **kwargs):
+    def __init__(self, volume_dims=(5, 16, 32, 64), *args, precision_level=2, train_mode=False, **kwargs):
         super().__init__()
         if args:
             raise TypeError("pass UNet arguments by keyword, as the reference config does")
         self.precision_level = precision_level  # not a reference kwarg: mvd_set_precision_level of a stand-alone engine
+        self.train_mode = train_mode            # not a reference kwarg: a stand-alone engine keeps master weights / gradients
         self.cfg = _unet_cfg(dict(kwargs, volume_dims=tuple(volume_dims)))
         self.cfg.validate()
         self._engine: Optional[Engine] = None
@@ -63,12 +64,12 @@ class DepthWiseAttention(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         """Standalone use: keys as in the reference UNet's own state_dict (no ``model.diffusion_model.`` prefix)."""
         if self._engine is None:
-            self._engine = Engine(self.cfg, VolumeConfig(), precision_level=self.precision_level)
+            self._engine = Engine(self.cfg, VolumeConfig(), precision_level=self.precision_level, train=self.train_mode)
             self._owns_engine = True
         from .spec import unet_manifest
         sd = {"model.diffusion_model." + k: v for k, v in state_dict.items()}
-        self._keep_trainable(state_dict)
         inc = self._engine.load_state_dict(sd, strict=strict, expected=unet_manifest(self.cfg))
+        self._keep_trainable(state_dict)
         n = len("model.diffusion_model.")
         return type(inc)([k[n:] for k in inc.missing_keys], [k[n:] for k in inc.unexpected_keys])
 
@@ -79,27 +80,40 @@ class DepthWiseAttention(nn.Module):
 
     def get_trainable_parameters(self):
         """attention.py:140-142: the parameters of middle_conditions and output_conditions, in the reference's registration
-        order.  fp32 master copies of the loaded tensors (nn.Parameter); ``backward_last_condition`` fills ``.grad`` of the
-        ones the built backward slice reaches (the last DepthTransformer), the others keep ``grad = None``."""
+        order.  With the engine in training mode they are VIEWS of its flat master-parameter arena (nn.Parameter, ``.grad`` a
+        view of the gradient arena: the training step accumulates into it, an optimiser step on them changes the engine's
+        masters -- call ``engine.repack()`` afterwards, ArenaAdamW does).  Otherwise detached fp32 copies of the loaded tensors."""
         return list(self._trainable.values())
+
+    def named_parameters_all(self):
+        """(key relative to the UNet, nn.Parameter view) of EVERY UNet parameter, the reference's ``self.model.parameters()``
+        (finetune_unet=True, morphable_diffusion.py:633-634).  Training mode only."""
+        eng = self._engine
+        pre = "model.diffusion_model."
+        if eng is None or not eng.train_mode:
+            raise RuntimeError("the engine was not created in training mode")
+        if not hasattr(self, "_all_params"):
+            self._all_params = {k[len(pre):]: _arena_param(eng, k) for k in sorted(eng.param_table) if k.startswith(pre)}
+        return list(self._all_params.items())
 
     def _keep_trainable(self, sd, prefix=""):
         from .spec import unet_manifest
         self._trainable = {}
+        self.__dict__.pop("_all_params", None)
+        eng = self._engine
         for k in unet_manifest(self.cfg, prefix=""):
             if k.startswith(("middle_conditions.", "output_conditions.")) and prefix + k in sd:
-                self._trainable[k] = nn.Parameter(sd[prefix + k].detach().float().clone())
+                if eng is not None and eng.train_mode and ("model.diffusion_model." + k) in eng.param_table:
+                    self._trainable[k] = _arena_param(eng, "model.diffusion_model." + k)
+                else:
+                    self._trainable[k] = nn.Parameter(sd[prefix + k].detach().float().clone())
         # deliberately NOT registered on the module: state_dict() stays what the reference's is (the engine owns the weights)
 
-    def backward_last_condition(self, dpred, ctx0):
-        """Back-propagates dL/d(output of the last forward, run with the tape on) into the last DepthTransformer's parameters."""
-        eng = self._engine
-        eng.backward_last_condition(dpred, ctx0)
-        last = max(int(k.split(".")[1]) for k in self._trainable if k.startswith("output_conditions."))
-        pre = f"output_conditions.{last}."
-        for k, p_ in self._trainable.items():
-            if k.startswith(pre):
-                p_.grad = eng.get_grad("model.diffusion_model." + k, p_.shape).to(p_.device)
+
+def _arena_param(eng, key):
+    p_ = nn.Parameter(eng.param_view(key), requires_grad=True)
+    p_.grad = eng.param_view(key, grad=True)
+    return p_
 
 
 class UNetWrapper(nn.Module):
@@ -145,6 +159,28 @@ class UNetWrapper(nn.Module):
         if self.use_zero_123:
             xc[:, :4] = xc[:, :4] / 0.18215
         return self.diffusion_model(torch.cat([x, xc], 1), t, clip_embed, source_dict=volume_feats)
+
+    def train_step(self, x, t, clip_embed, volume_feats, x_concat, target, drop_random=None, loss_scale=1.0, recompute=True):
+        """forward(is_train=True) (morphable_diffusion.py:95-130) + MSE + backward in one engine call.  Returns
+        (pred, loss, dsrc): dsrc[res] = dL/d(volume_feats[res]) * loss_scale, after the dropout mask."""
+        vm = None
+        if self.drop_conditions:
+            B = x.shape[0]
+            drop_clip, drop_volume, drop_concat, drop_all = self.get_drop_scheme(B, x.device, drop_random)
+            clip_embed = self.drop(clip_embed, 1.0 - (drop_clip | drop_all).float())
+            vm = 1.0 - (drop_volume | drop_all).float()
+            for k, v in volume_feats.items():
+                volume_feats[k] = self.drop(v, vm)
+            x_concat = self.drop(x_concat, 1.0 - (drop_concat | drop_all).float())
+        xc = x_concat * 1.0
+        if self.use_zero_123:
+            xc[:, :4] = xc[:, :4] / 0.18215
+        eng = self.diffusion_model._engine
+        pred, loss, dsrc = eng.train_unet_step(torch.cat([x, xc], 1), t, clip_embed, volume_feats, target, loss_scale=loss_scale,
+                                               recompute=recompute, want_dsrc=True)
+        if vm is not None:  # the dropout is a multiplication by the mask: so is its adjoint
+            dsrc = {k: self.drop(v, vm) for k, v in dsrc.items()}
+        return pred, loss, dsrc
 
     def predict_with_unconditional_scale(self, x, t, clip_embed, volume_feats, x_concat, unconditional_scale):
         x_ = torch.cat([x] * 2, 0)
@@ -239,8 +275,22 @@ class SyncMultiviewDiffusion(nn.Module):
                  projection="perspective", use_spatial_volume=False, view_num=16, image_size=256, cfg_scale=3.0,
                  output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
                  clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
-                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2):
+                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2,
+                 train_mode=False, loss_scale=1024.0, recompute=True):
+        """train_mode / loss_scale / recompute are not reference kwargs: train_mode keeps fp32 master parameters, gradients and
+        Adam moments in the engine (training_step runs the backward pass); loss_scale multiplies dL/dpred so that the fp16 MFMA
+        operands of the backward pass stay in range (un-done by the optimiser); recompute = per-block activation checkpointing
+        (the reference's use_checkpoint: True), False keeps every activation (fits the 288 GB of an MI355X, faster)."""
         super().__init__()
+        self.finetune_unet = finetune_unet
+        self.scheduler_config = scheduler_config
+        self.learning_rate = 5e-5  # train_morphable_diffusion.py:313-321 sets model.learning_rate before fit
+        self.train_mode = train_mode
+        self.loss_scale = float(loss_scale)
+        self.recompute = bool(recompute)
+        self.global_step = 0
+        self.global_rank = 0
+        self.image_dir = "."
         self.view_num = view_num
         self.viewpoint_dim = 4
         self.output_num = output_num
@@ -258,7 +308,7 @@ class SyncMultiviewDiffusion(nn.Module):
                                                input_image_size=image_size, projection=projection,
                                                use_spatial_volume=use_spatial_volume)
         self.engine = Engine(self.model.diffusion_model.cfg, self.spatial_volume.cfg, device=device,
-                             workspace_gb=workspace_gb, precision_level=precision_level)
+                             workspace_gb=workspace_gb, precision_level=precision_level, train=train_mode)
         self.model.diffusion_model.bind(self.engine)
         self.spatial_volume.bind(self.engine)
         self._device = torch.device(device)
@@ -274,8 +324,9 @@ class SyncMultiviewDiffusion(nn.Module):
         """generate_face.py:76 calls this with strict=False on ``ckpt['state_dict']``; returns torch's
         (missing_keys, unexpected_keys) pair w.r.t. the keys the denoising path consumes."""
         self.spatial_volume.invalidate()
+        inc = self.engine.load_state_dict(state_dict, strict=strict)
         self.model.diffusion_model._keep_trainable(state_dict, "model.diffusion_model.")
-        return self.engine.load_state_dict(state_dict, strict=strict)
+        return inc
 
     def get_viewpoint_embedding(self, batch):
         d_e = torch.deg2rad(batch["target_elevation"]) - torch.deg2rad(batch["input_elevation"])
@@ -309,17 +360,23 @@ class SyncMultiviewDiffusion(nn.Module):
         with torch.no_grad():
             return self.first_stage_model.decode(z / self.first_stage_scale_factor)
 
-    def prepare(self, batch):
-        """morphable_diffusion.py:473-489.  The reference also VAE-encodes the 16 target images and then
-        discards them at inference (:475-479,568); that dead work is skipped, but its side effect on the global RNG
-        stream is not: each of those N encodes draws ``posterior.sample()`` noise (distributions.py:36) BEFORE the input
-        image is encoded and before x_T is drawn, so the same draws are consumed here -- a run seeded with
-        torch.manual_seed sees the same stream position as the reference."""
+    def prepare(self, batch, encode_targets=False):
+        """morphable_diffusion.py:473-489.  ``encode_targets=True`` (the training step): the N target images are VAE-encoded
+        view by view with posterior.sample(), exactly as the reference does (:475-479), and returned as x [B,N,4,h,w].
+        At inference the reference encodes them too and then discards the result (:568); that dead work is skipped, but its
+        side effect on the global RNG stream is not: each of those N encodes draws ``posterior.sample()`` noise
+        (distributions.py:36) BEFORE the input image is encoded and before x_T is drawn, so the same draws are consumed here
+        -- a run seeded with torch.manual_seed sees the same stream position as the reference."""
+        x = None
         if "target_image" in batch and batch["target_image"] is not None:
             B, N = batch["target_image"].shape[:2]
-            h, w = batch["target_image"].shape[2] // 8, batch["target_image"].shape[3] // 8
-            for _ in range(N):
-                torch.randn([B, 4, h, w])
+            if encode_targets:
+                image_target = batch["target_image"].permute(0, 1, 4, 2, 3)  # b,n,h,w,3 -> b,n,3,h,w
+                x = torch.stack([self.encode_first_stage(image_target[:, ni], True) for ni in range(N)], 1)
+            else:
+                h, w = batch["target_image"].shape[2] // 8, batch["target_image"].shape[3] // 8
+                for _ in range(N):
+                    torch.randn([B, 4, h, w])
         image_input = batch["input_image"].permute(0, 3, 1, 2)
         x_input = self.encode_first_stage(image_input)
         input_info = {"image": image_input, "elevation": batch["input_elevation"][:, 0], "x": x_input}
@@ -330,7 +387,7 @@ class SyncMultiviewDiffusion(nn.Module):
         else:
             with torch.no_grad():
                 clip_embed = self.clip_image_encoder.encode(image_input)
-        return None, clip_embed, input_info
+        return x, clip_embed, input_info
 
     def add_noise(self, x_start, t, noise=None):
         """morphable_diffusion.py:551-565 (schedule buffers :428-450).  ``noise``: the N(0,1) draw (default: randn_like)."""
@@ -343,21 +400,27 @@ class SyncMultiviewDiffusion(nn.Module):
         return x_noisy, noise
 
     def training_step(self, batch, prepared=None, time_steps=None, noise=None, target_index=None, drop_random=None,
-                      backward=False):
-        """SyncMultiviewDiffusion.training_step (morphable_diffusion.py:520-549): FORWARD pass and loss in the HIP engine --
-        random time steps, add_noise, one random target view per sample, the 32^3 volume from ALL noisy views (BatchNorm in
-        train mode), one frustum volume per sample, the UNet with condition dropout, MSE against the injected noise.
-        ``prepared`` = (x, clip_embed, input_info) replaces self.prepare(batch); the four random draws may be passed in
-        (parity tests), otherwise they are drawn on the host in the reference's order (randint, randn_like, randint, rand) so
-        that torch.manual_seed reproduces the reference's CPU stream.  Returns the loss (a device scalar, no autograd graph);
-        the prediction is kept in ``self.last_noise_predict``.  ``backward=True`` also runs the part of the backward pass that
-        exists (first slice): dL/dpred = 2 (pred - target) / numel through the output head into every
-        parameter of the last DepthTransformer -- ``.grad`` of those entries of get_trainable_parameters() is set."""
+                      backward=None):
+        """SyncMultiviewDiffusion.training_step (morphable_diffusion.py:520-549) in the HIP engine: random time steps, prepare
+        (VAE-encode the N target views + the input view, CLIP), add_noise, one random target view per sample, the 32^3 volume
+        from ALL noisy views (BatchNorm in train mode), one frustum volume per sample, the UNet with condition dropout, MSE
+        against the injected noise -- and, with the engine in training mode (``backward`` defaults to that), loss.backward():
+        dL/dpred back through every UNet block; ``.grad`` of every UNet parameter (views of the engine's gradient arena,
+        multiplied by ``self.loss_scale``) is ACCUMULATED like torch does until zero_grad.  The gradients of ``spatial_volume`` /
+        ``time_embed`` (the conditioner's backward) are not built: ``self.last_dsrc`` holds dL/d(frustum volumes), the point
+        where that backward would start.
+        ``prepared`` = (x, clip_embed, input_info) replaces self.prepare(batch); the random draws may be passed in (parity
+        tests), otherwise they are made on the host in the reference's order (randint for the time steps BEFORE prepare's
+        posterior samples, then randn_like, randint, rand) so that torch.manual_seed reproduces the reference's CPU stream.
+        Returns the loss (a device scalar, no autograd graph); the prediction is kept in ``self.last_noise_predict``."""
         dev = self.device
-        x, clip_embed, input_info = self.prepare(batch) if prepared is None else prepared
-        B, N = x.shape[:2]
-        if time_steps is None:
+        if backward is None:
+            backward = self.train_mode
+        B = batch["target_image"].shape[0] if prepared is None else prepared[0].shape[0]
+        if time_steps is None:  # drawn first, as the reference does (:521-522)
             time_steps = torch.randint(0, self.num_timesteps, (B,)).long()
+        x, clip_embed, input_info = self.prepare(batch, encode_targets=True) if prepared is None else prepared
+        B, N = x.shape[:2]
         if noise is None:
             noise = torch.randn(x.shape)
         if target_index is None:
@@ -377,16 +440,63 @@ class SyncMultiviewDiffusion(nn.Module):
         finally:
             self.train(was_training)
         ar = torch.arange(B, device=dev)[:, None]
-        if backward:
-            self.engine.train_tape(B)
-        pred = self.model(x_noisy[ar, target_index][:, 0], time_steps, clip_, vf, xc, is_train=True, drop_random=drop_random)
-        self.last_noise_predict = pred
         target = noise[ar, target_index][:, 0].contiguous()
-        loss = self.engine.mse_loss(target, pred)
-        if backward:
-            dpred = (pred - target) * (2.0 / pred.numel())  # d mean((t - p)^2) / dp
-            self.model.diffusion_model.backward_last_condition(dpred, vf[self.image_size // 8])  # vf: after the dropout
+        x_t = x_noisy[ar, target_index][:, 0]
+        if not backward:
+            pred = self.model(x_t, time_steps, clip_, vf, xc, is_train=True, drop_random=drop_random)
+            self.last_noise_predict = pred
+            return self.engine.mse_loss(target, pred)
+        pred, loss, dsrc = self.model.train_step(x_t, time_steps, clip_, vf, xc, target, drop_random=drop_random,
+                                                 loss_scale=self.loss_scale, recompute=self.recompute)
+        self.last_noise_predict, self.last_dsrc = pred, dsrc
         return loss
+
+    # ---- optimiser surface (morphable_diffusion.py:627-646, train_morphable_diffusion.py:302-321) --------------------
+    def configure_optimizers(self):
+        """AdamW with the reference's parameter groups and LambdaLR on its scheduler_config: the UNet (all of it when
+        finetune_unet, else get_trainable_parameters()) at lr, time_embed and spatial_volume at 10 lr.  The optimiser is a
+        torch.optim.Optimizer whose step() runs ONE fused HIP kernel per group range on the engine's arenas and re-packs the
+        fp16 weights."""
+        from torch.optim.lr_scheduler import LambdaLR
+        lr = self.learning_rate
+        print(f"setting learning rate to {lr:.4f} ...")
+        if not self.train_mode:
+            raise RuntimeError("configure_optimizers needs the model created with train_mode=True")
+        dm = self.model.diffusion_model
+        unet = [p_ for _, p_ in dm.named_parameters_all()] if self.finetune_unet else self.model.get_trainable_parameters()
+        eng = self.engine
+        te = [_arena_param(eng, k) for k in sorted(eng.param_table) if k.startswith("time_embed.")]
+        sv = [_arena_param(eng, k) for k in sorted(eng.param_table) if k.startswith("spatial_volume.")]
+        paras = [{"params": unet, "lr": lr}, {"params": te, "lr": lr * 10.0}, {"params": sv, "lr": lr * 10.0}]
+        opt = ArenaAdamW(self, paras, lr=lr)
+        if self.scheduler_config is None:
+            return [opt], []
+        sched = LambdaLinearScheduler(**self.scheduler_config.get("params", {}))
+        print("Setting up LambdaLR scheduler...")
+        return [opt], [{"scheduler": LambdaLR(opt, lr_lambda=sched.schedule), "interval": "step", "frequency": 1}]
+
+    def sync_gradients(self):
+        """DDP's gradient averaging (train_morphable_diffusion.py:302-303: Lightning wraps the module in
+        DistributedDataParallel) as ONE all-reduce on the flat gradient arena -- RCCL over xGMI when the process group's
+        backend is nccl.  No-op without an initialised process group."""
+        return sync_flat_gradients(self.engine.flat_grads)
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """morphable_diffusion.py:601-617: rank 0 samples the first ``output_num`` items of the first validation batch and
+        writes the image grid <image_dir>/images/val/<step>.jpg."""
+        if batch_idx == 0 and self.global_rank == 0:
+            self.eval()
+            batch_ = {}
+            for k, v in batch.items():
+                batch_[k] = {k_: v_[:self.output_num] for k_, v_ in v.items()} if isinstance(v, dict) else v[:self.output_num]
+            x_sample = self.sample(self.sampler, batch_, self.cfg_scale, self.batch_view_num)
+            from pathlib import Path
+            from .batch import save_image_grid
+            out = Path(self.image_dir) / "images" / "val"
+            out.mkdir(exist_ok=True, parents=True)
+            save_image_grid(x_sample, batch_, str(out / f"{self.global_step}.jpg"))
+            return x_sample
 
     def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):
         B, _, H, W = x_input.shape
@@ -414,6 +524,80 @@ class SyncMultiviewDiffusion(nn.Module):
                    for ni in range(0, N, inter_view_interval)]
             return x_sample, torch.stack(res, 1)
         return x_sample
+
+
+def sync_flat_gradients(flat_grads):
+    """One all-reduce (mean) over the flat gradient buffer; returns True when a collective ran."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return False
+    dist.all_reduce(flat_grads)
+    flat_grads.mul_(1.0 / dist.get_world_size())
+    return True
+
+
+class ArenaAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (the reference's optimiser, morphable_diffusion.py:642) on the engine's flat arenas:
+    param_groups[0] = the UNet group, [1] / [2] = time_embed / spatial_volume (one learning rate: the reference gives both
+    10 lr).  step() = mvd_train_adamw_step (fused HIP kernel per contiguous group range, un-does the loss scale, skips the
+    update when a gradient overflowed) + in-place re-pack of the fp16 weights.  LR schedulers act on param_groups as usual."""
+
+    def __init__(self, model, params, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self.steps_done = 0
+        self.steps_skipped = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g0 = self.param_groups[0]
+        aux = self.param_groups[1]["lr"] if len(self.param_groups) > 1 else g0["lr"]
+        m = self.model
+        skipped = m.engine.adamw_step(g0["lr"], aux, self.steps_done + 1, betas=g0["betas"], eps=g0["eps"],
+                                      weight_decay=g0["weight_decay"], inv_scale=1.0 / m.loss_scale,
+                                      finetune_unet=m.finetune_unet)
+        if skipped:  # torch.cuda.amp.GradScaler's rule: back off and try again
+            self.steps_skipped += 1
+            m.loss_scale = max(1.0, m.loss_scale * 0.5)
+        else:
+            self.steps_done += 1
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        self.model.engine.zero_grad()  # the .grad views stay attached to the (now zero) arena
+
+
+class LambdaLinearScheduler:
+    """ldm/lr_scheduler.py:59-98 (LambdaWarmUpCosineScheduler2.find_in_interval + LambdaLinearScheduler.schedule): the
+    learning-rate multiplier of configs/facescape.yaml:17-24 -- linear warm-up f_start -> f_max, then linear decay to f_min
+    over the cycle."""
+
+    def __init__(self, warm_up_steps, f_min, f_max, f_start, cycle_lengths, verbosity_interval=0):
+        assert len(warm_up_steps) == len(f_min) == len(f_max) == len(f_start) == len(cycle_lengths)
+        self.lr_warm_up_steps, self.f_start, self.f_min, self.f_max = warm_up_steps, f_start, f_min, f_max
+        self.cycle_lengths = cycle_lengths
+        self.cum_cycles = np.cumsum([0] + list(cycle_lengths))
+        self.last_f = 0.0
+
+    def find_in_interval(self, n):
+        interval = 0
+        for cl in self.cum_cycles[1:]:
+            if n <= cl:
+                return interval
+            interval += 1
+
+    def schedule(self, n, **kwargs):
+        cycle = self.find_in_interval(n)
+        n = n - self.cum_cycles[cycle]
+        if n < self.lr_warm_up_steps[cycle]:
+            f = (self.f_max[cycle] - self.f_start[cycle]) / self.lr_warm_up_steps[cycle] * n + self.f_start[cycle]
+        else:
+            f = self.f_min[cycle] + (self.f_max[cycle] - self.f_min[cycle]) * (self.cycle_lengths[cycle] - n) / self.cycle_lengths[cycle]
+        self.last_f = f
+        return f
+
+    __call__ = schedule
 
 
 class DiagonalGaussianDistribution:

@@ -353,8 +353,8 @@ def gold_train(ns):
     condition dropout (:95-130), MSE -- then loss.backward().  ``prepare`` (VAE / CLIP) is replaced by seeded latents.
     The random draws are stored so that the HIP path can be fed the same ones; the dropout's uniform draw is INJECTED
     (torch.rand patched for that one call) so that all four branches of get_drop_scheme (:84-93) occur in a batch of 4.
-    Stored: loss, noise_predict, and the gradients of every parameter of the LAST DepthTransformer (output_conditions.8)
-    plus the gradient w.r.t. the UNet output."""
+    Stored: loss, noise_predict, dL/dpred, the gradient of EVERY UNet parameter (sample + norm; the 170 DepthTransformer
+    tensors with larger samples) and the gradient w.r.t. the four frustum volumes."""
     B, N = 4, 4
     ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
     model, _ = build_full_model(ns, ucfg, vcfg, N)
@@ -380,6 +380,9 @@ def gold_train(ns):
     sv = model.spatial_volume.construct_spatial_volume(x_noisy, t_embed, v_embed, batch)
     clip_, vf, xc = model.get_target_view_feats(x_in, sv, clip, t_embed, v_embed, target_index, batch)
     x_noisy_ = x_noisy[torch.arange(B)[:, None], target_index][:, 0]
+    vf_pre = dict(vf)  # UNetWrapper.forward replaces the dict entries by their dropped versions (:114-115)
+    for v_ in vf_pre.values():
+        v_.retain_grad()
     real_rand = torch.rand
     torch.rand = lambda *a, **k: drop_random.clone()
     try:
@@ -392,21 +395,31 @@ def gold_train(ns):
     loss.backward()
     packs = {"noise_predict": gi.pack(pred), "loss": gi.pack(loss.reshape(1)), "dpred": gi.pack(pred.grad),
              "x_noisy": gi.pack(x_noisy)}
-    names = []
-    for n_, p_ in model.model.diffusion_model.output_conditions[8].named_parameters():
-        assert p_.grad is not None and p_.grad.abs().max() > 0, n_
-        packs["grad." + n_] = gi.pack(p_.grad, limit=1 << 18)
+    # every parameter of the UNet (finetune_unet: True trains all of them, configs/facescape.yaml:10; the 170 tensors of
+    # get_trainable_parameters(), attention.py:140-142, are the middle_conditions / output_conditions entries): a strided
+    # sample + the L2 norm of each gradient
+    names, norms = [], []
+    for n_, p_ in model.model.diffusion_model.named_parameters():
+        if p_.grad is None:  # attn2.to_q / to_k / norm2 see a single context token: autograd may leave them untouched
+            g_ = torch.zeros_like(p_)
+        else:
+            g_ = p_.grad
+        cond = n_.startswith(("middle_conditions.", "output_conditions."))
+        packs["grad." + n_] = gi.pack(g_, limit=1 << 14 if cond else 2048, target=2048 if cond else 512)
         names.append(n_)
-    # the output head (openaimodel.py:717-721): trainable under finetune_unet=True (configs/facescape.yaml:10)
-    head = []
-    for n_, p_ in model.model.diffusion_model.out.named_parameters():
-        packs["gradout." + n_] = gi.pack(p_.grad, limit=1 << 18)
-        head.append(n_)
-    print("train golden: loss", float(loss), "pred std", float(pred.std()), "grads:", len(names), "+ head", head)
+        norms.append(float(g_.double().norm()))
+    # gradient w.r.t. the frustum volumes BEFORE the condition dropout: where the conditioner's backward starts
+    for k_, v_ in vf_pre.items():
+        packs[f"dsrc.{k_}"] = gi.pack(v_.grad, limit=2048, target=4096)
+    aux = {}
+    for n_, p_ in list(model.time_embed.named_parameters()) + [("sv." + a_, b_) for a_, b_ in model.spatial_volume.named_parameters()]:
+        aux[n_] = float(p_.grad.double().norm()) if p_.grad is not None else 0.0
+    print("train golden: loss", float(loss), "pred std", float(pred.std()), "UNet grads:", len(names), "zero-norm:",
+          [n for n, v in zip(names, norms) if v == 0.0][:8], "| conditioner grad norms (not stored):", len(aux))
     save("train_small.npz", packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
                                     "target_index": target_index.numpy(), "drop_random": drop_random.numpy(),
                                     "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names),
-                                    "head_names": np.array(head)})
+                                    "grad_norms": np.array(norms)})
 
 
 def gold_variants(ns):
