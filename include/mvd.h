@@ -183,6 +183,11 @@ int mvd_train_unet_step(mvd_ctx* ctx, const float* x, const int64_t* timesteps, 
                         const float* src1, const float* src2, const float* src3, int depth0, const float* target, float loss_scale,
                         int recompute, float* pred_out, float* loss_out, float* dsrc0, float* dsrc1, float* dsrc2, float* dsrc3,
                         void* stream);
+/* Parity hook: the backward pass of ONE DepthTransformer (attention.py:49-84; cond_index 0 = middle_conditions, 1 + k =
+ * output_conditions.k) given its input x [B,dim,H,W], its context volume [B,C_l,D_l,H,W] and dL/d(output) [B,dim,H,W]:
+ * dx, dcontext (may be NULL) are written, parameter gradients accumulated into the arena.  depth0 = D of the finest level. */
+int mvd_train_cond_backward(mvd_ctx* ctx, int cond_index, const float* x, const float* context, const float* d_out, int B, int H,
+                            int W, int depth0, float* dx, float* dcontext, void* stream);
 int mvd_train_get_grad(mvd_ctx* ctx, const char* name, float* out, size_t numel, void* stream);
 int mvd_train_adamw_step(mvd_ctx* ctx, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
                          float inv_scale, int finetune_unet, int* skipped_out, void* stream);

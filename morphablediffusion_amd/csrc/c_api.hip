@@ -85,7 +85,7 @@ int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int 
 int bwd_ln_max_blocks();
 int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
                    long lddx, int accum, float* part, int* nblk, hipStream_t s);
-int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s);
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split = 0);
 extern "C" {
 
 const char* mvd_last_error(void) { return g_err.c_str(); }
@@ -423,6 +423,35 @@ int mvd_train_unet_step(mvd_ctx* c, const float* x, const int64_t* timesteps, co
       const int sl = u.image_size >> l, Dl = depth0 >> l, C = u.volume_dims[l];
       RET_IF(launch_nhwc_to_nchw(dcl[l], C, B, C, Dl * sl * sl, douts[l], s));
     }
+  return 0;
+}
+
+int mvd_train_cond_backward(mvd_ctx* c, int cond_index, const float* x, const float* context, const float* d_out, int B, int H,
+                            int W, int depth0, float* dx, float* dcontext, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !c->finalized || !c->train_mode) return mvd_fail("mvd_train_cond_backward: context not finalized in training mode");
+  if (cond_index < 0 || cond_index >= (int)c->conds.size() || !x || !context || !d_out || !dx || B <= 0)
+    return mvd_fail("mvd_train_cond_backward: bad argument");
+  hipStream_t s = S(stream);
+  const CondW& cd = c->conds[cond_index];
+  int level = 0;
+  for (int r = c->u.image_size; r > H; r >>= 1) ++level;
+  if (level > 3 || (c->u.image_size >> level) != H || H != W) return mvd_fail("mvd_train_cond_backward: resolution is not a UNet level");
+  const int D = depth0 >> level, HW = H * W;
+  WsScope ws_scope(c);
+  float* xn = ws_alloc<float>(c, (size_t)B * HW * cd.dim);
+  float* dn = ws_alloc<float>(c, (size_t)B * HW * cd.dim);
+  float* gx = ws_alloc<float>(c, (size_t)B * HW * cd.dim);
+  float* cn = ws_alloc<float>(c, (size_t)B * D * HW * cd.Cc);
+  float* gc = ws_alloc<float>(c, (size_t)B * D * HW * cd.Cc);
+  WS_CHECK(xn && dn && gx && cn && gc);
+  RET_IF(launch_nchw_to_nhwc(x, B, cd.dim, HW, xn, cd.dim, cd.dim, s));
+  RET_IF(launch_nchw_to_nhwc(d_out, B, cd.dim, HW, dn, cd.dim, cd.dim, s));
+  RET_IF(launch_nchw_to_nhwc(context, B, cd.Cc, D * HW, cn, cd.Cc, cd.Cc, s));
+  HIP_CHECK_RET(hipMemsetAsync(gc, 0, (size_t)B * D * HW * cd.Cc * sizeof(float), s));
+  RET_IF(engine_train_cond_backward(c, cond_index, xn, cn, dn, B, H, W, level, depth0, gx, gc, s));
+  RET_IF(launch_nhwc_to_nchw(gx, cd.dim, B, cd.dim, HW, dx, s));
+  if (dcontext) RET_IF(launch_nhwc_to_nchw(gc, cd.Cc, B, cd.Cc, D * HW, dcontext, s));
   return 0;
 }
 

@@ -381,6 +381,8 @@ int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes);         // owned allocat
 // forward with the tape, loss = mean((pred - target)^2), dL/dpred * loss_scale back through every block; parameter gradients
 // are ACCUMULATED into the gradient arena (x loss_scale).  dsrc[l] (may be null): gradient w.r.t. the context volumes,
 // channels-last like src[l].  recompute: keep only block inputs and re-run each block before its backward.
+int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const float* ctx_vol, const float* dout, int B, int H, int W,
+                               int level, int depth0, float* dx, float* dctx, hipStream_t s);
 int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,
                       const Ctx5 src[4], const float* target_nhwc, float loss_scale, int recompute, float* pred_nhwc, float* loss_out,
                       float* const dsrc[4], hipStream_t s);

@@ -23,9 +23,9 @@
 #include "engine.h"
 
 // k_bwd.hip
-int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s);
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split = 0);
 int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int C, int stride, int ups, half_t* dst, int Rp, hipStream_t s);
-int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s);
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split = 0);
 int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s);
 int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
                    const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
@@ -166,38 +166,45 @@ struct Opnd {  // a GEMM operand in HBM
 
 // fp16 [rows][Kp] image of an operand: `stored_rows` = the operand is stored [rows][K] (row-major, stride ld), otherwise
 // [K][rows].  A row-major fp16 operand is used in place (need_dense: only when its rows are back to back).
-int operand16(mvd_ctx* c, const Opnd& o, int rows, int K, int Kp, bool stored_rows, bool need_dense, const half_t** out, int* ld,
-              hipStream_t s) {
+// split (1: [hi | lo | hi], 2: [hi | hi | lo], fp32 operands only): rows of 3 Kp halfs, see k_bwd.hip tcast_kernel.
+int operand16(mvd_ctx* c, const Opnd& o, int rows, int K, int Kp, bool stored_rows, bool need_dense, int split, const half_t** out,
+              int* ld, hipStream_t s) {
   if (stored_rows && !o.f32) {
+    if (split) return mvd_fail("tgemm: extended precision needs fp32 operands");
     if (o.ld % 8 || K != Kp || (((uintptr_t)o.p) & 15) || (need_dense && o.ld != Kp))
       return mvd_fail("tgemm: a row-major fp16 operand needs K % 8 == 0, ld % 8 == 0 (dense for the weight side)");
     *out = (const half_t*)o.p;
     *ld = (int)o.ld;
     return 0;
   }
-  half_t* d = ws_alloc<half_t>(c, (size_t)rows * Kp);
+  const int w = split ? 3 * Kp : Kp;
+  half_t* d = ws_alloc<half_t>(c, (size_t)rows * w);
   WS_CHECK(d);
-  if (stored_rows) RET_IF(bwd_cast_rows((const float*)o.p, o.ld, rows, K, Kp, d, s));
-  else RET_IF(bwd_tcast(o.p, o.f32, o.ld, K, rows, d, Kp, s));  // stored [K][rows] -> [rows][Kp]
+  if (stored_rows) RET_IF(bwd_cast_rows((const float*)o.p, o.ld, rows, K, Kp, d, s, split));
+  else RET_IF(bwd_tcast(o.p, o.f32, o.ld, K, rows, d, Kp, s, split));  // stored [K][rows] -> [rows][Kp]
   *out = d;
-  *ld = Kp;
+  *ld = w;
   return 0;
 }
 
 // C[M][N] (ldc) (+)= op(A)[M][K] op(B)[K][N] on the MFMA GEMM kernels.  A.trans: stored [K][M]; B.trans: stored [N][K]
-// (the weight layout), otherwise [K][N].
-int tgemm(mvd_ctx* c, Opnd A, Opnd Bm, float* C, int ldc, int M, int N, int K, bool accum, hipStream_t s) {
+// (the weight layout), otherwise [K][N].  xp: extended precision -- both operands split into fp16 hi + lo parts, three
+// products accumulated in fp32 (a_hi b_hi + a_lo b_hi + a_hi b_lo) by concatenation along K: ~2^-22 relative operand error
+// instead of 2^-11, at three times the MFMA work.  Used where the backward pass is ill-conditioned (the DepthTransformers'
+// softmax over nearly uniform depth weights, ReLU masks re-derived from re-computed activations).
+int tgemm(mvd_ctx* c, Opnd A, Opnd Bm, float* C, int ldc, int M, int N, int K, bool accum, hipStream_t s, bool xp = false) {
   if (M <= 0 || N <= 0 || K <= 0) return mvd_fail("tgemm: empty problem");
   WsScope scope(c, WS_TEMP);
   const int Kp = up8(K);
+  if (xp && (!A.f32 || !Bm.f32)) xp = false;
   const half_t *a16, *b16;
   int lda, ldb;
-  RET_IF(operand16(c, A, M, K, Kp, !A.trans, false, &a16, &lda, s));
-  RET_IF(operand16(c, Bm, N, K, Kp, Bm.trans != 0, true, &b16, &ldb, s));
+  RET_IF(operand16(c, A, M, K, Kp, !A.trans, false, xp ? 1 : 0, &a16, &lda, s));
+  RET_IF(operand16(c, Bm, N, K, Kp, Bm.trans != 0, true, xp ? 2 : 0, &b16, &ldb, s));
   ConvW w;
   w.w = const_cast<half_t*>(b16);
   w.N = N;
-  w.Cin = Kp;
+  w.Cin = xp ? 3 * Kp : Kp;
   w.taps = 1;
   GemmArgs g;
   g.a = a16; g.lda = lda; g.w = &w; g.out = C; g.ldc = ldc; g.use_bias = false;
@@ -538,10 +545,11 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
   float *a1 = F((size_t)R * I), *col1 = F((size_t)R * 9 * I), *o2 = F((size_t)R * I);
   float *a2 = F((size_t)R * I), *col2 = F((size_t)R * 9 * I);
   float *m_c1 = F((size_t)I * 9 * I), *m_c2 = F((size_t)dim * 9 * I);
-  float *dcol = F((size_t)R * 9 * I), *dI1 = F((size_t)R * I), *dI2 = F((size_t)R * I), *mg = F((size_t)dim * 9 * I);
+  const size_t wmax = (size_t)std::max(dim, I) * 9 * I;  // the larger of the two 3x3 conv weights
+  float *dcol = F((size_t)R * 9 * I), *dI1 = F((size_t)R * I), *dI2 = F((size_t)R * I), *mg = F(wmax);
   float *dk = F((size_t)RC * I), *dv = F((size_t)RC * I), *dcn = F((size_t)RC * Cc), *dpc = F((size_t)RC * Cc);
   float* dh = F((size_t)R * dim);
-  float* mgp = F((size_t)dim * 9 * I);
+  float* mgp = F(wmax);
   WS_CHECK(mgp);
   WS_CHECK(X && p && pn && pc && cn && q && k && v && attn && z && o && a1 && col1 && o2 && a2 && col2 && m_c1 && m_c2 && dcol && dI1 &&
            dI2 && mg && dk && dv && dcn && dpc && dh);
@@ -550,44 +558,44 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
   RET_IF(train_perm_w3(w_c1, I, I, 1, m_c1, s));
   RET_IF(train_perm_w3(w_c2, dim, I, 1, m_c2, s));
   // proj_in: conv1x1 + bias, GN8, SiLU        (attention.py:52-56)
-  RET_IF(tgemm(c, F32(X, dim, 0), F32(w_pi, dim, 1), p, I, R, I, dim, false, s));
+  RET_IF(tgemm(c, F32(X, dim, 0), F32(w_pi, dim, 1), p, I, R, I, dim, false, s, true));
   RET_IF(train_add_bias_rows(p, R, I, b_pi, s));
   RET_IF(train_gn_fwd(p, B, HW, I, 8, g_pi, e_pi, 1e-5f, ACT_SILU, pn, nullptr, s));
   // proj_context: conv1x1x1 (no bias), GN8, ReLU   (:57-61)
-  RET_IF(tgemm(c, F32(C0, Cc, 0), F32(w_pc, Cc, 1), pc, Cc, (int)RC, Cc, Cc, false, s));
+  RET_IF(tgemm(c, F32(C0, Cc, 0), F32(w_pc, Cc, 1), pc, Cc, (int)RC, Cc, Cc, false, s, true));
   RET_IF(train_gn_fwd(pc, B, D * HW, Cc, 8, g_pc, e_pc, 1e-5f, ACT_RELU, cn, nullptr, s));
   // depth attention   (:26-47)
-  RET_IF(tgemm(c, F32(pn, I, 0), F32(w_q, I, 1), q, I, R, I, I, false, s));
-  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_k, Cc, 1), k, I, (int)RC, I, Cc, false, s));
-  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_v, Cc, 1), v, I, (int)RC, I, Cc, false, s));
+  RET_IF(tgemm(c, F32(pn, I, 0), F32(w_q, I, 1), q, I, R, I, I, false, s, true));
+  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_k, Cc, 1), k, I, (int)RC, I, Cc, false, s, true));
+  RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_v, Cc, 1), v, I, (int)RC, I, Cc, false, s, true));
   RET_IF(train_depth_fwd(q, k, v, R, HW, D, hn, hd, scale, attn, z, s));
-  RET_IF(tgemm(c, F32(z, I, 0), F32(w_o, I, 1), o, I, R, I, I, false, s));
+  RET_IF(tgemm(c, F32(z, I, 0), F32(w_o, I, 1), o, I, R, I, I, false, s, true));
   // proj_out: GN8, ReLU, conv3x3, GN8, ReLU, conv3x3   (:63-70)
   RET_IF(train_gn_fwd(o, B, HW, I, 8, g_o0, e_o0, 1e-5f, ACT_RELU, a1, nullptr, s));
   RET_IF(train_im2col3(a1, B, H, W, I, col1, s));
-  RET_IF(tgemm(c, F32(col1, 9 * I, 0), F32(m_c1, 9 * I, 1), o2, I, R, I, 9 * I, false, s));
+  RET_IF(tgemm(c, F32(col1, 9 * I, 0), F32(m_c1, 9 * I, 1), o2, I, R, I, 9 * I, false, s, true));
   RET_IF(train_gn_fwd(o2, B, HW, I, 8, g_o3, e_o3, 1e-5f, ACT_RELU, a2, nullptr, s));
   RET_IF(train_im2col3(a2, B, H, W, I, col2, s));
   // ---------------- backward: dh = dL/d(x + proj_out(.)) ----------------
   // second conv3x3 of proj_out
-  RET_IF(tgemm(c, F32(dh, dim, 1), F32(col2, 9 * I, 0), mg, 9 * I, dim, 9 * I, R, false, s));      // wgrad [dim][9][I]
+  RET_IF(tgemm(c, F32(dh, dim, 1), F32(col2, 9 * I, 0), mg, 9 * I, dim, 9 * I, R, false, s, true));      // wgrad [dim][9][I]
   if (float* g_ = G("proj_out.5.weight")) {
     RET_IF(train_perm_w3(mg, dim, I, 0, mgp, s));  // [dim][9][I] -> the reference's [dim][I][3][3]
     RET_IF(train_add_inplace(g_, mgp, (size_t)dim * 9 * I, s));
   }
-  RET_IF(tgemm(c, F32(dh, dim, 0), F32(m_c2, 9 * I, 0), dcol, 9 * I, R, 9 * I, dim, false, s));
+  RET_IF(tgemm(c, F32(dh, dim, 0), F32(m_c2, 9 * I, 0), dcol, 9 * I, R, 9 * I, dim, false, s, true));
   RET_IF(train_col2im3(dcol, B, H, W, I, dI1, s));                                                   // d a2
   {
     NormW n;
     n.g = const_cast<float*>(g_o3); n.b = const_cast<float*>(e_o3); n.C = I; n.key = P + "proj_out.3";
     RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, o2, I, dI1, I, HW, dI2, I, false));
   }
-  RET_IF(tgemm(c, F32(dI2, I, 1), F32(col1, 9 * I, 0), mg, 9 * I, I, 9 * I, R, false, s));         // first conv3x3
+  RET_IF(tgemm(c, F32(dI2, I, 1), F32(col1, 9 * I, 0), mg, 9 * I, I, 9 * I, R, false, s, true));         // first conv3x3
   if (float* g_ = G("proj_out.2.weight")) {
     RET_IF(train_perm_w3(mg, I, I, 0, mgp, s));
     RET_IF(train_add_inplace(g_, mgp, (size_t)I * 9 * I, s));
   }
-  RET_IF(tgemm(c, F32(dI2, I, 0), F32(m_c1, 9 * I, 0), dcol, 9 * I, R, 9 * I, I, false, s));
+  RET_IF(tgemm(c, F32(dI2, I, 0), F32(m_c1, 9 * I, 0), dcol, 9 * I, R, 9 * I, I, false, s, true));
   RET_IF(train_col2im3(dcol, B, H, W, I, dI1, s));                                                   // d a1
   {
     NormW n;
@@ -595,33 +603,33 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
     RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, o, I, dI1, I, HW, dI2, I, false));
   }
   // to_out (1x1, no bias): dI2 = d o
-  if (float* g_ = G("depth_attn.to_out.weight")) RET_IF(tgemm(c, F32(dI2, I, 1), F32(z, I, 0), g_, I, I, I, R, true, s));
-  RET_IF(tgemm(c, F32(dI2, I, 0), F32(w_o, I, 0), dI1, I, R, I, I, false, s));                      // d z
+  if (float* g_ = G("depth_attn.to_out.weight")) RET_IF(tgemm(c, F32(dI2, I, 1), F32(z, I, 0), g_, I, I, I, R, true, s, true));
+  RET_IF(tgemm(c, F32(dI2, I, 0), F32(w_o, I, 0), dI1, I, R, I, I, false, s, true));                      // d z
   float* dq = dI2;
   RET_IF(train_depth_bwd(q, k, v, attn, dI1, R, HW, D, hn, hd, scale, dq, dk, dv, s));
-  if (float* g_ = G("depth_attn.to_q.weight")) RET_IF(tgemm(c, F32(dq, I, 1), F32(pn, I, 0), g_, I, I, I, R, true, s));
-  if (float* g_ = G("depth_attn.to_k.weight")) RET_IF(tgemm(c, F32(dk, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s));
-  if (float* g_ = G("depth_attn.to_v.weight")) RET_IF(tgemm(c, F32(dv, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s));
+  if (float* g_ = G("depth_attn.to_q.weight")) RET_IF(tgemm(c, F32(dq, I, 1), F32(pn, I, 0), g_, I, I, I, R, true, s, true));
+  if (float* g_ = G("depth_attn.to_k.weight")) RET_IF(tgemm(c, F32(dk, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s, true));
+  if (float* g_ = G("depth_attn.to_v.weight")) RET_IF(tgemm(c, F32(dv, I, 1), F32(cn, Cc, 0), g_, Cc, I, Cc, (int)RC, true, s, true));
   // d cn = dk W_k + dv W_v ; proj_context backward
-  RET_IF(tgemm(c, F32(dk, I, 0), F32(w_k, Cc, 0), dcn, Cc, (int)RC, Cc, I, false, s));
-  RET_IF(tgemm(c, F32(dv, I, 0), F32(w_v, Cc, 0), dcn, Cc, (int)RC, Cc, I, true, s));
+  RET_IF(tgemm(c, F32(dk, I, 0), F32(w_k, Cc, 0), dcn, Cc, (int)RC, Cc, I, false, s, true));
+  RET_IF(tgemm(c, F32(dv, I, 0), F32(w_v, Cc, 0), dcn, Cc, (int)RC, Cc, I, true, s, true));
   {
     NormW n;
     n.g = const_cast<float*>(g_pc); n.b = const_cast<float*>(e_pc); n.C = Cc; n.key = P + "proj_context.1";
     RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_RELU, pc, Cc, dcn, Cc, D * HW, dpc, Cc, false));
   }
-  if (float* g_ = G("proj_context.0.weight")) RET_IF(tgemm(c, F32(dpc, Cc, 1), F32(C0, Cc, 0), g_, Cc, Cc, Cc, (int)RC, true, s));
+  if (float* g_ = G("proj_context.0.weight")) RET_IF(tgemm(c, F32(dpc, Cc, 1), F32(C0, Cc, 0), g_, Cc, Cc, Cc, (int)RC, true, s, true));
   if (b.dsrc[level])  // gradient w.r.t. the context volume (several DepthTransformers share a level: accumulated)
-    RET_IF(tgemm(c, F32(dpc, Cc, 0), F32(w_pc, Cc, 0), b.dsrc[level], Cc, (int)RC, Cc, Cc, true, s));
+    RET_IF(tgemm(c, F32(dpc, Cc, 0), F32(w_pc, Cc, 0), b.dsrc[level], Cc, (int)RC, Cc, Cc, true, s, true));
   // d pn = dq W_q ; proj_in backward
-  RET_IF(tgemm(c, F32(dq, I, 0), F32(w_q, I, 0), dI1, I, R, I, I, false, s));
+  RET_IF(tgemm(c, F32(dq, I, 0), F32(w_q, I, 0), dI1, I, R, I, I, false, s, true));
   float* dp = dcol;  // [R][I] fits
   {
     NormW n;
     n.g = const_cast<float*>(g_pi); n.b = const_cast<float*>(e_pi); n.C = I; n.key = P + "proj_in.1";
     RET_IF(gn_backward(b, n, 8, 1e-5f, ACT_SILU, p, I, dI1, I, HW, dp, I, false));
   }
-  if (float* g_ = G("proj_in.0.weight")) RET_IF(tgemm(c, F32(dp, I, 1), F32(X, dim, 0), g_, dim, I, dim, R, true, s));
+  if (float* g_ = G("proj_in.0.weight")) RET_IF(tgemm(c, F32(dp, I, 1), F32(X, dim, 0), g_, dim, I, dim, R, true, s, true));
   if (float* g_ = G("proj_in.0.bias")) {
     float* part = F((size_t)B * I);
     WS_CHECK(part);
@@ -629,7 +637,7 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
     RET_IF(bwd_sum_rows_add(part, B, I, I, g_, 1, s));
   }
   // d x = dh (residual) + dp W_pi
-  RET_IF(tgemm(c, F32(dp, I, 0), F32(w_pi, dim, 0), din.p, din.ld, R, dim, I, accum, s));
+  RET_IF(tgemm(c, F32(dp, I, 0), F32(w_pi, dim, 0), din.p, din.ld, R, dim, I, accum, s, true));
   RET_IF(bwd_add_views(din.p, din.ld, dh, dim, nullptr, 0, R, dim, 1, s));
   return 0;
 }
@@ -867,4 +875,27 @@ int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* 
   RET_IF(bwd_emb(b));
   RET_IF(bwd_attn2(b));
   return 0;
+}
+
+// One DepthTransformer's backward on its own (parity hook): x / dout / dx channels-last [B*H*W][dim], ctx_vol / dctx
+// channels-last [B*D*H*W][Cc] with D = depth0 >> level.  Parameter gradients are accumulated into the arena.
+int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const float* ctx_vol, const float* dout, int B, int H, int W,
+                               int level, int depth0, float* dx, float* dctx, hipStream_t s) {
+  if (!c->finalized || !c->train_mode) return mvd_fail("cond backward: context not finalized in training mode");
+  if (cond_idx < 0 || cond_idx >= (int)c->conds.size() || level < 0 || level > 3) return mvd_fail("cond backward: bad index");
+  const CondW& cd = c->conds[cond_idx];
+  TrainTape tape;
+  tape.depth0 = depth0;
+  Ctx5 src[4];
+  src[level].p = ctx_vol;
+  src[level].f32 = 1;
+  tape.src = src;
+  Fwd f{c, s, B, B, depth0, nullptr, nullptr, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
+  Bwd b{c, s, B, &f, &tape};
+  b.dsrc[level] = dctx;
+  View in, g_out, g_in;
+  in.p = const_cast<float*>(x); in.ld = cd.dim; in.C = cd.dim;
+  g_out.p = const_cast<float*>(dout); g_out.ld = cd.dim; g_out.C = cd.dim;
+  g_in.p = dx; g_in.ld = cd.dim; g_in.C = cd.dim;
+  return bwd_cond(b, cd, in, g_out, g_in, false, H, W, level);
 }

@@ -23,20 +23,35 @@ __device__ __forceinline__ float ldf(const half_t* p) { return (float)*p; }
 // ---------------------------------------------------------------------------------------------------------------------
 // dst[c][r] = fp16(src[r][c]) for c < C, r < Rp (zero for r >= R): the K-contiguous operand of a wgrad GEMM.
 // 64 x 64 tiles through LDS; reads are coalesced along c, writes along r.
+// split != 0 (fp32 sources): every dst row holds three Rp-long segments -- split 1: [hi | lo | hi], split 2: [hi | hi | lo]
+// with hi = fp16(x), lo = fp16(x - hi) -- the two operand images of an extended-precision GEMM (a_hi b_hi + a_lo b_hi +
+// a_hi b_lo by concatenation along K, the forward pass's ConvW::xp trick).
 template <typename T>
-__global__ __launch_bounds__(256) void tcast_kernel(const T* __restrict__ src, long ld, int R, int C, half_t* __restrict__ dst, int Rp) {
-  __shared__ half_t tile[64][66];
+__global__ __launch_bounds__(256) void tcast_kernel(const T* __restrict__ src, long ld, int R, int C, half_t* __restrict__ dst, int Rp,
+                                                    int split) {
+  __shared__ float tile[64][65];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int rr = i >> 6, cc = i & 63;
     const int r = r0 + rr, c = c0 + cc;
-    tile[rr][cc] = (r < R && c < C) ? (half_t)ldf(src + (long)r * ld + c) : (half_t)0;
+    tile[rr][cc] = (r < R && c < C) ? ldf(src + (long)r * ld + c) : 0.f;
   }
   __syncthreads();
+  const long rowlen = split ? 3L * Rp : Rp;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int cc = i >> 6, rr = i & 63;
     const int r = r0 + rr, c = c0 + cc;
-    if (c < C && r < Rp) dst[(long)c * Rp + r] = tile[rr][cc];
+    if (c < C && r < Rp) {
+      const float v = tile[rr][cc];
+      const half_t hi = (half_t)v;
+      half_t* d = dst + (long)c * rowlen + r;
+      d[0] = hi;
+      if (split) {
+        const half_t lo = (half_t)(v - (float)hi);
+        d[Rp] = split == 1 ? lo : hi;
+        d[2L * Rp] = split == 1 ? hi : lo;
+      }
+    }
   }
 }
 
@@ -69,13 +84,22 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const T* __restrict__ src,
   }
 }
 
-// fp32 rows (stride ld) -> dense fp16 rows of width Cp >= C (zero padded), scaled
-__global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long rows, int C, int Cp, half_t* __restrict__ dst) {
+// fp32 rows (stride ld) -> dense fp16 rows of width Cp >= C (zero padded); split: rows of 3 Cp halfs, see tcast_kernel
+__global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long rows, int C, int Cp, half_t* __restrict__ dst, int split) {
   const long total = rows * Cp;
+  const long rowlen = split ? 3L * Cp : Cp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
     const long r = i / Cp;
-    dst[i] = c < C ? (half_t)src[r * ld + c] : (half_t)0;
+    const float v = c < C ? src[r * ld + c] : 0.f;
+    const half_t hi = (half_t)v;
+    half_t* d = dst + r * rowlen + c;
+    d[0] = hi;
+    if (split) {
+      const half_t lo = (half_t)(v - (float)hi);
+      d[Cp] = split == 1 ? lo : hi;
+      d[2L * Cp] = split == 1 ? hi : lo;
+    }
   }
 }
 
@@ -736,11 +760,12 @@ int launch_attn_bwd_t(const half_t* qkv, int ld3, const half_t* o, const half_t*
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
-int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s) {
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split) {
   if (R <= 0 || C <= 0 || Rp < R) return mvd_fail("bwd_tcast: bad shape");
+  if (split && !src_f32) return mvd_fail("bwd_tcast: the split layout needs an fp32 source");
   dim3 grid(cdiv(Rp, 64), cdiv(C, 64));
-  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp);
-  else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp);
+  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split);
+  else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp, 0);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -753,8 +778,8 @@ int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int 
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s) {
-  hipLaunchKernelGGL(cast_rows_kernel, dim3(gridn((size_t)rows * Cp)), dim3(256), 0, s, src, ld, rows, C, Cp, dst);
+int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split) {
+  hipLaunchKernelGGL(cast_rows_kernel, dim3(gridn((size_t)rows * Cp)), dim3(256), 0, s, src, ld, rows, C, Cp, dst, split);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

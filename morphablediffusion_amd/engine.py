@@ -292,6 +292,17 @@ class Engine:
             return pred, loss[0], {s >> lvl: dsrc[lvl] for lvl in range(4)}
         return pred, loss[0]
 
+    def train_cond_backward(self, cond_index, x, context, d_out):
+        """mvd_train_cond_backward (parity hook): one DepthTransformer's backward from exact inputs -> (dx, dcontext)."""
+        dev = self.device
+        x, context, d_out = _f32(x, dev), _f32(context, dev), _f32(d_out, dev)
+        B, _, H, W = x.shape
+        depth0 = context.shape[2] * (self.ucfg.image_size // H)
+        dx, dc = torch.empty_like(x), torch.empty_like(context)
+        L.check(self.lib.mvd_train_cond_backward(self._ctx, int(cond_index), L.ptr(x), L.ptr(context), L.ptr(d_out), B, H, W, depth0,
+                                                 L.ptr(dx), L.ptr(dc), _stream()))
+        return dx, dc
+
     def get_grad(self, key: str, shape):
         out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
         L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))

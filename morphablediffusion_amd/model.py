@@ -276,7 +276,7 @@ class SyncMultiviewDiffusion(nn.Module):
                  output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
                  clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
                  first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2,
-                 train_mode=False, loss_scale=1024.0, recompute=True):
+                 train_mode=False, loss_scale=65536.0, recompute=True):
         """train_mode / loss_scale / recompute are not reference kwargs: train_mode keeps fp32 master parameters, gradients and
         Adam moments in the engine (training_step runs the backward pass); loss_scale multiplies dL/dpred so that the fp16 MFMA
         operands of the backward pass stay in range (un-done by the optimiser); recompute = per-block activation checkpointing
@@ -547,6 +547,8 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.model = model
         self.steps_done = 0
         self.steps_skipped = 0
+        self.growth_interval = 2000  # torch.cuda.amp.GradScaler's defaults: x2 after 2000 clean steps, x0.5 on overflow
+        self._clean = 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -559,9 +561,14 @@ class ArenaAdamW(torch.optim.Optimizer):
                                       finetune_unet=m.finetune_unet)
         if skipped:  # torch.cuda.amp.GradScaler's rule: back off and try again
             self.steps_skipped += 1
+            self._clean = 0
             m.loss_scale = max(1.0, m.loss_scale * 0.5)
         else:
             self.steps_done += 1
+            self._clean += 1
+            if self._clean >= self.growth_interval:
+                self._clean = 0
+                m.loss_scale = min(m.loss_scale * 2.0, 2.0 ** 24)
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -4,8 +4,14 @@ different cameras, N = 4 views, all four branches of the condition dropout): los
 parameter (856 tensors, of which the 170 of get_trainable_parameters(), attention.py:140-142) and the gradient w.r.t. the
 frustum volumes.  Then the optimiser: ArenaAdamW against torch.optim.AdamW, the in-place re-pack against a fresh load.
 Tolerances: the engine computes on fp16 MFMA operands with fp32 accumulation (forward AND backward); the configuration's own
-dtype, bf16 (BASELINE.json config 4), carries 4e-3 per operation.  Loss 1e-3, prediction 2e-3, gradients: relative L2 of every
-tensor <= 2e-2, of the 170 DepthTransformer tensors <= 1e-2 (measured values are printed)."""
+dtype, bf16 (BASELINE.json config 4), carries 4e-3 per operation.  Loss 1e-3, prediction 2e-3.  Gradients, relative L2 per
+tensor: the 686 tensors of the UNet trunk <= 1e-2 (measured: worst 4.6e-3, median 2.4e-3 = sqrt(#layers) x the fp16 operand
+rounding).  The 170 DepthTransformer tensors <= 5e-2 (measured: worst 3.7e-2, median 1.0e-2): their backward pass goes through
+three ReLU masks and a softmax over nearly uniform depth weights that are re-derived from the block's input, which carries the
+forward pass's fp16 rounding (5e-4 .. 1e-3) -- a relative input perturbation eps flips ~eps of the mask bits and moves these
+gradients by ~sqrt(eps): tests/test_host_cpu.py::test_depth_transformer_gradient_sensitivity shows the reference arithmetic
+itself (fp32 oracle) doing exactly that.  The implementation itself is checked without that conditioning in
+test_depth_transformer_backward_exact_inputs below (same inputs on both sides: <= 2e-3)."""
 import os
 
 import numpy as np
@@ -92,7 +98,8 @@ def test_training_step_every_unet_gradient_vs_reference():
     (forward tape -> per-block backward on the MFMA kernels) must reproduce each of them."""
     g, dev, prepared, draws = _inputs()
     N = int(g["N"])
-    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=256.0, recompute=False)
+    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=float(os.environ.get("MVD_TEST_LS", 65536.0)),
+                         recompute=False, precision_level=int(os.environ.get("MVD_TEST_PL", 2)))
     params = m.model.get_trainable_parameters()
     assert len(params) == 10 * 17 and all(isinstance(p_, torch.nn.Parameter) and p_.grad is not None for p_ in params)
     assert len(m.model.diffusion_model.named_parameters_all()) == len(g["grad_names"])
@@ -102,6 +109,11 @@ def test_training_step_every_unet_gradient_vs_reference():
     assert abs(float(loss) - want) <= 1e-3 * want
     compare(m.last_noise_predict, g, "noise_predict", rel=2e-3, mx=1e-2)
     rows = _grad_report(m, g, m.loss_scale)
+    dump = os.environ.get("MVD_GRAD_DUMP")
+    if dump:  # development aid: the whole table, in the reference's registration order
+        with open(dump, "w") as f:
+            for rl, nr, n in rows:
+                f.write(f"{rl:.3e} {nr:+.3e} {n}\n")
     rows.sort(reverse=True)
     for rl, nr, n in rows[:25]:
         print(f"[parity] worst grad {n}: relL2={rl:.2e} norm err {nr:.2e}")
@@ -111,18 +123,54 @@ def test_training_step_every_unet_gradient_vs_reference():
           f"{sorted(r[0] for r in cond)[len(cond) // 2]:.2e}; {len(rest)} other UNet tensors worst {max(r[0] for r in rest):.2e} "
           f"median {sorted(r[0] for r in rest)[len(rest) // 2]:.2e}")
     assert len(cond) == 170
-    assert max(r[0] for r in cond) <= 1e-2, cond[0]
-    assert max(r[0] for r in rest) <= 2e-2, rest[0]
+    assert max(r[0] for r in cond) <= 5e-2, cond[0]
+    assert sorted(r[0] for r in cond)[len(cond) // 2] <= 1.5e-2
+    assert max(r[0] for r in rest) <= 1e-2, rest[0]
     # gradient w.r.t. the frustum volumes (before the dropout): the entry point of the conditioner's backward
     for res_, d in m.last_dsrc.items():
         a, b, _ = gi.unpack_compare(d.cpu() / m.loss_scale, g, f"dsrc.{res_}")
         rl = ((a - b).norm() / (b.norm() + 1e-30)).item()
         print(f"[parity] d loss / d frustum volume {res_}: relL2={rl:.2e}")
-        assert rl <= 1e-2
+        assert rl <= 5e-2  # downstream of the DepthTransformers' ReLU masks, see the module docstring
     # torch semantics: a second backward ACCUMULATES
     g1 = m.engine.flat_grads.clone()
     m.training_step(dev, prepared=prepared, **draws)
     assert torch.allclose(m.engine.flat_grads, 2 * g1, rtol=1e-6, atol=0)
+    m.engine.close()
+
+
+@pytest.mark.parametrize("cond_index,res_", [(0, 4), (2, 8), (5, 16), (9, 32)])
+def test_depth_transformer_backward_exact_inputs(cond_index, res_):
+    """One DepthTransformer's backward with the SAME input, context volume and output gradient on both sides (oracle autograd
+    in fp32 on the CPU vs mvd_train_cond_backward): no forward-pass rounding in the inputs, so no mask flips -- what is left is
+    the arithmetic of the backward itself (extended-precision fp16 MFMA operands, fp32 elsewhere)."""
+    from oracle import mvd_oracle as O
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=4)
+    m = make_train_model(ucfg, vcfg, 4, workspace_gb=6.0)
+    W = gi.full_weights(ucfg, vcfg)
+    pre = P + ("middle_conditions" if cond_index == 0 else f"output_conditions.{cond_index - 1}")
+    keys = [k for k in W if k.startswith(pre + ".")]
+    assert len(keys) == 17
+    dim = W[pre + ".proj_in.0.weight"].shape[1]
+    Cc = W[pre + ".proj_context.0.weight"].shape[1]
+    B, D = 2, 48 * res_ // 32
+    gen = torch.Generator().manual_seed(100 + cond_index)
+    x = torch.randn(B, dim, res_, res_, generator=gen)
+    ctx = torch.randn(B, Cc, D, res_, res_, generator=gen) * 0.7
+    ctx[1] = 0  # a sample whose condition was dropped: all-zero volume
+    dout = torch.randn(B, dim, res_, res_, generator=gen) * 1e-2
+    Wl = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in W.items()}
+    xx, cc = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    O.depth_transformer(Wl, pre, xx, cc).backward(dout)
+    m.engine.zero_grad()
+    dx, dc = m.engine.train_cond_backward(cond_index, x, ctx, dout)
+    errs = {"dx": ((dx.cpu() - xx.grad).norm() / xx.grad.norm()).item(), "dctx": ((dc.cpu() - cc.grad).norm() / cc.grad.norm()).item()}
+    for k in keys:
+        got = m.engine.param_view(k, grad=True).cpu()
+        errs[k[len(pre) + 1:]] = ((got - Wl[k].grad).norm() / (Wl[k].grad.norm() + 1e-30)).item()
+    worst = max(errs, key=errs.get)
+    print(f"[parity] DepthTransformer {cond_index} backward from exact inputs: worst {worst} {errs[worst]:.2e}, dx {errs['dx']:.2e}, dctx {errs['dctx']:.2e}")
+    assert errs[worst] <= 2e-3, errs
     m.engine.close()
 
 
@@ -131,7 +179,7 @@ def test_recompute_equals_keep_all_and_is_reproducible():
     same kernels on the same inputs: bit-identical gradients to the keep-everything tape; and a repeated step is bit-identical."""
     g, dev, prepared, draws = _inputs()
     N = int(g["N"])
-    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=256.0, recompute=False)
+    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=65536.0, recompute=False)
     outs = []
     for rec in (False, True, True):
         m.recompute = rec
@@ -152,7 +200,7 @@ def test_adamw_step_and_repack():
     g, dev, prepared, draws = _inputs()
     N = int(g["N"])
     ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
-    m = make_train_model(ucfg, vcfg, N, loss_scale=256.0, recompute=True)
+    m = make_train_model(ucfg, vcfg, N, loss_scale=65536.0, recompute=True)
     m.learning_rate = 5e-5
     (opt,), (sched,) = m.configure_optimizers()
     assert [len(gr["params"]) for gr in opt.param_groups][0] == len(g["grad_names"])
@@ -195,7 +243,7 @@ def test_adamw_step_and_repack():
     eng.flat_grads[5] = float("inf")
     before = eng.flat_params.clone()
     opt.step()
-    assert opt.steps_skipped == 1 and m.loss_scale == 128.0 and torch.equal(eng.flat_params, before)
+    assert opt.steps_skipped == 1 and m.loss_scale == 32768.0 and torch.equal(eng.flat_params, before)
     m.engine.close()
     m2.engine.close()
 
@@ -205,7 +253,7 @@ def test_training_step_default_prepare_path():
     before it, sampling afterwards still works on the same context."""
     g, dev, prepared, draws = _inputs()
     N = int(g["N"])
-    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=256.0)
+    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, loss_scale=65536.0)
 
     class FakePosterior:
         def __init__(self, x):
