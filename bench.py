@@ -139,6 +139,100 @@ def cpu_baseline(timeout_s=420):
                 "sample": f"the CPU oracle did not finish one step within {timeout_s} s on this host"}
 
 
+def train_main(args):
+    """``--config train`` (NOT the headline metric): BASELINE.json configs[3]'s unit of work -- one training step of
+    SyncMultiviewDiffusion (training_step morphable_diffusion.py:520-549 on B samples per GPU, N = 16 views, finetune_unet) =
+    conditioner + UNet forward, MSE, backward through every UNet block, ONE all-reduce of the flat gradient arena (N > 1),
+    fused AdamW on the arenas, in-place re-pack of the fp16 weights.  ``prepare`` (VAE / CLIP on images) is replaced by seeded
+    latents.  fp16 MFMA operands, fp32 accumulation and master weights, dynamic loss scale; the conditioner's own backward
+    (spatial_volume / time_embed gradients) is not built and not counted."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("MVD_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(os.environ.get("MVD_DIST_BACKEND", "nccl"))
+    dev = f"cuda:{local}"
+    from morphablediffusion_amd import synthetic
+    from morphablediffusion_amd.model import SyncMultiviewDiffusion
+    from morphablediffusion_amd.spec import UNetConfig, VolumeConfig, full_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    N, B = N_VIEWS, args.train_batch
+    ucfg, vcfg = UNetConfig(), VolumeConfig(num_views=N)
+    W = seeded_state_dict(full_manifest(ucfg, vcfg), 7)
+    sched_cfg = {"target": "ldm.lr_scheduler.LambdaLinearScheduler",
+                 "params": dict(warm_up_steps=[100], cycle_lengths=[100000], f_start=[0.02], f_max=[1.0], f_min=[1.0])}
+    model = SyncMultiviewDiffusion(
+        unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
+        scheduler_config=sched_cfg, finetune_unet=True, view_num=N, image_size=256, cfg_scale=2.0, device=dev, workspace_gb=96.0,
+        train_mode=True, recompute=not args.keep_activations)
+    model.load_state_dict(W)
+    (opt,), (sched,) = model.configure_optimizers()
+    b0 = synthetic.make_batch(N, "perspective", 5023, mesh_seed=1)
+    batch = {k: v.repeat(B, *([1] * (v.dim() - 1))).clone() for k, v in b0.items()}
+    for bi in range(B):  # a different camera rig order per sample
+        batch["target_K"][bi] = b0["target_K"][0].roll(bi + rank, 0)
+        batch["target_RT"][bi] = b0["target_RT"][0].roll(bi + rank, 0)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    g = torch.Generator().manual_seed(77 + rank)
+    prepared = ((torch.randn(B, N, 4, 32, 32, generator=g) * 0.8).to(dev), torch.randn(B, 1, 768, generator=g).to(dev),
+                {"x": (torch.randn(B, 4, 32, 32, generator=g) * 0.18215).to(dev)})
+    losses = []
+
+    def one_step():
+        opt.zero_grad()
+        loss = model.training_step(batch, prepared=prepared)
+        model.sync_gradients()
+        opt.step()
+        sched["scheduler"].step()
+        losses.append(loss)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lv = [float(l) for l in losses]
+    assert all(v == v and abs(v) < 1e6 for v in lv), lv
+    if rank == 0:
+        # algorithmic work of one step: UNet forward 202.0 GFLOP per sample (SURVEY 8(d)), backward = dgrad + wgrad = 2x,
+        # + one re-run of the forward when blocks are recomputed; the conditioner's forward is not counted
+        per_sample = 202.0e9 * (3 + (0 if args.keep_activations else 1))
+        out = {"metric": "NOT the headline metric: training samples/sec of BASELINE config 'train' (configs[3]: N=16 views, "
+                         "finetune_unet training step, full-width UNet)",
+               "value": B * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f16 operands / f32 accumulate and master weights (the configuration names bf16)", "data": "synthetic",
+               "config": {"workload": f"training step, {B} samples per GPU x {N} views (seeded latents instead of VAE/CLIP on "
+                                      f"images, 5023-vertex mesh per sample), full-width UNet (916.9M params, random init), "
+                                      f"finetune_unet=True, AdamW lr 5e-5 / 5e-4, "
+                                      f"{'all activations kept' if args.keep_activations else 'per-block activation recompute'}",
+                          "name": "train", "batch_per_gpu": B, "parallelism": f"data-parallel x{world}" if world > 1 else "single GPU"},
+               "unet_tflops": per_sample * B * world / (dt / args.steps) / 1e12,
+               "loss_first_last": [lv[0], lv[-1]], "loss_scale": model.loss_scale, "optimizer_steps_skipped": opt.steps_skipped,
+               "not_built": "backward of the conditioner (spatial_volume.*, time_embed.*): their gradients stay zero",
+               "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,10 +244,15 @@ def main():
                     help="skip the 50-step trajectory and the VAE decode reported next to the headline (profiling runs: the "
                          "process then executes only identical denoising steps)")
     ap.add_argument("--batch-view-num", type=int, default=0, help="views per UNet pass (0 = all local views)")
-    ap.add_argument("--config", default="headline", choices=["headline", "n8", "smplx32"],
+    ap.add_argument("--train-batch", type=int, default=8, help="--config train: samples per GPU and step")
+    ap.add_argument("--keep-activations", action="store_true",
+                    help="--config train: keep every activation of the forward pass instead of re-running each block before its "
+                         "backward (the reference's use_checkpoint: True is the default)")
+    ap.add_argument("--config", default="headline", choices=["headline", "n8", "smplx32", "train"],
                     help="headline = BASELINE.json's metric configuration (N=16, 256^2: configs[2], the default the driver "
                          "runs); n8 = configs[1] (N=8, 256^2); smplx32 = configs[4] (SMPL-X-sized mesh, N=32 views, 512^2 -> "
-                         "64^2 latents, orthographic cameras, 4 views per UNet pass).  Only 'headline' is the headline value")
+                         "64^2 latents, orthographic cameras, 4 views per UNet pass); train = configs[3]'s unit of work, one training step "
+                         "(forward, loss, UNet backward, gradient all-reduce, AdamW, re-pack).  Only 'headline' is the headline value")
     ap.add_argument("--probe-stride", type=int, default=4,
                     help="bracket 1 in N launches of the dominant kernel family with HIP events inside the timed region")
     ap.add_argument("--simulate-gpus", type=int, default=0,
@@ -162,6 +261,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_main()
+    if args.config == "train":
+        return train_main(args)
 
     # stdout carries exactly ONE JSON line: whatever libraries print there (gloo / RCCL connection chatter, sample()'s
     # progress lines) is sent to stderr at the file-descriptor level; the line itself is written to the saved descriptor

@@ -193,6 +193,46 @@ def test_recompute_equals_keep_all_and_is_reproducible():
     m.engine.close()
 
 
+def test_training_step_full_width_finite_and_reproducible():
+    """The 917 M-parameter UNet (configs/facescape.yaml's widths), B = 2 samples: one training step with per-block recompute --
+    loss and every gradient finite at the default loss scale, no optimiser step skipped, a repeated step bit-identical, the
+    keep-all tape gives the same bits."""
+    from morphablediffusion_amd import synthetic
+    N, B = 4, 2
+    ucfg, vcfg = gi.FULL_UNET, VolumeConfig(num_views=N)
+    m = make_train_model(ucfg, vcfg, N, workspace_gb=40.0, recompute=True)
+    m.model.drop_conditions = False  # configs/facescape.yaml:11
+    b0 = synthetic.make_batch(N, "perspective", 600, mesh_seed=1)
+    batch = {k: v.repeat(B, *([1] * (v.dim() - 1))).clone().cuda() for k, v in b0.items()}
+    gen = torch.Generator().manual_seed(5)
+    prepared = ((torch.randn(B, N, 4, 32, 32, generator=gen) * 0.8).cuda(), torch.randn(B, 1, 768, generator=gen).cuda(),
+                {"x": (torch.randn(B, 4, 32, 32, generator=gen) * 0.18215).cuda()})
+    draws = dict(time_steps=torch.tensor([301, 777]), noise=torch.randn(B, N, 4, 32, 32, generator=gen),
+                 target_index=torch.tensor([[1], [3]]))
+    outs = []
+    for rec in (True, True, False):
+        m.recompute = rec
+        m.engine.zero_grad()
+        loss = m.training_step(batch, prepared=prepared, **draws)
+        torch.cuda.synchronize()
+        outs.append((float(loss), m.engine.flat_grads.clone()))
+    g = outs[0][1]
+    assert np.isfinite(outs[0][0]) and torch.isfinite(g).all()
+    tab = m.engine.param_table
+    nz = sum(1 for k, (o, n, s_) in tab.items() if k.startswith(P) and g[o:o + n].abs().max() > 0)
+    total = sum(1 for k in tab if k.startswith(P))
+    print(f"[property] full-width training step: loss {outs[0][0]:.4f}, {nz} of {total} UNet tensors with a non-zero gradient, "
+          f"|g|max {g.abs().max().item() / m.loss_scale:.3e} (x loss scale {m.loss_scale:.0f} = {g.abs().max().item():.3e})")
+    assert total - nz == 16 * 4  # attn2.to_q / to_k / norm2.weight / norm2.bias of the 16 SpatialTransformers: exactly zero
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert outs[2][0] == outs[0][0] and torch.equal(outs[2][1], outs[0][1])
+    m.learning_rate = 5e-5
+    (opt,), _ = m.configure_optimizers()
+    opt.step()
+    assert opt.steps_skipped == 0 and opt.steps_done == 1
+    m.engine.close()
+
+
 def test_adamw_step_and_repack():
     """configure_optimizers (morphable_diffusion.py:627-646): parameter groups, LambdaLR, and one optimiser step against
     torch.optim.AdamW on copies of the same parameters / gradients; the re-packed engine equals a fresh load of the updated

@@ -253,3 +253,42 @@ def test_depth_transformer_gradient_sensitivity():
           f"(upstream of the softmax {up:.2e}); ResBlock gradients by up to {max(res_move.values()):.2e}")
     assert max(res_move.values()) <= 5 * eps            # smooth block: proportional
     assert up >= 8 * eps                                 # masked / softmax block: an order of magnitude more
+
+
+GRAD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from morphablediffusion_amd.model import sync_flat_gradients, LambdaLinearScheduler
+
+rank = int(sys.argv[1])
+assert sync_flat_gradients(torch.ones(4)) is False          # no process group: a no-op
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+# the flat gradient arena of each rank: parameter views alias it, so ONE collective averages every parameter's gradient
+flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+views = [flat[0:10].view(2, 5), flat[64:64 + 300].view(3, 100), flat[512:1000]]
+assert sync_flat_gradients(flat) is True
+want = torch.arange(1000, dtype=torch.float32) * 1.5        # mean of x1 and x2
+assert torch.equal(flat, want)
+assert torch.equal(views[1], want[64:364].view(3, 100))      # the views saw the averaged values
+# inf on one rank reaches every rank (the overflow check after the all-reduce then skips the step everywhere)
+flat[7] = float("inf") if rank == 1 else 1.0
+sync_flat_gradients(flat)
+assert torch.isinf(flat[7])
+s = LambdaLinearScheduler(warm_up_steps=[100], cycle_lengths=[100000], f_start=[0.02], f_max=[1.0], f_min=[1.0])
+assert abs(s.schedule(0) - 0.02) < 1e-12 and abs(s.schedule(50) - 0.51) < 1e-12 and s.schedule(100) == 1.0 and s.schedule(5000) == 1.0
+print("GRAD_OK", rank)
+dist.destroy_process_group()
+'''
+
+
+def test_flat_gradient_allreduce_two_ranks_gloo(tmp_path):
+    """DDP's gradient averaging (train_morphable_diffusion.py:302-303) as ONE all-reduce over the flat gradient arena:
+    2 gloo ranks, parameter-shaped views of the buffer see the mean; the LR schedule of configs/facescape.yaml:17-24."""
+    script = tmp_path / "gworker.py"
+    script.write_text(GRAD_WORKER % {"root": ROOT, "port": 29741})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"GRAD_OK {r}" in o, o[-2000:]
