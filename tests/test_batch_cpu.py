@@ -2,6 +2,7 @@
 the reference calls, generate_face.py:170,208) for the camera rotations and the axis-angle exponential, and the
 virtual-camera rig the goldens were generated with."""
 import numpy as np
+import pytest
 import torch
 from scipy.spatial.transform import Rotation as Rot
 
@@ -102,3 +103,53 @@ def test_real_camera_dict_and_stacked_batches():
     import pytest
     with pytest.raises(ValueError):
         BT.build_batch(img, v, num_views=4, cameras=(K[:3], RT[:3]))
+
+
+def test_camera_trajectory_vs_reference_golden():
+    """tests/golden/cameras.npz: generate_camera_trajectory extracted from the reference's generate_face.py (:25-45) and the
+    RT matrices its main loop builds with scipy (:166-173), for 16 and 8 cameras."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cameras.npz"))
+    for n in (16, 8):
+        pos, rot = B.generate_camera_trajectory(n)
+        assert np.allclose(np.array(pos), g[f"positions{n}"], atol=1e-12) and np.allclose(np.array(rot), g[f"rotations{n}"], atol=1e-12)
+        K, RT = B.virtual_cameras(n)
+        assert np.allclose(RT.numpy(), g[f"RT{n}"], atol=1e-6)
+
+
+def test_cli_flags_mesh_readers_and_image_loading(tmp_path):
+    """python -m morphablediffusion_amd.generate_face: the reference's flags with its defaults (generate_face.py:91-106), mesh
+    readers (what trimesh.load(process=False).vertices returns) and the input-image preparation (process_im :79-88)."""
+    import struct
+    from PIL import Image
+    from morphablediffusion_amd import generate_face as GF
+    fl = GF.build_parser().parse_args(["--input_img", "a/in.png", "--exp_img", "b/kiss.jpg", "--mesh", "m.ply", "--output_dir", "o"])
+    assert (fl.cfg, fl.ckpt, fl.cfg_scale, fl.batch_view_num, fl.seed, fl.sampler, fl.sample_steps, fl.camera_trajectory,
+            fl.prepare_neus2_data) == ("configs/facescape.yaml", "ckpt/facescape_flame.ckpt", 2.0, 8, 6033, "ddim", 50, "virtual", False)
+    with pytest.raises(SystemExit):
+        GF.build_parser().parse_args(["--input_img", "a.png"])  # --exp_img / --mesh / --output_dir are required
+    v = np.random.RandomState(0).randn(37, 3)
+    (tmp_path / "m.obj").write_text("# test\n" + "".join(f"v {a:.9f} {b:.9f} {c:.9f}\n" for a, b, c in v) + "f 1 2 3\n")
+    assert np.allclose(GF.read_mesh_vertices(tmp_path / "m.obj"), v, atol=1e-8)
+    hdr = "ply\nformat {}\nelement vertex 37\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n" \
+          "element face 1\nproperty list uchar int vertex_indices\nend_header\n"
+    (tmp_path / "a.ply").write_text(hdr.format("ascii 1.0") + "".join(f"{a:.9f} {b:.9f} {c:.9f} 7\n" for a, b, c in v) + "3 0 1 2\n")
+    assert np.allclose(GF.read_mesh_vertices(tmp_path / "a.ply"), v, atol=1e-8)
+    for fmt, e in (("binary_little_endian 1.0", "<"), ("binary_big_endian 1.0", ">")):
+        with open(tmp_path / "b.ply", "wb") as f:
+            f.write(hdr.format(fmt).encode())
+            for a, b, c in v:
+                f.write(struct.pack(e + "fffB", a, b, c, 7))
+            f.write(struct.pack(e + "Biii", 3, 0, 1, 2))
+        assert np.allclose(GF.read_mesh_vertices(tmp_path / "b.ply"), v.astype(np.float32), atol=0)
+    with pytest.raises(ValueError):
+        GF.read_mesh_vertices(tmp_path / "m.stl")
+    # RGBA input: composited on white with its alpha; RGB input: used as is; both resized to 256 (bicubic), [-1,1], HWC
+    rgba = np.zeros((64, 64, 4), np.uint8)
+    rgba[16:48, 16:48] = (255, 0, 0, 255)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "in.png")
+    im = GF.load_input_image(tmp_path / "in.png")
+    assert im.shape == (256, 256, 3) and im.dtype == torch.float32
+    assert torch.allclose(im[2, 2], torch.ones(3)) and torch.allclose(im[128, 128], torch.tensor([1.0, -1.0, -1.0]))
+    Image.fromarray(rgba[:, :, :3]).save(tmp_path / "rgb.jpg")
+    assert GF.load_input_image(tmp_path / "rgb.jpg").shape == (256, 256, 3)

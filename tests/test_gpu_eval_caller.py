@@ -152,3 +152,50 @@ def test_real_camera_dict_errors():
         BT.cameras_from_dict(d, N)
     with pytest.raises(KeyError):
         BT.cameras_from_dict({"intrinsics": [K[0, :3, :3].tolist()]}, 1)
+
+
+def test_generate_face_cli_end_to_end(tmp_path):
+    """f3: ``python -m morphablediffusion_amd.generate_face`` with the reference's flags (generate_face.py:91-106) on a
+    checkpoint FILE + YAML (16 views, as the script hard-wires), a PLY mesh and an RGBA image: writes the 17-view strip and the
+    NeuS2 folder (transform.json + 16 RGBA views, :145-192,255-262); same seed -> same image, byte for byte."""
+    import json
+    import struct
+    from PIL import Image
+    from morphablediffusion_amd import generate_face as GF
+    ucfg, vcfg = UNetConfig(model_channels=64), VolumeConfig(num_views=16)
+    W = seeded_state_dict(full_manifest(ucfg, vcfg), 7)
+    vae = VaeConfig(ch=32)
+    W.update(seeded_state_dict(vae_decoder_manifest(vae), 7))
+    W.update(seeded_state_dict(vae_encoder_manifest(vae), 7))
+    W.update({k: v.half() for k, v in seeded_state_dict(clip_manifest(ClipConfig(width=128, layers=2, heads=2, embed=768)), 7).items()})
+    torch.save({"state_dict": W}, tmp_path / "m.ckpt")
+    (tmp_path / "facescape.yaml").write_text(yaml.safe_dump(facescape_yaml(view_num=16)))
+    verts = synthetic.ellipsoid_mesh(900, 4, radii=(0.09, 0.11, 0.10)).numpy()  # FLAME-sized: align_flame_vertices scales by 2.7
+    with open(tmp_path / "face.ply", "wb") as f:
+        f.write(f"ply\nformat binary_little_endian 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\n"
+                f"property float z\nend_header\n".encode())
+        for v in verts:
+            f.write(struct.pack("<fff", *[float(t) for t in v]))
+    rgba = np.full((300, 280, 4), 255, np.uint8)
+    rgba[..., :3] = np.random.RandomState(1).randint(0, 255, (300, 280, 3))
+    rgba[:40, :, 3] = 0
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "subject.png")
+    args = ["--input_img", str(tmp_path / "subject.png"), "--exp_img", str(tmp_path / "kiss.jpg"), "--mesh", str(tmp_path / "face.ply"),
+            "--cfg", str(tmp_path / "facescape.yaml"), "--ckpt", str(tmp_path / "m.ckpt"), "--output_dir", str(tmp_path / "out"),
+            "--sample_steps", "4", "--batch_view_num", "8", "--prepare_neus2_data"]
+    GF.main(args)
+    out = tmp_path / "out" / "subject_kiss.png"
+    strip = np.asarray(Image.open(out))
+    assert strip.shape == (256, 17 * 256, 3) and strip.dtype == np.uint8 and strip[:, 256:].std() > 0
+    assert (strip[:30, :256] == 255).all()  # the transparent band of the input became white background
+    root = tmp_path / "out" / "neus2_data" / "subject_kiss"
+    tr = json.loads((root / "transform.json").read_text())
+    assert (tr["w"], tr["h"], tr["aabb_scale"], tr["offset"]) == (256, 256, 1.0, [0.5, 0.5, 0.5]) and len(tr["frames"]) == 16
+    assert tr["frames"][3]["file_path"] == "images/03.png" and np.asarray(tr["frames"][3]["transform_matrix"]).shape == (4, 4)
+    v5 = np.asarray(Image.open(root / "images" / "05.png"))
+    assert v5.shape == (256, 256, 4) and (v5[:, :, :3] == strip[:, 5 * 256:6 * 256]).all()
+    first = strip.copy()
+    GF.main(args)  # torch.random.manual_seed(flags.seed) makes the run reproducible
+    assert (np.asarray(Image.open(out)) == first).all()
+    GF.main(args[:-1] + ["--seed", "7"])
+    assert (np.asarray(Image.open(out)) != first).any()

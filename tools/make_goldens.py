@@ -421,6 +421,32 @@ def gold_train(ns):
                                     "grad_norms": np.array(norms)})
 
 
+def gold_cameras():
+    """generate_camera_trajectory of the reference's generate_face.py (:25-45), extracted from its source by name with ast (the
+    module itself cannot be imported here: torchvision / pytorch3d / carvekit) and executed; the camera matrices of the
+    script's main loop (:161-173) are then built from it with scipy, as the script does."""
+    import ast
+    from scipy.spatial.transform import Rotation as Rot
+    src = open("/root/reference/generate_face.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "generate_camera_trajectory"]
+    assert len(fn) == 1
+    scope = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "generate_face.py", "exec"), scope)
+    out = {}
+    for n in (16, 8):
+        pos, rot = scope["generate_camera_trajectory"](n)
+        RTs = []
+        for p_, r_ in zip(pos, rot):  # generate_face.py:166-173
+            R = Rot.from_euler("xyz", np.array(r_), True).as_matrix()
+            RT = np.zeros((3, 4))
+            RT[:3, :3] = R
+            RT[:3, 3] = (-R @ np.array(p_).reshape(3, 1)).reshape(3,)
+            RTs.append(RT)
+        out[f"positions{n}"], out[f"rotations{n}"], out[f"RT{n}"] = np.array(pos), np.array(rot), np.array(RTs)
+    np.savez_compressed(os.path.join(OUT, "cameras.npz"), **out)
+    print("wrote cameras.npz")
+
+
 def gold_variants(ns):
     """The other BASELINE.json configs as parity cases, at reduced UNet width:
     config 1 (N=8, 256^2), config 0 (one view, 64^2 latent, FLAME-sized mesh, first DDIM step without noise) and
@@ -441,12 +467,16 @@ def main():
     ap.add_argument("--only-train", action="store_true", help="only the training-step golden (loss + gradients)")
     ap.add_argument("--only-traj", action="store_true", help="only the multi-step trajectory golden")
     ap.add_argument("--only-trained", action="store_true", help="only the goldens on the trained-like weight set")
+    ap.add_argument("--only-cameras", action="store_true", help="only the camera-trajectory golden (ast-extracted from generate_face.py)")
     ap.add_argument("--only-clip", action="store_true", help="only the CLIP image-embedding goldens (needs transformers, not the reference)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     if args.only_clip:
         gold_clip()
+        return
+    if args.only_cameras:
+        gold_cameras()
         return
     ns = ref_import.import_reference_full()
     if args.only_variants:
@@ -473,6 +503,7 @@ def main():
         hot = gold_step(ns, "step_full.npz", gi.FULL_UNET, 16, "perspective", 49, True, 5023, 8, frustum_views=2)
     gold_traj(ns)
     gold_train(ns)
+    gold_cameras()
     gold_variants(ns)
     gold_trained(ns, not args.skip_full)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
