@@ -82,6 +82,10 @@ int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const flo
                    const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
                    float* db_part, float* dpre_part, hipStream_t s);
 int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s);
+int bwd_gn_slabs(int B, int G, int rows);
+int bwd_group_norm_slab(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                        const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* part,
+                        float* part2, float* dg_part, float* db_part, float* dpre_part, int S, hipStream_t s);
 int bwd_ln_max_blocks();
 int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
                    long lddx, int accum, float* part, int* nblk, hipStream_t s);
@@ -778,12 +782,20 @@ int mvd_op_group_norm_bwd(mvd_ctx* c, const float* x, const float* dy, int B, in
   if (!c) return mvd_fail("null context");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  float* dg = ws_alloc<float>(c, (size_t)B * C);
-  float* db = ws_alloc<float>(c, (size_t)B * C);
-  WS_CHECK(dg && db);
-  RET_IF(bwd_group_norm(x, C, nullptr, 0, dy, C, B, rows, C, groups, gamma, beta, eps, act, dx, C, 0, dg, db, nullptr, s));
-  RET_IF(bwd_sum_rows_add(dg, B, C, C, dgamma, 0, s));
-  return bwd_sum_rows_add(db, B, C, C, dbeta, 0, s);
+  // the slabbed form the training step uses; MVD_GN_BWD_ONE_BLOCK=1: the one-workgroup-per-(sample, group) kernel
+  static const bool one_block = getenv("MVD_GN_BWD_ONE_BLOCK") != nullptr;
+  const int S = one_block ? 1 : bwd_gn_slabs(B, groups, rows);
+  float* dg = ws_alloc<float>(c, (size_t)B * S * C);
+  float* db = ws_alloc<float>(c, (size_t)B * S * C);
+  float* part = ws_alloc<float>(c, (size_t)B * groups * S * 4);
+  WS_CHECK(dg && db && part);
+  if (one_block)
+    RET_IF(bwd_group_norm(x, C, nullptr, 0, dy, C, B, rows, C, groups, gamma, beta, eps, act, dx, C, 0, dg, db, nullptr, s));
+  else
+    RET_IF(bwd_group_norm_slab(x, C, nullptr, 0, dy, C, B, rows, C, groups, gamma, beta, eps, act, dx, C, 0, part,
+                               part + (size_t)B * groups * S * 2, dg, db, nullptr, S, s));
+  RET_IF(bwd_sum_rows_add(dg, B * S, C, C, dgamma, 0, s));
+  return bwd_sum_rows_add(db, B * S, C, C, dbeta, 0, s);
 }
 
 int mvd_op_layer_norm_bwd(mvd_ctx* c, const float* x, const float* dy, int rows, int C, const float* gamma, float* dx, float* dgamma,

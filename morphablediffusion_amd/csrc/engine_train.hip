@@ -31,6 +31,13 @@ int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const flo
                    const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
                    float* db_part, float* dpre_part, hipStream_t s);
 int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s);
+int bwd_gn_slabs(int B, int G, int rows);
+int bwd_group_norm_fwd(const float* x, long ld, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act,
+                       float* y, long ldy, float* part, int S, hipStream_t s);
+int bwd_group_norm_slab(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                        const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* part,
+                        float* part2, float* dg_part, float* db_part, float* dpre_part, int S, hipStream_t s);
+int bwd_outer_add(const float* a, long lda, const float* b, long ldb, float* C, int M, int N, int K, hipStream_t s);
 int bwd_colsum_samples(const void* v, int v_f32, long ld, int B, int rows, int C, float* out, long ldo, hipStream_t s);
 int bwd_ln_max_blocks();
 int bwd_layer_norm(const float* x, long ld, const float* dy, long ldy, int rows, int C, const float* gamma, float eps, float* dx,
@@ -319,19 +326,30 @@ int wgrad_conv3(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x
   }
   return 0;
 }
-// GroupNorm backward incl. its gain / bias gradients
+// GroupNorm backward incl. its gain / bias gradients (slabbed: B * G * S workgroups)
 int gn_backward(Bwd& b, const NormW& n, int groups, float eps, int act, const float* x, long ld, const float* dy, long ldy, int rows_ps,
                 float* dx, long lddx, bool accum) {
   mvd_ctx* c = b.c;
   WsScope scope(c, WS_TEMP);
-  float* dg = ws_alloc<float>(c, (size_t)b.B * n.C);
-  float* db = ws_alloc<float>(c, (size_t)b.B * n.C);
-  WS_CHECK(dg && db);
-  RET_IF(bwd_group_norm(x, ld, nullptr, 0, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, dg, db,
-                        nullptr, b.s));
-  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(dg, b.B, n.C, n.C, G, 1, b.s));
-  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(db, b.B, n.C, n.C, G, 1, b.s));
+  const int S = bwd_gn_slabs(b.B, groups, rows_ps);
+  float* dg = ws_alloc<float>(c, (size_t)b.B * S * n.C);
+  float* db = ws_alloc<float>(c, (size_t)b.B * S * n.C);
+  float* part = ws_alloc<float>(c, (size_t)b.B * groups * S * 4);
+  WS_CHECK(dg && db && part);
+  RET_IF(bwd_group_norm_slab(x, ld, nullptr, 0, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, part,
+                             part + (size_t)b.B * groups * S * 2, dg, db, nullptr, S, b.s));
+  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(dg, b.B * S, n.C, n.C, G, 1, b.s));
+  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(db, b.B * S, n.C, n.C, G, 1, b.s));
   return 0;
+}
+// GroupNorm forward in fp32 for the DepthTransformer re-computation
+int gn_forward32(Bwd& b, const float* x, int rows_ps, int C, int G, const float* gamma, const float* beta, int act, float* y) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  const int S = bwd_gn_slabs(b.B, G, rows_ps);
+  float* part = ws_alloc<float>(c, (size_t)b.B * G * S * 2);
+  WS_CHECK(part);
+  return bwd_group_norm_fwd(x, C, b.B, rows_ps, C, G, gamma, beta, 1e-5f, act, y, C, part, S, b.s);
 }
 int ln_backward(Bwd& b, const NormW& n, const float* x, long ld, const float* dy, long ldy, int rows, float* dx, long lddx, bool accum) {
   mvd_ctx* c = b.c;
@@ -560,10 +578,10 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
   // proj_in: conv1x1 + bias, GN8, SiLU        (attention.py:52-56)
   RET_IF(tgemm(c, F32(X, dim, 0), F32(w_pi, dim, 1), p, I, R, I, dim, false, s, true));
   RET_IF(train_add_bias_rows(p, R, I, b_pi, s));
-  RET_IF(train_gn_fwd(p, B, HW, I, 8, g_pi, e_pi, 1e-5f, ACT_SILU, pn, nullptr, s));
+  RET_IF(gn_forward32(b, p, HW, I, 8, g_pi, e_pi, ACT_SILU, pn));
   // proj_context: conv1x1x1 (no bias), GN8, ReLU   (:57-61)
   RET_IF(tgemm(c, F32(C0, Cc, 0), F32(w_pc, Cc, 1), pc, Cc, (int)RC, Cc, Cc, false, s, true));
-  RET_IF(train_gn_fwd(pc, B, D * HW, Cc, 8, g_pc, e_pc, 1e-5f, ACT_RELU, cn, nullptr, s));
+  RET_IF(gn_forward32(b, pc, D * HW, Cc, 8, g_pc, e_pc, ACT_RELU, cn));
   // depth attention   (:26-47)
   RET_IF(tgemm(c, F32(pn, I, 0), F32(w_q, I, 1), q, I, R, I, I, false, s, true));
   RET_IF(tgemm(c, F32(cn, Cc, 0), F32(w_k, Cc, 1), k, I, (int)RC, I, Cc, false, s, true));
@@ -571,10 +589,10 @@ int bwd_cond(Bwd& b, const CondW& cd, View in, View dout, View din, bool accum, 
   RET_IF(train_depth_fwd(q, k, v, R, HW, D, hn, hd, scale, attn, z, s));
   RET_IF(tgemm(c, F32(z, I, 0), F32(w_o, I, 1), o, I, R, I, I, false, s, true));
   // proj_out: GN8, ReLU, conv3x3, GN8, ReLU, conv3x3   (:63-70)
-  RET_IF(train_gn_fwd(o, B, HW, I, 8, g_o0, e_o0, 1e-5f, ACT_RELU, a1, nullptr, s));
+  RET_IF(gn_forward32(b, o, HW, I, 8, g_o0, e_o0, ACT_RELU, a1));
   RET_IF(train_im2col3(a1, B, H, W, I, col1, s));
   RET_IF(tgemm(c, F32(col1, 9 * I, 0), F32(m_c1, 9 * I, 1), o2, I, R, I, 9 * I, false, s, true));
-  RET_IF(train_gn_fwd(o2, B, HW, I, 8, g_o3, e_o3, 1e-5f, ACT_RELU, a2, nullptr, s));
+  RET_IF(gn_forward32(b, o2, HW, I, 8, g_o3, e_o3, ACT_RELU, a2));
   RET_IF(train_im2col3(a2, B, H, W, I, col2, s));
   // ---------------- backward: dh = dL/d(x + proj_out(.)) ----------------
   // second conv3x3 of proj_out
@@ -672,7 +690,7 @@ int bwd_emb(Bwd& b) {
   // d silu(emb) = demb W_all
   for (auto& r : c->res) {
     if (float* G = engine_grad(c, r.key + ".emb_layers.1.weight"))
-      RET_IF(tgemm(c, F32(b.demb + r.emb_off, ET, 1), F32(b.tape->e2, temb, 0), G, temb, r.cout, temb, B, true, s));
+      RET_IF(bwd_outer_add(b.demb + r.emb_off, ET, b.tape->e2, temb, G, r.cout, temb, B, s));
     if (float* G = engine_grad(c, r.key + ".emb_layers.1.bias")) RET_IF(bwd_sum_rows_add(b.demb + r.emb_off, B, r.cout, ET, G, 1, s));
   }
   RET_IF(tgemm(c, F32(b.demb, ET, 0), F16(c->emb_all.w, temb, 0), d_e2, temb, B, temb, ET, false, s));
@@ -689,11 +707,11 @@ int bwd_emb(Bwd& b) {
     RET_IF(run_linear(c, g, B, B, s));
   }
   RET_IF(bwd_silu_inplace(d_e2, u2, (size_t)B * temb, s));  // d u2
-  if (float* G = engine_grad(c, U + "time_embed.2.weight")) RET_IF(tgemm(c, F32(d_e2, temb, 1), F32(b.tape->e1, temb, 0), G, temb, temb, temb, B, true, s));
+  if (float* G = engine_grad(c, U + "time_embed.2.weight")) RET_IF(bwd_outer_add(d_e2, temb, b.tape->e1, temb, G, temb, temb, B, s));
   if (float* G = engine_grad(c, U + "time_embed.2.bias")) RET_IF(bwd_sum_rows_add(d_e2, B, temb, temb, G, 1, s));
   RET_IF(tgemm(c, F32(d_e2, temb, 0), F16(c->te2.w, temb, 0), d_e1, temb, B, temb, temb, false, s));
   RET_IF(bwd_silu_inplace(d_e1, u1, (size_t)B * temb, s));  // d u1
-  if (float* G = engine_grad(c, U + "time_embed.0.weight")) RET_IF(tgemm(c, F32(d_e1, temb, 1), F32(b.tape->e0, mc, 0), G, mc, temb, mc, B, true, s));
+  if (float* G = engine_grad(c, U + "time_embed.0.weight")) RET_IF(bwd_outer_add(d_e1, temb, b.tape->e0, mc, G, temb, mc, B, s));
   if (float* G = engine_grad(c, U + "time_embed.0.bias")) RET_IF(bwd_sum_rows_add(d_e1, B, temb, temb, G, 1, s));
   return 0;
 }
@@ -717,9 +735,9 @@ int bwd_attn2(Bwd& b) {
     const float* d = b.da2 + t.a2_off;
     RET_IF(tgemm(c, F32(b.tape->context, cd, 0), F32(wv, cd, 1), u, C, B, C, cd, false, s));
     if (float* G = engine_grad(c, a + "to_out.0.bias")) RET_IF(bwd_sum_rows_add(d, B, C, AT, G, 1, s));
-    if (float* G = engine_grad(c, a + "to_out.0.weight")) RET_IF(tgemm(c, F32(d, AT, 1), F32(u, C, 0), G, C, C, C, B, true, s));
+    if (float* G = engine_grad(c, a + "to_out.0.weight")) RET_IF(bwd_outer_add(d, AT, u, C, G, C, C, B, s));
     RET_IF(tgemm(c, F32(d, AT, 0), F32(wo, C, 0), du, C, B, C, C, false, s));
-    if (float* G = engine_grad(c, a + "to_v.weight")) RET_IF(tgemm(c, F32(du, C, 1), F32(b.tape->context, cd, 0), G, cd, C, cd, B, true, s));
+    if (float* G = engine_grad(c, a + "to_v.weight")) RET_IF(bwd_outer_add(du, C, b.tape->context, cd, G, C, cd, B, s));
   }
   return 0;
 }

@@ -213,6 +213,173 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ x
   }
 }
 
+// ---- slabbed GroupNorm forward / backward: one workgroup per (sample, group, row slab), so that the few (sample, group)
+// pairs of a small batch still fill the chip (B * G * S workgroups instead of B * G).  Three passes over the data:
+//   gn_slab_stats:  per-slab (sum, sumsq) of x (+ pre)                     -> part [B*G][S][2]
+//   gn_slab_sums:   mean / rstd from the S partials (fp64), then per-slab (sum dxhat, sum dxhat xhat) -> part2 [B*G][S][2]
+//                   and per-(sample, slab) channel sums of du xhat / du   -> dg_part / db_part [B*S][C]
+//   gn_slab_apply:  m1 / m2 from the S partials, dx for the slab's rows
+// The forward (fp32 out) is gn_slab_stats + gn_slab_fwd.  Same thread mapping as gn_bwd_kernel (fixed summation orders).
+__device__ __forceinline__ void gn_slab_meanrstd(const float* __restrict__ part, int S, float n, float eps, float* mean, float* rstd) {
+  double sx = 0.0, sq = 0.0;
+  for (int k = 0; k < S; ++k) {
+    sx += (double)part[2 * k];
+    sq += (double)part[2 * k + 1];
+  }
+  const double m = sx / (double)n;
+  double var = sq / (double)n - m * m;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_slab_stats_kernel(const float* __restrict__ x, long ld, const float* __restrict__ pre, int pld,
+                                                            int rows, int C, int G, int S, int rps, float* __restrict__ part) {
+  __shared__ float s_red[256];
+  const int bg = blockIdx.x, sl = blockIdx.y, b = bg / G, g = bg % G, cpg = C / G;
+  const int rpi = 256 / cpg, t = threadIdx.x;
+  const bool active = t < rpi * cpg;
+  const int c = t % cpg, r0 = t / cpg, ch = g * cpg + c;
+  const int rbeg = sl * rps, rend = min(rows, rbeg + rps);
+  const float* xb = x + (long)b * rows * ld + ch;
+  const float pv = (pre && active) ? pre[(long)b * pld + ch] : 0.f;
+  float a = 0.f, q = 0.f;
+  if (active)
+    for (int r = rbeg + r0; r < rend; r += rpi) {
+      const float v = xb[(long)r * ld] + pv;
+      a += v;
+      q += v * v;
+    }
+  const float sa = block_sum256(a, s_red), sq = block_sum256(q, s_red);
+  if (t == 0) {
+    part[((long)bg * S + sl) * 2] = sa;
+    part[((long)bg * S + sl) * 2 + 1] = sq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_slab_fwd_kernel(const float* __restrict__ x, long ld, const float* __restrict__ part, int rows,
+                                                          int C, int G, int S, int rps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int act, float* __restrict__ y,
+                                                          long ldy) {
+  const int bg = blockIdx.x, sl = blockIdx.y, b = bg / G, g = bg % G, cpg = C / G;
+  const int rpi = 256 / cpg, t = threadIdx.x;
+  if (t >= rpi * cpg) return;
+  const int c = t % cpg, r0 = t / cpg, ch = g * cpg + c;
+  float mean, rstd;
+  gn_slab_meanrstd(part + (long)bg * S * 2, S, (float)rows * (float)cpg, eps, &mean, &rstd);
+  const float gm = gamma[ch] * rstd, bt = beta[ch] - mean * rstd * gamma[ch];
+  const int rbeg = sl * rps, rend = min(rows, rbeg + rps);
+  for (int r = rbeg + r0; r < rend; r += rpi) {
+    const long o = ((long)b * rows + r);
+    y[o * ldy + ch] = act_f(x[o * ld + ch] * gm + bt, act);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_slab_sums_kernel(const float* __restrict__ x, long ld, const float* __restrict__ pre, int pld,
+                                                           const float* __restrict__ dy, long ldy, const float* __restrict__ part,
+                                                           int rows, int C, int G, int S, int rps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int act, float* __restrict__ part2,
+                                                           float* __restrict__ dg_part, float* __restrict__ db_part) {
+  __shared__ float s_red[256], s_a[256], s_b[256];
+  const int bg = blockIdx.x, sl = blockIdx.y, b = bg / G, g = bg % G, cpg = C / G;
+  const int rpi = 256 / cpg, t = threadIdx.x;
+  const bool active = t < rpi * cpg;
+  const int c = t % cpg, r0 = t / cpg, ch = g * cpg + c;
+  float mean, rstd;
+  gn_slab_meanrstd(part + (long)bg * S * 2, S, (float)rows * (float)cpg, eps, &mean, &rstd);
+  const int rbeg = sl * rps, rend = min(rows, rbeg + rps);
+  const float* xb = x + (long)b * rows * ld + ch;
+  const float* dyb = dy + (long)b * rows * ldy + ch;
+  const float pv = (pre && active) ? pre[(long)b * pld + ch] : 0.f;
+  const float gm = active ? gamma[ch] : 0.f, bt = active ? beta[ch] : 0.f;
+  float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
+  if (active)
+    for (int r = rbeg + r0; r < rend; r += rpi) {
+      const float xh = (xb[(long)r * ld] + pv - mean) * rstd;
+      const float du = dyb[(long)r * ldy] * act_d(gm * xh + bt, act);
+      const float dxh = du * gm;
+      s1 += dxh;
+      s2 += dxh * xh;
+      dg += du * xh;
+      db += du;
+    }
+  const float t1 = block_sum256(s1, s_red), t2 = block_sum256(s2, s_red);
+  if (t == 0) {
+    part2[((long)bg * S + sl) * 2] = t1;
+    part2[((long)bg * S + sl) * 2 + 1] = t2;
+  }
+  s_a[t] = dg;
+  s_b[t] = db;
+  __syncthreads();
+  if (t < cpg) {
+    float ag = 0.f, ab = 0.f;
+    for (int k = 0; k < rpi; ++k) {
+      ag += s_a[k * cpg + t];
+      ab += s_b[k * cpg + t];
+    }
+    const long o = ((long)b * S + sl) * C + g * cpg + t;
+    if (dg_part) dg_part[o] = ag;
+    if (db_part) db_part[o] = ab;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_slab_apply_kernel(const float* __restrict__ x, long ld, const float* __restrict__ pre, int pld,
+                                                            const float* __restrict__ dy, long ldy, const float* __restrict__ part,
+                                                            const float* __restrict__ part2, int rows, int C, int G, int S, int rps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            int act, float* __restrict__ dx, long lddx, int accum,
+                                                            float* __restrict__ dpre_part) {
+  __shared__ float s_red[256];
+  const int bg = blockIdx.x, sl = blockIdx.y, b = bg / G, g = bg % G, cpg = C / G;
+  const int rpi = 256 / cpg, t = threadIdx.x;
+  const bool active = t < rpi * cpg;
+  const int c = t % cpg, r0 = t / cpg, ch = g * cpg + c;
+  const float n = (float)rows * (float)cpg;
+  float mean, rstd;
+  gn_slab_meanrstd(part + (long)bg * S * 2, S, n, eps, &mean, &rstd);
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < S; ++k) {
+    a1 += (double)part2[((long)bg * S + k) * 2];
+    a2 += (double)part2[((long)bg * S + k) * 2 + 1];
+  }
+  const float m1 = (float)(a1 / (double)n), m2 = (float)(a2 / (double)n);
+  const int rbeg = sl * rps, rend = min(rows, rbeg + rps);
+  const float pv = (pre && active) ? pre[(long)b * pld + ch] : 0.f;
+  const float gm = active ? gamma[ch] : 0.f, bt = active ? beta[ch] : 0.f;
+  float dsum = 0.f;
+  if (active)
+    for (int r = rbeg + r0; r < rend; r += rpi) {
+      const long o = (long)b * rows + r;
+      const float xh = (x[o * ld + ch] + pv - mean) * rstd;
+      const float du = dy[o * ldy + ch] * act_d(gm * xh + bt, act);
+      const float v = rstd * (du * gm - m1 - xh * m2);
+      dsum += v;
+      dx[o * lddx + ch] = accum ? dx[o * lddx + ch] + v : v;
+    }
+  if (dpre_part) {
+    s_red[t] = dsum;
+    __syncthreads();
+    if (t < cpg) {
+      float ad = 0.f;
+      for (int k = 0; k < rpi; ++k) ad += s_red[k * cpg + t];
+      dpre_part[((long)b * S + sl) * C + g * cpg + t] = ad;
+    }
+  }
+}
+
+// C[m][n] += sum_{k < K} a[k][m] * b[k][n] (fp32, exact summation order): the weight gradient of a Linear layer applied to a
+// handful of rows (K = samples: time-embedding / attn2 projections), where a GEMM launch would be all overhead
+__global__ void outer_add_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, float* __restrict__ C,
+                                 int M, int N, int K) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), m = (int)(i / N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += a[(long)k * lda + m] * b[(long)k * ldb + n];
+    C[i] += acc;
+  }
+}
+
 // out[c] (+)= sum_r part[r][c] (fixed order), r < R small (samples / workgroup partials)
 __global__ void sum_rows_add_kernel(const float* __restrict__ part, int R, int C, long ldp, float* __restrict__ out, int accum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -794,6 +961,43 @@ int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const flo
   if (C % G || C / G > 256) return mvd_fail("bwd_group_norm: channels per group must divide C and be <= 256");
   hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, ld, pre, pld, dy, ldy, rows, C, G, gamma, beta, eps, act, dx, lddx,
                      accum, dg_part, db_part, dpre_part);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// slab plan: S row slabs per (sample, group) so that B * G * S is about 1024 workgroups, at least 8 rows per slab
+int bwd_gn_slabs(int B, int G, int rows) {
+  int S = 1024 / (B * G);
+  if (S > rows / 8) S = rows / 8;
+  if (S > 64) S = 64;
+  return S < 1 ? 1 : S;
+}
+// GroupNorm forward in fp32 (x [B][rows][ld] -> y [B][rows][ldy]); part: [B*G*S*2] floats of scratch
+int bwd_group_norm_fwd(const float* x, long ld, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act,
+                       float* y, long ldy, float* part, int S, hipStream_t s) {
+  if (C % G || C / G > 256) return mvd_fail("bwd_group_norm_fwd: channels per group must divide C and be <= 256");
+  const int rps = cdiv(rows, S);
+  hipLaunchKernelGGL(gn_slab_stats_kernel, dim3(B * G, S), dim3(256), 0, s, x, ld, (const float*)nullptr, 0, rows, C, G, S, rps, part);
+  hipLaunchKernelGGL(gn_slab_fwd_kernel, dim3(B * G, S), dim3(256), 0, s, x, ld, part, rows, C, G, S, rps, gamma, beta, eps, act, y, ldy);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// slabbed backward: part / part2 [B*G*S*2], dg_part / db_part / dpre_part [B*S][C] (sum over the B*S rows with bwd_sum_rows_add)
+int bwd_group_norm_slab(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
+                        const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* part,
+                        float* part2, float* dg_part, float* db_part, float* dpre_part, int S, hipStream_t s) {
+  if (C % G || C / G > 256) return mvd_fail("bwd_group_norm: channels per group must divide C and be <= 256");
+  const int rps = cdiv(rows, S);
+  dim3 grid(B * G, S);
+  hipLaunchKernelGGL(gn_slab_stats_kernel, grid, dim3(256), 0, s, x, ld, pre, pld, rows, C, G, S, rps, part);
+  hipLaunchKernelGGL(gn_slab_sums_kernel, grid, dim3(256), 0, s, x, ld, pre, pld, dy, ldy, part, rows, C, G, S, rps, gamma, beta, eps, act,
+                     part2, dg_part, db_part);
+  hipLaunchKernelGGL(gn_slab_apply_kernel, grid, dim3(256), 0, s, x, ld, pre, pld, dy, ldy, part, part2, rows, C, G, S, rps, gamma, beta,
+                     eps, act, dx, lddx, accum, dpre_part);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_outer_add(const float* a, long lda, const float* b, long ldb, float* C, int M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(outer_add_kernel, dim3(gridn((size_t)M * N)), dim3(256), 0, s, a, lda, b, ldb, C, M, N, K);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
