@@ -70,6 +70,11 @@ int mvd_upload_weight(mvd_ctx* ctx, const char* name, const float* data, const i
  * full-resolution input blocks.  Measured error of the UNet's eps against the fp32 reference: 9.3e-4
  * at level 0, 5.8e-4 at level 2, 4.4e-4 at level 4, for +2.2 % / +5.1 % step time. */
 int mvd_set_precision_level(mvd_ctx* ctx, int level);
+/* First-stage model (mvd_vae_decode / mvd_vae_encode), to be set before mvd_finalize_weights.  0 (default): fp16 MFMA operands
+ * like the UNet -- ~30 convolutions in series leave 1.8-2.0e-3 relative L2 in the decoded image (at most 0.8 of an 8-bit step).
+ * 1 ("exact"): every convolution, the attention projections and both attention products run in extended precision (fp16 hi + lo
+ * operand split, three products accumulated in fp32): the reference's fp32 result to ~1e-5, at about three times the cost. */
+int mvd_set_vae_precision(mvd_ctx* ctx, int exact);
 /* Packs/folds the uploaded tensors into their MFMA layouts; fails (listing the key) if one is missing. */
 int mvd_finalize_weights(mvd_ctx* ctx);
 

@@ -173,6 +173,13 @@ int mvd_set_precision_level(mvd_ctx* c, int level) {
   return 0;
 }
 
+int mvd_set_vae_precision(mvd_ctx* c, int exact) {
+  if (!c) return mvd_fail("null context");
+  if (c->finalized) return mvd_fail("mvd_set_vae_precision: weights already finalized");
+  c->vae_exact = exact != 0;
+  return 0;
+}
+
 int mvd_finalize_weights(mvd_ctx* c) {
   if (!c) return mvd_fail("null context");
   if (c->finalized) return 0;

@@ -190,6 +190,7 @@ struct mvd_ctx {
   int device = 0;
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
+  bool vae_exact = false;   // first-stage encoder / decoder with every conv and the attention in extended precision (mvd_set_vae_precision)
   int precision_level = 2;  // extended-precision policy (engine_weights.hip: apply_xp_policy), mvd_set_precision_level
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum

@@ -253,11 +253,11 @@ int build_vae_res(mvd_ctx* c, const std::string& p, VaeResW* r) {
   r->cout = (int)w1->shape[0];
   r->cin = (int)w1->shape[1];
   RET_IF(load_norm(c, p + ".norm1", &r->n1));
-  RET_IF(pack_conv(c, p + ".conv1.weight", p + ".conv1.bias", false, false, &r->c1));
+  RET_IF(pack_conv(c, p + ".conv1.weight", p + ".conv1.bias", false, false, &r->c1, 0, c->vae_exact));
   RET_IF(load_norm(c, p + ".norm2", &r->n2));
-  RET_IF(pack_conv(c, p + ".conv2.weight", p + ".conv2.bias", false, false, &r->c2));
+  RET_IF(pack_conv(c, p + ".conv2.weight", p + ".conv2.bias", false, false, &r->c2, 0, c->vae_exact));
   r->has_skip = c->raw.count(p + ".nin_shortcut.weight") > 0;
-  if (r->has_skip) RET_IF(pack_conv(c, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", false, false, &r->skip));
+  if (r->has_skip) RET_IF(pack_conv(c, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", false, false, &r->skip, 0, c->vae_exact));
   else if (r->cin != r->cout) return mvd_fail("VAE ResnetBlock changes width but has no nin_shortcut (conv_shortcut is not used by the reference config)");
   return 0;
 }
@@ -274,10 +274,10 @@ __global__ void vae_fold_v_bias_kernel(const float* __restrict__ wp, const float
 
 int build_vae_attn(mvd_ctx* c, const std::string& p, VaeAttnW* a) {
   RET_IF(load_norm(c, p + ".norm", &a->norm));
-  RET_IF(pack_conv(c, p + ".q.weight", p + ".q.bias", false, false, &a->q));
-  RET_IF(pack_conv(c, p + ".k.weight", p + ".k.bias", false, false, &a->k));
-  RET_IF(pack_conv(c, p + ".v.weight", "", false, false, &a->v));
-  RET_IF(pack_conv(c, p + ".proj_out.weight", "", false, false, &a->proj));
+  RET_IF(pack_conv(c, p + ".q.weight", p + ".q.bias", false, false, &a->q, 0, c->vae_exact));
+  RET_IF(pack_conv(c, p + ".k.weight", p + ".k.bias", false, false, &a->k, 0, c->vae_exact));
+  RET_IF(pack_conv(c, p + ".v.weight", "", false, false, &a->v, 0, c->vae_exact));
+  RET_IF(pack_conv(c, p + ".proj_out.weight", "", false, false, &a->proj, 0, c->vae_exact));
   RawTensor *wp, *bv, *bp;
   RET_IF(get_raw(c, p + ".proj_out.weight", &wp));
   RET_IF(get_raw(c, p + ".v.bias", &bv));
@@ -377,7 +377,7 @@ int build_vae_encoder(mvd_ctx* c) {
   v.in_ch = (int)ci->shape[1];
   v.mom = (int)q->shape[0];
   if (v.in_ch > 8 || (v.mom & 3) || (q->shape[1] & 7)) return mvd_fail("VAE encoder: in_channels <= 8, moments % 4 == 0 expected");
-  RET_IF(pack_conv(c, E + "conv_in.weight", E + "conv_in.bias", false, false, &v.conv_in, 8));
+  RET_IF(pack_conv(c, E + "conv_in.weight", E + "conv_in.bias", false, false, &v.conv_in, 8, c->vae_exact));
   v.nlev = 0;
   while (c->raw.count(E + "down." + std::to_string(v.nlev) + ".block.0.conv1.weight")) ++v.nlev;
   if (v.nlev < 1) return mvd_fail("VAE encoder: no down blocks uploaded");
@@ -390,14 +390,14 @@ int build_vae_encoder(mvd_ctx* c) {
       RET_IF(build_vae_res(c, L + ".block." + std::to_string(i), &r));
       v.down[l].push_back(r);
     }
-    if (l < v.nlev - 1) RET_IF(pack_conv(c, L + ".downsample.conv.weight", L + ".downsample.conv.bias", false, false, &v.down_conv[l]));
+    if (l < v.nlev - 1) RET_IF(pack_conv(c, L + ".downsample.conv.weight", L + ".downsample.conv.bias", false, false, &v.down_conv[l], 0, c->vae_exact));
   }
   RET_IF(build_vae_res(c, E + "mid.block_1", &v.mid1));
   RET_IF(build_vae_attn(c, E + "mid.attn_1", &v.attn));
   RET_IF(build_vae_res(c, E + "mid.block_2", &v.mid2));
   RET_IF(load_norm(c, E + "norm_out", &v.norm_out));
-  RET_IF(pack_conv(c, E + "conv_out.weight", E + "conv_out.bias", false, false, &v.conv_out));
-  RET_IF(pack_conv(c, V + "quant_conv.weight", V + "quant_conv.bias", false, false, &v.quant));
+  RET_IF(pack_conv(c, E + "conv_out.weight", E + "conv_out.bias", false, false, &v.conv_out, 0, c->vae_exact));
+  RET_IF(pack_conv(c, V + "quant_conv.weight", V + "quant_conv.bias", false, false, &v.quant, 0, c->vae_exact));
   v.present = true;
   return 0;
 }
@@ -416,8 +416,8 @@ int build_vae(mvd_ctx* c) {
   v.embed = (int)pq->shape[1];
   if (v.out_ch > 4 || v.zc > 8 || (v.zc & 3) || v.embed > 8)
     return mvd_fail("VAE decoder: out_ch <= 4, z_channels in {4, 8} and embed_dim <= 8 expected");
-  RET_IF(pack_conv(c, V + "post_quant_conv.weight", V + "post_quant_conv.bias", false, false, &v.post_quant, 8));
-  RET_IF(pack_conv(c, D + "conv_in.weight", D + "conv_in.bias", false, false, &v.conv_in, 8));
+  RET_IF(pack_conv(c, V + "post_quant_conv.weight", V + "post_quant_conv.bias", false, false, &v.post_quant, 8, c->vae_exact));
+  RET_IF(pack_conv(c, D + "conv_in.weight", D + "conv_in.bias", false, false, &v.conv_in, 8, c->vae_exact));
   RET_IF(build_vae_res(c, D + "mid.block_1", &v.mid1));
   RET_IF(build_vae_res(c, D + "mid.block_2", &v.mid2));
   RET_IF(build_vae_attn(c, D + "mid.attn_1", &v.attn));
@@ -435,11 +435,13 @@ int build_vae(mvd_ctx* c) {
     }
     if (l > 0) {
       ConvW& uc = v.up_conv[l];
-      RET_IF(pack_conv(c, L + ".upsample.conv.weight", L + ".upsample.conv.bias", false, false, &uc));
+      RET_IF(pack_conv(c, L + ".upsample.conv.weight", L + ".upsample.conv.bias", false, false, &uc, 0, c->vae_exact));
       RawTensor* r;
       RET_IF(get_raw(c, L + ".upsample.conv.weight", &r));
-      RET_IF(dmalloc(c, (void**)&uc.w_up, (size_t)16 * uc.N * uc.Cin * sizeof(half_t)));
-      RET_IF(launch_pack_upconv_weight(r->d, uc.N, uc.Cin, uc.w_up, 0));
+      if (!c->vae_exact) {  // the parity-folded form (pre-summed taps) exists for plain fp16 weights only
+        RET_IF(dmalloc(c, (void**)&uc.w_up, (size_t)16 * uc.N * uc.Cin * sizeof(half_t)));
+        RET_IF(launch_pack_upconv_weight(r->d, uc.N, uc.Cin, uc.w_up, 0));
+      }
     }
   }
   RET_IF(load_norm(c, D + "norm_out", &v.norm_out));
@@ -459,7 +461,7 @@ int build_vae(mvd_ctx* c) {
     HIP_CHECK_RET(hipMemcpy(padb.d, b->d, b->numel * sizeof(float), hipMemcpyDeviceToDevice));
     c->raw[D + "conv_out.weight.pad4"] = pad;
     c->raw[D + "conv_out.bias.pad4"] = padb;
-    RET_IF(pack_conv(c, D + "conv_out.weight.pad4", D + "conv_out.bias.pad4", false, false, &v.conv_out));
+    RET_IF(pack_conv(c, D + "conv_out.weight.pad4", D + "conv_out.bias.pad4", false, false, &v.conv_out, 0, c->vae_exact));
   }
   v.present = true;
   return 0;

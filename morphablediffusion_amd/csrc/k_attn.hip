@@ -225,7 +225,52 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// fp32 -> fp32 variant (in place allowed): the extended-precision attention of the first-stage model
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ s, int cols, float* __restrict__ p) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float* sr = s + row * cols;
+  float* pr = p + row * cols;
+  float v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    v[i] = c < cols ? sr[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = expf(v[i] - mx);
+    sum += v[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < cols) pr[c] = v[i] * inv;
+  }
+}
+
 }  // namespace
+
+int launch_softmax_rows_f32(const float* s, long rows, int cols, float* p, hipStream_t st) {
+  if (cols > 4096 || rows > 0x7FFFFFFF) return mvd_fail("softmax_rows: cols <= 4096 expected");
+  hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st) {
   if (cols > 4096 || rows > 0x7FFFFFFF) return mvd_fail("softmax_rows: cols <= 4096 expected");

@@ -24,10 +24,11 @@ MAX_SAMPLE_SLOTS = 8  # per-sample mesh / camera tables kept resident in the con
 
 class Engine:
     def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0,
-                 precision_level: int = 2, train: bool = False):
+                 precision_level: int = 2, train: bool = False, vae_exact: bool = False):
         """precision_level: mvd_set_precision_level (0..6): how many of the output-side layers run with split fp16 operands
         (extended precision); 2 is the default the parity bounds are stated for."""
         self.precision_level = int(precision_level)
+        self.vae_exact = bool(vae_exact)  # mvd_set_vae_precision: first-stage model in extended precision (~3x its cost)
         self.train_mode = bool(train)  # mvd_train_enable: master parameters / gradients kept in flat arenas (training step)
         if not torch.cuda.is_available():
             raise L.MvdError("no MI355X visible: the denoiser has no CPU path")
@@ -67,6 +68,7 @@ class Engine:
                                         C.c_size_t(int(workspace_gb * (1 << 30))), C.byref(self._ctx)))
         L.check(self.lib.mvd_set_precision_level(self._ctx, self.precision_level))
         L.check(self.lib.mvd_train_enable(self._ctx, 1 if self.train_mode else 0))
+        L.check(self.lib.mvd_set_vae_precision(self._ctx, 1 if self.vae_exact else 0))
         self._loaded = False
         self.flat_params = self.flat_grads = self.flat_m = self.flat_v = None
         self.param_table = {}

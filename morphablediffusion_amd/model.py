@@ -276,11 +276,15 @@ class SyncMultiviewDiffusion(nn.Module):
                  output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
                  clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
                  first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2,
-                 train_mode=False, loss_scale=65536.0, recompute=True):
+                 train_mode=False, loss_scale=65536.0, recompute=True, first_stage_precision="fast"):
         """train_mode / loss_scale / recompute are not reference kwargs: train_mode keeps fp32 master parameters, gradients and
         Adam moments in the engine (training_step runs the backward pass); loss_scale multiplies dL/dpred so that the fp16 MFMA
         operands of the backward pass stay in range (un-done by the optimiser); recompute = per-block activation checkpointing
-        (the reference's use_checkpoint: True), False keeps every activation (fits the 288 GB of an MI355X, faster)."""
+        (the reference's use_checkpoint: True), False keeps every activation (fits the 288 GB of an MI355X, faster).
+        first_stage_precision: "fast" (fp16 operands: decoded images within 0.8 of an 8-bit step of the reference's) or "exact"
+        (extended precision: <= 1e-3 relative, ~3x the first-stage time)."""
+        if first_stage_precision not in ("fast", "exact"):
+            raise ValueError("first_stage_precision must be 'fast' or 'exact'")
         super().__init__()
         self.finetune_unet = finetune_unet
         self.scheduler_config = scheduler_config
@@ -308,7 +312,8 @@ class SyncMultiviewDiffusion(nn.Module):
                                                input_image_size=image_size, projection=projection,
                                                use_spatial_volume=use_spatial_volume)
         self.engine = Engine(self.model.diffusion_model.cfg, self.spatial_volume.cfg, device=device,
-                             workspace_gb=workspace_gb, precision_level=precision_level, train=train_mode)
+                             workspace_gb=workspace_gb, precision_level=precision_level, train=train_mode,
+                             vae_exact=first_stage_precision == "exact")
         self.model.diffusion_model.bind(self.engine)
         self.spatial_volume.bind(self.engine)
         self._device = torch.device(device)
