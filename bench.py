@@ -143,9 +143,9 @@ def train_main(args):
     """``--config train`` (NOT the headline metric): BASELINE.json configs[3]'s unit of work -- one training step of
     SyncMultiviewDiffusion (training_step morphable_diffusion.py:520-549 on B samples per GPU, N = 16 views, finetune_unet) =
     conditioner + UNet forward, MSE, backward through every UNet block, ONE all-reduce of the flat gradient arena (N > 1),
-    fused AdamW on the arenas, in-place re-pack of the fp16 weights.  ``prepare`` (VAE / CLIP on images) is replaced by seeded
-    latents.  fp16 MFMA operands, fp32 accumulation and master weights, dynamic loss scale; the conditioner's own backward
-    (spatial_volume / time_embed gradients) is not built and not counted."""
+    fused AdamW on the arenas, in-place re-pack of the fp16 weights; the conditioner's backward (spatial_volume / time_embed
+    gradients) runs per sample.  ``prepare`` (VAE / CLIP on images) is replaced by seeded latents.  fp16 MFMA operands, fp32
+    accumulation and master weights, dynamic loss scale."""
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -226,7 +226,7 @@ def train_main(args):
                           "name": "train", "batch_per_gpu": B, "parallelism": f"data-parallel x{world}" if world > 1 else "single GPU"},
                "unet_tflops": per_sample * B * world / (dt / args.steps) / 1e12,
                "loss_first_last": [lv[0], lv[-1]], "loss_scale": model.loss_scale, "optimizer_steps_skipped": opt.steps_skipped,
-               "not_built": "backward of the conditioner (spatial_volume.*, time_embed.*): their gradients stay zero",
+               "not_built": "bf16 storage (fp16 operands + loss scale instead)",
                "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -188,6 +188,17 @@ int mvd_train_unet_step(mvd_ctx* ctx, const float* x, const int64_t* timesteps, 
                         const float* src1, const float* src2, const float* src3, int depth0, const float* target, float loss_scale,
                         int recompute, float* pred_out, float* loss_out, float* dsrc0, float* dsrc1, float* dsrc2, float* dsrc3,
                         void* stream);
+/* The conditioner's backward for ONE sample (its mesh / cameras active: mvd_select_sample): re-runs construct_spatial_volume and
+ * construct_view_frustum_volume (morphable_diffusion.py:203-320: step embedding, 2-D encoder on the N noisy views, vertex gather,
+ * view fusion, sparse voxel CNN in train mode, lattice gather, frustum gather and FrustumTV3DNet for the target view) with every
+ * intermediate kept, then back-propagates dsrc{0..3} = dL/d(frustum volume l) [1,C_l,D_l,s_l,s_l] (what mvd_train_unet_step
+ * returns for that sample, after the condition-dropout mask) into the gradients of spatial_volume.* and time_embed.*
+ * (accumulated into the arena).  x_noisy [N,4,s,s], v_embed [N,view_dim] device pointers; timestep / target_index host values.
+ * dbg_* (each may be NULL): dL/d(32^3 volume) [64,V,V,V], dL/d(fused vertex features) [Nv,16], dL/d(2-D encoder output)
+ * [N,16,s,s], dL/d(step embedding) [time_dim] -- for the parity tests.  The three gather adjoints use fp32 atomic adds. */
+int mvd_train_conditioner_backward(mvd_ctx* ctx, const float* x_noisy, int64_t timestep, const float* v_embed, int n_views,
+                                   int target_index, const float* dsrc0, const float* dsrc1, const float* dsrc2, const float* dsrc3,
+                                   float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream);
 /* Parity hook: the backward pass of ONE DepthTransformer (attention.py:49-84; cond_index 0 = middle_conditions, 1 + k =
  * output_conditions.k) given its input x [B,dim,H,W], its context volume [B,C_l,D_l,H,W] and dL/d(output) [B,dim,H,W]:
  * dx, dcontext (may be NULL) are written, parameter gradients accumulated into the arena.  depth0 = D of the finest level. */

@@ -43,6 +43,7 @@ struct NormW {
   std::string key;  // state_dict prefix ("....norm"): <key>.weight / <key>.bias
 };
 struct LinW {  // small per-sample linear: fp16 [N][K]
+  std::string key;  // state_dict prefix (<key>.weight / <key>.bias); empty for stacked matrices
   half_t* w = nullptr;
   float* bias = nullptr;
   int N = 0, K = 0;
@@ -137,6 +138,8 @@ struct FrustumBlockW {
   int cin = 0, cout = 0, stride = 1;
 };
 struct SparseLayerW {
+  std::string wkey, bnkey;  // state_dict keys of the conv weight / of its BatchNorm1d (prefix)
+  int layout = 0;           // layout of the uploaded weight (build_sparse_layer): the gradient goes back in the same one
   float* w = nullptr;      // [27][Cin][Cout] fp32
   float* scale = nullptr;  // folded eval BatchNorm
   float* shift = nullptr;
@@ -375,6 +378,7 @@ int engine_repack(mvd_ctx* c);
 int engine_train_setup(mvd_ctx* c);     // finalize, train mode: masters into the arena
 bool engine_hot_key(const std::string& k);  // a key of the re-packable sections (UNet / conditioner / step embedding)
 int engine_build_dgrad(mvd_ctx* c);     // adjoint weights of every UNet GEMM (ConvW::wT)
+int engine_build_dgrad_cond(mvd_ctx* c);  // ... of the conditioner's dense convolutions
 float* engine_grad(mvd_ctx* c, const std::string& key);         // gradient / master of a state_dict entry (nullptr: not a parameter)
 const float* engine_master(mvd_ctx* c, const std::string& key);
 int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes);         // owned allocation; replays the recorded one while re-packing
@@ -382,6 +386,13 @@ int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes);         // owned allocat
 // forward with the tape, loss = mean((pred - target)^2), dL/dpred * loss_scale back through every block; parameter gradients
 // are ACCUMULATED into the gradient arena (x loss_scale).  dsrc[l] (may be null): gradient w.r.t. the context volumes,
 // channels-last like src[l].  recompute: keep only block inputs and re-run each block before its backward.
+// Backward of the mesh conditioner for ONE sample (its mesh / cameras active): re-runs construct_spatial_volume +
+// construct_view_frustum_volume (morphable_diffusion.py:203-320) for the sample's N noisy views and target view with every
+// intermediate kept, then back-propagates dsrc[l] = dL/d(frustum volume l) (channels-last) into the parameters of
+// spatial_volume.* and time_embed.*.  dbg_*: optional outputs for the parity tests.
+int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int64_t timestep, const float* v_embed, int n_views,
+                                      int target_idx, float* const dsrc[4], float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats,
+                                      float* dbg_dtembed, hipStream_t s);
 int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const float* ctx_vol, const float* dout, int B, int H, int W,
                                int level, int depth0, float* dx, float* dctx, hipStream_t s);
 int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,

@@ -26,7 +26,7 @@
 int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split = 0);
 int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int C, int stride, int ups, half_t* dst, int Rp, hipStream_t s);
 int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split = 0);
-int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s);
+int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s, int flip = 1);
 int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const float* dy, long ldy, int B, int rows, int C, int G,
                    const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
                    float* db_part, float* dpre_part, hipStream_t s);
@@ -50,6 +50,23 @@ int bwd_col2im3(const float* dcol, int B, int H, int W, int C, int stride, float
 int bwd_silu_inplace(float* g, const float* u, size_t n, hipStream_t s);
 int bwd_attention(const half_t* qkv, int ld3, const half_t* o, const half_t* dO, int ldo, half_t* dqkv, int ldd, float* lse, float* delta,
                   int B, int T, int heads, int d, hipStream_t s);
+int bwd_silu_fwd(const float* u, float* out, size_t n, hipStream_t s);
+// k_cond_bwd.hip
+int cbwd_frustum_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V, float vol_len, int persp,
+                         float* d_vol, hipStream_t s);
+int cbwd_latent_scatter(const float* d_vol, const int* grid, int gd, int gh, int gw, const float* min_xyz, const int* out_sh, float voxel,
+                        int V, float vol_len, float* d_rows, hipStream_t s);
+int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
+                        float vol_len, int S, int persp, float* d_feats, hipStream_t s);
+int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views, int Nv, int total_views, float* d_vf, float* dw, float* db,
+              hipStream_t s);
+int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, float eps, float* dgamma,
+                      float* dbeta, hipStream_t s);
+int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
+                     float* dw_packed, hipStream_t s);
+int cbwd_sparse_w_unpack_add(const float* pk, int Cin, int Cout, int layout, float* dst, hipStream_t s);
+int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, int W, int C, int stride, half_t* dst, int Rp, hipStream_t s);
+int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_t* w, int K, float* out, long ldo, int accum, hipStream_t s);
 // k_train.hip
 int train_im2col3(const float* X, int B, int H, int W, int C, float* col, hipStream_t s);
 int train_col2im3(const float* dcol, int B, int H, int W, int C, float* dX, hipStream_t s);
@@ -127,12 +144,12 @@ const float* engine_master(mvd_ctx* c, const std::string& key) {
 
 // adjoint weights of every GEMM of the UNet trunk (ResBlocks, SpatialTransformers, conv_in / down / up, the output conv)
 namespace {
-int make_wT(mvd_ctx* c, ConvW& w) {
+int make_wT(mvd_ctx* c, ConvW& w, int flip = 1) {
   if (!w.w) return 0;
   const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
   w.Np = up8(w.N);
   RET_IF(engine_dmalloc(c, (void**)&w.wT, (size_t)w.taps * Cl * w.Np * sizeof(half_t)));
-  return bwd_pack_dgrad(w.w, w.taps, w.N, w.Cin, Cl, w.Np, w.wT, 0);
+  return bwd_pack_dgrad(w.w, w.taps, w.N, w.Cin, Cl, w.Np, w.wT, 0, flip);
 }
 }  // namespace
 int engine_build_dgrad(mvd_ctx* c) {
@@ -145,6 +162,19 @@ int engine_build_dgrad(mvd_ctx* c) {
     for (ConvW* w : {&t.proj_in, &t.qkv, &t.attn_out, &t.ff1, &t.ff2, &t.proj_out}) RET_IF(make_wT(c, *w));
   for (auto& w : c->convs) RET_IF(make_wT(c, w));
   RET_IF(make_wT(c, c->out_conv));
+  return 0;
+}
+// ... and of the conditioner's dense convolutions.  A strided conv's adjoint is launched as a transposed conv and vice versa
+// (their tap tables carry the o = 2 i - 1 + k relation), so those packs are transposed but not tap-flipped.
+int engine_build_dgrad_cond(mvd_ctx* c) {
+  for (int i = 0; i < 3; ++i) {
+    RET_IF(make_wT(c, c->enc_blocks[i].c1));
+    RET_IF(make_wT(c, c->enc_blocks[i].c2));
+  }
+  RET_IF(make_wT(c, c->enc_final));
+  RET_IF(make_wT(c, c->fr_conv0));
+  for (int i = 0; i < 6; ++i) RET_IF(make_wT(c, c->fr_blocks[i].conv, c->fr_blocks[i].stride == 1 ? 1 : 0));
+  for (int i = 0; i < 3; ++i) RET_IF(make_wT(c, c->fr_up[i].conv, 0));
   return 0;
 }
 
@@ -327,19 +357,23 @@ int wgrad_conv3(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x
   return 0;
 }
 // GroupNorm backward incl. its gain / bias gradients (slabbed: B * G * S workgroups)
+// pre / pld: the per-sample pre-add of the forward norm (FiLM); dpre [B][ldp] (may be null) receives its gradient
 int gn_backward(Bwd& b, const NormW& n, int groups, float eps, int act, const float* x, long ld, const float* dy, long ldy, int rows_ps,
-                float* dx, long lddx, bool accum) {
+                float* dx, long lddx, bool accum, const float* pre = nullptr, int pld = 0, float* dpre = nullptr, long ldp = 0) {
   mvd_ctx* c = b.c;
   WsScope scope(c, WS_TEMP);
   const int S = bwd_gn_slabs(b.B, groups, rows_ps);
   float* dg = ws_alloc<float>(c, (size_t)b.B * S * n.C);
   float* db = ws_alloc<float>(c, (size_t)b.B * S * n.C);
+  float* dp = dpre ? ws_alloc<float>(c, (size_t)b.B * S * n.C) : nullptr;
   float* part = ws_alloc<float>(c, (size_t)b.B * groups * S * 4);
-  WS_CHECK(dg && db && part);
-  RET_IF(bwd_group_norm_slab(x, ld, nullptr, 0, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, part,
-                             part + (size_t)b.B * groups * S * 2, dg, db, nullptr, S, b.s));
+  WS_CHECK(dg && db && part && (dp || !dpre));
+  RET_IF(bwd_group_norm_slab(x, ld, pre, pld, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, part,
+                             part + (size_t)b.B * groups * S * 2, dg, db, dp, S, b.s));
   if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(dg, b.B * S, n.C, n.C, G, 1, b.s));
   if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(db, b.B * S, n.C, n.C, G, 1, b.s));
+  if (dpre)
+    for (int i = 0; i < b.B; ++i) RET_IF(bwd_sum_rows_add(dp + (size_t)i * S * n.C, S, n.C, n.C, dpre + (size_t)i * ldp, 0, b.s));
   return 0;
 }
 // GroupNorm forward in fp32 for the DepthTransformer re-computation
@@ -742,6 +776,85 @@ int bwd_attn2(Bwd& b) {
   return 0;
 }
 
+// ---- mesh conditioner (SpatialVolumeNet) -------------------------------------------------------------------------------
+// weight + bias gradient of a 3x3x3 conv (stride as in the forward): dy fp32 [rows_out][N] channels-last, x [B,D,H,W,K]
+int wgrad_conv3d(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int D, int H, int W, int K,
+                 int stride) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int rows = b.B * Do * Ho * Wo, Rp = up64(rows), N = w.N;
+  if (float* G = engine_grad(c, w.key)) {
+    half_t* dyT = ws_alloc<half_t>(c, (size_t)N * Rp);
+    half_t* colT = ws_alloc<half_t>(c, (size_t)K * 27 * Rp);
+    WS_CHECK(dyT && colT);
+    RET_IF(bwd_tcast(dy, 1, ldy, rows, N, dyT, Rp, b.s));
+    RET_IF(cbwd_im2colT3d(x, x_f32, ldx, b.B, D, H, W, K, stride, colT, Rp, b.s));
+    RET_IF(wgrad_gemm(b, dyT, N, colT, K * 27, Rp, G));
+  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
+    float* part = ws_alloc<float>(c, (size_t)b.B * N);
+    WS_CHECK(part);
+    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, Do * Ho * Wo, N, part, N, b.s));
+    RET_IF(bwd_sum_rows_add(part, b.B, N, N, Gb, 1, b.s));
+  }
+  return 0;
+}
+// ConvTranspose3d(k3, s2, p1, op1), weight [Cin][Cout][27]:  dW[ci][co*27 + k] = sum_i x[i][ci] dy[2 i - 1 + k][co] -- the strided
+// conv's weight gradient with the roles swapped: dy (the fine volume [B,2D,2H,2W,Cout]) is the image, x [B,D,H,W,Cin] the "output
+// gradient"
+int wgrad_convT3d(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int D, int H, int W) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  const int Cin = w.cin_l > 0 ? w.cin_l : w.Cin, Cout = w.N;
+  const int rows = b.B * D * H * W, Rp = up64(rows);
+  if (float* G = engine_grad(c, w.key)) {
+    half_t* xT = ws_alloc<half_t>(c, (size_t)Cin * Rp);
+    half_t* colT = ws_alloc<half_t>(c, (size_t)Cout * 27 * Rp);
+    WS_CHECK(xT && colT);
+    RET_IF(bwd_tcast(x, x_f32, ldx, rows, Cin, xT, Rp, b.s));
+    RET_IF(cbwd_im2colT3d(dy, 1, ldy, b.B, 2 * D, 2 * H, 2 * W, Cout, 2, colT, Rp, b.s));
+    RET_IF(wgrad_gemm(b, xT, Cin, colT, Cout * 27, Rp, G));
+  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
+    float* part = ws_alloc<float>(c, (size_t)b.B * Cout);
+    WS_CHECK(part);
+    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, 8 * D * H * W, Cout, part, Cout, b.s));
+    RET_IF(bwd_sum_rows_add(part, b.B, Cout, Cout, Gb, 1, b.s));
+  }
+  return 0;
+}
+// adjoint of a 3x3x3 conv w.r.t. its input.  kind 0: stride-1 conv (the forward kernel on the flipped pack); 1: stride-2 conv
+// (launched as a transposed conv from dy's coarse grid D,H,W); 2: transposed conv (launched as a stride-2 conv from dy's fine grid)
+int dgrad_conv3d(Bwd& b, const ConvW& w, int kind, const half_t* dy16, float* dx, int lddx, int D, int H, int W, bool accum) {
+  if (!w.wT || w.taps != 27) return mvd_fail("training backward: 3x3x3 adjoint weights missing");
+  ConvW t;
+  t.w = w.wT;
+  t.N = w.cin_l > 0 ? w.cin_l : w.Cin;
+  t.Cin = w.Np;
+  t.taps = 27;
+  GemmArgs g;
+  g.a = dy16; g.lda = w.Np; g.w = &t; g.out = dx; g.ldc = lddx; g.use_bias = false;
+  if (accum) {
+    g.resid = dx;
+    g.ldr = lddx;
+  }
+  if (kind == 1) return run_convT3d(b.c, g, b.B, D, H, W, b.s);
+  return run_conv3d(b.c, g, b.B, D, H, W, kind == 2 ? 2 : 1, b.s);
+}
+// weight / bias gradient of a per-sample Linear (FiLM projections, step MLP): dW[N][K] += sum_r g[r][n] x[r][k], db += sum_r g
+int lin_wgrad(mvd_ctx* c, const std::string& key, const float* g, long ldg, const float* x, long ldx, int rows, int N, int K, hipStream_t s) {
+  if (float* G = engine_grad(c, key + ".weight")) RET_IF(bwd_outer_add(g, ldg, x, ldx, G, N, K, rows, s));
+  if (float* G = engine_grad(c, key + ".bias")) RET_IF(bwd_sum_rows_add(g, rows, N, ldg, G, 1, s));
+  return 0;
+}
+
+__global__ void iota_kernel(int* p, int n, int start) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = start + i;
+}
+__global__ void set_i64_kernel(int64_t* p, int64_t v) { *p = v; }
+
 __global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, float k, size_t n, float* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = k * (pred[i] - target[i]);
 }
@@ -916,4 +1029,322 @@ int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const f
   g_out.p = const_cast<float*>(dout); g_out.ld = cd.dim; g_out.C = cd.dim;
   g_in.p = dx; g_in.ld = cd.dim; g_in.C = cd.dim;
   return bwd_cond(b, cd, in, g_out, g_in, false, H, W, level);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int64_t timestep, const float* v_embed, int n_views,
+                                      int target_idx, float* const dsrc[4], float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats,
+                                      float* dbg_dtembed, hipStream_t s) {
+  if (!c->finalized || !c->train_mode) return mvd_fail("conditioner backward: context not finalized in training mode");
+  if (!c->has_cond || !c->has_step) return mvd_fail("conditioner backward: spatial_volume / time_embed weights not uploaded");
+  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
+  if (n_views != c->v.num_views || target_idx < 0 || target_idx >= n_views) return mvd_fail("conditioner backward: bad view arguments");
+  for (int l = 0; l < 4; ++l)
+    if (!dsrc[l]) return mvd_fail("conditioner backward: dL/d(frustum volume) of every level is required");
+  WsScope scope(c);
+  MeshTables& m = c->mesh;
+  const int N = n_views, S = c->u.image_size, HW = S * S, rows = N * HW, td = c->v.time_dim, vd = c->v.view_dim, Nv = m.Nv;
+  const int V = c->v.spatial_volume_size, persp = c->v.projection == 0;
+  const std::string SV = "spatial_volume.", FV = SV + "frustum_volume_feats.";
+  auto F = [&](size_t n) { return ws_alloc<float>(c, n); };
+  auto H16 = [&](size_t n) { return ws_alloc<half_t>(c, n); };
+  // ================= forward, every intermediate kept =================
+  // step embedding (morphable_diffusion.py:491-494): t_emb = W2 silu(W0 temb(t) + b0) + b2
+  int64_t* t_dev = (int64_t*)c->ws.alloc(sizeof(int64_t));
+  float *e0 = F(td), *u1 = F(td), *e1 = F(td), *t_emb = F(td);
+  int* vidx = (int*)c->ws.alloc(sizeof(int) * (N + 1));
+  WS_CHECK(t_dev && e0 && u1 && e1 && t_emb && vidx);
+  hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, t_dev, timestep);
+  hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx, N, 0);
+  hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx + N, 1, target_idx);
+  HIP_CHECK_RET(hipGetLastError());
+  RET_IF(launch_timestep_embedding(t_dev, 1, td, e0, s));
+  RET_IF(launch_small_linear(e0, td, 1, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, u1, td, 0, s));
+  RET_IF(bwd_silu_fwd(u1, e1, td, s));
+  RET_IF(launch_small_linear(e1, td, 1, td, c->step_te2.w, c->step_te2.bias, td, ACT_NONE, t_emb, td, 0, s));
+  // 2-D encoder (NoisyTargetViewEncoder, network.py:181-207), layer by layer and in EXTENDED precision (hi/lo operand split on
+  // packs made here from the master weights; 16 channels: the cost is nothing): the sparse CNN behind it has nine BatchNorm +
+  // ReLU layers whose masks are re-derived from these features -- an fp16-rounded encoder moves the gradients upstream of them
+  // by 4-10e-2 (measured), the extended-precision one by 1e-3
+  float *x8 = F((size_t)rows * 8), *pre_e = F((size_t)N * 48), *feats = F((size_t)rows * 16);
+  float* cur_e[4];
+  float* r1_e[3];
+  half_t *a1_e[3], *a2_e[3], *af = H16((size_t)rows * 48), *x8s = H16((size_t)rows * 24);
+  for (int i = 0; i < 4; ++i) cur_e[i] = F((size_t)rows * 16);
+  for (int i = 0; i < 3; ++i) {
+    r1_e[i] = F((size_t)rows * 16);
+    a1_e[i] = H16((size_t)rows * 48);
+    a2_e[i] = H16((size_t)rows * 48);
+    WS_CHECK(r1_e[i] && a1_e[i] && a2_e[i]);
+  }
+  WS_CHECK(x8 && pre_e && feats && af && x8s && cur_e[0] && cur_e[1] && cur_e[2] && cur_e[3]);
+  auto xp_pack = [&](const ConvW& w, int cin_src, ConvW* o) -> int {
+    const float* mw = engine_master(c, w.key);
+    if (!mw) return mvd_fail("conditioner backward: encoder master weights missing");
+    *o = w;
+    const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
+    o->xp = 1;
+    o->cin_l = Cl;
+    o->Cin = 3 * Cl;
+    o->wT = nullptr;
+    o->w = H16((size_t)w.taps * w.N * 3 * Cl);
+    WS_CHECK(o->w);
+    return launch_pack_weight(mw, w.N, 3 * Cl, w.taps, 0, 0, o->w, s, cin_src, 1);
+  };
+  ConvW x_init, x_c1[3], x_c2[3], x_final;
+  RET_IF(xp_pack(c->enc_init, 4, &x_init));
+  for (int i = 0; i < 3; ++i) {
+    RET_IF(xp_pack(c->enc_blocks[i].c1, 16, &x_c1[i]));
+    RET_IF(xp_pack(c->enc_blocks[i].c2, 16, &x_c2[i]));
+  }
+  RET_IF(xp_pack(c->enc_final, 16, &x_final));
+  RET_IF(launch_small_linear(t_emb, td, -N, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre_e, 48, 0, s));
+  RET_IF(launch_small_linear(v_embed, vd, N, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre_e, 48, 1, s));
+  RET_IF(launch_nchw_to_nhwc(x_noisy_nchw, N, 4, HW, x8, 8, 8, s));
+  RET_IF(launch_rows_f32_to_f16_split(x8, 8, rows, 8, x8s, s));
+  GemmArgs g;
+  g.a = x8s; g.lda = 24; g.w = &x_init; g.out = cur_e[0]; g.ldc = 16; g.force_splitk = 1;
+  RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
+  for (int i = 0; i < 3; ++i) {
+    const EncBlockW& e = c->enc_blocks[i];
+    RET_IF(run_group_norm(c, cur_e[i], 16, N, HW, e.n1, 8, 1e-5f, ACT_SILU, pre_e + 16 * i, a1_e[i], 48, s, 48, 1));
+    g = GemmArgs();
+    g.a = a1_e[i]; g.lda = 48; g.w = &x_c1[i]; g.out = r1_e[i]; g.ldc = 16; g.force_splitk = 1;
+    RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
+    RET_IF(run_group_norm(c, r1_e[i], 16, N, HW, e.n2, 8, 1e-5f, ACT_SILU, nullptr, a2_e[i], 48, s, 0, 1));
+    g = GemmArgs();
+    g.a = a2_e[i]; g.lda = 48; g.w = &x_c2[i]; g.out = cur_e[i + 1]; g.ldc = 16; g.resid = cur_e[i]; g.ldr = 16; g.force_splitk = 1;
+    RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
+  }
+  RET_IF(run_group_norm(c, cur_e[3], 16, N, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, af, 48, s, 0, 1));
+  g = GemmArgs();
+  g.a = af; g.lda = 48; g.w = &x_final; g.out = feats; g.ldc = 16; g.force_splitk = 1;
+  RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
+  // vertex features, view fusion
+  float *vf = F((size_t)N * Nv * 16), *fused = F((size_t)Nv * 16);
+  WS_CHECK(vf && fused);
+  RET_IF(launch_vertex_gather(feats, c->cams, vidx, N, m.verts, Nv, V, c->v.spatial_volume_length, S, persp, vf, s));
+  RET_IF(launch_fuse_views(vf, N, Nv, N, c->fuse_w, c->fuse_b, fused, 0, s));
+  // sparse voxel CNN, train mode: raw conv output and post-activation rows of every layer
+  const float* sp_in[9];
+  float *sp_raw[9], *sp_post[9];
+  const int* sp_nbr[9];
+  int sp_nout[9], sp_nin[9];
+  {
+    const float* in = fused;
+    int lvl = 0, n_in = Nv;
+    for (int i = 0; i < 9; ++i) {
+      const SparseLayerW& L = c->sparse[i];
+      if (L.strided) {
+        sp_nbr[i] = m.nbr_down[lvl];
+        ++lvl;
+      } else {
+        sp_nbr[i] = m.nbr_subm[lvl];
+      }
+      sp_nout[i] = m.n_sites[lvl];
+      sp_nin[i] = n_in;
+      sp_in[i] = in;
+      sp_raw[i] = F((size_t)sp_nout[i] * L.cout);
+      sp_post[i] = F((size_t)sp_nout[i] * L.cout);
+      WS_CHECK(sp_raw[i] && sp_post[i]);
+      RET_IF(launch_sparse_conv(in, sp_nbr[i], sp_nout[i], L.cin, L.cout, L.w, nullptr, nullptr, sp_raw[i], s));
+      HIP_CHECK_RET(hipMemcpyAsync(sp_post[i], sp_raw[i], (size_t)sp_nout[i] * L.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+      RET_IF(launch_bn_rows_relu(sp_post[i], sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, s));
+      in = sp_post[i];
+      n_in = sp_nout[i];
+    }
+  }
+  float* volume = F((size_t)V * V * V * 64);
+  WS_CHECK(volume);
+  RET_IF(launch_latent_gather(sp_post[8], m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
+                              c->v.spatial_volume_length, volume, s));
+  // frustum gather + FrustumTV3DNet (network.py:313-347) for the target view
+  const int* fd = c->v.frustum_dims;
+  int Dl[4], Sl[4];
+  size_t vox[4];
+  for (int l = 0; l < 4; ++l) {
+    Dl[l] = l ? (Dl[l - 1] - 1) / 2 + 1 : c->v.frustum_volume_depth;
+    Sl[l] = l ? (Sl[l - 1] - 1) / 2 + 1 : c->v.input_image_size / 8;
+    vox[l] = (size_t)Dl[l] * Sl[l] * Sl[l];
+  }
+  const int FT = c->film_total;
+  half_t* gath = H16(vox[0] * 64);
+  float* pre_f = F(FT);
+  float *xd[4], *xf[4], *tmp_f[3];
+  half_t *a1_f[3], *a2_f[3], *au_f[3];
+  for (int l = 0; l < 4; ++l) {
+    xd[l] = F(vox[l] * fd[l]);
+    xf[l] = F(vox[l] * fd[l]);
+    WS_CHECK(xd[l] && xf[l]);
+  }
+  for (int l = 0; l < 3; ++l) {
+    tmp_f[l] = F(vox[l + 1] * fd[l + 1]);
+    a1_f[l] = H16(vox[l] * fd[l]);
+    a2_f[l] = H16(vox[l + 1] * fd[l + 1]);
+    au_f[l] = H16(vox[l + 1] * fd[l + 1]);
+    WS_CHECK(tmp_f[l] && a1_f[l] && a2_f[l] && au_f[l]);
+  }
+  WS_CHECK(gath && pre_f);
+  RET_IF(launch_frustum_gather(volume, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp, gath, s));
+  g = GemmArgs();
+  g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = xd[0]; g.ldc = fd[0];
+  RET_IF(run_conv3d(c, g, 1, Dl[0], Sl[0], Sl[0], 1, s));
+  RET_IF(launch_small_linear(t_emb, td, 1, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre_f, FT, 0, s));
+  RET_IF(launch_small_linear(v_embed + (size_t)target_idx * vd, vd, 1, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre_f, FT, 1, s));
+  for (int l = 0; l < 3; ++l) {
+    const FrustumBlockW& b1 = c->fr_blocks[2 * l];
+    const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
+    RET_IF(run_group_norm(c, xd[l], fd[l], 1, (int)vox[l], b1.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l], a1_f[l], fd[l], s, FT));
+    g = GemmArgs();
+    g.a = a1_f[l]; g.lda = fd[l]; g.w = &b1.conv; g.out = tmp_f[l]; g.ldc = fd[l + 1];
+    RET_IF(run_conv3d(c, g, 1, Dl[l], Sl[l], Sl[l], 2, s));
+    RET_IF(run_group_norm(c, tmp_f[l], fd[l + 1], 1, (int)vox[l + 1], b2.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l + 1], a2_f[l],
+                          fd[l + 1], s, FT));
+    g = GemmArgs();
+    g.a = a2_f[l]; g.lda = fd[l + 1]; g.w = &b2.conv; g.out = xd[l + 1]; g.ldc = fd[l + 1];
+    RET_IF(run_conv3d(c, g, 1, Dl[l + 1], Sl[l + 1], Sl[l + 1], 1, s));
+  }
+  HIP_CHECK_RET(hipMemcpyAsync(xf[3], xd[3], vox[3] * fd[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int l = 2; l >= 0; --l) {
+    const FrustumBlockW& u = c->fr_up[2 - l];
+    RET_IF(run_group_norm(c, xf[l + 1], fd[l + 1], 1, (int)vox[l + 1], u.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[6 + (2 - l)], au_f[l],
+                          fd[l + 1], s, FT));
+    g = GemmArgs();
+    g.a = au_f[l]; g.lda = fd[l + 1]; g.w = &u.conv; g.out = xf[l]; g.ldc = fd[l]; g.resid = xd[l]; g.ldr = fd[l];
+    RET_IF(run_convT3d(c, g, 1, Dl[l + 1], Sl[l + 1], Sl[l + 1], s));
+  }
+  // ================= backward =================
+  Fwd f{c, s, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  TrainTape tape;
+  Bwd b{c, s, 1, &f, &tape};
+  float* d_pre_f = F(FT);
+  float* d_temb = F(td);
+  WS_CHECK(d_pre_f && d_temb);
+  HIP_CHECK_RET(hipMemsetAsync(d_pre_f, 0, FT * sizeof(float), s));
+  HIP_CHECK_RET(hipMemsetAsync(d_temb, 0, td * sizeof(float), s));
+  float* gl[4] = {dsrc[0], dsrc[1], dsrc[2], dsrc[3]};  // dL/d x_l, accumulated in place
+  half_t* dy16;
+  // up path (forward order l = 2, 1, 0): x_l = xd_l + convT(silu(GN(xf_{l+1} + film)))
+  for (int l = 0; l <= 2; ++l) {
+    WsScope sc(c, WS_BLOCK);
+    const FrustumBlockW& u = c->fr_up[2 - l];
+    float* d_au = F(vox[l + 1] * fd[l + 1]);
+    WS_CHECK(d_au);
+    RET_IF(grad16(c, gl[l], fd[l], (long)vox[l], fd[l], &dy16, s));
+    RET_IF(dgrad_conv3d(b, u.conv, 2, dy16, d_au, fd[l + 1], Dl[l], Sl[l], Sl[l], false));
+    RET_IF(wgrad_convT3d(b, u.conv, gl[l], fd[l], au_f[l], 0, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1]));
+    RET_IF(gn_backward(b, u.gn, 8, 1e-5f, ACT_SILU, xf[l + 1], fd[l + 1], d_au, fd[l + 1], (int)vox[l + 1], gl[l + 1], fd[l + 1], true,
+                       pre_f + c->film_off[6 + (2 - l)], FT, d_pre_f + c->film_off[6 + (2 - l)], FT));
+  }
+  // down path (forward order l = 0, 1, 2)
+  for (int l = 2; l >= 0; --l) {
+    WsScope sc(c, WS_BLOCK);
+    const FrustumBlockW& b1 = c->fr_blocks[2 * l];
+    const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
+    float *d_a2 = F(vox[l + 1] * fd[l + 1]), *d_tmp = F(vox[l + 1] * fd[l + 1]), *d_a1 = F(vox[l] * fd[l]);
+    WS_CHECK(d_a2 && d_tmp && d_a1);
+    RET_IF(grad16(c, gl[l + 1], fd[l + 1], (long)vox[l + 1], fd[l + 1], &dy16, s));
+    RET_IF(dgrad_conv3d(b, b2.conv, 0, dy16, d_a2, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1], false));
+    RET_IF(wgrad_conv3d(b, b2.conv, gl[l + 1], fd[l + 1], a2_f[l], 0, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1], fd[l + 1], 1));
+    RET_IF(gn_backward(b, b2.gn, 8, 1e-5f, ACT_SILU, tmp_f[l], fd[l + 1], d_a2, fd[l + 1], (int)vox[l + 1], d_tmp, fd[l + 1], false,
+                       pre_f + c->film_off[2 * l + 1], FT, d_pre_f + c->film_off[2 * l + 1], FT));
+    RET_IF(grad16(c, d_tmp, fd[l + 1], (long)vox[l + 1], fd[l + 1], &dy16, s));
+    RET_IF(dgrad_conv3d(b, b1.conv, 1, dy16, d_a1, fd[l], Dl[l + 1], Sl[l + 1], Sl[l + 1], false));
+    RET_IF(wgrad_conv3d(b, b1.conv, d_tmp, fd[l + 1], a1_f[l], 0, fd[l], Dl[l], Sl[l], Sl[l], fd[l], 2));
+    RET_IF(gn_backward(b, b1.gn, 8, 1e-5f, ACT_SILU, xd[l], fd[l], d_a1, fd[l], (int)vox[l], gl[l], fd[l], true,
+                       pre_f + c->film_off[2 * l], FT, d_pre_f + c->film_off[2 * l], FT));
+  }
+  // conv0 on the gathered frustum features
+  float* d_gath = F(vox[0] * 64);
+  WS_CHECK(d_gath);
+  RET_IF(grad16(c, gl[0], fd[0], (long)vox[0], fd[0], &dy16, s));
+  RET_IF(dgrad_conv3d(b, c->fr_conv0, 0, dy16, d_gath, 64, Dl[0], Sl[0], Sl[0], false));
+  RET_IF(wgrad_conv3d(b, c->fr_conv0, gl[0], fd[0], gath, 0, 64, Dl[0], Sl[0], Sl[0], 64, 1));
+  // FiLM projections of the nine frustum blocks: film = t_conv(t_emb) + v_conv(v_embed[target])
+  for (int i = 0; i < 9; ++i) {
+    const FrustumBlockW& fb = i < 6 ? c->fr_blocks[i] : c->fr_up[i - 6];
+    const float* dp = d_pre_f + c->film_off[i];
+    RET_IF(lin_wgrad(c, fb.t_conv.key, dp, FT, t_emb, td, 1, fb.cin, td, s));
+    RET_IF(lin_wgrad(c, fb.v_conv.key, dp, FT, v_embed + (size_t)target_idx * vd, vd, 1, fb.cin, vd, s));
+  }
+  RET_IF(cbwd_small_linear_bwd(d_pre_f, FT, 1, FT, c->film_t.w, td, d_temb, td, 1, s));
+  // frustum gather, latent-code gather: scatter adjoints
+  float* d_vol = F((size_t)V * V * V * 64);
+  float* d_cur = F((size_t)sp_nout[8] * 64);
+  WS_CHECK(d_vol && d_cur);
+  HIP_CHECK_RET(hipMemsetAsync(d_vol, 0, (size_t)V * V * V * 64 * sizeof(float), s));
+  HIP_CHECK_RET(hipMemsetAsync(d_cur, 0, (size_t)sp_nout[8] * 64 * sizeof(float), s));
+  RET_IF(cbwd_frustum_scatter(d_gath, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp, d_vol, s));
+  if (dbg_dvolume) RET_IF(launch_nhwc_to_nchw(d_vol, 64, 1, 64, V * V * V, dbg_dvolume, s));
+  RET_IF(cbwd_latent_scatter(d_vol, m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
+                             c->v.spatial_volume_length, d_cur, s));
+  // sparse voxel CNN
+  for (int i = 8; i >= 0; --i) {
+    const SparseLayerW& L = c->sparse[i];
+    float* Gg = engine_grad(c, L.bnkey + ".weight");
+    float* Gb = engine_grad(c, L.bnkey + ".bias");
+    float* Gw = engine_grad(c, L.wkey);
+    if (!Gg || !Gb || !Gw) return mvd_fail("conditioner backward: sparse layer parameters missing from the arena");
+    RET_IF(cbwd_bn_rows_relu(sp_raw[i], d_cur, sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, Gg, Gb, s));
+    float* dwp = F((size_t)27 * L.cin * L.cout);
+    float* d_in = F((size_t)sp_nin[i] * L.cin);
+    WS_CHECK(dwp && d_in);
+    HIP_CHECK_RET(hipMemsetAsync(d_in, 0, (size_t)sp_nin[i] * L.cin * sizeof(float), s));
+    RET_IF(cbwd_sparse_conv(sp_in[i], sp_nbr[i], d_cur, sp_nout[i], L.cin, L.cout, L.w, d_in, dwp, s));
+    RET_IF(cbwd_sparse_w_unpack_add(dwp, L.cin, L.cout, L.layout, Gw, s));
+    d_cur = d_in;
+  }
+  float* d_fused = d_cur;  // [Nv][16]
+  if (dbg_dfused) HIP_CHECK_RET(hipMemcpyAsync(dbg_dfused, d_fused, (size_t)Nv * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // view fusion, vertex gather
+  float *d_vf = F((size_t)N * Nv * 16), *d_feats = F((size_t)rows * 16);
+  WS_CHECK(d_vf && d_feats);
+  RET_IF(cbwd_fuse(d_fused, vf, c->fuse_w, N, Nv, N, d_vf, engine_grad(c, SV + "smpl_feature_extractor.conv0.weight"),
+                   engine_grad(c, SV + "smpl_feature_extractor.conv0.bias"), s));
+  HIP_CHECK_RET(hipMemsetAsync(d_feats, 0, (size_t)rows * 16 * sizeof(float), s));
+  RET_IF(cbwd_vertex_scatter(d_vf, c->cams, vidx, N, m.verts, Nv, V, c->v.spatial_volume_length, S, persp, d_feats, s));
+  if (dbg_dfeats) RET_IF(launch_nhwc_to_nchw(d_feats, 16, N, 16, HW, dbg_dfeats, s));
+  // 2-D encoder, the N views as the batch
+  b.B = N;
+  float *d_a = F((size_t)rows * 16), *d_r = F((size_t)rows * 16), *d_x = F((size_t)rows * 16), *d_nxt = F((size_t)rows * 16);
+  float* d_pre_e = F((size_t)N * 48);
+  WS_CHECK(d_a && d_r && d_x && d_nxt && d_pre_e);
+  RET_IF(grad16(c, d_feats, 16, rows, 16, &dy16, s));
+  RET_IF(dgrad_conv3(b, c->enc_final, dy16, d_a, 16, S, S, false));
+  RET_IF(wgrad_conv3(b, c->enc_final, d_feats, 16, af, 0, 48, S, S, 16, 1, 0));
+  RET_IF(gn_backward(b, c->enc_final_norm, 8, 1e-5f, ACT_SILU, cur_e[3], 16, d_a, 16, HW, d_nxt, 16, false));
+  for (int i = 2; i >= 0; --i) {
+    const EncBlockW& e = c->enc_blocks[i];
+    RET_IF(grad16(c, d_nxt, 16, rows, 16, &dy16, s));
+    RET_IF(dgrad_conv3(b, e.c2, dy16, d_a, 16, S, S, false));
+    RET_IF(wgrad_conv3(b, e.c2, d_nxt, 16, a2_e[i], 0, 48, S, S, 16, 1, 0));
+    RET_IF(gn_backward(b, e.n2, 8, 1e-5f, ACT_SILU, r1_e[i], 16, d_a, 16, HW, d_r, 16, false));
+    RET_IF(grad16(c, d_r, 16, rows, 16, &dy16, s));
+    RET_IF(dgrad_conv3(b, e.c1, dy16, d_a, 16, S, S, false));
+    RET_IF(wgrad_conv3(b, e.c1, d_r, 16, a1_e[i], 0, 48, S, S, 16, 1, 0));
+    RET_IF(gn_backward(b, e.n1, 8, 1e-5f, ACT_SILU, cur_e[i], 16, d_a, 16, HW, d_x, 16, false, pre_e + 16 * i, 48, d_pre_e + 16 * i, 48));
+    RET_IF(bwd_add_views(d_x, 16, d_nxt, 16, nullptr, 0, rows, 16, 1, s));  // + the residual branch
+    std::swap(d_x, d_nxt);
+  }
+  RET_IF(wgrad_conv3(b, c->enc_init, d_nxt, 16, x8, 1, 8, S, S, 4, 1, 0));  // 4 latent channels (the pack pads them to 8)
+  {  // FiLM of the three encoder blocks: pre[v] = time_embed_i(t_emb) + view_embed_i(v_embed[v])
+    float* dsum = F(48);
+    WS_CHECK(dsum);
+    RET_IF(bwd_sum_rows_add(d_pre_e, N, 48, 48, dsum, 0, s));
+    for (int i = 0; i < 3; ++i) {
+      const EncBlockW& e = c->enc_blocks[i];
+      RET_IF(lin_wgrad(c, e.t.key, dsum + 16 * i, 48, t_emb, td, 1, 16, td, s));
+      RET_IF(lin_wgrad(c, e.v.key, d_pre_e + 16 * i, 48, v_embed, vd, N, 16, vd, s));
+    }
+    RET_IF(cbwd_small_linear_bwd(dsum, 48, 1, 48, c->enc_t.w, td, d_temb, td, 1, s));
+  }
+  if (dbg_dtembed) HIP_CHECK_RET(hipMemcpyAsync(dbg_dtembed, d_temb, td * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // step MLP
+  RET_IF(lin_wgrad(c, c->step_te2.key, d_temb, td, e1, td, 1, td, td, s));
+  float* d_e1 = F(td);
+  WS_CHECK(d_e1);
+  RET_IF(cbwd_small_linear_bwd(d_temb, td, 1, td, c->step_te2.w, td, d_e1, td, 0, s));
+  RET_IF(bwd_silu_inplace(d_e1, u1, td, s));
+  RET_IF(lin_wgrad(c, c->step_te0.key, d_e1, td, e0, td, 1, td, td, s));
+  return 0;
 }

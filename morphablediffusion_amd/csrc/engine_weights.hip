@@ -92,6 +92,7 @@ int pack_lin(mvd_ctx* c, const std::string& wkey, const std::string& bkey, LinW*
   RET_IF(get_raw(c, wkey, &r));
   o->N = (int)r->shape[0];
   o->K = (int)(r->numel / r->shape[0]);
+  o->key = wkey.size() > 7 ? wkey.substr(0, wkey.size() - 7) : wkey;  // strip ".weight"
   RET_IF(dmalloc(c, (void**)&o->w, r->numel * sizeof(half_t)));
   RET_IF(launch_f32_to_f16(r->d, o->w, r->numel, 0));
   if (!bkey.empty()) RET_IF(copy_f32(c, bkey, &o->bias));
@@ -200,6 +201,9 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   L->cin = cin;
   L->cout = cout;
   L->strided = strided;
+  L->wkey = wk;
+  L->bnkey = bn;
+  L->layout = layout;
   std::vector<float> hw(w->numel), pk(w->numel), hg(cout), hb(cout), hm(cout), hv(cout), sc(cout), sh(cout);
   HIP_CHECK_RET(hipMemcpy(hw.data(), w->d, w->numel * 4, hipMemcpyDeviceToHost));
   HIP_CHECK_RET(hipMemcpy(hg.data(), g->d, cout * 4, hipMemcpyDeviceToHost));
@@ -810,7 +814,10 @@ int build_hot_sections(mvd_ctx* c) {
     if (c->train_mode) RET_IF(engine_build_dgrad(c));
   }
   if (c->has_step) RET_IF(build_step_section(c));
-  if (c->has_cond) RET_IF(build_condnet_section(c));
+  if (c->has_cond) {
+    RET_IF(build_condnet_section(c));
+    if (c->train_mode) RET_IF(engine_build_dgrad_cond(c));
+  }
   return 0;
 }
 

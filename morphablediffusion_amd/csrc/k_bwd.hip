@@ -105,13 +105,15 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long ro
 
 // packed forward weight fp16 [taps][N][ldw] (first Cl columns of each row are w_hi) -> dgrad weight [taps][Cl][Np]:
 // wT[taps-1-t][ci][co] = w[t][co][ci]  (the tap flip turns the forward cross-correlation into its adjoint; Np >= N zero padded)
-__global__ void pack_dgrad_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np, half_t* __restrict__ wT) {
+// flip = 0: the taps keep their index (the adjoint of a strided conv / of a transposed conv is launched as the OTHER kind, whose
+// tap tables already carry the index relation o = 2 i - 1 + k)
+__global__ void pack_dgrad_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np, half_t* __restrict__ wT, int flip) {
   const long total = (long)taps * Cl * Np;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i % Np);
     const long tc = i / Np;
     const int ci = (int)(tc % Cl), t2 = (int)(tc / Cl);
-    const int t = taps - 1 - t2;
+    const int t = flip ? taps - 1 - t2 : t2;
     wT[i] = co < N ? w[((long)t * N + co) * ldw + ci] : (half_t)0;
   }
 }
@@ -576,6 +578,10 @@ __global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= act_d(u[i], ACT_SILU);
 }
 
+__global__ void silu_fwd_kernel(const float* __restrict__ u, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = act_f(u[i], ACT_SILU);
+}
+
 // d timestep_embedding is not needed (the time steps are data); the sinusoid itself is recomputed by the forward kernels.
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -950,8 +956,8 @@ int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* d
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s) {
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(gridn((size_t)taps * Cl * Np)), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT);
+int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s, int flip) {
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(gridn((size_t)taps * Cl * Np)), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -1053,6 +1059,11 @@ int bwd_col2im3(const float* dcol, int B, int H, int W, int C, int stride, float
 }
 int bwd_silu_inplace(float* g, const float* u, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(gridn(n)), dim3(256), 0, s, g, u, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int bwd_silu_fwd(const float* u, float* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(gridn(n)), dim3(256), 0, s, u, out, n);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,403 @@
+// Backward kernels of the mesh conditioner (SpatialVolumeNet, morphable_diffusion.py:151-320; networks network.py): the
+// adjoints of the gathers of k_cond.hip (same index arithmetic, scatter instead of gather), the sparse voxel CNN's layers in
+// train mode (conv dgrad / wgrad through the neighbour tables, BatchNorm1d with batch statistics + ReLU), the view fusion, and
+// the transposing im2col for the frustum network's 3-D convolutions.
+// The three scatters use hardware fp32 atomic adds (unordered: the conditioner's gradients are reproducible to rounding, not bit
+// for bit -- the UNet's are); everything else has fixed summation orders.
+#include "common.h"
+
+namespace {
+
+inline int gridn(size_t n, int cap = 8192) {
+  size_t g = (n + 255) / 256;
+  return (int)(g > (size_t)cap ? (size_t)cap : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ float linspace_at(float a, float b, int n, int i) {
+  const float step = (b - a) / (float)(n - 1);
+  return i < n / 2 ? a + step * (float)i : b - step * (float)(n - 1 - i);
+}
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const half_t* p) { return (float)*p; }
+
+// adjoint of frustum_gather_kernel: d_vol[corner][c] += w * d_out[point][c]   (d_out fp32 [TN*D*S*S][64])
+__global__ __launch_bounds__(256) void frustum_scatter_kernel(const float* __restrict__ d_out, const ViewCam* __restrict__ cams,
+                                                              const int* __restrict__ view_idx, int TN, int D, int S, int V, float vol_len,
+                                                              int persp, float* __restrict__ d_vol) {
+  constexpr int C = 64;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pt = gid >> 4;
+  const int cq = (int)(gid & 15) * 4;
+  const long npts = (long)TN * D * S * S;
+  if (pt >= npts) return;
+  const int x = (int)(pt % S), y = (int)((pt / S) % S), d = (int)((pt / ((long)S * S)) % D), tv = (int)(pt / ((long)S * S * D));
+  const ViewCam cam = cams[view_idx[tv]];
+  const float depth = linspace_at(0.f, 1.f, D, d) * (cam.far_ - cam.near_) + cam.near_;
+  float wx, wy, wz;
+  if (persp) {
+    const float a = (float)x * depth, b = (float)y * depth, c = depth;
+    wx = cam.Pinv[0] * a + cam.Pinv[1] * b + cam.Pinv[2] * c + cam.Pinv[3];
+    wy = cam.Pinv[4] * a + cam.Pinv[5] * b + cam.Pinv[6] * c + cam.Pinv[7];
+    wz = cam.Pinv[8] * a + cam.Pinv[9] * b + cam.Pinv[10] * c + cam.Pinv[11];
+  } else {
+    const float gx = 2.f * (float)x / (float)(S - 1) - 1.f, gy = 2.f * (float)y / (float)(S - 1) - 1.f;
+    const float a = cam.Kinv[0] * gx + cam.Kinv[1] * gy + cam.Kinv[2];
+    const float b = cam.Kinv[3] * gx + cam.Kinv[4] * gy + cam.Kinv[5];
+    const float c = depth;
+    wx = cam.Pinv[0] * a + cam.Pinv[1] * b + cam.Pinv[2] * c + cam.Pinv[3];
+    wy = cam.Pinv[4] * a + cam.Pinv[5] * b + cam.Pinv[6] * c + cam.Pinv[7];
+    wz = cam.Pinv[8] * a + cam.Pinv[9] * b + cam.Pinv[10] * c + cam.Pinv[11];
+  }
+  const float px = (wx / vol_len + 1.f) * 0.5f * (float)(V - 1), py = (wy / vol_len + 1.f) * 0.5f * (float)(V - 1),
+              pz = (wz / vol_len + 1.f) * 0.5f * (float)(V - 1);
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const float tx = px - fx, ty = py - fy, tz = pz - fz;
+  const float4 g = *(const float4*)(d_out + pt * C + cq);
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+    const int xx = x0 + bx, yy = y0 + by, zz = z0 + bz;
+    if (xx < 0 || xx > V - 1 || yy < 0 || yy > V - 1 || zz < 0 || zz > V - 1) continue;
+    const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
+    float* o = d_vol + (((long)zz * V + yy) * V + xx) * C + cq;
+    atomicAdd(o + 0, wgt * g.x);
+    atomicAdd(o + 1, wgt * g.y);
+    atomicAdd(o + 2, wgt * g.z);
+    atomicAdd(o + 3, wgt * g.w);
+  }
+}
+
+// adjoint of latent_gather_kernel: d_rows[row][c] += w * d_vol[point][c]
+__global__ void latent_scatter_kernel(const float* __restrict__ d_vol, const int* __restrict__ grid, int gd, int gh, int gw, float minx,
+                                      float miny, float minz, float shx, float shy, float shz, float voxel, int V, float vol_len, int C,
+                                      float* __restrict__ d_rows) {
+  const long total = (long)V * V * V * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int pt = (int)(idx / C);
+    const int ix = pt % V, iy = (pt / V) % V, iz = pt / (V * V);
+    const float X = linspace_at(-vol_len, vol_len, V, ix), Y = linspace_at(-vol_len, vol_len, V, iy),
+                Z = linspace_at(-vol_len, vol_len, V, iz);
+    const float gx = (X - minx) / voxel / shx * 2.f - 1.f;
+    const float gy = (Y - miny) / voxel / shy * 2.f - 1.f;
+    const float gz = (Z - minz) / voxel / shz * 2.f - 1.f;
+    const float px = (gx + 1.f) * 0.5f * (float)(gw - 1), py = (gy + 1.f) * 0.5f * (float)(gh - 1),
+                pz = (gz + 1.f) * 0.5f * (float)(gd - 1);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float tx = px - fx, ty = py - fy, tz = pz - fz;
+    const float g = d_vol[idx];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+      const int xx = x0 + bx, yy = y0 + by, zz = z0 + bz;
+      if (xx < 0 || xx > gw - 1 || yy < 0 || yy > gh - 1 || zz < 0 || zz > gd - 1) continue;
+      const int row = grid[((long)zz * gh + yy) * gw + xx];
+      if (row < 0) continue;
+      const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
+      atomicAdd(d_rows + (long)row * C + c, wgt * g);
+    }
+  }
+}
+
+// adjoint of vertex_gather_kernel: d_feats[view][pixel][c] += w2 * d_out[view][vertex][c]
+__global__ __launch_bounds__(256) void vertex_scatter_kernel(const float* __restrict__ d_out, const ViewCam* __restrict__ cams,
+                                                             const int* __restrict__ view_idx, int n_views, const float* __restrict__ verts,
+                                                             int Nv, int V, float vol_len, int S, int persp, float* __restrict__ d_feats) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_views * Nv) return;
+  const int view = idx / Nv, vi = idx - view * Nv;
+  const ViewCam cam = cams[view_idx[view]];
+  float pos[3], fr[3];
+  int lo[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float g = verts[vi * 3 + a] / vol_len;
+    pos[a] = (g + 1.0f) * 0.5f * (float)(V - 1);
+    const float f = floorf(pos[a]);
+    lo[a] = (int)f;
+    fr[a] = pos[a] - f;
+  }
+  float g16[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) g16[c] = d_out[(long)idx * 16 + c];
+  float* fv = d_feats + (long)view * S * S * 16;
+  for (int corner = 0; corner < 8; ++corner) {
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+    const int ix = lo[0] + bx, iy = lo[1] + by, iz = lo[2] + bz;
+    if (ix < 0 || ix > V - 1 || iy < 0 || iy > V - 1 || iz < 0 || iz > V - 1) continue;
+    const float w3 = (bx ? fr[0] : 1.f - fr[0]) * (by ? fr[1] : 1.f - fr[1]) * (bz ? fr[2] : 1.f - fr[2]);
+    const float X = linspace_at(-vol_len, vol_len, V, ix), Y = linspace_at(-vol_len, vol_len, V, iy),
+                Z = linspace_at(-vol_len, vol_len, V, iz);
+    const float u = cam.P[0] * X + cam.P[1] * Y + cam.P[2] * Z + cam.P[3];
+    const float v = cam.P[4] * X + cam.P[5] * Y + cam.P[6] * Z + cam.P[7];
+    float px, py;
+    if (persp) {
+      float w = cam.P[8] * X + cam.P[9] * Y + cam.P[10] * Z + cam.P[11];
+      w = w < 1e-4f ? 1e-4f : w;
+      const float hs = (float)(S - 1) * 0.5f;
+      px = ((u / w) / hs - 1.0f + 1.0f) * 0.5f * (float)(S - 1);
+      py = ((v / w) / hs - 1.0f + 1.0f) * 0.5f * (float)(S - 1);
+    } else {
+      px = (u + 1.0f) * 0.5f * (float)(S - 1);
+      py = (v + 1.0f) * 0.5f * (float)(S - 1);
+    }
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float tx = px - fx0, ty = py - fy0;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
+      if (xx < 0 || xx > S - 1 || yy < 0 || yy > S - 1) continue;
+      const float w2 = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * w3;
+      float* o = fv + ((long)yy * S + xx) * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) atomicAdd(o + c, w2 * g16[c]);
+    }
+  }
+}
+
+// ---- view fusion (SMPLFeatureExtractor, network.py:41-72): fused[v][co] = sum_ci w[co][ci] mean_view vf[view][v][ci] + b[co] ----
+// d_vf[view][v][ci] = (1 / total_views) sum_co w[co][ci] d_fused[v][co]  (the same for every view)
+__global__ void fuse_bwd_dvf_kernel(const float* __restrict__ d_fused, const float* __restrict__ w, int n_views, int Nv, int total_views,
+                                    float* __restrict__ d_vf) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Nv * 16) return;
+  const int v = idx >> 4, ci = idx & 15;
+  float acc = 0.f;
+#pragma unroll
+  for (int co = 0; co < 16; ++co) acc += w[co * 16 + ci] * d_fused[(long)v * 16 + co];
+  acc /= (float)total_views;
+  for (int view = 0; view < n_views; ++view) d_vf[((long)view * Nv + v) * 16 + ci] = acc;
+}
+// dw[co][ci] += sum_v d_fused[v][co] mean_view vf[.][v][ci];  db[co] += sum_v d_fused[v][co]: one workgroup per (co, ci)
+__global__ __launch_bounds__(256) void fuse_bwd_w_kernel(const float* __restrict__ d_fused, const float* __restrict__ vf, int n_views, int Nv,
+                                                         int total_views, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float s_a[256], s_b[256];
+  const int co = blockIdx.x >> 4, ci = blockIdx.x & 15, t = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int v = t; v < Nv; v += 256) {
+    float m = 0.f;
+    for (int view = 0; view < n_views; ++view) m += vf[((long)view * Nv + v) * 16 + ci];
+    const float g = d_fused[(long)v * 16 + co];
+    a += g * m / (float)total_views;
+    b += g;
+  }
+  s_a[t] = a;
+  s_b[t] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      s_a[t] += s_a[t + o];
+      s_b[t] += s_b[t + o];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    dw[co * 16 + ci] += s_a[0];
+    if (ci == 0) db[co] += s_b[0];
+  }
+}
+
+// ---- sparse voxel CNN, train mode -------------------------------------------------------------------------------------
+// BatchNorm1d (batch statistics over the n active rows, biased variance) + ReLU backward, one workgroup per channel:
+// xraw = the conv output, dy = gradient w.r.t. relu(bn(xraw)); writes d xraw over dy (in place), dgamma / dbeta accumulated.
+__global__ __launch_bounds__(256) void bn_rows_relu_bwd_kernel(const float* __restrict__ xraw, float* __restrict__ dy, int n, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_red[256];
+  auto bsum = [&](float v) {
+    s_red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+      __syncthreads();
+    }
+    const float r = s_red[0];
+    __syncthreads();
+    return r;
+  };
+  const int c = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int r = t; r < n; r += 256) a += xraw[(long)r * C + c];
+  const float mean = bsum(a) / (float)n;
+  float q = 0.f;
+  for (int r = t; r < n; r += 256) {
+    const float d = xraw[(long)r * C + c] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(bsum(q) / (float)n + eps), g = gamma[c], b = beta[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = t; r < n; r += 256) {
+    const float xh = (xraw[(long)r * C + c] - mean) * rstd;
+    const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
+    s1 += du;
+    s2 += du * xh;
+  }
+  const float S1 = bsum(s1), S2 = bsum(s2);
+  for (int r = t; r < n; r += 256) {
+    const float xh = (xraw[(long)r * C + c] - mean) * rstd;
+    const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
+    dy[(long)r * C + c] = g * rstd * (du - S1 / (float)n - xh * S2 / (float)n);
+  }
+  if (t == 0) {
+    dgamma[c] += S2;
+    dbeta[c] += S1;
+  }
+}
+
+// d_in[nbr[site][k]][ci] += sum_co w[k][ci][co] d_out[site][co]: one workgroup per output site
+__global__ __launch_bounds__(256) void sparse_conv_dgrad_kernel(const float* __restrict__ d_out, const int* __restrict__ nbr, int Cin,
+                                                                int Cout, const float* __restrict__ w, float* __restrict__ d_in) {
+  __shared__ int s_nb[27];
+  __shared__ float s_g[256];
+  const int site = blockIdx.x, t = threadIdx.x;
+  if (t < 27) s_nb[t] = nbr[(long)site * 27 + t];
+  if (t < Cout) s_g[t] = d_out[(long)site * Cout + t];
+  __syncthreads();
+  const int ci = t % Cin, p = t / Cin, P = 256 / Cin;
+  if (p >= P) return;
+  for (int k = p; k < 27; k += P) {
+    const int nb = s_nb[k];
+    if (nb < 0) continue;
+    const float* wk = w + ((long)k * Cin + ci) * Cout;
+    float acc = 0.f;
+    for (int co = 0; co < Cout; ++co) acc += wk[co] * s_g[co];
+    atomicAdd(d_in + (long)nb * Cin + ci, acc);
+  }
+}
+
+// dw[k][ci][co] = sum_site in[nbr[site][k]][ci] d_out[site][co]  (fixed order); grid (27, ceil(Cin*Cout / 256))
+__global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
+                                                                const float* __restrict__ d_out, int n_out, int Cin, int Cout,
+                                                                float* __restrict__ dw) {
+  const int k = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= Cin * Cout) return;
+  const int ci = e / Cout, co = e - ci * Cout;
+  float acc = 0.f;
+  for (int site = 0; site < n_out; ++site) {
+    const int nb = nbr[(long)site * 27 + k];
+    if (nb >= 0) acc += in[(long)nb * Cin + ci] * d_out[(long)site * Cout + co];
+  }
+  dw[((long)k * Cin + ci) * Cout + co] = acc;
+}
+
+// packed [27][Cin][Cout] gradient -> added to the parameter's own layout (engine_weights.hip: build_sparse_layer)
+__global__ void sparse_w_unpack_add_kernel(const float* __restrict__ pk, int Cin, int Cout, int layout, float* __restrict__ dst) {
+  const long total = (long)27 * Cin * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), k = (int)(i / ((long)Cout * Cin));
+    const long d = layout == 0 ? ((long)co * Cin + ci) * 27 + k : layout == 1 ? ((long)co * 27 + k) * Cin + ci : i;
+    dst[d] += pk[i];
+  }
+}
+
+// ---- transposing im2col of a 3-D conv (k3, pad 1, stride s): dst[(ci*27 + tap)][r] = X[b, zo*s+kz-1, yo*s+ky-1, xo*s+kx-1, ci] ----
+template <typename T>
+__global__ __launch_bounds__(256) void im2colT3d_kernel(const T* __restrict__ src, long ld, int B, int D, int H, int W, int C, int stride,
+                                                        int Do, int Ho, int Wo, half_t* __restrict__ dst, int Rp) {
+  __shared__ half_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int kz = tap / 9 - 1, ky = (tap / 3) % 3 - 1, kx = tap % 3 - 1;
+  const int R = B * Do * Ho * Wo;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    half_t v = (half_t)0;
+    if (r < R && c < C) {
+      const int xo = r % Wo, yo = (r / Wo) % Ho, zo = (r / (Wo * Ho)) % Do, b = r / (Wo * Ho * Do);
+      const int z = zo * stride + kz, y = yo * stride + ky, x = xo * stride + kx;
+      if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) v = (half_t)ldf(src + ((((long)b * D + z) * H + y) * W + x) * ld + c);
+    }
+    tile[rr][cc] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cc = i >> 6, rr = i & 63;
+    const int r = r0 + rr, c = c0 + cc;
+    if (c < C && r < Rp) dst[((long)c * 27 + tap) * Rp + r] = tile[rr][cc];
+  }
+}
+
+// dx[i] = sum over rows of a [rows][N] matrix times W[N][K] for a handful of rows (FiLM / step-MLP adjoints): out[r][k] (+)=
+// sum_n g[r][n] w[n][k]   (w fp16 [N][K], the LinW pack)
+__global__ void small_linear_bwd_kernel(const float* __restrict__ g, long ldg, int rows, int N, const half_t* __restrict__ w, int K,
+                                        float* __restrict__ out, long ldo, int accum) {
+  const long total = (long)rows * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K), r = (int)(i / K);
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += g[r * ldg + n] * (float)w[(long)n * K + k];
+    out[r * ldo + k] = accum ? out[r * ldo + k] + acc : acc;
+  }
+}
+
+}  // namespace
+
+int cbwd_frustum_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int TN, int D, int S, int V, float vol_len, int persp,
+                         float* d_vol, hipStream_t s) {
+  const long threads = (long)TN * D * S * S * 16;
+  hipLaunchKernelGGL(frustum_scatter_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, d_out, cams, view_idx, TN, D, S, V,
+                     vol_len, persp, d_vol);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_latent_scatter(const float* d_vol, const int* grid, int gd, int gh, int gw, const float* min_xyz, const int* out_sh, float voxel,
+                        int V, float vol_len, float* d_rows, hipStream_t s) {
+  const int C = 64;
+  const size_t total = (size_t)V * V * V * C;
+  hipLaunchKernelGGL(latent_scatter_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, d_vol, grid, gd, gh, gw, min_xyz[0],
+                     min_xyz[1], min_xyz[2], (float)out_sh[2], (float)out_sh[1], (float)out_sh[0], voxel, V, vol_len, C, d_rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
+                        float vol_len, int S, int persp, float* d_feats, hipStream_t s) {
+  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(cdiv(n_views * Nv, 256)), dim3(256), 0, s, d_out, cams, view_idx, n_views, verts, Nv, V,
+                     vol_len, S, persp, d_feats);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views, int Nv, int total_views, float* d_vf, float* dw, float* db,
+              hipStream_t s) {
+  hipLaunchKernelGGL(fuse_bwd_dvf_kernel, dim3(cdiv(Nv * 16, 256)), dim3(256), 0, s, d_fused, w, n_views, Nv, total_views, d_vf);
+  if (dw && db) hipLaunchKernelGGL(fuse_bwd_w_kernel, dim3(256), dim3(256), 0, s, d_fused, vf, n_views, Nv, total_views, dw, db);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, float eps, float* dgamma,
+                      float* dbeta, hipStream_t s) {
+  if (n <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(bn_rows_relu_bwd_kernel, dim3(C), dim3(256), 0, s, xraw, dy, n, C, gamma, beta, eps, dgamma, dbeta);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
+                     float* dw_packed, hipStream_t s) {
+  if (n_out <= 0) return 0;
+  if (Cin > 256 || Cout > 256) return mvd_fail("sparse conv backward: channel count > 256");
+  if (d_in) hipLaunchKernelGGL(sparse_conv_dgrad_kernel, dim3(n_out), dim3(256), 0, s, d_out, nbr, Cin, Cout, w, d_in);
+  if (dw_packed) hipLaunchKernelGGL(sparse_conv_wgrad_kernel, dim3(27, cdiv(Cin * Cout, 256)), dim3(256), 0, s, in, nbr, d_out, n_out, Cin, Cout, dw_packed);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_sparse_w_unpack_add(const float* pk, int Cin, int Cout, int layout, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(sparse_w_unpack_add_kernel, dim3(gridn((size_t)27 * Cin * Cout)), dim3(256), 0, s, pk, Cin, Cout, layout, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, int W, int C, int stride, half_t* dst, int Rp, hipStream_t s) {
+  const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (Rp < B * Do * Ho * Wo) return mvd_fail("im2colT3d: bad shape");
+  dim3 grid(cdiv(Rp, 64), cdiv(C, 64), 27);
+  if (src_f32) hipLaunchKernelGGL(im2colT3d_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
+  else hipLaunchKernelGGL(im2colT3d_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_t* w, int K, float* out, long ldo, int accum, hipStream_t s) {
+  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(gridn((size_t)rows * K)), dim3(256), 0, s, g, ldg, rows, N, w, K, out, ldo, accum);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

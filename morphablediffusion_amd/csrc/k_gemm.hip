@@ -606,7 +606,15 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   if (M <= 0 || g.N <= 0) return 0;
   if (g.splitk > 1 && !g.partial) return mvd_fail("gemm_dma: split-K without a partial buffer");
   if (g.npar > 0 && (g.npar > 8 || g.splitk > 1)) return mvd_fail("gemm_dma: parity batch needs npar <= 8 and no split-K");
-  if ((long)g.B * g.PZ * g.PY * g.PX * g.lda * 2 >= 0xFFFFFF00L || (long)MVD_MAX_TAPS * g.N * g.Cin * 2 >= 0xFFFFFF00L)
+  // 32-bit buffer offsets: the weight operand spans (highest slab index used + 1) slabs of N x Cin halfs
+  int slabs = 1;
+  if (g.npar > 0) {
+    for (int p = 0; p < g.npar; ++p)
+      for (int t = 0; t < g.par_ntaps[p]; ++t) slabs = (g.par_tap[p][t] >> 8) + 1 > slabs ? (g.par_tap[p][t] >> 8) + 1 : slabs;
+  } else {
+    for (int t = 0; t < g.ntaps; ++t) slabs = (g.tap[t] >> 8) + 1 > slabs ? (g.tap[t] >> 8) + 1 : slabs;
+  }
+  if ((long)g.B * g.PZ * g.PY * g.PX * g.lda * 2 >= 0xFFFFFF00L || (long)slabs * g.N * g.Cin * 2 >= 0xFFFFFF00L)
     return mvd_fail("gemm_dma: operand exceeds 4 GiB buffer addressing");
   if (g.gn_partial || g.rowscale) {  // folded-GroupNorm passes: plain GEMM, 64 / 128 wide tiles
     if (g.ntaps != 1 || g.splitk > 1 || g.npar > 0 || g.geglu || !g.out_linear || (g.bn != 64 && g.bn != 128))

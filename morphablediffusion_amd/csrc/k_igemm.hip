@@ -454,7 +454,9 @@ int launch_igemm(const IGemm& g, hipStream_t s) {
   if (g.splitk > 1 && !g.partial) return mvd_fail("igemm: split-K without a partial buffer");
   {  // 32-bit buffer offsets
     const long a_bytes = (long)g.B * g.PZ * g.PY * g.PX * g.lda * (g.a_f32 ? 4 : 2);
-    const long w_bytes = (long)MVD_MAX_TAPS * g.N * g.Cin * 2;
+    int slabs = 1;
+    for (int t = 0; t < g.ntaps; ++t) slabs = (g.tap[t] >> 8) + 1 > slabs ? (g.tap[t] >> 8) + 1 : slabs;
+    const long w_bytes = (long)slabs * g.N * g.Cin * 2;
     if (a_bytes >= 0xFFFFFF00L || w_bytes >= 0xFFFFFF00L) return mvd_fail("igemm: operand exceeds 4 GiB buffer addressing");
   }
   const int bn = g.bn ? g.bn : igemm_pick_bn(g.N, g.geglu);

@@ -305,6 +305,24 @@ class Engine:
                                                  L.ptr(dx), L.ptr(dc), _stream()))
         return dx, dc
 
+    def train_conditioner_backward(self, x_noisy, timestep, v_embed, target_index, dsrc, debug=False):
+        """mvd_train_conditioner_backward for the ACTIVE sample: x_noisy [N,4,s,s], v_embed [N,4], dsrc {res: [1,C,D,res,res]}
+        (loss-scaled).  Accumulates the gradients of spatial_volume.* / time_embed.*; debug=True also returns the intermediate
+        gradients (d volume, d fused, d encoder features, d step embedding)."""
+        dev = self.device
+        x, ve = _f32(x_noisy, dev), _f32(v_embed, dev)
+        s = self.vcfg.input_image_size // 8
+        ds = [_f32(dsrc[s >> lvl], dev) for lvl in range(4)]
+        dbg = [None] * 4
+        if debug:
+            V = self.vcfg.spatial_volume_size
+            dbg = [torch.empty(64, V, V, V, device=dev), torch.empty(self.num_vertices, 16, device=dev),
+                   torch.empty(x.shape[0], 16, x.shape[2], x.shape[3], device=dev), torch.empty(self.vcfg.time_dim, device=dev)]
+        L.check(self.lib.mvd_train_conditioner_backward(self._ctx, L.ptr(x), C.c_int64(int(timestep)), L.ptr(ve), x.shape[0],
+                                                        int(target_index), L.ptr(ds[0]), L.ptr(ds[1]), L.ptr(ds[2]), L.ptr(ds[3]),
+                                                        L.ptr(dbg[0]), L.ptr(dbg[1]), L.ptr(dbg[2]), L.ptr(dbg[3]), _stream()))
+        return dbg if debug else None
+
     def get_grad(self, key: str, shape):
         out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
         L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))

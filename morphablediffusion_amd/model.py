@@ -290,6 +290,7 @@ class SyncMultiviewDiffusion(nn.Module):
         self.scheduler_config = scheduler_config
         self.learning_rate = 5e-5  # train_morphable_diffusion.py:313-321 sets model.learning_rate before fit
         self.train_mode = train_mode
+        self.train_conditioner = True  # training_step also back-propagates into spatial_volume.* / time_embed.*
         self.loss_scale = float(loss_scale)
         self.recompute = bool(recompute)
         self.global_step = 0
@@ -411,9 +412,9 @@ class SyncMultiviewDiffusion(nn.Module):
         from ALL noisy views (BatchNorm in train mode), one frustum volume per sample, the UNet with condition dropout, MSE
         against the injected noise -- and, with the engine in training mode (``backward`` defaults to that), loss.backward():
         dL/dpred back through every UNet block; ``.grad`` of every UNet parameter (views of the engine's gradient arena,
-        multiplied by ``self.loss_scale``) is ACCUMULATED like torch does until zero_grad.  The gradients of ``spatial_volume`` /
-        ``time_embed`` (the conditioner's backward) are not built: ``self.last_dsrc`` holds dL/d(frustum volumes), the point
-        where that backward would start.
+        multiplied by ``self.loss_scale``) is ACCUMULATED like torch does until zero_grad.  ``self.last_dsrc`` holds dL/d(frustum
+        volumes); from it the conditioner's backward (``self.train_conditioner``, default on) fills the gradients of
+        ``spatial_volume.*`` and ``time_embed.*`` sample by sample.
         ``prepared`` = (x, clip_embed, input_info) replaces self.prepare(batch); the random draws may be passed in (parity
         tests), otherwise they are made on the host in the reference's order (randint for the time steps BEFORE prepare's
         posterior samples, then randn_like, randint, rand) so that torch.manual_seed reproduces the reference's CPU stream.
@@ -454,6 +455,13 @@ class SyncMultiviewDiffusion(nn.Module):
         pred, loss, dsrc = self.model.train_step(x_t, time_steps, clip_, vf, xc, target, drop_random=drop_random,
                                                  loss_scale=self.loss_scale, recompute=self.recompute)
         self.last_noise_predict, self.last_dsrc = pred, dsrc
+        if self.train_conditioner:  # spatial_volume.* / time_embed.*: per sample, from dL/d(its frustum volumes)
+            hs = [int(v) for v in time_steps.tolist()]
+            ti = [int(v) for v in target_index[:, 0].tolist()]
+            for bi in range(B):
+                self.spatial_volume._set_sample(batch, bi)
+                self.engine.train_conditioner_backward(x_noisy[bi], hs[bi], v_embed[bi], ti[bi],
+                                                       {k: v[bi:bi + 1] for k, v in dsrc.items()})
         return loss
 
     # ---- optimiser surface (morphable_diffusion.py:627-646, train_morphable_diffusion.py:302-321) --------------------

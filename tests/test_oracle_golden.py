@@ -314,6 +314,10 @@ def test_training_step_loss_and_gradients():
     assert len(names) == 856 and sum(n.startswith(("middle_conditions.", "output_conditions.")) for n in names) == 170
     for n in names:
         W[P + n].requires_grad_(True)
+    cnames = [str(n) for n in g["cond_names"]]
+    assert len(cnames) == 149
+    for n in cnames:  # spatial_volume.* and the step-embedding MLP time_embed.*
+        W[n].requires_grad_(True)
     loss, pred = O.training_step(W, build_unet_plan(ucfg), vcfg, x0, x_in, clip, batch, ts, noise, ti, dr)
     pred.retain_grad()
     loss.backward()
@@ -327,5 +331,8 @@ def test_training_step_loss_and_gradients():
             continue
         check(gr, g, "grad." + n, 2e-3)
         assert abs(float(gr.double().norm()) - want_norm) <= 2e-3 * want_norm, n
+    for n, want_norm in zip(cnames, g["cond_norms"]):
+        check(W[n].grad, g, "gradc." + n, 2e-3)
+        assert abs(float(W[n].grad.double().norm()) - want_norm) <= 2e-3 * want_norm, n
     m_clip, m_vol, m_cat = O.drop_masks(dr)
     assert m_clip.tolist() == [0, 1, 1, 1] and m_vol.tolist() == [0, 0, 1, 1] and m_cat.tolist() == [0, 1, 0, 1]

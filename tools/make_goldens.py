@@ -413,12 +413,34 @@ def gold_train(ns):
     # gradient w.r.t. the frustum volumes BEFORE the condition dropout: where the conditioner's backward starts
     for k_, v_ in vf_pre.items():
         packs[f"dsrc.{k_}"] = gi.pack(v_.grad, limit=2048, target=4096)
+    # second pass with the FULL graph (frustum volumes attached to the conditioner): the gradients of spatial_volume.* and of
+    # the step-embedding MLP time_embed.* (the reference's second and third optimiser groups, morphable_diffusion.py:639-640)
+    model.zero_grad()
+    t_embed2 = model.embed_time(time_steps)
+    sv2 = model.spatial_volume.construct_spatial_volume(x_noisy, t_embed2, v_embed, batch)
+    clip2, vf2, xc2 = model.get_target_view_feats(x_in, sv2, clip, t_embed2, v_embed, target_index, batch)
+    torch.rand = lambda *a, **k: drop_random.clone()
+    try:
+        pred2 = model.model(x_noisy_, time_steps, clip2, vf2, xc2, is_train=True)
+    finally:
+        torch.rand = real_rand
+    assert torch.equal(pred2, pred)
+    torch.nn.functional.mse_loss(noise_target, pred2, reduction="none").mean().backward()
+    cnames, cnorms = [], []
+    for pre_, mod_ in (("time_embed.", model.time_embed), ("spatial_volume.", model.spatial_volume)):
+        for n_, p_ in mod_.named_parameters():
+            g_ = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            packs["gradc." + pre_ + n_] = gi.pack(g_, limit=2048, target=512)
+            cnames.append(pre_ + n_)
+            cnorms.append(float(g_.double().norm()))
+    extra_c = {"cond_names": np.array(cnames), "cond_norms": np.array(cnorms)}
     print("train golden: loss", float(loss), "pred std", float(pred.std()), "UNet grads:", len(names), "zero-norm:",
-          [n for n, v in zip(names, norms) if v == 0.0][:8])
+          [n for n, v in zip(names, norms) if v == 0.0][:8], "| conditioner grads:", len(cnames), "zero-norm:",
+          [n for n, v in zip(cnames, cnorms) if v == 0.0][:6])
     save("train_small.npz", packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
                                     "target_index": target_index.numpy(), "drop_random": drop_random.numpy(),
                                     "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names),
-                                    "grad_norms": np.array(norms)})
+                                    "grad_norms": np.array(norms), **extra_c})
 
 
 def gold_cameras():
