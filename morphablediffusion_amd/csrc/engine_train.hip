@@ -62,8 +62,9 @@ int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views
               hipStream_t s);
 int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, float eps, float* dgamma,
                       float* dbeta, hipStream_t s);
+int cbwd_sparse_wgrad_chunks(int n_out);
 int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
-                     float* dw_packed, hipStream_t s);
+                     float* dw_packed, float* dw_part, hipStream_t s);
 int cbwd_sparse_w_unpack_add(const float* pk, int Cin, int Cout, int layout, float* dst, hipStream_t s);
 int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, int W, int C, int stride, half_t* dst, int Rp, hipStream_t s);
 int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_t* w, int K, float* out, long ldo, int accum, hipStream_t s);
@@ -777,6 +778,19 @@ int bwd_attn2(Bwd& b) {
 }
 
 // ---- mesh conditioner (SpatialVolumeNet) -------------------------------------------------------------------------------
+// G[n] += sum over ALL rows of dy[row][n]: the rows are cut into up to 64 equal slabs ("pseudo samples") so that a one-sample
+// volume of 49152 rows is summed by 64 x N/64 workgroups instead of N/64
+int colsum_all(Bwd& b, const float* dy, long ldy, long rows, int N, float* G) {
+  mvd_ctx* c = b.c;
+  WsScope scope(c, WS_TEMP);
+  int S = 64;
+  while (S > 1 && rows % S) S >>= 1;
+  float* part = ws_alloc<float>(c, (size_t)S * N);
+  WS_CHECK(part);
+  RET_IF(bwd_colsum_samples(dy, 1, ldy, S, (int)(rows / S), N, part, N, b.s));
+  return bwd_sum_rows_add(part, S, N, N, G, 1, b.s);
+}
+
 // weight + bias gradient of a 3x3x3 conv (stride as in the forward): dy fp32 [rows_out][N] channels-last, x [B,D,H,W,K]
 int wgrad_conv3d(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int D, int H, int W, int K,
                  int stride) {
@@ -792,12 +806,7 @@ int wgrad_conv3d(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* 
     RET_IF(cbwd_im2colT3d(x, x_f32, ldx, b.B, D, H, W, K, stride, colT, Rp, b.s));
     RET_IF(wgrad_gemm(b, dyT, N, colT, K * 27, Rp, G));
   }
-  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
-    float* part = ws_alloc<float>(c, (size_t)b.B * N);
-    WS_CHECK(part);
-    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, Do * Ho * Wo, N, part, N, b.s));
-    RET_IF(bwd_sum_rows_add(part, b.B, N, N, Gb, 1, b.s));
-  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) RET_IF(colsum_all(b, dy, ldy, (long)rows, N, Gb));
   return 0;
 }
 // ConvTranspose3d(k3, s2, p1, op1), weight [Cin][Cout][27]:  dW[ci][co*27 + k] = sum_i x[i][ci] dy[2 i - 1 + k][co] -- the strided
@@ -816,12 +825,7 @@ int wgrad_convT3d(Bwd& b, const ConvW& w, const float* dy, long ldy, const void*
     RET_IF(cbwd_im2colT3d(dy, 1, ldy, b.B, 2 * D, 2 * H, 2 * W, Cout, 2, colT, Rp, b.s));
     RET_IF(wgrad_gemm(b, xT, Cin, colT, Cout * 27, Rp, G));
   }
-  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) {
-    float* part = ws_alloc<float>(c, (size_t)b.B * Cout);
-    WS_CHECK(part);
-    RET_IF(bwd_colsum_samples(dy, 1, ldy, b.B, 8 * D * H * W, Cout, part, Cout, b.s));
-    RET_IF(bwd_sum_rows_add(part, b.B, Cout, Cout, Gb, 1, b.s));
-  }
+  if (float* Gb = w.bkey.empty() ? nullptr : engine_grad(c, w.bkey)) RET_IF(colsum_all(b, dy, ldy, (long)rows * 8, Cout, Gb));
   return 0;
 }
 // adjoint of a 3x3x3 conv w.r.t. its input.  kind 0: stride-1 conv (the forward kernel on the flipped pack); 1: stride-2 conv
@@ -1290,7 +1294,12 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     float* d_in = F((size_t)sp_nin[i] * L.cin);
     WS_CHECK(dwp && d_in);
     HIP_CHECK_RET(hipMemsetAsync(d_in, 0, (size_t)sp_nin[i] * L.cin * sizeof(float), s));
-    RET_IF(cbwd_sparse_conv(sp_in[i], sp_nbr[i], d_cur, sp_nout[i], L.cin, L.cout, L.w, d_in, dwp, s));
+    {
+      WsScope sc(c, WS_TEMP);
+      float* dw_part = F((size_t)cbwd_sparse_wgrad_chunks(sp_nout[i]) * 27 * L.cin * L.cout);
+      WS_CHECK(dw_part);
+      RET_IF(cbwd_sparse_conv(sp_in[i], sp_nbr[i], d_cur, sp_nout[i], L.cin, L.cout, L.w, d_in, dwp, dw_part, s));
+    }
     RET_IF(cbwd_sparse_w_unpack_add(dwp, L.cin, L.cout, L.layout, Gw, s));
     d_cur = d_in;
   }

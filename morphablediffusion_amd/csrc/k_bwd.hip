@@ -382,13 +382,22 @@ __global__ void outer_add_kernel(const float* __restrict__ a, long lda, const fl
   }
 }
 
-// out[c] (+)= sum_r part[r][c] (fixed order), r < R small (samples / workgroup partials)
-__global__ void sum_rows_add_kernel(const float* __restrict__ part, int R, int C, long ldp, float* __restrict__ out, int accum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum_r part[r][c]: a workgroup owns 8 columns, 32 row lanes each, combined through LDS in lane order (fixed order
+// for a given R)
+__global__ __launch_bounds__(256) void sum_rows_add_kernel(const float* __restrict__ part, int R, int C, long ldp, float* __restrict__ out,
+                                                           int accum) {
+  __shared__ float s_p[32][9];
+  const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cc;
   float a = 0.f;
-  for (int r = 0; r < R; ++r) a += part[(long)r * ldp + c];
-  out[c] = accum ? out[c] + a : a;
+  if (c < C)
+    for (int r = rl; r < R; r += 32) a += part[(long)r * ldp + c];
+  s_p[rl][cc] = a;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+    for (int i = 0; i < 32; ++i) t += s_p[i][cc];
+    out[c] = accum ? out[c] + t : t;
+  }
 }
 
 // out[b][c] = sum over the rows of sample b of v[b*rows + r][c] (ld): one workgroup per (sample, 64-channel slab); 4 row
@@ -1008,7 +1017,7 @@ int bwd_outer_add(const float* a, long lda, const float* b, long ldb, float* C, 
   return 0;
 }
 int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s) {
-  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, R, C, ldp, out, accum);
+  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, part, R, C, ldp, out, accum);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

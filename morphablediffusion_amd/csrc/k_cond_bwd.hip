@@ -101,29 +101,29 @@ __global__ void latent_scatter_kernel(const float* __restrict__ d_vol, const int
   }
 }
 
-// adjoint of vertex_gather_kernel: d_feats[view][pixel][c] += w2 * d_out[view][vertex][c]
-__global__ __launch_bounds__(256) void vertex_scatter_kernel(const float* __restrict__ d_out, const ViewCam* __restrict__ cams,
-                                                             const int* __restrict__ view_idx, int n_views, const float* __restrict__ verts,
-                                                             int Nv, int V, float vol_len, int S, int persp, float* __restrict__ d_feats) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_views * Nv) return;
-  const int view = idx / Nv, vi = idx - view * Nv;
+// adjoint of vertex_gather_kernel: d_feats[view][pixel][c] += w2 * d_out[view][vertex][c].  One workgroup per view accumulates the
+// whole S x S x 16 image in LDS (ds_add_f32: thousands of vertices land on the same few hundred pixels) and writes it once.
+__global__ __launch_bounds__(1024) void vertex_scatter_kernel(const float* __restrict__ d_out, const ViewCam* __restrict__ cams,
+                                                              const int* __restrict__ view_idx, const float* __restrict__ verts, int Nv, int V,
+                                                              float vol_len, int S, int persp, float* __restrict__ d_feats) {
+  extern __shared__ float s_img[];  // [S*S][16]
+  const int view = blockIdx.x;
   const ViewCam cam = cams[view_idx[view]];
-  float pos[3], fr[3];
-  int lo[3];
+  for (int i = threadIdx.x; i < S * S * 16; i += blockDim.x) s_img[i] = 0.f;
+  __syncthreads();
+  // thread = (vertex, corner): 8 threads share a vertex
+  for (int job = threadIdx.x; job < Nv * 8; job += blockDim.x) {
+    const int vi = job >> 3, corner = job & 7;
+    float fr[3];
+    int lo[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float g = verts[vi * 3 + a] / vol_len;
-    pos[a] = (g + 1.0f) * 0.5f * (float)(V - 1);
-    const float f = floorf(pos[a]);
-    lo[a] = (int)f;
-    fr[a] = pos[a] - f;
-  }
-  float g16[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) g16[c] = d_out[(long)idx * 16 + c];
-  float* fv = d_feats + (long)view * S * S * 16;
-  for (int corner = 0; corner < 8; ++corner) {
+    for (int a = 0; a < 3; ++a) {
+      const float g = verts[vi * 3 + a] / vol_len;
+      const float pos = (g + 1.0f) * 0.5f * (float)(V - 1);
+      const float f = floorf(pos);
+      lo[a] = (int)f;
+      fr[a] = pos - f;
+    }
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
     const int ix = lo[0] + bx, iy = lo[1] + by, iz = lo[2] + bz;
     if (ix < 0 || ix > V - 1 || iy < 0 || iy > V - 1 || iz < 0 || iz > V - 1) continue;
@@ -146,16 +146,23 @@ __global__ __launch_bounds__(256) void vertex_scatter_kernel(const float* __rest
     const float fx0 = floorf(px), fy0 = floorf(py);
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float tx = px - fx0, ty = py - fy0;
+    const float* gsrc = d_out + ((long)view * Nv + vi) * 16;
+    float g16[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) g16[c] = gsrc[c];
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
       const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
       if (xx < 0 || xx > S - 1 || yy < 0 || yy > S - 1) continue;
       const float w2 = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * w3;
-      float* o = fv + ((long)yy * S + xx) * 16;
+      float* o = s_img + ((long)yy * S + xx) * 16;
 #pragma unroll
       for (int c = 0; c < 16; ++c) atomicAdd(o + c, w2 * g16[c]);
     }
   }
+  __syncthreads();
+  float* fv = d_feats + (long)view * S * S * 16;
+  for (int i = threadIdx.x; i < S * S * 16; i += blockDim.x) fv[i] += s_img[i];
 }
 
 // ---- view fusion (SMPLFeatureExtractor, network.py:41-72): fused[v][co] = sum_ci w[co][ci] mean_view vf[view][v][ci] + b[co] ----
@@ -268,19 +275,32 @@ __global__ __launch_bounds__(256) void sparse_conv_dgrad_kernel(const float* __r
   }
 }
 
-// dw[k][ci][co] = sum_site in[nbr[site][k]][ci] d_out[site][co]  (fixed order); grid (27, ceil(Cin*Cout / 256))
+// dw[k][ci][co] = sum_site in[nbr[site][k]][ci] d_out[site][co]: grid (27, ceil(Cin*Cout / 256), site chunks); every chunk of
+// SP_CHUNK sites writes its partial product to part[chunk][27][Cin][Cout], summed in chunk order by sparse_wgrad_reduce_kernel
+constexpr int SP_CHUNK = 128;
 __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
                                                                 const float* __restrict__ d_out, int n_out, int Cin, int Cout,
-                                                                float* __restrict__ dw) {
-  const int k = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x;
+                                                                float* __restrict__ part) {
+  __shared__ int s_nb[SP_CHUNK];
+  const int k = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x, chunk = blockIdx.z;
+  const int s0 = chunk * SP_CHUNK, s1 = min(n_out, s0 + SP_CHUNK);
+  for (int i = threadIdx.x; i < SP_CHUNK; i += 256) s_nb[i] = s0 + i < s1 ? nbr[(long)(s0 + i) * 27 + k] : -1;
+  __syncthreads();
   if (e >= Cin * Cout) return;
   const int ci = e / Cout, co = e - ci * Cout;
   float acc = 0.f;
-  for (int site = 0; site < n_out; ++site) {
-    const int nb = nbr[(long)site * 27 + k];
+  for (int site = s0; site < s1; ++site) {
+    const int nb = s_nb[site - s0];
     if (nb >= 0) acc += in[(long)nb * Cin + ci] * d_out[(long)site * Cout + co];
   }
-  dw[((long)k * Cin + ci) * Cout + co] = acc;
+  part[(((long)chunk * 27 + k) * Cin + ci) * Cout + co] = acc;
+}
+__global__ void sparse_wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long n, float* __restrict__ dw) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int c = 0; c < nchunk; ++c) a += part[(long)c * n + i];
+    dw[i] = a;
+  }
 }
 
 // packed [27][Cin][Cout] gradient -> added to the parameter's own layout (engine_weights.hip: build_sparse_layer)
@@ -320,16 +340,21 @@ __global__ __launch_bounds__(256) void im2colT3d_kernel(const T* __restrict__ sr
   }
 }
 
-// dx[i] = sum over rows of a [rows][N] matrix times W[N][K] for a handful of rows (FiLM / step-MLP adjoints): out[r][k] (+)=
-// sum_n g[r][n] w[n][k]   (w fp16 [N][K], the LinW pack)
-__global__ void small_linear_bwd_kernel(const float* __restrict__ g, long ldg, int rows, int N, const half_t* __restrict__ w, int K,
-                                        float* __restrict__ out, long ldo, int accum) {
-  const long total = (long)rows * K;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K), r = (int)(i / K);
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += g[r * ldg + n] * (float)w[(long)n * K + k];
-    out[r * ldo + k] = accum ? out[r * ldo + k] + acc : acc;
+// out[r][k] (+)= sum_n g[r][n] w[n][k]  (w fp16 [N][K], the LinW pack) for a handful of rows (FiLM / step-MLP adjoints).
+// One workgroup = 16 consecutive k x 16 lanes over n, combined through LDS in lane order.
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* __restrict__ g, long ldg, int N, const half_t* __restrict__ w,
+                                                               int K, float* __restrict__ out, long ldo, int accum) {
+  __shared__ float s_p[16][17];
+  const int r = blockIdx.y, kk = threadIdx.x & 15, nl = threadIdx.x >> 4, k = blockIdx.x * 16 + kk;
+  float acc = 0.f;
+  if (k < K)
+    for (int n = nl; n < N; n += 16) acc += g[r * ldg + n] * (float)w[(long)n * K + k];
+  s_p[nl][kk] = acc;
+  __syncthreads();
+  if (nl == 0 && k < K) {
+    float a = 0.f;
+    for (int i = 0; i < 16; ++i) a += s_p[i][kk];
+    out[r * ldo + k] = accum ? out[r * ldo + k] + a : a;
   }
 }
 
@@ -354,8 +379,16 @@ int cbwd_latent_scatter(const float* d_vol, const int* grid, int gd, int gh, int
 }
 int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
                         float vol_len, int S, int persp, float* d_feats, hipStream_t s) {
-  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(cdiv(n_views * Nv, 256)), dim3(256), 0, s, d_out, cams, view_idx, n_views, verts, Nv, V,
-                     vol_len, S, persp, d_feats);
+  const int lds = S * S * 16 * (int)sizeof(float);
+  if (lds > 160 * 1024) return mvd_fail("vertex scatter: feature map too large for the LDS accumulation");
+  static bool attr_done[MVD_MAX_DEVICES] = {false};
+  bool& attr_set = attr_done[mvd_current_device()];
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)vertex_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(n_views), dim3(1024), lds, s, d_out, cams, view_idx, verts, Nv, V, vol_len, S, persp,
+                     d_feats);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -373,12 +406,20 @@ int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* g
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+int cbwd_sparse_wgrad_chunks(int n_out) { return cdiv(n_out, SP_CHUNK); }
+// dw_part: scratch of cbwd_sparse_wgrad_chunks(n_out) * 27 * Cin * Cout floats
 int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
-                     float* dw_packed, hipStream_t s) {
+                     float* dw_packed, float* dw_part, hipStream_t s) {
   if (n_out <= 0) return 0;
   if (Cin > 256 || Cout > 256) return mvd_fail("sparse conv backward: channel count > 256");
   if (d_in) hipLaunchKernelGGL(sparse_conv_dgrad_kernel, dim3(n_out), dim3(256), 0, s, d_out, nbr, Cin, Cout, w, d_in);
-  if (dw_packed) hipLaunchKernelGGL(sparse_conv_wgrad_kernel, dim3(27, cdiv(Cin * Cout, 256)), dim3(256), 0, s, in, nbr, d_out, n_out, Cin, Cout, dw_packed);
+  if (dw_packed) {
+    const int nchunk = cdiv(n_out, SP_CHUNK);
+    const long n = (long)27 * Cin * Cout;
+    hipLaunchKernelGGL(sparse_conv_wgrad_kernel, dim3(27, cdiv(Cin * Cout, 256), nchunk), dim3(256), 0, s, in, nbr, d_out, n_out, Cin, Cout,
+                       dw_part);
+    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(gridn((size_t)n)), dim3(256), 0, s, dw_part, nchunk, n, dw_packed);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -397,7 +438,7 @@ int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, i
   return 0;
 }
 int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_t* w, int K, float* out, long ldo, int accum, hipStream_t s) {
-  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(gridn((size_t)rows * K)), dim3(256), 0, s, g, ldg, rows, N, w, K, out, ldo, accum);
+  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(cdiv(K, 16), rows), dim3(256), 0, s, g, ldg, N, w, K, out, ldo, accum);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
