@@ -377,8 +377,11 @@ int mvd_train_adopt_arena(mvd_ctx* c, int which, float* ptr, int64_t numel) {
   if (old && c->arena_owned[which]) hipFree(old);
   *slot[which] = ptr;
   c->arena_owned[which] = false;
-  if (which == 0)
+  if (which == 0) {
     for (auto& r : c->params) c->raw[r.key].d = ptr + r.off;
+    // biases / norm gains are read in place from the master arena (engine_weights.hip: copy_f32): every such pointer is refreshed
+    RET_IF(engine_repack(c));
+  }
   return 0;
 }
 

@@ -40,6 +40,11 @@ int get_raw(mvd_ctx* c, const std::string& k, RawTensor** out) {
 int copy_f32(mvd_ctx* c, const std::string& k, float** out, int* n = nullptr) {
   RawTensor* r;
   RET_IF(get_raw(c, k, &r));
+  if (c->train_mode && c->param_index.count(k)) {  // biases / gains are read straight from the master arena: always current,
+    *out = r->d;                                    // no copy to refresh at re-pack time
+    if (n) *n = (int)r->numel;
+    return 0;
+  }
   RET_IF(dmalloc(c, (void**)out, r->numel * sizeof(float)));
   HIP_CHECK_RET(hipMemcpy(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice));
   if (n) *n = (int)r->numel;

@@ -2,7 +2,7 @@
 // adjoints of the gathers of k_cond.hip (same index arithmetic, scatter instead of gather), the sparse voxel CNN's layers in
 // train mode (conv dgrad / wgrad through the neighbour tables, BatchNorm1d with batch statistics + ReLU), the view fusion, and
 // the transposing im2col for the frustum network's 3-D convolutions.
-// The three scatters use hardware fp32 atomic adds (unordered: the conditioner's gradients are reproducible to rounding, not bit
+// The three scatters use hardware fp32 atomic adds (unsafeAtomicAdd: the returning CAS loop of plain atomicAdd is 30x slower here) (unordered: the conditioner's gradients are reproducible to rounding, not bit
 // for bit -- the UNet's are); everything else has fixed summation orders.
 #include "common.h"
 
@@ -61,10 +61,10 @@ __global__ __launch_bounds__(256) void frustum_scatter_kernel(const float* __res
     if (xx < 0 || xx > V - 1 || yy < 0 || yy > V - 1 || zz < 0 || zz > V - 1) continue;
     const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
     float* o = d_vol + (((long)zz * V + yy) * V + xx) * C + cq;
-    atomicAdd(o + 0, wgt * g.x);
-    atomicAdd(o + 1, wgt * g.y);
-    atomicAdd(o + 2, wgt * g.z);
-    atomicAdd(o + 3, wgt * g.w);
+    unsafeAtomicAdd(o + 0, wgt * g.x);
+    unsafeAtomicAdd(o + 1, wgt * g.y);
+    unsafeAtomicAdd(o + 2, wgt * g.z);
+    unsafeAtomicAdd(o + 3, wgt * g.w);
   }
 }
 
@@ -96,7 +96,7 @@ __global__ void latent_scatter_kernel(const float* __restrict__ d_vol, const int
       const int row = grid[((long)zz * gh + yy) * gw + xx];
       if (row < 0) continue;
       const float wgt = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz);
-      atomicAdd(d_rows + (long)row * C + c, wgt * g);
+      unsafeAtomicAdd(d_rows + (long)row * C + c, wgt * g);
     }
   }
 }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(1024) void vertex_scatter_kernel(const float* __res
       const float w2 = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * w3;
       float* o = s_img + ((long)yy * S + xx) * 16;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) atomicAdd(o + c, w2 * g16[c]);
+      for (int c = 0; c < 16; ++c) unsafeAtomicAdd(o + c, w2 * g16[c]);
     }
   }
   __syncthreads();
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void sparse_conv_dgrad_kernel(const float* __r
     const float* wk = w + ((long)k * Cin + ci) * Cout;
     float acc = 0.f;
     for (int co = 0; co < Cout; ++co) acc += wk[co] * s_g[co];
-    atomicAdd(d_in + (long)nb * Cin + ci, acc);
+    unsafeAtomicAdd(d_in + (long)nb * Cin + ci, acc);
   }
 }
 

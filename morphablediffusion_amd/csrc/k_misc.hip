@@ -220,33 +220,34 @@ __global__ void fill_rows_f16_kernel(half_t* __restrict__ out, int ld, int rows,
   }
 }
 
-// W_qk[hn*Cc + j][i] = scale * sum_c Wk[hn*hd + c][j] * Wq[hn*hd + c][i]
-__global__ void fold_qk_kernel(const float* __restrict__ wq, const float* __restrict__ wk, int heads, int hd, int Cc,
-                               int I, float scale, half_t* __restrict__ out, float* __restrict__ out32) {
-  const long total = (long)heads * Cc * I;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(idx % I);
-    const int row = (int)(idx / I);
-    const int hn = row / Cc, j = row - hn * Cc;
-    double acc = 0.0;
-    for (int c = 0; c < hd; ++c) acc += (double)wk[(long)(hn * hd + c) * Cc + j] * (double)wq[(long)(hn * hd + c) * I + i];
-    if (out32) out32[idx] = (float)(acc * scale);
-    else out[idx] = (half_t)(float)(acc * scale);
+// C[z][m][n] = scale * sum_k A_z(m,k) B_z(k,n) with strided operands (element (m,k) of A at a[z*a_zs + m*a_rs + k*a_cs], ...),
+// fp64 accumulation, 16 x 16 tiles through LDS: the weight folds below (a few GFLOP at finalize / re-pack time; the one-thread-
+// per-output form they replace ran at 1 TFLOP/s and was 40 % of a re-pack)
+__global__ __launch_bounds__(256) void fold_gemm_kernel(const float* __restrict__ a, long a_zs, long a_rs, long a_cs,
+                                                        const float* __restrict__ b, long b_zs, long b_rs, long b_cs, int M, int N, int K,
+                                                        float scale, long c_zs, long c_rs, long c_cs, half_t* __restrict__ out,
+                                                        float* __restrict__ out32) {
+  __shared__ float sA[16][17], sB[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, z = blockIdx.z;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  const float* az = a + z * a_zs;
+  const float* bz = b + z * b_zs;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // A tile [m][k]: thread (ty, tx) loads (m = m0 + ty, k = k0 + tx); B tile [k][n]: (k = k0 + ty, n = n0 + tx)
+    const int ka = k0 + tx, kb = k0 + ty;
+    sA[ty][tx] = (m < M && ka < K) ? az[(long)m * a_rs + (long)ka * a_cs] : 0.f;
+    sB[ty][tx] = (kb < K && n < N) ? bz[(long)kb * b_rs + (long)n * b_cs] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc += (double)sA[ty][kk] * (double)sB[kk][tx];
+    __syncthreads();
   }
-}
-
-// W_ov[i][hn*Cc + j] = sum_c Wo[i][hn*hd + c] * Wv[hn*hd + c][j]
-__global__ void fold_ov_kernel(const float* __restrict__ wo, const float* __restrict__ wv, int heads, int hd, int Cc,
-                               int I, half_t* __restrict__ out, float* __restrict__ out32) {
-  const long total = (long)I * heads * Cc;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int col = (int)(idx % (heads * Cc));
-    const int i = (int)(idx / (heads * Cc));
-    const int hn = col / Cc, j = col - hn * Cc;
-    double acc = 0.0;
-    for (int c = 0; c < hd; ++c) acc += (double)wo[(long)i * I + hn * hd + c] * (double)wv[(long)(hn * hd + c) * Cc + j];
-    if (out32) out32[idx] = (float)acc;
-    else out[idx] = (half_t)(float)acc;
+  if (m < M && n < N) {
+    const long o = z * c_zs + (long)m * c_rs + (long)n * c_cs;
+    const float v = (float)(acc * (double)scale);
+    if (out32) out32[o] = v;
+    else out[o] = (half_t)v;
   }
 }
 
@@ -372,16 +373,18 @@ int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n
 
 int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
                    hipStream_t s, float* out32) {
-  hipLaunchKernelGGL(fold_qk_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wq, wk, heads, hd, Cc, I,
-                     scale, out, out32);
+  // W_qk[hn*Cc + j][i] = scale * sum_c Wk[hn*hd + c][j] * Wq[hn*hd + c][i]:  per head  C[j][i] = sum_c Wk^T(j,c) Wq(c,i)
+  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(I, 16), cdiv(Cc, 16), heads), dim3(256), 0, s, wk, (long)hd * Cc, 1L, (long)Cc, wq,
+                     (long)hd * I, (long)I, 1L, Cc, I, hd, scale, (long)Cc * I, (long)I, 1L, out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s,
                    float* out32) {
-  hipLaunchKernelGGL(fold_ov_kernel, dim3(grid_for((size_t)heads * Cc * I)), dim3(256), 0, s, wo, wv, heads, hd, Cc, I,
-                     out, out32);
+  // W_ov[i][hn*Cc + j] = sum_c Wo[i][hn*hd + c] * Wv[hn*hd + c][j]:  per head  C[i][j] = sum_c Wo(i, hn*hd + c) Wv(hn*hd + c, j)
+  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(Cc, 16), cdiv(I, 16), heads), dim3(256), 0, s, wo, (long)hd, (long)I, 1L, wv,
+                     (long)hd * Cc, (long)Cc, 1L, I, Cc, hd, 1.0f, (long)Cc, (long)heads * Cc, 1L, out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
