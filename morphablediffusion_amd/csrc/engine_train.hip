@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "engine.h"
 
@@ -1046,6 +1047,16 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   for (int l = 0; l < 4; ++l)
     if (!dsrc[l]) return mvd_fail("conditioner backward: dL/d(frustum volume) of every level is required");
   WsScope scope(c);
+  // MVD_COND_BWD_TIMING=1: host-side enqueue time of each phase on stderr (development aid)
+  static const bool host_timing = getenv("MVD_COND_BWD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = now();
+  auto mark = [&](const char* what) {
+    if (!host_timing) return;
+    const double t = now();
+    fprintf(stderr, "[cond-bwd host] %-28s %7.3f ms\n", what, t - t_last);
+    t_last = t;
+  };
   MeshTables& m = c->mesh;
   const int N = n_views, S = c->u.image_size, HW = S * S, rows = N * HW, td = c->v.time_dim, vd = c->v.view_dim, Nv = m.Nv;
   const int V = c->v.spatial_volume_size, persp = c->v.projection == 0;
@@ -1124,6 +1135,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   g = GemmArgs();
   g.a = af; g.lda = 48; g.w = &x_final; g.out = feats; g.ldc = 16; g.force_splitk = 1;
   RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
+  mark("fwd: step mlp + 2-D encoder");
   // vertex features, view fusion
   float *vf = F((size_t)N * Nv * 16), *fused = F((size_t)Nv * 16);
   WS_CHECK(vf && fused);
@@ -1158,6 +1170,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
       n_in = sp_nout[i];
     }
   }
+  mark("fwd: gather, fuse, sparse net");
   float* volume = F((size_t)V * V * V * 64);
   WS_CHECK(volume);
   RET_IF(launch_latent_gather(sp_post[8], m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
@@ -1217,6 +1230,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     g.a = au_f[l]; g.lda = fd[l + 1]; g.w = &u.conv; g.out = xf[l]; g.ldc = fd[l]; g.resid = xd[l]; g.ldr = fd[l];
     RET_IF(run_convT3d(c, g, 1, Dl[l + 1], Sl[l + 1], Sl[l + 1], s));
   }
+  mark("fwd: volume, frustum net");
   // ================= backward =================
   Fwd f{c, s, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
   TrainTape tape;
@@ -1240,6 +1254,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     RET_IF(gn_backward(b, u.gn, 8, 1e-5f, ACT_SILU, xf[l + 1], fd[l + 1], d_au, fd[l + 1], (int)vox[l + 1], gl[l + 1], fd[l + 1], true,
                        pre_f + c->film_off[6 + (2 - l)], FT, d_pre_f + c->film_off[6 + (2 - l)], FT));
   }
+  mark("bwd: frustum up path");
   // down path (forward order l = 0, 1, 2)
   for (int l = 2; l >= 0; --l) {
     WsScope sc(c, WS_BLOCK);
@@ -1258,6 +1273,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     RET_IF(gn_backward(b, b1.gn, 8, 1e-5f, ACT_SILU, xd[l], fd[l], d_a1, fd[l], (int)vox[l], gl[l], fd[l], true,
                        pre_f + c->film_off[2 * l], FT, d_pre_f + c->film_off[2 * l], FT));
   }
+  mark("bwd: frustum down path");
   // conv0 on the gathered frustum features
   float* d_gath = F(vox[0] * 64);
   WS_CHECK(d_gath);
@@ -1272,6 +1288,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     RET_IF(lin_wgrad(c, fb.v_conv.key, dp, FT, v_embed + (size_t)target_idx * vd, vd, 1, fb.cin, vd, s));
   }
   RET_IF(cbwd_small_linear_bwd(d_pre_f, FT, 1, FT, c->film_t.w, td, d_temb, td, 1, s));
+  mark("bwd: conv0 + FiLM");
   // frustum gather, latent-code gather: scatter adjoints
   float* d_vol = F((size_t)V * V * V * 64);
   float* d_cur = F((size_t)sp_nout[8] * 64);
@@ -1282,6 +1299,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   if (dbg_dvolume) RET_IF(launch_nhwc_to_nchw(d_vol, 64, 1, 64, V * V * V, dbg_dvolume, s));
   RET_IF(cbwd_latent_scatter(d_vol, m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
                              c->v.spatial_volume_length, d_cur, s));
+  mark("bwd: scatters");
   // sparse voxel CNN
   for (int i = 8; i >= 0; --i) {
     const SparseLayerW& L = c->sparse[i];
@@ -1303,6 +1321,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     RET_IF(cbwd_sparse_w_unpack_add(dwp, L.cin, L.cout, L.layout, Gw, s));
     d_cur = d_in;
   }
+  mark("bwd: sparse net");
   float* d_fused = d_cur;  // [Nv][16]
   if (dbg_dfused) HIP_CHECK_RET(hipMemcpyAsync(dbg_dfused, d_fused, (size_t)Nv * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
   // view fusion, vertex gather
@@ -1313,6 +1332,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   HIP_CHECK_RET(hipMemsetAsync(d_feats, 0, (size_t)rows * 16 * sizeof(float), s));
   RET_IF(cbwd_vertex_scatter(d_vf, c->cams, vidx, N, m.verts, Nv, V, c->v.spatial_volume_length, S, persp, d_feats, s));
   if (dbg_dfeats) RET_IF(launch_nhwc_to_nchw(d_feats, 16, N, 16, HW, dbg_dfeats, s));
+  mark("bwd: fuse + vertex scatter");
   // 2-D encoder, the N views as the batch
   b.B = N;
   float *d_a = F((size_t)rows * 16), *d_r = F((size_t)rows * 16), *d_x = F((size_t)rows * 16), *d_nxt = F((size_t)rows * 16);
@@ -1347,6 +1367,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     }
     RET_IF(cbwd_small_linear_bwd(dsum, 48, 1, 48, c->enc_t.w, td, d_temb, td, 1, s));
   }
+  mark("bwd: 2-D encoder + FiLM");
   if (dbg_dtembed) HIP_CHECK_RET(hipMemcpyAsync(dbg_dtembed, d_temb, td * sizeof(float), hipMemcpyDeviceToDevice, s));
   // step MLP
   RET_IF(lin_wgrad(c, c->step_te2.key, d_temb, td, e1, td, 1, td, td, s));

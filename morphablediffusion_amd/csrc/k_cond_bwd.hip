@@ -103,16 +103,19 @@ __global__ void latent_scatter_kernel(const float* __restrict__ d_vol, const int
 
 // adjoint of vertex_gather_kernel: d_feats[view][pixel][c] += w2 * d_out[view][vertex][c].  One workgroup per view accumulates the
 // whole S x S x 16 image in LDS (ds_add_f32: thousands of vertices land on the same few hundred pixels) and writes it once.
+// gridDim.y workgroups share a view (each takes a slice of the vertices, its own LDS image, and adds it to HBM with fp32 atomics).
 __global__ __launch_bounds__(1024) void vertex_scatter_kernel(const float* __restrict__ d_out, const ViewCam* __restrict__ cams,
                                                               const int* __restrict__ view_idx, const float* __restrict__ verts, int Nv, int V,
                                                               float vol_len, int S, int persp, float* __restrict__ d_feats) {
-  extern __shared__ float s_img[];  // [S*S][16]
+  extern __shared__ float s_img[];  // [16][S*S] channel-major: the lanes of a wave hit different pixels, i.e. different banks
+  const int SS = S * S;
   const int view = blockIdx.x;
   const ViewCam cam = cams[view_idx[view]];
   for (int i = threadIdx.x; i < S * S * 16; i += blockDim.x) s_img[i] = 0.f;
   __syncthreads();
   // thread = (vertex, corner): 8 threads share a vertex
-  for (int job = threadIdx.x; job < Nv * 8; job += blockDim.x) {
+  const int per = (Nv + gridDim.y - 1) / gridDim.y, v_beg = blockIdx.y * per, v_end = min(Nv, v_beg + per);
+  for (int job = v_beg * 8 + threadIdx.x; job < v_end * 8; job += blockDim.x) {
     const int vi = job >> 3, corner = job & 7;
     float fr[3];
     int lo[3];
@@ -155,14 +158,17 @@ __global__ __launch_bounds__(1024) void vertex_scatter_kernel(const float* __res
       const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
       if (xx < 0 || xx > S - 1 || yy < 0 || yy > S - 1) continue;
       const float w2 = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * w3;
-      float* o = s_img + ((long)yy * S + xx) * 16;
+      float* o = s_img + yy * S + xx;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) unsafeAtomicAdd(o + c, w2 * g16[c]);
+      for (int c = 0; c < 16; ++c) unsafeAtomicAdd(o + c * SS, w2 * g16[c]);
     }
   }
   __syncthreads();
   float* fv = d_feats + (long)view * S * S * 16;
-  for (int i = threadIdx.x; i < S * S * 16; i += blockDim.x) fv[i] += s_img[i];
+  for (int i = threadIdx.x; i < S * S * 16; i += blockDim.x) {
+    const float v = s_img[(i & 15) * SS + (i >> 4)];
+    if (v != 0.f) unsafeAtomicAdd(fv + i, v);
+  }
 }
 
 // ---- view fusion (SMPLFeatureExtractor, network.py:41-72): fused[v][co] = sum_ci w[co][ci] mean_view vf[view][v][ci] + b[co] ----
@@ -387,7 +393,7 @@ int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)vertex_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(n_views), dim3(1024), lds, s, d_out, cams, view_idx, verts, Nv, V, vol_len, S, persp,
+  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(n_views, 8), dim3(1024), lds, s, d_out, cams, view_idx, verts, Nv, V, vol_len, S, persp,
                      d_feats);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

@@ -37,7 +37,7 @@ def tick(name, fn):
     return r
 
 
-for it in range(4):
+for it in range(2 if os.environ.get('PROFILE_COND') else 4):
     if it == 1:
         T.clear()
     dev = "cuda"
@@ -61,7 +61,17 @@ for it in range(4):
     tick("cond bwd", cb)
     tick("adamw", lambda: m.engine.lib.mvd_train_adamw_step(m.engine._ctx, *[__import__("ctypes").c_float(v) for v in (1e-6, 1e-5, 0.9, 0.999, 1e-8, 0.01)], it + 1, __import__("ctypes").c_float(1.0 / m.loss_scale), 1, None, None))
     tick("repack", m.engine.repack)
+if os.environ.get("PROFILE_COND"):  # rocprofv3 aid: 10 more conditioner backward passes, nothing else
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        cb()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"conditioner backward x {10 * B}: host enqueue {1e3 * (t1 - t0) / (10 * B):.2f} ms per sample, "
+          f"with the device drained {1e3 * (t2 - t0) / (10 * B):.2f} ms per sample")
 tot = sum(T.values())
 for k, v in T.items():
-    print(f"{k:28s} {1e3 * v / 3:8.2f} ms/step  {100 * v / tot:5.1f} %")
-print(f"{'total':28s} {1e3 * tot / 3:8.2f} ms/step  (B = {B}, recompute = {m.recompute})")
+    print(f"{k:28s} {1e3 * v / max(1, it):8.2f} ms/step  {100 * v / tot:5.1f} %")
+print(f"{'total':28s} {1e3 * tot / max(1, it):8.2f} ms/step  (B = {B}, recompute = {m.recompute})")
