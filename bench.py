@@ -27,6 +27,21 @@ PEAK_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBS = 8000.0     # HBM3E, same guide
 
 
+PMC_TRAFFIC_FILE = os.environ.get("MVD_PMC_TRAFFIC", os.path.join("profiles", "pmc_traffic.json"))
+
+
+def pmc_traffic(family, config):
+    """HBM-side bytes per launch of ``family`` from the PMC summary (tools/pmc_traffic.py ... out.json), or None."""
+    try:
+        with open(os.path.join(ROOT, PMC_TRAFFIC_FILE) if not os.path.isabs(PMC_TRAFFIC_FILE) else PMC_TRAFFIC_FILE) as f:
+            d = json.load(f)
+        if d.get("config") != config:
+            return None
+        return d["bytes_per_launch"].get(family)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def unet_kwargs(cfg):
     return dict(volume_dims=list(cfg.volume_dims), image_size=cfg.image_size, in_channels=8, out_channels=4,
                 model_channels=cfg.model_channels, attention_resolutions=[4, 2, 1], num_res_blocks=2,
@@ -433,11 +448,11 @@ def main():
             "roofline": None if dom is None else {
                 "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                 "frac": dom["achieved"] / dom["peak"],
-                # HBM-side bytes per launch of this family from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 per the
-                # gfx950 correction + WRITE_SIZE; profiles/r02_b_pmc_hbm_traffic.txt), known for the headline workload only
-                "traffic": 109.5e6 if (dominant == "gemm_dma_kernel<128,0>" and args.config == "headline" and world == 1
-                                      and not args.simulate_gpus) else None,
-                "traffic_unit": "bytes per launch, family average (algorithmic: 52.2e6)",
+                # HBM-side bytes per launch of this family: read from the PMC summary that tools/pmc_traffic.py writes from separate
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this build (FETCH x 2 per the gfx950 correction); null when
+                # no summary for this workload is present -- the number is never hard-coded here
+                "traffic": pmc_traffic(dominant, args.config) if (world == 1 and not args.simulate_gpus) else None,
+                "traffic_unit": "bytes per launch, family average, from " + PMC_TRAFFIC_FILE,
                 "kernel": dominant,
                 "how": f"HIP events on the launch stream around a deterministic 1-in-{args.probe_stride} sample of this "
                        f"family's launches INSIDE the timed region ({dom['launches_bracketed']} of {dom['launches']} launches, "

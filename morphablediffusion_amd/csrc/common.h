@@ -25,6 +25,7 @@ struct IGemm {
   int a_f32;            // 1: fp32 source (converted to fp16 while staging), 0: fp16 source
   int lda;              // elements between consecutive pixels
   int Cin;              // channels per tap (multiple of 8)
+  int cin_alg;          // the layer's own channel count (Cin / 3 for extended-precision layers): algorithmic FLOP bookkeeping
   // logical output grid; M = B*Z*Y*X
   int B, Z, Y, X;
   // virtual input extent (after nearest upsample), strides, physical extent = virtual >> ups

@@ -27,6 +27,7 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.a_f32 = ga.a_f32;
   g.lda = ga.lda;
   g.Cin = ga.w->Cin;
+  g.cin_alg = ga.w->xp ? ga.w->cin_l : ga.w->Cin;
   g.w = ga.w->w;
   g.N = ga.w->N;
   g.out = ga.out;
@@ -71,7 +72,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     g.splitk = 1;
     g.partial = nullptr;
     double fl = 0.0;
-    for (int p = 0; p < g.npar; ++p) fl += 2.0 * M * g.N * (double)g.Cin * g.par_ntaps[p];
+    for (int p = 0; p < g.npar; ++p) fl += 2.0 * M * g.N * (double)(g.cin_alg ? g.cin_alg : g.Cin) * g.par_ntaps[p];
     const double by = (double)g.B * g.PZ * g.PY * g.PX * g.Cin * 2 + (double)g.npar * kmax * g.N * g.Cin * 2 +
                       (double)M * g.npar * g.N * (g.out_f32 ? 4 : 2) + (g.resid ? (double)M * g.npar * g.N * (g.resid_f32 ? 4 : 2) : 0.0);
     char fam[64];
@@ -177,10 +178,12 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
   }
   int r;
   // algorithmic work of this launch: every operand and the result once (gathered taps re-read the same input pixels)
-  const double flops = 2.0 * M * g.N * (double)g.Cin * (g.npar > 0 ? 1 : g.ntaps);
+  // algorithmic FLOPs: the layer's own K (an extended-precision layer executes 3x that), every tap once
+  const double flops = 2.0 * M * g.N * (double)(g.cin_alg ? g.cin_alg : g.Cin) * g.ntaps;
   const double in_rows = (double)g.B * g.PZ * g.PY * g.PX;
   const double out_cols = g.geglu ? g.N / 2 : g.N;
-  double bytes = in_rows * g.Cin * (g.a_f32 ? 4 : 2) + (double)g.ntaps * g.N * g.Cin * 2 +
+  const double kalg = (double)(g.cin_alg ? g.cin_alg : g.Cin);
+  double bytes = in_rows * kalg * (g.a_f32 ? 4 : 2) + (double)g.ntaps * g.N * kalg * 2 +
                  (g.gn_partial ? 0.0 : (double)M * out_cols * (g.out_f32 ? 4 : 2));
   if (g.resid) bytes += (double)M * g.N * (g.resid_f32 ? 4 : 2);
   char fam[64];

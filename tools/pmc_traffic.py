@@ -6,6 +6,7 @@ gfx950 (same guide) and shown as reported.  Units: MB per step."""
 import collections, csv, json, re, sys
 
 steps = float(sys.argv[4]) if len(sys.argv) > 4 else 5.0
+json_out = sys.argv[5] if len(sys.argv) > 5 else None  # {family: HBM-side bytes per launch}: what bench.py reports as roofline.traffic
 PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel)<[^>]*>|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv|target_encoder"
 
 
@@ -50,3 +51,13 @@ for k in sorted(fe, key=lambda k: -fe[k]):
     a_mb = a / 1e6 if a else None
     print(f"{k:34s} {len(nf[k]) / steps:8.1f} {f2:10.1f} {w:9.1f} {a_mb if a_mb is None else round(a_mb, 1)!s:>12s} "
           f"{'' if not a_mb else round((f2 + w) / a_mb, 2)!s:>22s}")
+
+if json_out:
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                     "--no-extras; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, family average",
+           "config": line["config"].get("name"), "bytes_per_launch": {}}
+    for k in fe:
+        n = len(nf[k])
+        if n:
+            out["bytes_per_launch"][k] = (2 * fe[k] + wr.get(k, 0.0)) * 1024.0 / n
+    json.dump(out, open(json_out, "w"), indent=1)
