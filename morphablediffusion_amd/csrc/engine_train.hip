@@ -32,6 +32,8 @@ int bwd_group_norm(const float* x, long ld, const float* pre, int pld, const flo
                    const float* gamma, const float* beta, float eps, int act, float* dx, long lddx, int accum, float* dg_part,
                    float* db_part, float* dpre_part, hipStream_t s);
 int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s);
+int bwd_sum_rows_multi(int n, const float* const* part, const int* R, const int* C, const long* ldp, float* const* out, const int* accum,
+                       hipStream_t s);
 int bwd_gn_slabs(int B, int G, int rows);
 int bwd_group_norm_fwd(const float* x, long ld, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act,
                        float* y, long ldy, float* part, int S, hipStream_t s);
@@ -358,6 +360,18 @@ int wgrad_conv3(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x
   }
   return 0;
 }
+// gain and bias gradients of a norm in one launch: Gw[c] += sum_r pw[r * ldp + c], Gb[c] += sum_r pb[r * ldp + c]
+int sum_pair(Bwd& b, const float* pw, const float* pb, int R, int C, long ldp, float* Gw, float* Gb) {
+  const float* part[2];
+  float* out[2];
+  int n = 0;
+  if (Gw) part[n] = pw, out[n++] = Gw;
+  if (Gb) part[n] = pb, out[n++] = Gb;
+  if (!n) return 0;
+  const int Rs[2] = {R, R}, Cs[2] = {C, C}, acc[2] = {1, 1};
+  const long lds[2] = {ldp, ldp};
+  return bwd_sum_rows_multi(n, part, Rs, Cs, lds, out, acc, b.s);
+}
 // GroupNorm backward incl. its gain / bias gradients (slabbed: B * G * S workgroups)
 // pre / pld: the per-sample pre-add of the forward norm (FiLM); dpre [B][ldp] (may be null) receives its gradient
 int gn_backward(Bwd& b, const NormW& n, int groups, float eps, int act, const float* x, long ld, const float* dy, long ldy, int rows_ps,
@@ -372,10 +386,8 @@ int gn_backward(Bwd& b, const NormW& n, int groups, float eps, int act, const fl
   WS_CHECK(dg && db && part && (dp || !dpre));
   RET_IF(bwd_group_norm_slab(x, ld, pre, pld, dy, ldy, b.B, rows_ps, n.C, groups, n.g, n.b, eps, act, dx, lddx, accum ? 1 : 0, part,
                              part + (size_t)b.B * groups * S * 2, dg, db, dp, S, b.s));
-  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(dg, b.B * S, n.C, n.C, G, 1, b.s));
-  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(db, b.B * S, n.C, n.C, G, 1, b.s));
-  if (dpre)
-    for (int i = 0; i < b.B; ++i) RET_IF(bwd_sum_rows_add(dp + (size_t)i * S * n.C, S, n.C, n.C, dpre + (size_t)i * ldp, 0, b.s));
+  RET_IF(sum_pair(b, dg, db, b.B * S, n.C, n.C, engine_grad(c, n.key + ".weight"), engine_grad(c, n.key + ".bias")));
+  if (dpre) RET_IF(bwd_colsum_samples(dp, 1, n.C, b.B, S, n.C, dpre, ldp, b.s));  // per sample: its S slab rows
   return 0;
 }
 // GroupNorm forward in fp32 for the DepthTransformer re-computation
@@ -394,9 +406,7 @@ int ln_backward(Bwd& b, const NormW& n, const float* x, long ld, const float* dy
   WS_CHECK(part);
   int nblk = 0;
   RET_IF(bwd_layer_norm(x, ld, dy, ldy, rows, n.C, n.g, 1e-5f, dx, lddx, accum ? 1 : 0, part, &nblk, b.s));
-  if (float* G = engine_grad(c, n.key + ".weight")) RET_IF(bwd_sum_rows_add(part, nblk, n.C, 2 * n.C, G, 1, b.s));
-  if (float* G = engine_grad(c, n.key + ".bias")) RET_IF(bwd_sum_rows_add(part + n.C, nblk, n.C, 2 * n.C, G, 1, b.s));
-  return 0;
+  return sum_pair(b, part, part + n.C, nblk, n.C, 2 * n.C, engine_grad(c, n.key + ".weight"), engine_grad(c, n.key + ".bias"));
 }
 
 // ---- ResBlock (openaimodel.py:256-276) ------------------------------------------------------------------------------

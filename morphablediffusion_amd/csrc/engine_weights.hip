@@ -46,7 +46,7 @@ int copy_f32(mvd_ctx* c, const std::string& k, float** out, int* n = nullptr) {
     return 0;
   }
   RET_IF(dmalloc(c, (void**)out, r->numel * sizeof(float)));
-  HIP_CHECK_RET(hipMemcpy(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice));
+  HIP_CHECK_RET(hipMemcpyAsync(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
   if (n) *n = (int)r->numel;
   return 0;
 }
@@ -362,7 +362,7 @@ int build_clip(mvd_ctx* c) {
     RET_IF(load_norm(c, L + ".ln_2", &b.ln2));
     RET_IF(pack_rows(c, iw->d, 3 * w, w, w, &b.qkv));  // in_proj_weight is q | k | v stacked already
     RET_IF(dmalloc(c, (void**)&b.qkv.bias, (size_t)3 * w * sizeof(float)));
-    HIP_CHECK_RET(hipMemcpy(b.qkv.bias, ib->d, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_CHECK_RET(hipMemcpyAsync(b.qkv.bias, ib->d, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToDevice, 0));
     HIP_CHECK_RET(hipMemset(b.qkv.bias + 2 * w, 0, (size_t)w * sizeof(float)));  // b_v lives in out.bias
     RET_IF(pack_conv(c, L + ".attn.out_proj.weight", "", false, false, &b.out));
     RET_IF(dmalloc(c, (void**)&b.out.bias, (size_t)w * sizeof(float)));
@@ -462,12 +462,12 @@ int build_vae(mvd_ctx* c) {
     pad.numel = 4 * per;
     HIP_CHECK_RET(hipMalloc((void**)&pad.d, pad.numel * sizeof(float)));
     HIP_CHECK_RET(hipMemset(pad.d, 0, pad.numel * sizeof(float)));
-    HIP_CHECK_RET(hipMemcpy(pad.d, co->d, co->numel * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_CHECK_RET(hipMemcpyAsync(pad.d, co->d, co->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
     padb.shape = {4};
     padb.numel = 4;
     HIP_CHECK_RET(hipMalloc((void**)&padb.d, 4 * sizeof(float)));
     HIP_CHECK_RET(hipMemset(padb.d, 0, 4 * sizeof(float)));
-    HIP_CHECK_RET(hipMemcpy(padb.d, b->d, b->numel * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_CHECK_RET(hipMemcpyAsync(padb.d, b->d, b->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
     c->raw[D + "conv_out.weight.pad4"] = pad;
     c->raw[D + "conv_out.bias.pad4"] = padb;
     RET_IF(pack_conv(c, D + "conv_out.weight.pad4", D + "conv_out.bias.pad4", false, false, &v.conv_out, 0, c->vae_exact));
@@ -692,7 +692,7 @@ int build_unet_section(mvd_ctx* c) {
       RET_IF(get_raw(c, pz.key + ".weight", &w));
       RET_IF(get_raw(c, pz.key + ".bias", &b));
       RET_IF(launch_f32_to_f16(w->d, c->emb_all.w + (size_t)off * temb, w->numel, 0));
-      HIP_CHECK_RET(hipMemcpy(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      HIP_CHECK_RET(hipMemcpyAsync(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice, 0));
       off += pz.cout;
     }
   }
@@ -712,7 +712,7 @@ int build_unet_section(mvd_ctx* c) {
       RET_IF(get_raw(c, k + ".to_out.0.bias", &bo));
       const int C = (int)bo->numel;
       RET_IF(launch_fold_ov(wo->d, wv->d, 1, C, u.context_dim, C, c->a2_all.w + off * u.context_dim, 0));
-      HIP_CHECK_RET(hipMemcpy(c->a2_all.bias + off, bo->d, C * sizeof(float), hipMemcpyDeviceToDevice));
+      HIP_CHECK_RET(hipMemcpyAsync(c->a2_all.bias + off, bo->d, C * sizeof(float), hipMemcpyDeviceToDevice, 0));
       off += C;
     }
   }
@@ -789,7 +789,7 @@ int build_condnet_section(mvd_ctx* c) {
       size_t off = 0;
       for (size_t i = 0; i < ws.size(); ++i) {
         RET_IF(launch_f32_to_f16(ws[i]->d, out->w + off * K, ws[i]->numel, 0));
-        HIP_CHECK_RET(hipMemcpy(out->bias + off, bs[i]->d, bs[i]->numel * sizeof(float), hipMemcpyDeviceToDevice));
+        HIP_CHECK_RET(hipMemcpyAsync(out->bias + off, bs[i]->d, bs[i]->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
         off += ws[i]->shape[0];
       }
       return 0;

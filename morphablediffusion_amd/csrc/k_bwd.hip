@@ -107,14 +107,23 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long ro
 // wT[taps-1-t][ci][co] = w[t][co][ci]  (the tap flip turns the forward cross-correlation into its adjoint; Np >= N zero padded)
 // flip = 0: the taps keep their index (the adjoint of a strided conv / of a transposed conv is launched as the OTHER kind, whose
 // tap tables already carry the index relation o = 2 i - 1 + k)
-__global__ void pack_dgrad_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np, half_t* __restrict__ wT, int flip) {
-  const long total = (long)taps * Cl * Np;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Np);
-    const long tc = i / Np;
-    const int ci = (int)(tc % Cl), t2 = (int)(tc / Cl);
-    const int t = flip ? taps - 1 - t2 : t2;
-    wT[i] = co < N ? w[((long)t * N + co) * ldw + ci] : (half_t)0;
+// 64 x 64 tiles through LDS: 128-byte row segments on both sides (the element-per-thread form read 2 bytes per cache line)
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np,
+                                                         half_t* __restrict__ wT, int flip) {
+  __shared__ half_t tile[64][66];
+  const int t2 = blockIdx.z, t = flip ? taps - 1 - t2 : t2;
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int co = co0 + ty + 4 * i, ci = ci0 + tx;
+    tile[ty + 4 * i][tx] = (co < N && ci < Cl) ? w[((long)t * N + co) * ldw + ci] : (half_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ci = ci0 + ty + 4 * i, co = co0 + tx;
+    if (ci < Cl && co < Np) wT[((long)t2 * Cl + ci) * Np + co] = tile[tx][ty + 4 * i];
   }
 }
 
@@ -384,10 +393,19 @@ __global__ void outer_add_kernel(const float* __restrict__ a, long lda, const fl
 
 // out[c] (+)= sum_r part[r][c]: a workgroup owns 8 columns, 32 row lanes each, combined through LDS in lane order (fixed order
 // for a given R)
-__global__ __launch_bounds__(256) void sum_rows_add_kernel(const float* __restrict__ part, int R, int C, long ldp, float* __restrict__ out,
-                                                           int accum) {
+struct SumJobs {  // up to four independent column sums in one launch (blockIdx.y picks the job)
+  const float* part[4];
+  float* out[4];
+  long ldp[4];
+  int R[4], C[4], accum[4];
+};
+__global__ __launch_bounds__(256) void sum_rows_add_kernel(const SumJobs j) {
   __shared__ float s_p[32][9];
+  const int k = blockIdx.y, C = j.C[k], R = j.R[k];
   const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cc;
+  if (blockIdx.x * 8 >= C) return;
+  const float* __restrict__ part = j.part[k];
+  const long ldp = j.ldp[k];
   float a = 0.f;
   if (c < C)
     for (int r = rl; r < R; r += 32) a += part[(long)r * ldp + c];
@@ -396,23 +414,38 @@ __global__ __launch_bounds__(256) void sum_rows_add_kernel(const float* __restri
   if (rl == 0 && c < C) {
     float t = 0.f;
     for (int i = 0; i < 32; ++i) t += s_p[i][cc];
-    out[c] = accum ? out[c] + t : t;
+    float* out = j.out[k];
+    out[c] = j.accum[k] ? out[c] + t : t;
   }
 }
 
-// out[b][c] = sum over the rows of sample b of v[b*rows + r][c] (ld): one workgroup per (sample, 64-channel slab); 4 row
-// lanes x 64 channels, fixed order
+// out[b][c] = sum over the rows of sample b of v[b*rows + r][c] (ld): one workgroup per (sample, 64-channel slab); 16 row
+// lanes x 64 channels with four loads in flight per lane, fixed order
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_samples_kernel(const T* __restrict__ v, long ld, int rows, int C, float* __restrict__ out,
-                                                             long ldo) {
-  __shared__ float s[4][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  float a = 0.f;
-  if (c < C)
-    for (int r = rl; r < rows; r += 4) a += ldf(v + ((long)b * rows + r) * ld + c);
-  s[rl][threadIdx.x & 63] = a;
+__global__ __launch_bounds__(1024) void colsum_samples_kernel(const T* __restrict__ v, long ld, int rows, int C, float* __restrict__ out,
+                                                              long ldo) {
+  __shared__ float s[16][64];
+  const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    const T* p = v + (long)b * rows * ld + c;
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+      a0 += ldf(p + (long)r * ld);
+      a1 += ldf(p + (long)(r + 16) * ld);
+      a2 += ldf(p + (long)(r + 32) * ld);
+      a3 += ldf(p + (long)(r + 48) * ld);
+    }
+    for (; r < rows; r += 16) a0 += ldf(p + (long)r * ld);
+  }
+  s[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (rl == 0 && c < C) out[(long)b * ldo + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s[i][cl];
+    out[(long)b * ldo + c] = t;
+  }
 }
 
 // LayerNorm backward over rows of C <= 64 * LN_NC channels: one wave per row, lanes own columns lane + 64 k.
@@ -966,7 +999,7 @@ int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* d
   return 0;
 }
 int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s, int flip) {
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(gridn((size_t)taps * Cl * Np)), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(Np, 64), cdiv(Cl, 64), taps), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -1017,13 +1050,29 @@ int bwd_outer_add(const float* a, long lda, const float* b, long ldb, float* C, 
   return 0;
 }
 int bwd_sum_rows_add(const float* part, int R, int C, long ldp, float* out, int accum, hipStream_t s) {
-  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, part, R, C, ldp, out, accum);
+  SumJobs j{};
+  j.part[0] = part, j.out[0] = out, j.ldp[0] = ldp, j.R[0] = R, j.C[0] = C, j.accum[0] = accum;
+  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(C, 8), 1), dim3(256), 0, s, j);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// n <= 4 column sums in one launch: out[k][c] (+)= sum_r part[k][r * ldp[k] + c]
+int bwd_sum_rows_multi(int n, const float* const* part, const int* R, const int* C, const long* ldp, float* const* out, const int* accum,
+                       hipStream_t s) {
+  if (n < 1 || n > 4) return mvd_fail("bwd_sum_rows_multi: 1..4 jobs");
+  SumJobs j{};
+  int cmax = 0;
+  for (int k = 0; k < n; ++k) {
+    j.part[k] = part[k], j.out[k] = out[k], j.ldp[k] = ldp[k], j.R[k] = R[k], j.C[k] = C[k], j.accum[k] = accum[k];
+    cmax = C[k] > cmax ? C[k] : cmax;
+  }
+  hipLaunchKernelGGL(sum_rows_add_kernel, dim3(cdiv(cmax, 8), n), dim3(256), 0, s, j);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 int bwd_colsum_samples(const void* v, int v_f32, long ld, int B, int rows, int C, float* out, long ldo, hipStream_t s) {
-  if (v_f32) hipLaunchKernelGGL(colsum_samples_kernel<float>, dim3(cdiv(C, 64), B), dim3(256), 0, s, (const float*)v, ld, rows, C, out, ldo);
-  else hipLaunchKernelGGL(colsum_samples_kernel<half_t>, dim3(cdiv(C, 64), B), dim3(256), 0, s, (const half_t*)v, ld, rows, C, out, ldo);
+  if (v_f32) hipLaunchKernelGGL(colsum_samples_kernel<float>, dim3(cdiv(C, 64), B), dim3(1024), 0, s, (const float*)v, ld, rows, C, out, ldo);
+  else hipLaunchKernelGGL(colsum_samples_kernel<half_t>, dim3(cdiv(C, 64), B), dim3(1024), 0, s, (const half_t*)v, ld, rows, C, out, ldo);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

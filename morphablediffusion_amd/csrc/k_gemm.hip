@@ -434,8 +434,13 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
             const float bx = (g.bias && okc) ? g.bias[nx] : 0.f, bg = (g.bias && okc) ? g.bias[nx + 32] : 0.f;
             f32x16 v;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              v[r] = (acc[2 * p][r] * g.alpha + bx) * gelu_erf(acc[2 * p + 1][r] * g.alpha + bg);
+            for (int r = 0; r < 16; r += 2) {  // packed fp32: two rows per instruction
+              const f32x2 xv = f32x2{acc[2 * p][r], acc[2 * p][r + 1]} * g.alpha + bx;
+              const f32x2 qv = f32x2{acc[2 * p + 1][r], acc[2 * p + 1][r + 1]} * g.alpha + bg;
+              const f32x2 o = geglu_pair(xv, qv);
+              v[r] = o.x;
+              v[r + 1] = o.y;
+            }
             if (PLAIN && epilogue8_ok(g, N >> 1))
               epilogue8_frag_store<true>(g, v, scratch, lane, m0 + wave * 32, M, (n0 >> 1) + p * 32, N >> 1, nullptr);
             else

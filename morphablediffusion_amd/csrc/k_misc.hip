@@ -146,6 +146,37 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int N, int Cin
   }
 }
 
+// The same packing for conv weights (taps > 1, not transposed): one workgroup per (output row, 64 input channels) reads its
+// 64 * taps source floats as one contiguous run and writes 128-byte row segments per tap (the element-per-thread form reads
+// with a stride of taps * 4 bytes, once per tap).
+__global__ __launch_bounds__(256) void pack_weight_taps_kernel(const float* __restrict__ src, int N, int Cin, int taps, int geglu, int cin_src,
+                                                               half_t* __restrict__ dst, int xp) {
+  __shared__ float sw[64 * 27];
+  const int Cl = xp ? Cin / 3 : Cin;
+  const int nd = blockIdx.y, c0 = blockIdx.x * 64;
+  int n = nd;
+  if (geglu) {
+    const int j = nd >> 6, wi = nd & 63;
+    n = wi < 32 ? 32 * j + wi : N / 2 + 32 * j + (wi - 32);
+  }
+  const int nc = min(64, cin_src - c0);  // source channels of this tile (<= 0: pure padding)
+  const float* p = src + ((long)n * cin_src + c0) * taps;
+  for (int i = threadIdx.x; i < nc * taps; i += 256) sw[i] = p[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * taps; i += 256) {
+    const int t = i >> 6, cl = i & 63, c = c0 + cl;
+    if (c >= Cl) continue;
+    const float w = cl < nc ? sw[cl * taps + t] : 0.f;
+    const half_t hi = (half_t)w;
+    half_t* d = dst + ((long)t * N + nd) * Cin + c;
+    d[0] = hi;
+    if (xp) {
+      d[Cl] = hi;
+      d[2 * Cl] = (half_t)(w - (float)hi);
+    }
+  }
+}
+
 __global__ void permute_geglu_bias_kernel(const float* __restrict__ src, int N, float* __restrict__ dst) {
   const int nd = blockIdx.x * blockDim.x + threadIdx.x;
   if (nd >= N) return;
@@ -327,6 +358,12 @@ int launch_pack_weight(const float* src, int N, int Cin, int taps, int transpose
                        hipStream_t s, int cin_src, int xp) {
   if (xp && Cin % 3) return mvd_fail("pack_weight: the extended-precision layout needs Cin = 3 * Cl");
   if (cin_src <= 0) cin_src = xp ? Cin / 3 : Cin;
+  if (taps > 1 && taps <= 27 && !transposed && N <= 65535) {
+    const int Cl = xp ? Cin / 3 : Cin;
+    hipLaunchKernelGGL(pack_weight_taps_kernel, dim3(cdiv(Cl, 64), N), dim3(256), 0, s, src, N, Cin, taps, geglu, cin_src, dst, xp);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)N * Cin * taps)), dim3(256), 0, s, src, N, Cin, taps,
                      transposed, geglu, cin_src, dst, xp);
   HIP_CHECK_RET(hipGetLastError());

@@ -48,14 +48,6 @@ __global__ void perm_w3_kernel(const float* __restrict__ src, int N, int C, int 
 }
 
 __device__ __forceinline__ float act_f(float u, int act) { return act == ACT_SILU ? u / (1.f + __expf(-u)) : (act == ACT_RELU ? fmaxf(u, 0.f) : u); }
-__device__ __forceinline__ float act_d(float u, int act) {
-  if (act == ACT_SILU) {
-    const float s = 1.f / (1.f + __expf(-u));
-    return s * (1.f + u * (1.f - s));
-  }
-  return act == ACT_RELU ? (u > 0.f ? 1.f : 0.f) : 1.f;
-}
-
 __device__ float block_sum256(float v, float* s_red) {
   const int t = threadIdx.x;
   s_red[t] = v;
