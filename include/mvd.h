@@ -103,6 +103,27 @@ int mvd_set_mesh(mvd_ctx* ctx, const float* vertices, const int32_t* coord, cons
 int mvd_select_sample(mvd_ctx* ctx, int slot);
 /* target_K [N,4,4], target_RT [N,3,4] fp32 HOST pointers (batch['target_K'], batch['target_RT']) */
 int mvd_set_cameras(mvd_ctx* ctx, const float* K, const float* RT, int N);
+/* The same two uploads in the order of `stream`, for callers whose mesh changes at every step (a training step sees a new
+ * batch, generate_face.py one mesh per trajectory): the host pointers are read before the call returns, the tables go to the
+ * device as ONE copy enqueued on `stream` -- launches enqueued on `stream` earlier keep reading the previous tables, later
+ * ones read the new tables; nothing is allocated and nothing synchronises once the slot's pools have grown to the mesh size.
+ * All launches of this context that read the slot must be on `stream` (or ordered after it by the caller). */
+int mvd_set_mesh_async(mvd_ctx* ctx, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
+                       int Nv, void* stream);
+int mvd_set_cameras_async(mvd_ctx* ctx, const float* K, const float* RT, int N, void* stream);
+/* A whole batch at once (the reference's ``for bi in range(B)`` loop over a NEW batch, morphable_diffusion.py:245-254: spconv
+ * regenerates its indices for every sample at every call): sample i's mesh and cameras go to slot slots[i] (distinct). The B
+ * rule books are built on B host threads, every sample is validated before the first table is replaced, the uploads are
+ * enqueued on `stream` as in the two calls above.  The active slot is unchanged on return. */
+int mvd_set_samples_async(mvd_ctx* ctx, int B, const int* slots, const float* const* vertices, const int32_t* const* coord,
+                          const int32_t* const* out_sh, const float* const* bounds, const int* Nv, const float* const* K,
+                          const float* const* RT, int N, void* stream);
+/* Host-only view of the rule book (no context, no GPU: used by the CPU tests): builds the tables of one mesh on the calling
+ * thread -- n_sites[3] active sites per level, lens[6] = ints in nbr_subm[0..2] ([n_sites][27], -1 = inactive), nbr_down[0..1]
+ * ([n_sites of the next level][27]) and the coarse index grid -- and mvd_rulebook_table copies table `which` (0..5) of that
+ * build.  force_hash != 0 takes the open-addressing path that grids of more than 2^25 cells use. */
+int mvd_rulebook_build(const int32_t* coord, const int32_t* out_sh, int Nv, int force_hash, int32_t* n_sites, int64_t* lens);
+int mvd_rulebook_table(int which, int32_t* out);
 
 /* First half of SpatialVolumeNet.construct_spatial_volume (morphable_diffusion.py:203-231) for the views
  * view_idx[0..n_local): x_noisy [n_local,4,s,s], t_embed [time_dim], v_embed [n_local,view_dim];
@@ -285,7 +306,9 @@ int mvd_clip_embed_dim(mvd_ctx* ctx);
  * mode 2: only `family`, a deterministic pseudo-random 1-in-`stride` sample of its launches (for the timed region).
  * A non-zero mode resets the counters.  mvd_probe_report synchronises on the recorded events and writes a JSON array
  * [{"family", "launches", "sampled", "ms", "flops", "bytes", "all_flops", "all_bytes"}, ...] (ms / flops / bytes: the bracketed
- * launches; all_*: every launch seen) into buf. */
+ * launches; all_*: every launch seen) into buf.  In mode 1 the report also carries the pseudo-family "(empty bracket)": event
+ * pairs with NOTHING between them, recorded after every 8th launch -- ms / sampled of that row is what a bracket adds to a
+ * launch's own duration (the second event's barrier packet), for the caller to subtract. */
 int mvd_probe_config(mvd_ctx* ctx, int mode, const char* family, int stride);
 int mvd_probe_report(mvd_ctx* ctx, char* buf, size_t cap);
 /* same for a Linear layer [M,K] x [N,K]^T (fp16 operands in HBM); flags: 1 = fp32 residual add, 2 = fp16 output,

@@ -7,10 +7,15 @@
 
 #include "engine.h"
 
-int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N);
+int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipStream_t s);
 int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
-                    int Nv);
+                    int Nv, hipStream_t s);
 int engine_select_sample(mvd_ctx* c, int slot);
+int engine_set_samples(mvd_ctx* c, int B, const int* slots, const float* const* vertices, const int32_t* const* coord,
+                       const int32_t* const* out_sh, const float* const* bounds, const int* Nv, const float* const* K,
+                       const float* const* RT, int N, hipStream_t s);
+int engine_rulebook_build(const int32_t* coord, const int32_t* out_sh, int Nv, int force_hash, int32_t* n_sites, int64_t* lens);
+int engine_rulebook_table(int which, int32_t* out);
 void mesh_free(MeshTables& m);
 
 static thread_local std::string g_err;
@@ -127,9 +132,15 @@ void mvd_destroy(mvd_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   mesh_free(c->mesh);
   hipFree(c->cams);
+  auto free_stage = [](mvd_ctx::CamStage& st) {
+    if (st.h) hipHostFree(st.h);
+    if (st.staged) hipEventDestroy(st.staged);
+  };
+  free_stage(c->cam_stage);
   for (auto& sl : c->slots) {
     mesh_free(sl.mesh);
     hipFree(sl.cams);
+    free_stage(sl.cam_stage);
   }
   hipFree(c->volume);
   hipFree(c->ws.base);
@@ -189,7 +200,17 @@ int mvd_finalize_weights(mvd_ctx* c) {
 int mvd_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds, int Nv) {
   if (!c || !vertices || !coord || !out_sh || !bounds || Nv <= 0) return mvd_fail("mvd_set_mesh: bad argument");
   HIP_CHECK_RET(hipSetDevice(c->device));
-  return engine_set_mesh(c, vertices, coord, out_sh, bounds, Nv);
+  HIP_CHECK_RET(hipDeviceSynchronize());  // launches on ANY stream may still read the tables being replaced
+  RET_IF(engine_set_mesh(c, vertices, coord, out_sh, bounds, Nv, nullptr));
+  HIP_CHECK_RET(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+int mvd_set_mesh_async(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds, int Nv,
+                       void* stream) {
+  if (!c || !vertices || !coord || !out_sh || !bounds || Nv <= 0) return mvd_fail("mvd_set_mesh_async: bad argument");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_set_mesh(c, vertices, coord, out_sh, bounds, Nv, S(stream));
 }
 
 int mvd_select_sample(mvd_ctx* c, int slot) {
@@ -201,7 +222,40 @@ int mvd_select_sample(mvd_ctx* c, int slot) {
 int mvd_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
   if (!c || !K || !RT || N <= 0) return mvd_fail("mvd_set_cameras: bad argument");
   HIP_CHECK_RET(hipSetDevice(c->device));
-  return engine_set_cameras(c, K, RT, N);
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  RET_IF(engine_set_cameras(c, K, RT, N, nullptr));
+  HIP_CHECK_RET(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+int mvd_set_samples_async(mvd_ctx* c, int B, const int* slots, const float* const* vertices, const int32_t* const* coord,
+                          const int32_t* const* out_sh, const float* const* bounds, const int* Nv, const float* const* K,
+                          const float* const* RT, int N, void* stream) {
+  if (!c || B <= 0 || !slots || !vertices || !coord || !out_sh || !bounds || !Nv || !K || !RT || N <= 0)
+    return mvd_fail("mvd_set_samples_async: bad argument");
+  for (int i = 0; i < B; ++i) {
+    if (!vertices[i] || !coord[i] || !out_sh[i] || !bounds[i] || !K[i] || !RT[i] || Nv[i] <= 0 || slots[i] < 0 || slots[i] >= 64)
+      return mvd_fail("mvd_set_samples_async: bad argument");
+    for (int j = 0; j < i; ++j)
+      if (slots[j] == slots[i]) return mvd_fail("mvd_set_samples_async: a slot appears twice");
+  }
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_set_samples(c, B, slots, vertices, coord, out_sh, bounds, Nv, K, RT, N, S(stream));
+}
+
+int mvd_rulebook_build(const int32_t* coord, const int32_t* out_sh, int Nv, int force_hash, int32_t* n_sites, int64_t* lens) {
+  if (!coord || !out_sh || Nv <= 0 || !n_sites || !lens) return mvd_fail("mvd_rulebook_build: bad argument");
+  return engine_rulebook_build(coord, out_sh, Nv, force_hash, n_sites, lens);
+}
+int mvd_rulebook_table(int which, int32_t* out) {
+  if (!out) return mvd_fail("mvd_rulebook_table: bad argument");
+  return engine_rulebook_table(which, out);
+}
+
+int mvd_set_cameras_async(mvd_ctx* c, const float* K, const float* RT, int N, void* stream) {
+  if (!c || !K || !RT || N <= 0) return mvd_fail("mvd_set_cameras_async: bad argument");
+  HIP_CHECK_RET(hipSetDevice(c->device));
+  return engine_set_cameras(c, K, RT, N, S(stream));
 }
 
 int mvd_embed_time(mvd_ctx* c, const int64_t* t, int B, float* out, void* stream) {
@@ -910,6 +964,7 @@ int mvd_probe_config(mvd_ctx* c, int mode, const char* family, int stride) {
     c->probe_used = 0;
     c->probe_counter = 0;
     c->probe_fam.clear();
+    c->probe_empty.clear();
   }
   return 0;
 }
@@ -935,6 +990,21 @@ int mvd_probe_report(mvd_ctx* c, char* buf, size_t cap) {
              kv.second.flops, kv.second.bytes);
     out += line;
     first = false;
+  }
+  if (!c->probe_empty.empty()) {  // what a bracket costs by itself (survey mode), as a pseudo-family
+    double ms = 0.0;
+    for (size_t e : c->probe_empty) {
+      HIP_CHECK_RET(hipEventSynchronize(c->probe_ev[e + 1]));
+      float t = 0.f;
+      HIP_CHECK_RET(hipEventElapsedTime(&t, c->probe_ev[e], c->probe_ev[e + 1]));
+      ms += t;
+    }
+    char line[256];
+    snprintf(line, sizeof line,
+             "%s{\"family\": \"(empty bracket)\", \"launches\": %zu, \"sampled\": %zu, \"ms\": %.6f, \"flops\": 0, \"bytes\": 0, "
+             "\"all_flops\": 0, \"all_bytes\": 0}",
+             first ? "" : ", ", c->probe_empty.size(), c->probe_empty.size(), ms);
+    out += line;
   }
   out += "]";
   if (out.size() + 1 > cap) return mvd_fail("mvd_probe_report: buffer too small");

@@ -185,6 +185,13 @@ struct MeshTables {
   float min_xyz[3];
   int out_sh[3];
   float* feat[2] = {nullptr, nullptr};  // ping-pong feature buffers [max_sites][64]
+  // storage: verts / nbr_* / grid2 point into ONE device pool that is filled by one stream-ordered copy from a pinned host
+  // image, so a rebuild (a new mesh in this slot: every training step) neither allocates nor synchronises once the pools have
+  // grown to the mesh size; `staged` marks the end of the last copy out of `h_pool`
+  int* pool = nullptr;
+  int* h_pool = nullptr;
+  size_t pool_cap = 0, feat_cap = 0;  // ints / floats per feat buffer
+  hipEvent_t staged = nullptr;
 };
 
 struct mvd_ctx {
@@ -217,6 +224,7 @@ struct mvd_ctx {
   std::map<std::string, ProbeFam> probe_fam;
   std::vector<hipEvent_t> probe_ev;   // pool, two events per bracketed launch
   size_t probe_used = 0;
+  std::vector<size_t> probe_empty;    // survey mode: brackets with NOTHING between the two events (what a bracket itself costs)
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
 
@@ -285,10 +293,17 @@ struct mvd_ctx {
   MeshTables mesh;
   ViewCam* cams = nullptr;  // device [n_cams]
   int n_cams = 0;
+  struct CamStage {  // pinned host image of `cams` + the end of its last upload (same scheme as MeshTables::h_pool)
+    ViewCam* h = nullptr;
+    int cap = 0;
+    hipEvent_t staged = nullptr;
+  };
+  CamStage cam_stage;
   struct SampleSlot {
     MeshTables mesh;
     ViewCam* cams = nullptr;
     int n_cams = 0;
+    CamStage cam_stage;
   };
   std::vector<SampleSlot> slots;
   int cur_slot = 0;
@@ -527,7 +542,24 @@ struct ProbeScope {
     hipEventRecord(c->probe_ev[slot], s);
   }
   ~ProbeScope() {
-    if (slot != (size_t)-1) hipEventRecord(c->probe_ev[slot + 1], s);
+    if (slot == (size_t)-1) return;
+    hipEventRecord(c->probe_ev[slot + 1], s);
+    // survey mode: after every 8th bracketed launch an EMPTY bracket (two events, nothing between) on the same stream -- its
+    // elapsed time is what the bracket adds to a launch's own duration (the second event's barrier packet); reported as the
+    // pseudo-family "(empty bracket)" so that the caller can subtract it
+    if (c->probe_mode == 1 && (slot & 14) == 0) {
+      if (c->probe_used + 2 > c->probe_ev.size())
+        for (int i = 0; i < 2; ++i) {
+          hipEvent_t ev;
+          if (hipEventCreate(&ev) != hipSuccess) return;
+          c->probe_ev.push_back(ev);
+        }
+      const size_t e = c->probe_used;
+      c->probe_used += 2;
+      c->probe_empty.push_back(e);
+      hipEventRecord(c->probe_ev[e], s);
+      hipEventRecord(c->probe_ev[e + 1], s);
+    }
   }
   ProbeScope(const ProbeScope&) = delete;
   ProbeScope& operator=(const ProbeScope&) = delete;

@@ -8,6 +8,9 @@
 #include <unordered_map>
 
 #include "engine.h"
+#include <chrono>
+#include <string>
+#include <thread>
 
 namespace {
 
@@ -50,20 +53,45 @@ void mul4(const double* a, const double* b, double* o) {
 
 inline long key3(int z, int y, int x) { return ((long)z << 40) | ((long)y << 20) | (long)x; }
 
-int upload_ints(const std::vector<int>& h, int** d) {
-  if (*d) hipFree(*d);
-  *d = nullptr;
-  HIP_CHECK_RET(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(int)));
-  if (!h.empty()) HIP_CHECK_RET(hipMemcpy(*d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
-  return 0;
-}
+// open-addressing map voxel key -> first row with that key (linear probing, power-of-two table): the rule book does
+// ~30 lookups per active site, std::unordered_map made that the most expensive part of a mesh upload
+struct VoxelMap {
+  std::vector<long> keys;
+  std::vector<int> vals;
+  size_t mask = 0;
+  void reset(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    keys.assign(cap, -1);
+    vals.resize(cap);
+    mask = cap - 1;
+  }
+  static size_t hash(long k) { return (size_t)((unsigned long)k * 0x9E3779B97F4A7C15ul >> 20); }
+  void insert_first(long k, int v) {  // keeps the FIRST value of a key
+    size_t i = hash(k) & mask;
+    while (keys[i] != -1) {
+      if (keys[i] == k) return;
+      i = (i + 1) & mask;
+    }
+    keys[i] = k;
+    vals[i] = v;
+  }
+  int find(long k) const {
+    size_t i = hash(k) & mask;
+    while (keys[i] != -1) {
+      if (keys[i] == k) return vals[i];
+      i = (i + 1) & mask;
+    }
+    return -1;
+  }
+};
 
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------
 // mvd_set_cameras: construct_project_matrix (utils.py:46-69), the inverse used by create_target_volume
 // (utils.py:79-153) and near/far from the camera distance (morphable_diffusion.py:281-299), once per sample.
-int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
+int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipStream_t s) {
   std::vector<ViewCam> cams(N);
   const double ratio = (double)(c->v.input_image_size / 8) / (double)c->v.input_image_size;
   for (int i = 0; i < N; ++i) {
@@ -105,15 +133,27 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
     v.near_ = (float)dist - c->v.frustum_volume_length;
     v.far_ = (float)dist + c->v.frustum_volume_length;
   }
-  ViewCam* dn = nullptr;  // new table first, swap on success
-  HIP_CHECK_RET(hipMalloc((void**)&dn, N * sizeof(ViewCam)));
-  if (hipMemcpy(dn, cams.data(), N * sizeof(ViewCam), hipMemcpyHostToDevice) != hipSuccess) {
-    hipFree(dn);
-    return mvd_fail("set_cameras: upload failed");
+  // upload: pinned host image -> device table by ONE stream-ordered copy; both grow only when N does
+  mvd_ctx::CamStage& st = c->cam_stage;
+  if (N > st.cap) {
+    ViewCam *dn = nullptr, *hn = nullptr;
+    HIP_CHECK_RET(hipMalloc((void**)&dn, N * sizeof(ViewCam)));
+    if (hipHostMalloc((void**)&hn, N * sizeof(ViewCam)) != hipSuccess) {
+      hipFree(dn);
+      return mvd_fail("set_cameras: pinned allocation failed");
+    }
+    HIP_CHECK_RET(hipDeviceSynchronize());  // nothing in flight may still read the table being replaced
+    if (c->cams) hipFree(c->cams);
+    if (st.h) hipHostFree(st.h);
+    c->cams = dn;
+    st.h = hn;
+    st.cap = N;
   }
-  HIP_CHECK_RET(hipDeviceSynchronize());
-  if (c->cams) hipFree(c->cams);
-  c->cams = dn;
+  if (!st.staged) HIP_CHECK_RET(hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
+  else HIP_CHECK_RET(hipEventSynchronize(st.staged));  // the previous upload has left the host image
+  memcpy(st.h, cams.data(), N * sizeof(ViewCam));
+  HIP_CHECK_RET(hipMemcpyAsync(c->cams, st.h, N * sizeof(ViewCam), hipMemcpyHostToDevice, s));
+  HIP_CHECK_RET(hipEventRecord(st.staged, s));
   c->n_cams = N;
   return 0;
 }
@@ -122,118 +162,279 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N) {
 // mvd_set_mesh: the "rulebook" spconv would build per call (SubMConv3d k3 / SparseConv3d k3 s2 p1), built
 // once per mesh on the host because coord/out_sh/bounds are step-invariant (SURVEY gotcha G15).
 void mesh_free(MeshTables& m) {
-  hipFree(m.verts);
-  for (int i = 0; i < 3; ++i) hipFree(m.nbr_subm[i]);
-  for (int i = 0; i < 2; ++i) {
-    hipFree(m.nbr_down[i]);
-    hipFree(m.feat[i]);
-  }
-  hipFree(m.grid2);
+  hipFree(m.pool);
+  if (m.h_pool) hipHostFree(m.h_pool);
+  for (int i = 0; i < 2; ++i) hipFree(m.feat[i]);
+  if (m.staged) hipEventDestroy(m.staged);
   m = MeshTables();
 }
 
 namespace {
-// builds every table of the new mesh into `m` (fresh allocations); on failure the caller frees `m`
-int mesh_build(MeshTables& m, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
-               int Nv) {
-  // validate first: nothing is allocated for a mesh that cannot be used
+// The rule book of one mesh on the host: what spconv's indice generation produces per call (SubMConv3d k3 / SparseConv3d k3 s2
+// p1 on three levels), plus the coarse index grid.
+struct HostMesh {
+  int n_sites[3], shapes[3][3], max_sites = 0;
+  std::vector<int> nbr_subm[3], nbr_down[2], grid;
+  // scratch
+  std::vector<std::array<int, 3>> sites, osites;
+  std::vector<int> dense;        // voxel -> first row (dense path)
+  std::vector<unsigned char> mark;
+  VoxelMap idx;                  // (hash path: grids of more than 2^25 cells)
+};
+
+// Pure host code (no context, no HIP): safe to run for several samples on several threads.
+// Lookups go through a dense voxel -> row grid of the level (4 bytes per cell; a 100^3 head grid is 4 MB) when it has at
+// most 2^25 cells, through the open-addressing map otherwise; the strided level's output sites are enumerated in (z,y,x)
+// order either way.
+int host_mesh_build(const int32_t* coord, const int32_t* out_sh, int Nv, HostMesh& h, size_t dense_limit = (size_t)1 << 25) {
   for (int i = 0; i < Nv; ++i)
     for (int a = 0; a < 3; ++a)
       if (coord[i * 3 + a] < 0 || coord[i * 3 + a] >= out_sh[a]) return mvd_fail("set_mesh: voxel coordinate outside out_sh");
   for (int a = 0; a < 3; ++a)
     if (out_sh[a] <= 0 || out_sh[a] >= (1 << 20)) return mvd_fail("set_mesh: out_sh out of range");
+  auto& sites = h.sites;
+  auto& osites = h.osites;
+  sites.resize(Nv);
+  for (int i = 0; i < Nv; ++i) sites[i] = {coord[i * 3], coord[i * 3 + 1], coord[i * 3 + 2]};
+  int shape[3] = {out_sh[0], out_sh[1], out_sh[2]};
+  h.max_sites = Nv;
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const int ns = (int)sites.size();
+    const size_t cells = (size_t)shape[0] * shape[1] * shape[2];
+    const bool use_dense = cells <= dense_limit;
+    // several vertices in one voxel: the FIRST one is the voxel's representative (spconv's hash table also keeps one row per
+    // voxel and resolves every neighbour lookup, the centre tap included, through it; which row wins there is a race).  Later
+    // duplicates still get an output row, identical to the representative's.
+    if (use_dense) {
+      h.dense.assign(cells, -1);
+      for (int i = 0; i < ns; ++i) {
+        int& d = h.dense[((size_t)sites[i][0] * shape[1] + sites[i][1]) * shape[2] + sites[i][2]];
+        if (d < 0) d = i;
+      }
+    } else {
+      h.idx.reset(ns);
+      for (int i = 0; i < ns; ++i) h.idx.insert_first(key3(sites[i][0], sites[i][1], sites[i][2]), i);
+    }
+    const int s0 = shape[0], s1 = shape[1], s2 = shape[2];
+    auto find = [&](int z, int y, int x) -> int {
+      if ((unsigned)z >= (unsigned)s0 || (unsigned)y >= (unsigned)s1 || (unsigned)x >= (unsigned)s2) return -1;
+      return use_dense ? h.dense[((size_t)z * s1 + y) * s2 + x] : h.idx.find(key3(z, y, x));
+    };
+    h.n_sites[lvl] = ns;
+    for (int a = 0; a < 3; ++a) h.shapes[lvl][a] = shape[a];
+    std::vector<int>& nbr = h.nbr_subm[lvl];
+    nbr.resize((size_t)ns * 27);
+    for (int i = 0; i < ns; ++i) {
+      int* o = &nbr[(size_t)i * 27];
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) *o++ = find(sites[i][0] + dz, sites[i][1] + dy, sites[i][2] + dx);
+    }
+    if (lvl == 2) {
+      h.grid.assign(cells, -1);
+      for (int i = 0; i < ns; ++i) h.grid[((size_t)sites[i][0] * shape[1] + sites[i][1]) * shape[2] + sites[i][2]] = i;
+      break;
+    }
+    // strided conv to the next level: input i feeds output o = (i + 1 - k) / 2 for every tap k that makes it integral and in
+    // range; the output sites are the distinct ones, in (z,y,x) order
+    const int oshape[3] = {(shape[0] - 1) / 2 + 1, (shape[1] - 1) / 2 + 1, (shape[2] - 1) / 2 + 1};
+    const size_t ocells = (size_t)oshape[0] * oshape[1] * oshape[2];
+    osites.clear();
+    auto outputs_of = [&](const std::array<int, 3>& st, auto&& emit) {
+      for (int kz = 0; kz < 3; ++kz) {
+        const int nz = st[0] + 1 - kz;
+        if ((nz & 1) || nz < 0 || nz / 2 >= oshape[0]) continue;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int ny = st[1] + 1 - ky;
+          if ((ny & 1) || ny < 0 || ny / 2 >= oshape[1]) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int nx = st[2] + 1 - kx;
+            if ((nx & 1) || nx < 0 || nx / 2 >= oshape[2]) continue;
+            emit(nz / 2, ny / 2, nx / 2);
+          }
+        }
+      }
+    };
+    if (ocells <= dense_limit) {
+      h.mark.assign(ocells, 0);
+      for (auto& st : sites) outputs_of(st, [&](int oz, int oy, int ox) { h.mark[((size_t)oz * oshape[1] + oy) * oshape[2] + ox] = 1; });
+      for (int oz = 0; oz < oshape[0]; ++oz)
+        for (int oy = 0; oy < oshape[1]; ++oy) {
+          const unsigned char* row = &h.mark[((size_t)oz * oshape[1] + oy) * oshape[2]];
+          for (int ox = 0; ox < oshape[2]; ++ox)
+            if (row[ox]) osites.push_back({oz, oy, ox});
+        }
+    } else {
+      std::vector<long> keys;
+      for (auto& st : sites) outputs_of(st, [&](int oz, int oy, int ox) { keys.push_back(key3(oz, oy, ox)); });
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      for (long k : keys) osites.push_back({(int)(k >> 40), (int)((k >> 20) & 0xFFFFF), (int)(k & 0xFFFFF)});
+    }
+    std::vector<int>& dn = h.nbr_down[lvl];
+    dn.resize(osites.size() * 27);
+    for (size_t o = 0; o < osites.size(); ++o) {
+      int* d = &dn[o * 27];
+      for (int kz = 0; kz < 3; ++kz)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) *d++ = find(2 * osites[o][0] - 1 + kz, 2 * osites[o][1] - 1 + ky, 2 * osites[o][2] - 1 + kx);
+    }
+    sites.swap(osites);
+    for (int a = 0; a < 3; ++a) shape[a] = oshape[a];
+    h.max_sites = std::max(h.max_sites, (int)sites.size());
+  }
+  return 0;
+}
+
+// The tables of `h` become the ACTIVE slot's mesh: ONE copy in the order of stream `s` out of the slot's pinned host image
+// (launches enqueued on `s` before this call still read the old tables, later ones the new tables).  A failure (allocation)
+// leaves the active mesh exactly as it was.
+int mesh_commit(mvd_ctx* c, HostMesh& h, const float* vertices, const int32_t* out_sh, const float* bounds, int Nv, hipStream_t s) {
+  std::vector<int>*nbr_subm = h.nbr_subm, *nbr_down = h.nbr_down;
+  std::vector<int>& grid = h.grid;
+  const int* n_sites = h.n_sites;
+  const int(*shapes)[3] = h.shapes;
+  const int max_sites = h.max_sites;
+  // ---- pool layout (ints; every table 64-byte aligned): verts | nbr_subm[0..2] | nbr_down[0..1] | grid2 ----
+  auto up16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+  size_t off[7], total = 0;
+  const size_t lens[7] = {(size_t)Nv * 3, nbr_subm[0].size(), nbr_subm[1].size(), nbr_subm[2].size(), nbr_down[0].size(),
+                          nbr_down[1].size(), grid.size()};
+  for (int i = 0; i < 7; ++i) {
+    off[i] = total;
+    total += up16(std::max<size_t>(lens[i], 1));
+  }
+  MeshTables& m = c->mesh;
+  if (!c->volume) {
+    const int V = c->v.spatial_volume_size;
+    if (hipMalloc((void**)&c->volume, (size_t)V * V * V * 64 * sizeof(float)) != hipSuccess)
+      return mvd_fail("set_mesh: volume allocation failed");
+  }
+  if (total > m.pool_cap || (size_t)max_sites * 64 > m.feat_cap) {  // grow (new first, swap on success)
+    const size_t ncap = std::max(total + total / 4, m.pool_cap), nfeat = std::max((size_t)max_sites * 64 * 5 / 4, m.feat_cap);
+    int *dp = nullptr, *hp = nullptr;
+    float* f[2] = {nullptr, nullptr};
+    bool ok = hipMalloc((void**)&dp, ncap * sizeof(int)) == hipSuccess && hipHostMalloc((void**)&hp, ncap * sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&f[0], nfeat * sizeof(float)) == hipSuccess && hipMalloc((void**)&f[1], nfeat * sizeof(float)) == hipSuccess;
+    if (!ok) {
+      hipFree(dp);
+      if (hp) hipHostFree(hp);
+      hipFree(f[0]);
+      hipFree(f[1]);
+      return mvd_fail("set_mesh: table allocation failed");
+    }
+    HIP_CHECK_RET(hipDeviceSynchronize());  // nothing in flight may still read the tables being replaced
+    hipFree(m.pool);
+    if (m.h_pool) hipHostFree(m.h_pool);
+    hipFree(m.feat[0]);
+    hipFree(m.feat[1]);
+    m.pool = dp;
+    m.h_pool = hp;
+    m.feat[0] = f[0];
+    m.feat[1] = f[1];
+    m.pool_cap = ncap;
+    m.feat_cap = nfeat;
+  }
+  if (!m.staged) HIP_CHECK_RET(hipEventCreateWithFlags(&m.staged, hipEventDisableTiming));
+  else HIP_CHECK_RET(hipEventSynchronize(m.staged));  // the previous upload has left the host image
+  memcpy(m.h_pool + off[0], vertices, (size_t)Nv * 3 * sizeof(float));
+  const std::vector<int>* src[6] = {&nbr_subm[0], &nbr_subm[1], &nbr_subm[2], &nbr_down[0], &nbr_down[1], &grid};
+  for (int i = 0; i < 6; ++i)
+    if (!src[i]->empty()) memcpy(m.h_pool + off[i + 1], src[i]->data(), src[i]->size() * sizeof(int));
+  HIP_CHECK_RET(hipMemcpyAsync(m.pool, m.h_pool, total * sizeof(int), hipMemcpyHostToDevice, s));
+  HIP_CHECK_RET(hipEventRecord(m.staged, s));
   m.Nv = Nv;
-  HIP_CHECK_RET(hipMalloc((void**)&m.verts, (size_t)Nv * 3 * sizeof(float)));
-  HIP_CHECK_RET(hipMemcpy(m.verts, vertices, (size_t)Nv * 3 * sizeof(float), hipMemcpyHostToDevice));
+  m.verts = (float*)(m.pool + off[0]);
+  for (int l = 0; l < 3; ++l) {
+    m.nbr_subm[l] = m.pool + off[1 + l];
+    m.n_sites[l] = n_sites[l];
+    for (int a = 0; a < 3; ++a) m.shape[l][a] = shapes[l][a];
+  }
+  for (int l = 0; l < 2; ++l) m.nbr_down[l] = m.pool + off[4 + l];
+  m.grid2 = m.pool + off[6];
   for (int a = 0; a < 3; ++a) {
     m.min_xyz[a] = bounds[a];
     m.out_sh[a] = out_sh[a];
   }
-  std::vector<std::array<int, 3>> sites(Nv);
-  for (int i = 0; i < Nv; ++i) sites[i] = {coord[i * 3], coord[i * 3 + 1], coord[i * 3 + 2]};
-  int shape[3] = {out_sh[0], out_sh[1], out_sh[2]};
-  int max_sites = Nv;
-  for (int lvl = 0; lvl < 3; ++lvl) {
-    std::unordered_map<long, int> idx;
-    idx.reserve(sites.size() * 2);
-    for (int i = 0; i < (int)sites.size(); ++i) {
-      auto& s = sites[i];
-      // several vertices in one voxel: the FIRST one is the voxel's representative (spconv's hash table also keeps one
-      // row per voxel and resolves every neighbour lookup, the centre tap included, through it; which row wins there is
-      // a race).  Later duplicates still get an output row, identical to the representative's.
-      idx.emplace(key3(s[0], s[1], s[2]), i);
-    }
-    m.n_sites[lvl] = (int)sites.size();
-    for (int a = 0; a < 3; ++a) m.shape[lvl][a] = shape[a];
-    std::vector<int> nbr(sites.size() * 27);
-    for (int i = 0; i < (int)sites.size(); ++i)
-      for (int k = 0; k < 27; ++k) {
-        const int z = sites[i][0] + k / 9 - 1, y = sites[i][1] + (k / 3) % 3 - 1, x = sites[i][2] + k % 3 - 1;
-        auto it = (z < 0 || y < 0 || x < 0) ? idx.end() : idx.find(key3(z, y, x));
-        nbr[(size_t)i * 27 + k] = it == idx.end() ? -1 : it->second;
-      }
-    RET_IF(upload_ints(nbr, &m.nbr_subm[lvl]));
-    if (lvl == 2) {
-      std::vector<int> grid((size_t)shape[0] * shape[1] * shape[2], -1);
-      for (int i = 0; i < (int)sites.size(); ++i)
-        grid[((size_t)sites[i][0] * shape[1] + sites[i][1]) * shape[2] + sites[i][2]] = i;
-      RET_IF(upload_ints(grid, &m.grid2));
-      break;
-    }
-    // strided conv to the next level: o = (i + 1 - k) / 2 when integral and in range
-    int oshape[3] = {(shape[0] - 1) / 2 + 1, (shape[1] - 1) / 2 + 1, (shape[2] - 1) / 2 + 1};
-    std::vector<long> keys;
-    for (auto& s : sites)
-      for (int k = 0; k < 27; ++k) {
-        const int nz = s[0] + 1 - k / 9, ny = s[1] + 1 - (k / 3) % 3, nx = s[2] + 1 - k % 3;
-        if ((nz & 1) || (ny & 1) || (nx & 1) || nz < 0 || ny < 0 || nx < 0) continue;
-        const int oz = nz / 2, oy = ny / 2, ox = nx / 2;
-        if (oz >= oshape[0] || oy >= oshape[1] || ox >= oshape[2]) continue;
-        keys.push_back(key3(oz, oy, ox));
-      }
-    std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-    std::vector<std::array<int, 3>> osites(keys.size());
-    std::vector<int> dn(keys.size() * 27);
-    for (size_t o = 0; o < keys.size(); ++o) {
-      const int oz = (int)(keys[o] >> 40), oy = (int)((keys[o] >> 20) & 0xFFFFF), ox = (int)(keys[o] & 0xFFFFF);
-      osites[o] = {oz, oy, ox};
-      for (int k = 0; k < 27; ++k) {
-        const int z = 2 * oz - 1 + k / 9, y = 2 * oy - 1 + (k / 3) % 3, x = 2 * ox - 1 + k % 3;
-        auto it = (z < 0 || y < 0 || x < 0) ? idx.end() : idx.find(key3(z, y, x));
-        dn[o * 27 + k] = it == idx.end() ? -1 : it->second;
-      }
-    }
-    RET_IF(upload_ints(dn, &m.nbr_down[lvl]));
-    sites.swap(osites);
-    for (int a = 0; a < 3; ++a) shape[a] = oshape[a];
-    max_sites = std::max(max_sites, (int)sites.size());
-  }
-  for (int b = 0; b < 2; ++b) HIP_CHECK_RET(hipMalloc((void**)&m.feat[b], (size_t)max_sites * 64 * sizeof(float)));
   return 0;
 }
+
 }  // namespace
 
-// Transactional: the new tables are built beside the old ones and swapped in only when complete; a failed call (bad
-// coordinates, allocation failure) leaves the active mesh exactly as it was.
-int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
-                    int Nv) {
-  MeshTables nm;
-  const int r = mesh_build(nm, vertices, coord, out_sh, bounds, Nv);
-  if (r) {
-    mesh_free(nm);
-    return r;
+// Transactional: validation and the host-side build touch nothing of the active mesh; a failed call (bad coordinates,
+// allocation failure) leaves it exactly as it was.
+int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds, int Nv,
+                    hipStream_t s) {
+  static const bool timing = getenv("MVD_MESH_TIMING") != nullptr;  // development aid: host phases of this call on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  static thread_local HostMesh h;
+  RET_IF(host_mesh_build(coord, out_sh, Nv, h));
+  const auto t1 = std::chrono::steady_clock::now();
+  RET_IF(mesh_commit(c, h, vertices, out_sh, bounds, Nv, s));
+  if (timing)
+    fprintf(stderr, "[set_mesh] Nv %d sites %d/%d/%d: build %.2f ms, stage + enqueue %.2f ms\n", Nv, h.n_sites[0], h.n_sites[1],
+            h.n_sites[2], std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return 0;
+}
+
+// host-only probes of the rule book (tests without a GPU): build, then read the tables of the last build on this thread
+static thread_local HostMesh t_probe;
+int engine_rulebook_build(const int32_t* coord, const int32_t* out_sh, int Nv, int force_hash, int32_t* n_sites, int64_t* lens) {
+  RET_IF(host_mesh_build(coord, out_sh, Nv, t_probe, force_hash ? 0 : (size_t)1 << 25));
+  for (int l = 0; l < 3; ++l) {
+    n_sites[l] = t_probe.n_sites[l];
+    lens[l] = (int64_t)t_probe.nbr_subm[l].size();
   }
-  if (!c->volume) {
-    const int V = c->v.spatial_volume_size;
-    if (hipMalloc((void**)&c->volume, (size_t)V * V * V * 64 * sizeof(float)) != hipSuccess) {
-      mesh_free(nm);
-      return mvd_fail("set_mesh: volume allocation failed");
-    }
+  lens[3] = (int64_t)t_probe.nbr_down[0].size();
+  lens[4] = (int64_t)t_probe.nbr_down[1].size();
+  lens[5] = (int64_t)t_probe.grid.size();
+  return 0;
+}
+int engine_rulebook_table(int which, int32_t* out) {
+  const std::vector<int>* v = which < 3 ? &t_probe.nbr_subm[which] : which < 5 ? &t_probe.nbr_down[which - 3] : &t_probe.grid;
+  if (which < 0 || which > 5) return mvd_fail("mvd_rulebook_table: table index 0..5");
+  if (!v->empty()) memcpy(out, v->data(), v->size() * sizeof(int));
+  return 0;
+}
+
+int engine_select_sample(mvd_ctx* c, int slot);
+// mvd_set_samples_async: the tables of B samples (a training step's new batch) -- the rule books are built on B host threads,
+// then committed slot by slot in the order of stream `s`.  Validation of ALL samples precedes the first commit.
+int engine_set_samples(mvd_ctx* c, int B, const int* slots, const float* const* vertices, const int32_t* const* coord,
+                       const int32_t* const* out_sh, const float* const* bounds, const int* Nv, const float* const* K,
+                       const float* const* RT, int N, hipStream_t s) {
+  static const bool timing = getenv("MVD_MESH_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  static thread_local std::vector<HostMesh> hs;  // scratch kept between steps
+  if ((int)hs.size() < B) hs.resize(B);
+  HostMesh* const hp = hs.data();  // (a thread_local name inside a worker's lambda would be the WORKER's instance)
+  std::vector<int> rc(B, 0);
+  std::vector<std::string> err(B);
+  {
+    std::vector<std::thread> th;
+    for (int i = 1; i < B; ++i)
+      th.emplace_back([&, i]() {
+        rc[i] = host_mesh_build(coord[i], out_sh[i], Nv[i], hp[i]);
+        if (rc[i]) err[i] = mvd_last_error();  // thread-local message: carry it to the caller's thread
+      });
+    rc[0] = host_mesh_build(coord[0], out_sh[0], Nv[0], hp[0]);
+    for (auto& t : th) t.join();
   }
-  HIP_CHECK_RET(hipDeviceSynchronize());  // nothing in flight may still read the tables being replaced
-  mesh_free(c->mesh);
-  c->mesh = nm;
+  for (int i = 0; i < B; ++i)
+    if (rc[i]) return i ? mvd_fail(err[i].c_str()) : rc[i];
+  const auto t1 = std::chrono::steady_clock::now();
+  const int back = c->cur_slot;
+  for (int i = 0; i < B; ++i) {
+    RET_IF(engine_select_sample(c, slots[i]));
+    RET_IF(mesh_commit(c, hp[i], vertices[i], out_sh[i], bounds[i], Nv[i], s));
+    RET_IF(engine_set_cameras(c, K[i], RT[i], N, s));
+  }
+  RET_IF(engine_select_sample(c, back));
+  if (timing)
+    fprintf(stderr, "[set_samples] %d samples: build (threads) %.2f ms, commit %.2f ms\n", B,
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   return 0;
 }
 
@@ -247,10 +448,12 @@ int engine_select_sample(mvd_ctx* c, int slot) {
   cur.mesh = c->mesh;
   cur.cams = c->cams;
   cur.n_cams = c->n_cams;
+  cur.cam_stage = c->cam_stage;
   mvd_ctx::SampleSlot& nxt = c->slots[slot];
   c->mesh = nxt.mesh;
   c->cams = nxt.cams;
   c->n_cams = nxt.n_cams;
+  c->cam_stage = nxt.cam_stage;
   nxt = mvd_ctx::SampleSlot();  // the active copy is the owner now
   c->cur_slot = slot;
   return 0;

@@ -19,7 +19,7 @@ def _f32(t, device):
 
 
 IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
-MAX_SAMPLE_SLOTS = 8  # per-sample mesh / camera tables kept resident in the context (mvd_select_sample)
+MAX_SAMPLE_SLOTS = 64  # per-sample mesh / camera tables kept resident in the context (mvd_select_sample)
 
 
 class Engine:
@@ -164,21 +164,46 @@ class Engine:
         self.num_vertices = self._slot_nv.get(self._slot, 0)
 
     def set_mesh(self, vertices, coord, out_sh, bounds):
-        """Per-sample, step-invariant mesh metadata (hoists the .tolist() sync of morphable_diffusion.py:251-252)."""
+        """Per-sample mesh metadata (hoists the .tolist() sync of morphable_diffusion.py:251-252).  Host tensors are read before
+        the call returns; the tables reach the device in the order of the current stream (mvd_set_mesh_async), so a training
+        step that sees a new mesh per sample neither allocates nor synchronises here."""
         v = vertices.detach().cpu().float().contiguous()
         c = coord.detach().cpu().to(torch.int32).contiguous()
         o = out_sh.detach().cpu().to(torch.int32).contiguous()
         b = bounds.detach().cpu().float().contiguous()
-        L.check(self.lib.mvd_set_mesh(self._ctx, L.ptr(v), L.ptr(c), L.ptr(o), L.ptr(b), v.shape[0]))
+        L.check(self.lib.mvd_set_mesh_async(self._ctx, L.ptr(v), L.ptr(c), L.ptr(o), L.ptr(b), v.shape[0], _stream()))
         self.num_vertices = v.shape[0]
         self._slot_nv[getattr(self, "_slot", 0)] = v.shape[0]
+
+    def set_samples(self, slots, vertices, coord, out_sh, bounds, K, RT):
+        """mvd_set_samples_async: mesh + cameras of several samples (lists, one entry per sample) into the slots ``slots``; the
+        rule books are built on one host thread per sample, the uploads are enqueued on the current stream."""
+        n = len(slots)
+        v = [t.detach().cpu().float().contiguous() for t in vertices]
+        c = [t.detach().cpu().to(torch.int32).contiguous() for t in coord]
+        o = [t.detach().cpu().to(torch.int32).contiguous() for t in out_sh]
+        b = [t.detach().cpu().float().contiguous() for t in bounds]
+        k = [t.detach().cpu().float().contiguous() for t in K]
+        r = [t.detach().cpu().float().contiguous() for t in RT]
+        if any(t.shape[-2:] != (4, 4) for t in k):
+            raise ValueError("target_K must be [N,4,4] (morphable_diffusion.py:296)")
+        if len({t.shape[0] for t in k}) != 1:
+            raise ValueError("every sample of a batch has the same number of target views")
+        arr = lambda ts, ty: (ty * n)(*[C.cast(L.ptr(t), ty) for t in ts])
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.check(self.lib.mvd_set_samples_async(self._ctx, n, (C.c_int * n)(*[int(x) for x in slots]), arr(v, fp), arr(c, ip), arr(o, ip),
+                                               arr(b, fp), (C.c_int * n)(*[t.shape[0] for t in v]), arr(k, fp), arr(r, fp),
+                                               k[0].shape[0], _stream()))
+        for sl, t in zip(slots, v):
+            self._slot_nv[int(sl)] = t.shape[0]
+        self.num_vertices = self._slot_nv.get(getattr(self, "_slot", 0), 0)
 
     def set_cameras(self, K, RT):
         K = K.detach().cpu().float().contiguous()
         RT = RT.detach().cpu().float().contiguous()
         if K.shape[-2:] != (4, 4):
             raise ValueError("target_K must be [N,4,4] (morphable_diffusion.py:296)")
-        L.check(self.lib.mvd_set_cameras(self._ctx, L.ptr(K), L.ptr(RT), K.shape[0]))
+        L.check(self.lib.mvd_set_cameras_async(self._ctx, L.ptr(K), L.ptr(RT), K.shape[0], _stream()))
 
     def vertex_features(self, x_noisy, t_embed, v_embed, view_idx, add_bias=True):
         dev = self.device

@@ -213,6 +213,7 @@ class SpatialVolumeNet(nn.Module):
         self.spatial_volume_size = spatial_volume_size
         self._engine: Optional[Engine] = None
         self._slots = {}  # slot -> (key, tensors): per-sample tables resident in the engine
+        self._host = (None, None, None)  # (key, tensors, host copies) of the batch whose tables were staged last
 
     def bind(self, engine: Engine):
         self._engine = engine
@@ -223,6 +224,16 @@ class SpatialVolumeNet(nn.Module):
         """Forget which meshes / cameras are resident: the next step re-reads the batch (SyncDDIMSampler.sample does this
         on entry, so every sampling run uploads at least once -- the reference re-reads the batch at every step)."""
         self._slots = {}
+        self._host = (None, None, None)
+
+    def _host_tables(self, batch):
+        """Host copies of the table inputs of ``batch``: ONE device-to-host transfer per tensor and batch (not per sample: every
+        transfer drains the launch queue), none at all when the loader left them on the CPU."""
+        ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in ts)
+        if self._host[0] != key:
+            self._host = (key, ts, {k: t.detach().cpu() for k, t in zip(self._SAMPLE_KEYS, ts)})
+        return self._host[2]
 
     def _set_sample(self, batch, bi):
         """Makes sample ``bi`` of ``batch`` the engine's active mesh + cameras.  The tables are step-invariant, so they are
@@ -230,16 +241,41 @@ class SpatialVolumeNet(nn.Module):
         and torch's in-place version counter -- and the cache holds references to those tensors, so a freed tensor's address
         cannot come back under the same key."""
         from .engine import MAX_SAMPLE_SLOTS
-        ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
-        key = (bi,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in ts)
         slot = bi % MAX_SAMPLE_SLOTS
-        self._engine.select_sample(slot)
         held = self._slots.get(slot)
-        if held is None or held[0] != key:
-            self._slots.pop(slot, None)  # a failed upload must not leave a stale key behind
-            self._engine.set_mesh(batch["vertices"][bi], batch["coord"][bi], batch["out_sh"][bi], batch["bounds"][bi])
-            self._engine.set_cameras(batch["target_K"][bi], batch["target_RT"][bi])
-            self._slots[slot] = (key, ts)
+        if held is None or held[0] != self._sample_key(batch, bi):
+            self._upload_batch(batch)
+        self._engine.select_sample(slot)
+
+    def _sample_key(self, batch, bi):
+        ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
+        return (bi,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in ts)
+
+    def _upload_batch(self, batch):
+        """Tables of every sample of ``batch`` that is not resident yet, in ONE call: the rule books are built on one host thread
+        per sample and uploaded in stream order (mvd_set_samples_async) -- a training step sees a new batch every time."""
+        from .engine import MAX_SAMPLE_SLOTS
+        ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
+        B = batch["vertices"].shape[0]
+        todo = []
+        for bi in range(min(B, MAX_SAMPLE_SLOTS)):
+            held = self._slots.get(bi % MAX_SAMPLE_SLOTS)
+            if held is None or held[0] != self._sample_key(batch, bi):
+                todo.append(bi)
+        if B > MAX_SAMPLE_SLOTS:  # more samples than slots: the surplus shares slots and is re-uploaded on use
+            todo = sorted(set(todo) | {bi for bi in range(MAX_SAMPLE_SLOTS, B)
+                                       if (self._slots.get(bi % MAX_SAMPLE_SLOTS) or (None,))[0] != self._sample_key(batch, bi)})
+            todo = list({bi % MAX_SAMPLE_SLOTS: bi for bi in reversed(todo)}.values())  # one sample per slot and call
+        if not todo:
+            return
+        h = self._host_tables(batch)
+        for bi in todo:
+            self._slots.pop(bi % MAX_SAMPLE_SLOTS, None)  # a failed upload must not leave a stale key behind
+        self._engine.set_samples([bi % MAX_SAMPLE_SLOTS for bi in todo], [h["vertices"][bi] for bi in todo],
+                                 [h["coord"][bi] for bi in todo], [h["out_sh"][bi] for bi in todo], [h["bounds"][bi] for bi in todo],
+                                 [h["target_K"][bi] for bi in todo], [h["target_RT"][bi] for bi in todo])
+        for bi in todo:
+            self._slots[bi % MAX_SAMPLE_SLOTS] = (self._sample_key(batch, bi), ts)
 
     def construct_spatial_volume(self, x, t_embed, v_embed, batch):
         """train mode (nn.Module.train(), as Lightning sets it for training_step): the sparse CNN's BatchNorm layers use

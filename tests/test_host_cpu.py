@@ -292,3 +292,69 @@ def test_flat_gradient_allreduce_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"GRAD_OK {r}" in o, o[-2000:]
+
+
+def _rulebook_reference(coord, out_sh):
+    """Independent restatement of the sparse-conv rule book (SubMConv3d k3 / SparseConv3d k3 s2 p1, three levels): dicts and
+    sorted sets, the way engine_cond.hip's first version did it."""
+    sites = [tuple(int(v) for v in r) for r in coord.tolist()]
+    shape = [int(v) for v in out_sh.tolist()]
+    subm, down, n_sites = [], [], []
+    for lvl in range(3):
+        idx = {}
+        for i, s in enumerate(sites):
+            idx.setdefault(s, i)  # first row of a voxel is its representative
+        n_sites.append(len(sites))
+        subm.append([[idx.get((s[0] + dz, s[1] + dy, s[2] + dx), -1) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+                     for s in sites])
+        if lvl == 2:
+            grid = -np.ones(shape, dtype=np.int32)
+            for i, s in enumerate(sites):
+                grid[s] = i
+            break
+        oshape = [(v - 1) // 2 + 1 for v in shape]
+        outs = set()
+        for s in sites:
+            for k in range(27):
+                n = (s[0] + 1 - k // 9, s[1] + 1 - (k // 3) % 3, s[2] + 1 - k % 3)
+                if any(v % 2 or v < 0 for v in n):
+                    continue
+                o = tuple(v // 2 for v in n)
+                if all(o[a] < oshape[a] for a in range(3)):
+                    outs.add(o)
+        osites = sorted(outs)
+        down.append([[idx.get((2 * o[0] - 1 + k // 9, 2 * o[1] - 1 + (k // 3) % 3, 2 * o[2] - 1 + k % 3), -1) for k in range(27)]
+                     for o in osites])
+        sites, shape = osites, oshape
+    return n_sites, subm, down, grid
+
+
+@pytest.mark.parametrize("force_hash", [0, 1])
+def test_rulebook_host_build_matches_reference_restatement(force_hash):
+    """The host rule-book builder behind mvd_set_mesh (dense-grid path and the hash path of very large grids) against an
+    independent dict-based restatement, on a mesh with duplicate voxels and sites on the grid border."""
+    import ctypes as C
+    from morphablediffusion_amd import lib as L, synthetic
+    lib = L.load()
+    verts = synthetic.ellipsoid_mesh(700, 5, (0.22, 0.28, 0.25))
+    coord, out_sh, _ = synthetic.voxelize(verts)
+    coord = torch.cat([coord, coord[:40]], 0).to(torch.int32).contiguous()  # duplicates: the first row must win
+    out_sh = out_sh.to(torch.int32).contiguous()
+    n_sites = (C.c_int32 * 3)()
+    lens = (C.c_int64 * 6)()
+    L.check(lib.mvd_rulebook_build(L.ptr(coord), L.ptr(out_sh), coord.shape[0], force_hash, n_sites, lens))
+    ref_n, ref_subm, ref_down, ref_grid = _rulebook_reference(coord, out_sh)
+    assert list(n_sites) == ref_n
+    tabs = []
+    for w in range(6):
+        t = torch.empty(max(int(lens[w]), 1), dtype=torch.int32)
+        L.check(lib.mvd_rulebook_table(w, L.ptr(t)))
+        tabs.append(t[:int(lens[w])])
+    for l in range(3):
+        assert torch.equal(tabs[l].view(-1, 27), torch.tensor(ref_subm[l], dtype=torch.int32))
+    for l in range(2):
+        assert torch.equal(tabs[3 + l].view(-1, 27), torch.tensor(ref_down[l], dtype=torch.int32))
+    assert torch.equal(tabs[5], torch.from_numpy(ref_grid).reshape(-1))
+    bad = coord.clone()
+    bad[3, 2] = out_sh[2]
+    assert lib.mvd_rulebook_build(L.ptr(bad), L.ptr(out_sh), bad.shape[0], force_hash, n_sites, lens) != 0

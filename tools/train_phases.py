@@ -1,5 +1,6 @@
 """Where one training step's time goes (development aid): the phases of SyncMultiviewDiffusion.training_step + optimiser, each
-bracketed by device synchronisation.  python tools/train_phases.py [B]"""
+bracketed by device synchronisation.  python tools/train_phases.py [B]   (FRESH=1: new batch tensors every step, KEEP=1: no
+activation recompute, PROFILE_COND=1: ten extra conditioner backward passes for rocprofv3)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -42,6 +43,8 @@ for it in range(2 if os.environ.get('PROFILE_COND') else 4):
         T.clear()
     dev = "cuda"
     tsd, tid = ts.cuda(), ti.cuda()
+    if os.environ.get("FRESH"):  # a new batch per step (fresh tensors): the per-sample tables are rebuilt inside the step
+        batch = {k: v.clone() for k, v in batch.items()}
     tick("zero_grad", opt.zero_grad)
     x_noisy, nz = m.add_noise(x0, tsd, noise)
     m.train()
