@@ -584,20 +584,23 @@ void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b,
       }
     }
     if (geglu) continue;
-    for (int sk = 2; sk <= 16 && sk * 2 <= ksteps; ++sk) {
+    // Reductions of more than 512 k-steps (K > 32768: only the weight-gradient GEMMs of a training step, whose K is the row
+    // count of a layer) may split further than 16 ways: a [128 x 64] result over K = 1.18 M ran 690 us as 16 workgroups.
+    const int sk_max = ksteps > 512 ? 256 : 16;
+    for (int sk = 2; sk <= sk_max && sk * 2 <= ksteps; sk += (sk < 16 ? 1 : (sk < 64 ? 4 : 16))) {
       const int per = cdiv(ksteps, sk), sk_eff = cdiv(ksteps, per);  // no empty split
-      if (sk_eff != sk) continue;
-      const int wgs = tiles_m * tiles_n * sk, rounds = cdiv(wgs, CUS);
+      if (sk_eff != sk && sk <= 16) continue;
+      const int wgs = tiles_m * tiles_n * sk_eff, rounds = cdiv(wgs, CUS);
       const int in_round = wgs < CUS ? wgs : CUS;
       double t_epi = in_round * 256.0 * bn * 4.0 / 6e6;
       if (t_epi < 2.5) t_epi = 2.5;
       const double mn = (double)M * N;
-      const double t = rounds * (2.8 + per * t_step + t_epi) + 2.0 + 5.0 + (sk * mn * 4.0 + mn * (out_b + res_b)) / 6e6;
+      const double t = rounds * (2.8 + per * t_step + t_epi) + 2.0 + 5.0 + (sk_eff * mn * 4.0 + mn * (out_b + res_b)) / 6e6;
       if (t < best) {
         best = t;
         best_bn = bn;
         best_nch = 1;
-        best_sk = sk;
+        best_sk = sk_eff;
       }
     }
   }

@@ -41,6 +41,8 @@ def tick(name, fn):
 for it in range(2 if os.environ.get('PROFILE_COND') else 4):
     if it == 1:
         T.clear()
+    if os.environ.get("MVD_LAYER_TIMING"):
+        print("[step-begin]", file=sys.stderr, flush=True)  # tools/layer_agg.py aggregates the GEMM lines of the last step
     dev = "cuda"
     tsd, tid = ts.cuda(), ti.cuda()
     if os.environ.get("FRESH"):  # a new batch per step (fresh tensors): the per-sample tables are rebuilt inside the step
