@@ -282,22 +282,51 @@ __global__ __launch_bounds__(256) void sparse_conv_dgrad_kernel(const float* __r
 }
 
 // dw[k][ci][co] = sum_site in[nbr[site][k]][ci] d_out[site][co]: grid (27, ceil(Cin*Cout / 256), site chunks); every chunk of
-// SP_CHUNK sites writes its partial product to part[chunk][27][Cin][Cout], summed in chunk order by sparse_wgrad_reduce_kernel
-constexpr int SP_CHUNK = 128;
+// SP_CHUNK sites writes its partial product to part[chunk][27][Cin][Cout], summed in chunk order by sparse_wgrad_reduce_kernel.
+// Only ~30 % of a surface mesh's (site, tap) pairs are active: each wave first compacts the active pairs of its quarter of the
+// chunk into LDS (ballot + prefix popcount: site order is kept, so the sum order is fixed), then every thread walks the four
+// lists -- a third of the iterations, none of them a skipped one, four independent loads in flight.
+constexpr int SP_CHUNK = 512;
 __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
                                                                 const float* __restrict__ d_out, int n_out, int Cin, int Cout,
                                                                 float* __restrict__ part) {
-  __shared__ int s_nb[SP_CHUNK];
+  __shared__ int s_nb[4][SP_CHUNK / 4], s_site[4][SP_CHUNK / 4], s_cnt[4];
   const int k = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x, chunk = blockIdx.z;
-  const int s0 = chunk * SP_CHUNK, s1 = min(n_out, s0 + SP_CHUNK);
-  for (int i = threadIdx.x; i < SP_CHUNK; i += 256) s_nb[i] = s0 + i < s1 ? nbr[(long)(s0 + i) * 27 + k] : -1;
+  const int s0 = chunk * SP_CHUNK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < SP_CHUNK / 256; ++j) {
+    const int site = s0 + wave * (SP_CHUNK / 4) + j * 64 + lane;
+    const int nb = site < n_out ? nbr[(long)site * 27 + k] : -1;
+    const unsigned long long m = __ballot(nb >= 0);
+    if (nb >= 0) {
+      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      s_nb[wave][pos] = nb;
+      s_site[wave][pos] = site;
+    }
+    cnt += __popcll(m);
+  }
+  if (lane == 0) s_cnt[wave] = cnt;
   __syncthreads();
   if (e >= Cin * Cout) return;
   const int ci = e / Cout, co = e - ci * Cout;
+  const float* pin = in + ci;
+  const float* pd = d_out + co;
   float acc = 0.f;
-  for (int site = s0; site < s1; ++site) {
-    const int nb = s_nb[site - s0];
-    if (nb >= 0) acc += in[(long)nb * Cin + ci] * d_out[(long)site * Cout + co];
+  for (int w = 0; w < 4; ++w) {
+    const int n = s_cnt[w];
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      const float a0 = pin[(long)s_nb[w][i] * Cin], a1 = pin[(long)s_nb[w][i + 1] * Cin], a2 = pin[(long)s_nb[w][i + 2] * Cin],
+                  a3 = pin[(long)s_nb[w][i + 3] * Cin];
+      const float b0 = pd[(long)s_site[w][i] * Cout], b1 = pd[(long)s_site[w][i + 1] * Cout], b2 = pd[(long)s_site[w][i + 2] * Cout],
+                  b3 = pd[(long)s_site[w][i + 3] * Cout];
+      acc += a0 * b0;
+      acc += a1 * b1;
+      acc += a2 * b2;
+      acc += a3 * b3;
+    }
+    for (; i < n; ++i) acc += pin[(long)s_nb[w][i] * Cin] * pd[(long)s_site[w][i] * Cout];
   }
   part[(((long)chunk * 27 + k) * Cin + ci) * Cout + co] = acc;
 }
