@@ -253,7 +253,8 @@ def train_main(args):
                                       f"and camera tables are rebuilt inside the step), full-width UNet (916.9M params, random init), "
                                       f"finetune_unet=True, AdamW lr 5e-5 / 5e-4, "
                                       f"{'all activations kept' if args.keep_activations else 'per-block activation recompute'}",
-                          "name": "train", "batch_per_gpu": B, "parallelism": f"data-parallel x{world}" if world > 1 else "single GPU"},
+                          "name": "train", "batch_per_gpu": B, "mesh_vertices_requested": NV,
+                          "mesh_vertices_after_voxel_dedup": int(nv_min), "parallelism": f"data-parallel x{world}" if world > 1 else "single GPU"},
                "unet_tflops": per_sample * B * world / (dt / args.steps) / 1e12,
                "loss_first_last": [lv[0], lv[-1]], "loss_scale": model.loss_scale, "optimizer_steps_skipped": opt.steps_skipped,
                "not_built": "bf16 storage (fp16 operands + loss scale instead)",
