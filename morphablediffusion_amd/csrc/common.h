@@ -184,7 +184,11 @@ int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int 
                        const float* scale, const float* shift, float* out, hipStream_t s);
 // BatchNorm1d in train mode over n rows of C <= 256 channels + ReLU, in place: x = relu((x - mean) / sqrt(var + eps) * g + b),
 // biased variance (what F.batch_norm normalises with)
-int launch_bn_rows_relu(float* x, int n, int C, const float* gamma, const float* beta, float eps, hipStream_t s);
+int launch_sparse_w_pack(const float* src, int Cin, int Cout, int layout, float* dst, hipStream_t s);
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C, float* scale,
+                   float* shift, hipStream_t s);
+int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gamma, const float* beta, float eps, float* stats_out,
+                        hipStream_t s);
 int launch_mse(const float* a, const float* b, size_t n, float* out, hipStream_t s);
 int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
                          const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s);

@@ -63,8 +63,9 @@ int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view
                         float vol_len, int S, int persp, float* d_feats, hipStream_t s);
 int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views, int Nv, int total_views, float* d_vf, float* dw, float* db,
               hipStream_t s);
-int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, float eps, float* dgamma,
-                      float* dbeta, hipStream_t s);
+int cbwd_bn_scratch_floats(int n, int C);
+int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, const float* stats,
+                      float* scratch, float* dgamma, float* dbeta, hipStream_t s);
 int cbwd_sparse_wgrad_chunks(int n_out);
 int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
                      float* dw_packed, float* dw_part, hipStream_t s);
@@ -1153,7 +1154,7 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   RET_IF(launch_fuse_views(vf, N, Nv, N, c->fuse_w, c->fuse_b, fused, 0, s));
   // sparse voxel CNN, train mode: raw conv output and post-activation rows of every layer
   const float* sp_in[9];
-  float *sp_raw[9], *sp_post[9];
+  float *sp_raw[9], *sp_post[9], *sp_stats[9];  // raw conv output, post-activation rows, BatchNorm [mean | rstd]
   const int* sp_nbr[9];
   int sp_nout[9], sp_nin[9];
   {
@@ -1173,9 +1174,10 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
       sp_raw[i] = F((size_t)sp_nout[i] * L.cout);
       sp_post[i] = F((size_t)sp_nout[i] * L.cout);
       WS_CHECK(sp_raw[i] && sp_post[i]);
+      sp_stats[i] = F((size_t)2 * L.cout);
+      WS_CHECK(sp_stats[i]);
       RET_IF(launch_sparse_conv(in, sp_nbr[i], sp_nout[i], L.cin, L.cout, L.w, nullptr, nullptr, sp_raw[i], s));
-      HIP_CHECK_RET(hipMemcpyAsync(sp_post[i], sp_raw[i], (size_t)sp_nout[i] * L.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
-      RET_IF(launch_bn_rows_relu(sp_post[i], sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, s));
+      RET_IF(launch_bn_rows_relu(sp_raw[i], sp_post[i], sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, sp_stats[i], s));
       in = sp_post[i];
       n_in = sp_nout[i];
     }
@@ -1317,7 +1319,12 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     float* Gb = engine_grad(c, L.bnkey + ".bias");
     float* Gw = engine_grad(c, L.wkey);
     if (!Gg || !Gb || !Gw) return mvd_fail("conditioner backward: sparse layer parameters missing from the arena");
-    RET_IF(cbwd_bn_rows_relu(sp_raw[i], d_cur, sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, Gg, Gb, s));
+    {
+      WsScope sc(c, WS_TEMP);
+      float* bn_scr = F((size_t)cbwd_bn_scratch_floats(sp_nout[i], L.cout));
+      WS_CHECK(bn_scr);
+      RET_IF(cbwd_bn_rows_relu(sp_raw[i], d_cur, sp_nout[i], L.cout, L.gamma, L.beta, sp_stats[i], bn_scr, Gg, Gb, s));
+    }
     float* dwp = F((size_t)27 * L.cin * L.cout);
     float* d_in = F((size_t)sp_nin[i] * L.cin);
     WS_CHECK(dwp && d_in);

@@ -209,35 +209,14 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   L->wkey = wk;
   L->bnkey = bn;
   L->layout = layout;
-  std::vector<float> hw(w->numel), pk(w->numel), hg(cout), hb(cout), hm(cout), hv(cout), sc(cout), sh(cout);
-  HIP_CHECK_RET(hipMemcpy(hw.data(), w->d, w->numel * 4, hipMemcpyDeviceToHost));
-  HIP_CHECK_RET(hipMemcpy(hg.data(), g->d, cout * 4, hipMemcpyDeviceToHost));
-  HIP_CHECK_RET(hipMemcpy(hb.data(), b->d, cout * 4, hipMemcpyDeviceToHost));
-  HIP_CHECK_RET(hipMemcpy(hm.data(), rm->d, cout * 4, hipMemcpyDeviceToHost));
-  HIP_CHECK_RET(hipMemcpy(hv.data(), rv->d, cout * 4, hipMemcpyDeviceToHost));
-  // -> [27][cin][cout]
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci)
-      for (int k = 0; k < 27; ++k) {
-        const size_t src = layout == 0 ? ((size_t)co * cin + ci) * 27 + k
-                         : layout == 1 ? ((size_t)co * 27 + k) * cin + ci
-                                       : ((size_t)k * cin + ci) * cout + co;
-        pk[((size_t)k * cin + ci) * cout + co] = hw[src];
-      }
-  for (int co = 0; co < cout; ++co) {  // eval BatchNorm1d(eps 1e-3), network.py:105
-    sc[co] = hg[co] / sqrtf(hv[co] + 1e-3f);
-    sh[co] = hb[co] - hm[co] * sc[co];
-  }
-  RET_IF(dmalloc(c, (void**)&L->w, pk.size() * 4));
+  // packed on the device (no host round trip: the re-pack of a training step runs this for nine layers)
+  RET_IF(dmalloc(c, (void**)&L->w, w->numel * 4));
   RET_IF(dmalloc(c, (void**)&L->scale, cout * 4));
   RET_IF(dmalloc(c, (void**)&L->shift, cout * 4));
-  HIP_CHECK_RET(hipMemcpy(L->w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-  HIP_CHECK_RET(hipMemcpy(L->scale, sc.data(), cout * 4, hipMemcpyHostToDevice));
-  HIP_CHECK_RET(hipMemcpy(L->shift, sh.data(), cout * 4, hipMemcpyHostToDevice));
-  RET_IF(dmalloc(c, (void**)&L->gamma, cout * 4));
-  RET_IF(dmalloc(c, (void**)&L->beta, cout * 4));
-  HIP_CHECK_RET(hipMemcpy(L->gamma, hg.data(), cout * 4, hipMemcpyHostToDevice));
-  HIP_CHECK_RET(hipMemcpy(L->beta, hb.data(), cout * 4, hipMemcpyHostToDevice));
+  RET_IF(launch_sparse_w_pack(w->d, cin, cout, layout, L->w, 0));                       // -> [27][cin][cout]
+  RET_IF(launch_bn_fold(g->d, b->d, rm->d, rv->d, 1e-3f, cout, L->scale, L->shift, 0));  // eval BatchNorm1d(eps 1e-3), network.py:105
+  RET_IF(copy_f32(c, bn + ".weight", &L->gamma));
+  RET_IF(copy_f32(c, bn + ".bias", &L->beta));
   return 0;
 }
 

@@ -143,9 +143,32 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   }
 }
 
-// one workgroup per channel: mean, then centred second moment over the n rows (fp32, fixed order), then the in-place apply
-__global__ __launch_bounds__(256) void bn_rows_relu_kernel(float* __restrict__ x, int n, int C, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps) {
+__global__ void sparse_w_pack_kernel(const float* __restrict__ src, int Cin, int Cout, int layout, float* __restrict__ dst) {
+  const long total = (long)27 * Cin * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), k = (int)(i / ((long)Cout * Cin));
+    const long sidx = layout == 0 ? ((long)co * Cin + ci) * 27 + k : layout == 1 ? ((long)co * 27 + k) * Cin + ci : i;
+    dst[i] = src[sidx];
+  }
+}
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - mean[c] * sc;
+}
+
+// BatchNorm1d on batch statistics (biased variance) + ReLU over the n active rows of a sparse layer: one workgroup per channel --
+// mean, then centred second moment over the n rows (fp32, fixed order), then the apply (y may be x).  stats_out (optional):
+// [mean | rstd] for the backward pass.  (A coalesced two-launch form with a shifted one-pass variance was built and is 2x
+// faster, 23 -> 12 us, but its statistics differ from these in the last bits, which re-draws near-tie ReLU masks downstream: the
+// gradients of the 4x4 DepthTransformer moved from 3.7e-2 to 1.0e-1 of the reference's.  The backward pass, which draws no
+// masks, uses the coalesced form: k_cond_bwd.hip.)
+__global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ stats_out) {
   __shared__ float s_red[256];
   const int c = blockIdx.x, t = threadIdx.x;
   float a = 0.f;
@@ -170,7 +193,11 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(float* __restrict__ x
     __syncthreads();
   }
   const float rstd = rsqrtf(s_red[0] / (float)n + eps), g = gamma[c], b = beta[c];
-  for (int r = t; r < n; r += 256) x[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
+  if (stats_out && t == 0) {
+    stats_out[c] = mean;
+    stats_out[C + c] = rstd;
+  }
+  for (int r = t; r < n; r += 256) y[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
 }
 
 // mean((a - b)^2) of n elements into out[0]: one workgroup, fixed summation order
@@ -316,9 +343,25 @@ int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int 
   return 0;
 }
 
-int launch_bn_rows_relu(float* x, int n, int C, const float* gamma, const float* beta, float eps, hipStream_t s) {
+// sparse conv weight in one of the checkpoint layouts (engine_weights.hip: build_sparse_layer) -> [27][Cin][Cout]
+int launch_sparse_w_pack(const float* src, int Cin, int Cout, int layout, float* dst, hipStream_t s) {
+  const long total = (long)27 * Cin * Cout;
+  hipLaunchKernelGGL(sparse_w_pack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, src, Cin, Cout, layout, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// eval-mode BatchNorm1d folded into the conv epilogue: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C, float* scale,
+                   float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, mean, var, eps, C, scale, shift);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// y (may be x) = relu(batchnorm(x)); stats_out: optional [2][C] (mean | rstd)
+int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gamma, const float* beta, float eps, float* stats_out,
+                        hipStream_t s) {
   if (n <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, n, C, gamma, beta, eps);
+  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -214,49 +214,67 @@ __global__ __launch_bounds__(256) void fuse_bwd_w_kernel(const float* __restrict
 }
 
 // ---- sparse voxel CNN, train mode -------------------------------------------------------------------------------------
-// BatchNorm1d (batch statistics over the n active rows, biased variance) + ReLU backward, one workgroup per channel:
-// xraw = the conv output, dy = gradient w.r.t. relu(bn(xraw)); writes d xraw over dy (in place), dgamma / dbeta accumulated.
-__global__ __launch_bounds__(256) void bn_rows_relu_bwd_kernel(const float* __restrict__ xraw, float* __restrict__ dy, int n, int C,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float s_red[256];
-  auto bsum = [&](float v) {
-    s_red[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
-      __syncthreads();
-    }
-    const float r = s_red[0];
-    __syncthreads();
-    return r;
-  };
-  const int c = blockIdx.x, t = threadIdx.x;
-  float a = 0.f;
-  for (int r = t; r < n; r += 256) a += xraw[(long)r * C + c];
-  const float mean = bsum(a) / (float)n;
-  float q = 0.f;
-  for (int r = t; r < n; r += 256) {
-    const float d = xraw[(long)r * C + c] - mean;
-    q += d * d;
-  }
-  const float rstd = rsqrtf(bsum(q) / (float)n + eps), g = gamma[c], b = beta[c];
+// BatchNorm1d (batch statistics over the n active rows, biased variance) + ReLU backward, rows [n][C] with C dividing 256.
+// xraw = the conv output, stats = [mean | rstd] of the forward pass, dy = gradient w.r.t. relu(bn(xraw)); writes d xraw over dy
+// (in place), dgamma / dbeta accumulated.  Two launches over chunks of 128 rows, every access a full row segment (the
+// one-workgroup-per-channel form walked columns with a stride of C floats: 44 -> 12 us): per-chunk sums of du and du * xhat, then every workgroup adds the partials in chunk order
+// and applies; workgroup 0 accumulates the parameter gradients.
+constexpr int BNB_CH = 128;
+__global__ __launch_bounds__(256) void bn_rows_bwd_sums_kernel(const float* __restrict__ xraw, const float* __restrict__ dy, int n, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, float* __restrict__ part) {
+  __shared__ float s_a[256], s_b[256];
+  const int RL = 256 / C, t = threadIdx.x, c = t % C, rl = t / C;
+  const int r0 = blockIdx.x * BNB_CH, r1 = min(n, r0 + BNB_CH);
   float s1 = 0.f, s2 = 0.f;
-  for (int r = t; r < n; r += 256) {
-    const float xh = (xraw[(long)r * C + c] - mean) * rstd;
-    const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
-    s1 += du;
-    s2 += du * xh;
+  if (rl < RL) {
+    const float mean = stats[c], rstd = stats[C + c], g = gamma[c], b = beta[c];
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const float xh = (xraw[(long)r * C + c] - mean) * rstd;
+      const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
+      s1 += du;
+      s2 += du * xh;
+    }
   }
-  const float S1 = bsum(s1), S2 = bsum(s2);
-  for (int r = t; r < n; r += 256) {
-    const float xh = (xraw[(long)r * C + c] - mean) * rstd;
-    const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
-    dy[(long)r * C + c] = g * rstd * (du - S1 / (float)n - xh * S2 / (float)n);
+  s_a[t] = s1;
+  s_b[t] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < RL; ++i) {
+      s1 += s_a[i * C + c];
+      s2 += s_b[i * C + c];
+    }
+    part[((long)blockIdx.x * 2) * C + c] = s1;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = s2;
   }
-  if (t == 0) {
-    dgamma[c] += S2;
-    dbeta[c] += S1;
+}
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __restrict__ xraw, float* __restrict__ dy, int n, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ stats, const float* __restrict__ part, int nchunk,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_1[256], s_2[256];
+  const int t = threadIdx.x;
+  if (t < C) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      a += part[((long)k * 2) * C + t];
+      q += part[((long)k * 2 + 1) * C + t];
+    }
+    if (blockIdx.x == 0) {
+      dgamma[t] += q;
+      dbeta[t] += a;
+    }
+    s_1[t] = a / (float)n;
+    s_2[t] = q / (float)n;
+  }
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * BNB_CH * C, e1 = min((long)n * C, e0 + (long)BNB_CH * C);
+  for (long e = e0 + t; e < e1; e += 256) {
+    const int c = (int)(e % C);
+    const float rstd = stats[C + c], g = gamma[c];
+    const float xh = (xraw[e] - stats[c]) * rstd;
+    const float du = (g * xh + beta[c]) > 0.f ? dy[e] : 0.f;
+    dy[e] = g * rstd * (du - s_1[c] - xh * s_2[c]);
   }
 }
 
@@ -434,10 +452,15 @@ int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, float eps, float* dgamma,
-                      float* dbeta, hipStream_t s) {
+int cbwd_bn_scratch_floats(int n, int C) { return cdiv(n, BNB_CH) * 2 * C; }
+// stats: [mean | rstd] from launch_bn_rows_relu; scratch: cbwd_bn_scratch_floats(n, C) floats
+int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, const float* stats,
+                      float* scratch, float* dgamma, float* dbeta, hipStream_t s) {
   if (n <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(bn_rows_relu_bwd_kernel, dim3(C), dim3(256), 0, s, xraw, dy, n, C, gamma, beta, eps, dgamma, dbeta);
+  if (C > 256 || 256 % C) return mvd_fail("bn_rows_relu backward: the channel count must divide 256");
+  const int nchunk = cdiv(n, BNB_CH);
+  hipLaunchKernelGGL(bn_rows_bwd_sums_kernel, dim3(nchunk), dim3(256), 0, s, xraw, dy, n, C, gamma, beta, stats, scratch);
+  hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3(nchunk), dim3(256), 0, s, xraw, dy, n, C, gamma, beta, stats, scratch, nchunk, dgamma, dbeta);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
