@@ -236,15 +236,23 @@ class SpatialVolumeNet(nn.Module):
         return self._host[2]
 
     def _set_sample(self, batch, bi):
-        """Makes sample ``bi`` of ``batch`` the engine's active mesh + cameras.  The tables are step-invariant, so they are
-        rebuilt only when the batch content changes: the key covers every tensor that feeds them -- storage address, shape
-        and torch's in-place version counter -- and the cache holds references to those tensors, so a freed tensor's address
-        cannot come back under the same key."""
+        """Makes sample ``bi`` of ``batch`` the engine's active mesh + cameras.  The tables are rebuilt only when the batch content
+        changes: the key covers every tensor that feeds them -- storage address, shape and torch's in-place version counter --
+        and the cache holds references to those tensors, so a freed tensor's address cannot come back under the same key.  A
+        batch whose tables are not resident (a training step's new batch) is uploaded as a whole, once."""
         from .engine import MAX_SAMPLE_SLOTS
         slot = bi % MAX_SAMPLE_SLOTS
         held = self._slots.get(slot)
         if held is None or held[0] != self._sample_key(batch, bi):
-            self._upload_batch(batch)
+            if batch["vertices"].shape[0] <= MAX_SAMPLE_SLOTS:
+                self._upload_batch(batch)
+            else:  # more samples than slots: samples share slots and are uploaded one by one, on use
+                self._slots.pop(slot, None)
+                h = self._host_tables(batch)
+                self._engine.select_sample(slot)
+                self._engine.set_mesh(h["vertices"][bi], h["coord"][bi], h["out_sh"][bi], h["bounds"][bi])
+                self._engine.set_cameras(h["target_K"][bi], h["target_RT"][bi])
+                self._slots[slot] = (self._sample_key(batch, bi), tuple(batch[k] for k in self._SAMPLE_KEYS))
         self._engine.select_sample(slot)
 
     def _sample_key(self, batch, bi):
@@ -252,30 +260,21 @@ class SpatialVolumeNet(nn.Module):
         return (bi,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in ts)
 
     def _upload_batch(self, batch):
-        """Tables of every sample of ``batch`` that is not resident yet, in ONE call: the rule books are built on one host thread
-        per sample and uploaded in stream order (mvd_set_samples_async) -- a training step sees a new batch every time."""
-        from .engine import MAX_SAMPLE_SLOTS
+        """Tables of every sample of ``batch`` (at most MAX_SAMPLE_SLOTS) that is not resident yet, in ONE call: the rule books are
+        built on one host thread per sample and uploaded in stream order (mvd_set_samples_async)."""
         ts = tuple(batch[k] for k in self._SAMPLE_KEYS)
-        B = batch["vertices"].shape[0]
-        todo = []
-        for bi in range(min(B, MAX_SAMPLE_SLOTS)):
-            held = self._slots.get(bi % MAX_SAMPLE_SLOTS)
-            if held is None or held[0] != self._sample_key(batch, bi):
-                todo.append(bi)
-        if B > MAX_SAMPLE_SLOTS:  # more samples than slots: the surplus shares slots and is re-uploaded on use
-            todo = sorted(set(todo) | {bi for bi in range(MAX_SAMPLE_SLOTS, B)
-                                       if (self._slots.get(bi % MAX_SAMPLE_SLOTS) or (None,))[0] != self._sample_key(batch, bi)})
-            todo = list({bi % MAX_SAMPLE_SLOTS: bi for bi in reversed(todo)}.values())  # one sample per slot and call
+        todo = [bi for bi in range(batch["vertices"].shape[0])
+                if (self._slots.get(bi) or (None,))[0] != self._sample_key(batch, bi)]
         if not todo:
             return
         h = self._host_tables(batch)
         for bi in todo:
-            self._slots.pop(bi % MAX_SAMPLE_SLOTS, None)  # a failed upload must not leave a stale key behind
-        self._engine.set_samples([bi % MAX_SAMPLE_SLOTS for bi in todo], [h["vertices"][bi] for bi in todo],
-                                 [h["coord"][bi] for bi in todo], [h["out_sh"][bi] for bi in todo], [h["bounds"][bi] for bi in todo],
+            self._slots.pop(bi, None)  # a failed upload must not leave a stale key behind
+        self._engine.set_samples(todo, [h["vertices"][bi] for bi in todo], [h["coord"][bi] for bi in todo],
+                                 [h["out_sh"][bi] for bi in todo], [h["bounds"][bi] for bi in todo],
                                  [h["target_K"][bi] for bi in todo], [h["target_RT"][bi] for bi in todo])
         for bi in todo:
-            self._slots[bi % MAX_SAMPLE_SLOTS] = (self._sample_key(batch, bi), ts)
+            self._slots[bi] = (self._sample_key(batch, bi), ts)
 
     def construct_spatial_volume(self, x, t_embed, v_embed, batch):
         """train mode (nn.Module.train(), as Lightning sets it for training_step): the sparse CNN's BatchNorm layers use

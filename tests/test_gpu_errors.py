@@ -117,6 +117,50 @@ def test_set_mesh_is_transactional_and_sample_slots_keep_their_tables():
     e.close()
 
 
+def test_set_samples_equals_per_sample_upload_and_validates_the_whole_batch_first():
+    """mvd_set_samples_async (a training step's new batch: rule books built on host threads, stream-ordered upload) gives the
+    same tables as mvd_set_mesh / mvd_set_cameras per sample; one bad sample fails the call before ANY table is replaced."""
+    from morphablediffusion_amd import synthetic
+    from morphablediffusion_amd.engine import Engine
+    from morphablediffusion_amd.spec import VolumeConfig
+    N = 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    e = Engine(ucfg, vcfg, workspace_gb=2.0)
+    e.load_state_dict(gi.full_weights(ucfg, vcfg))
+    bs = [synthetic.make_batch(N, "perspective", 500 + 60 * i, mesh_seed=3 + i, radii=(0.2 + 0.01 * i, 0.25, 0.27)) for i in range(3)]
+    x = torch.randn(N, 4, 32, 32, generator=torch.Generator().manual_seed(0)).cuda()
+    te, ve = torch.zeros(256).cuda(), torch.zeros(N, 4).cuda()
+
+    def vol(slot):
+        e.select_sample(slot)
+        return e.volume_from_fused(e.vertex_features(x, te, ve, torch.arange(N)))
+
+    ref = []
+    for i, b in enumerate(bs):  # one by one, synchronous entries
+        e.select_sample(10 + i)
+        e.set_mesh(b["vertices"][0], b["coord"][0], b["out_sh"][0], b["bounds"][0])
+        e.set_cameras(b["target_K"][0], b["target_RT"][0])
+        ref.append(vol(10 + i))
+    args = lambda key: [b[key][0] for b in bs]
+    e.set_samples([0, 1, 2], args("vertices"), args("coord"), args("out_sh"), args("bounds"), args("target_K"), args("target_RT"))
+    for i in range(3):
+        assert torch.equal(vol(i), ref[i])
+    # a second upload into the same slots (other order: pools are reused, sizes differ), then a batch with one bad sample
+    order = [2, 0, 1]
+    pick = lambda key: [bs[j][key][0] for j in order]
+    e.set_samples([0, 1, 2], pick("vertices"), pick("coord"), pick("out_sh"), pick("bounds"), pick("target_K"), pick("target_RT"))
+    for i, j in enumerate(order):
+        assert torch.equal(vol(i), ref[j])
+    bad = args("coord")
+    bad[2] = bad[2].clone()
+    bad[2][5, 0] = bs[2]["out_sh"][0, 0] + 1
+    with pytest.raises(L.MvdError, match="outside out_sh"):
+        e.set_samples([0, 1, 2], args("vertices"), bad, args("out_sh"), args("bounds"), args("target_K"), args("target_RT"))
+    for i, j in enumerate(order):  # nothing was replaced
+        assert torch.equal(vol(i), ref[j])
+    e.close()
+
+
 def test_unsupported_arguments_keep_the_reference_exceptions():
     e, cfg = _unet_engine(1.0)
     x, t, ctx, sd = gi.unet_inputs(cfg, Bv=1)
