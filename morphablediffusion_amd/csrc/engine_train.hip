@@ -76,13 +76,10 @@ int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_
 int train_im2col3(const float* X, int B, int H, int W, int C, float* col, hipStream_t s);
 int train_col2im3(const float* dcol, int B, int H, int W, int C, float* dX, hipStream_t s);
 int train_perm_w3(const float* src, int N, int C, int to_mat, float* dst, hipStream_t s);
-int train_gn_fwd(const float* x, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act, float* y,
-                 float* stats, hipStream_t s);
 int train_depth_fwd(const float* q, const float* k, const float* v, int R, int HW, int D, int hn, int hd, float scale, float* attn,
                     float* z, hipStream_t s);
 int train_depth_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dz, int R, int HW, int D, int hn,
                     int hd, float scale, float* dq, float* dk, float* dv, hipStream_t s);
-int train_scale_sub(const float* a, const float* b, float k, size_t n, float* out, hipStream_t s);
 int train_add_inplace(float* a, const float* b, size_t n, hipStream_t s);
 int train_copy_rows(const float* src, int ld, long rows, int C, float* dst, hipStream_t s);
 int train_add_bias_rows(float* x, long rows, int C, const float* bias, hipStream_t s);

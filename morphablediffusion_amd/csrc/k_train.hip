@@ -1,6 +1,6 @@
 // Training-step helper kernels: the fp32 pieces of the DepthTransformer backward (attention.py:49-84) that
 // are bandwidth-bound and stay off the matrix cores -- gather-form im2col / col2im for its two 3x3 convs (their GEMMs run on
-// the MFMA kernels through engine_train.hip: tgemm), GroupNorm forward in fp32, the depth attention forward / backward, row
+// the MFMA kernels through engine_train.hip: tgemm), the depth attention forward / backward, row
 // utilities.  Deterministic (fixed summation orders, no atomics).
 #include "common.h"
 
@@ -47,57 +47,8 @@ __global__ void perm_w3_kernel(const float* __restrict__ src, int N, int C, int 
   }
 }
 
-__device__ __forceinline__ float act_f(float u, int act) { return act == ACT_SILU ? u / (1.f + __expf(-u)) : (act == ACT_RELU ? fmaxf(u, 0.f) : u); }
-__device__ float block_sum256(float v, float* s_red) {
-  const int t = threadIdx.x;
-  s_red[t] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) s_red[t] += s_red[t + o];
-    __syncthreads();
-  }
-  const float r = s_red[0];
-  __syncthreads();
-  return r;
-}
 
-// GroupNorm forward on x [B][rows][C] (channels-last), one block per (b, g): y = act(gamma xhat + beta); stats [B][G][2]
-__global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x, int rows, int C, int G, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, int act, float* __restrict__ y,
-                                                     float* __restrict__ stats) {
-  __shared__ float s_red[256];
-  const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, n = rows * cpg;
-  const float* xb = x + (long)b * rows * C + g * cpg;
-  float a = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) a += xb[(long)(e / cpg) * C + e % cpg];
-  const float mean = block_sum256(a, s_red) / (float)n;
-  float q = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const float d = xb[(long)(e / cpg) * C + e % cpg] - mean;
-    q += d * d;
-  }
-  const float rstd = rsqrtf(block_sum256(q, s_red) / (float)n + eps);
-  if (threadIdx.x == 0 && stats) {
-    stats[(b * G + g) * 2] = mean;
-    stats[(b * G + g) * 2 + 1] = rstd;
-  }
-  float* yb = y + (long)b * rows * C + g * cpg;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int c = e % cpg;
-    const long o = (long)(e / cpg) * C + c;
-    yb[o] = act_f((xb[o] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c], act);
-  }
-}
 
-// out[c] = sum over R rows of v[r][c]: one block per channel, fixed order (two-level: 256 partial sums, tree)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ v, long R, int C, float* __restrict__ out) {
-  __shared__ float s_red[256];
-  const int c = blockIdx.x;
-  float a = 0.f;
-  for (long r = threadIdx.x; r < R; r += 256) a += v[r * C + c];
-  const float s = block_sum256(a, s_red);
-  if (threadIdx.x == 0) out[c] = s;
-}
 
 // DepthAttention.forward (attention.py:26-47) per pixel; q [R][I], k / v [B*D*HW][I] (row = (b*D + d)*HW + p), I = hn * hd.
 // One workgroup of 256 threads per pixel: the hn * D scores are wave-parallel dot products of length hd, the softmax over the
@@ -185,9 +136,6 @@ __global__ __launch_bounds__(256) void depth_bwd_kernel(const float* __restrict_
   }
 }
 
-__global__ void scale_sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float k, size_t n, float* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = k * (a[i] - b[i]);
-}
 __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
@@ -224,17 +172,6 @@ int train_perm_w3(const float* src, int N, int C, int to_mat, float* dst, hipStr
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int train_gn_fwd(const float* x, int B, int rows, int C, int G, const float* gamma, const float* beta, float eps, int act, float* y,
-                 float* stats, hipStream_t s) {
-  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B * G), dim3(256), 0, s, x, rows, C, G, gamma, beta, eps, act, y, stats);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-int train_colsum(const float* v, long R, int C, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, s, v, R, C, out);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
 int train_depth_fwd(const float* q, const float* k, const float* v, int R, int HW, int D, int hn, int hd, float scale, float* attn,
                     float* z, hipStream_t s) {
   if (hn > DEPTH_MAX_H || hn * hd > DEPTH_MAX_I || D > DEPTH_MAX_D) return mvd_fail("train_depth: needs heads <= 4, heads*dim_head <= 1024, D <= 64");
@@ -246,11 +183,6 @@ int train_depth_bwd(const float* q, const float* k, const float* v, const float*
                     int hd, float scale, float* dq, float* dk, float* dv, hipStream_t s) {
   if (hn > DEPTH_MAX_H || hn * hd > DEPTH_MAX_I || D > DEPTH_MAX_D) return mvd_fail("train_depth: needs heads <= 4, heads*dim_head <= 1024, D <= 64");
   hipLaunchKernelGGL(depth_bwd_kernel, dim3(R), dim3(256), 0, s, q, k, v, attn, dz, HW, D, hn, hd, scale, dq, dk, dv);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-int train_scale_sub(const float* a, const float* b, float k, size_t n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(scale_sub_kernel, dim3(gridn(n)), dim3(256), 0, s, a, b, k, n, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
