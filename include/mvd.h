@@ -226,6 +226,13 @@ int mvd_train_conditioner_backward(mvd_ctx* ctx, const float* x_noisy, int64_t t
 int mvd_train_cond_backward(mvd_ctx* ctx, int cond_index, const float* x, const float* context, const float* d_out, int B, int H,
                             int W, int depth0, float* dx, float* dcontext, void* stream);
 int mvd_train_get_grad(mvd_ctx* ctx, const char* name, float* out, size_t numel, void* stream);
+/* Checkpoint export of a training context (what Lightning's ModelCheckpoint gets from ``state_dict()``): the current value of a
+ * resident tensor by its state_dict key -- a master parameter, or a BatchNorm running_mean / running_var buffer of the sparse
+ * CNN, which train-mode forwards (mvd_volume_from_fused_train) update with momentum 0.01 like nn.BatchNorm1d (network.py:105).
+ * out: device pointer, numel floats.  mvd_train_bn_calls: the number of such forwards since the weights were loaded (what
+ * ``num_batches_tracked`` advanced by). */
+int mvd_train_get_tensor(mvd_ctx* ctx, const char* name, float* out, size_t numel, void* stream);
+int64_t mvd_train_bn_calls(mvd_ctx* ctx);
 int mvd_train_adamw_step(mvd_ctx* ctx, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
                          float inv_scale, int finetune_unet, int* skipped_out, void* stream);
 int mvd_train_repack(mvd_ctx* ctx);

@@ -558,6 +558,19 @@ int mvd_train_get_grad(mvd_ctx* c, const char* name, float* out, size_t numel, v
   return 0;
 }
 
+int mvd_train_get_tensor(mvd_ctx* c, const char* name, float* out, size_t numel, void* stream) {
+  if (!c || !name || !out) return mvd_fail("mvd_train_get_tensor: null argument");
+  if (!c->train_mode || !c->finalized) return mvd_fail("mvd_train_get_tensor: context not finalized in training mode");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  auto it = c->raw.find(name);  // parameters (their storage is the master arena) and the resident buffers
+  if (it == c->raw.end()) return mvd_fail("mvd_train_get_tensor: not a resident tensor of this context");
+  if (it->second.numel != numel) return mvd_fail("mvd_train_get_tensor: size mismatch");
+  HIP_CHECK_RET(hipMemcpyAsync(out, it->second.d, numel * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
+  return 0;
+}
+
+int64_t mvd_train_bn_calls(mvd_ctx* c) { return c ? (int64_t)c->bn_train_calls : 0; }
+
 int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
                          float inv_scale, int finetune_unet, int* skipped_out, void* stream) {
   if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_adamw_step: context not finalized in training mode");

@@ -188,7 +188,7 @@ int launch_sparse_w_pack(const float* src, int Cin, int Cout, int layout, float*
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C, float* scale,
                    float* shift, hipStream_t s);
 int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gamma, const float* beta, float eps, float* stats_out,
-                        hipStream_t s);
+                        hipStream_t s, float* rmean = nullptr, float* rvar = nullptr, float momentum = 0.f);
 int launch_mse(const float* a, const float* b, size_t n, float* out, hipStream_t s);
 int launch_latent_gather(const float* feats, const int* grid, int gd, int gh, int gw, const float* min_xyz,
                          const int* out_sh, float voxel, int V, float vol_len, float* out, hipStream_t s);

@@ -145,6 +145,8 @@ struct SparseLayerW {
   float* shift = nullptr;
   float* gamma = nullptr;  // BatchNorm weight / bias themselves (train mode: batch statistics, engine_volume_from_fused)
   float* beta = nullptr;
+  float* rmean = nullptr;  // training contexts: the running_mean / running_var buffers themselves -- a train-mode forward updates
+  float* rvar = nullptr;   // them as nn.BatchNorm1d(momentum=0.01) does (network.py:105), the re-pack folds the updated values
   int cin = 0, cout = 0;
   bool strided = false;
 };
@@ -306,6 +308,7 @@ struct mvd_ctx {
     CamStage cam_stage;
   };
   std::vector<SampleSlot> slots;
+  long bn_train_calls = 0;  // train-mode forwards of the sparse CNN since the weights were loaded (num_batches_tracked)
   int cur_slot = 0;
   float* volume = nullptr;  // device [V][V][V][64] fp32 (channels-last)
   hipEvent_t vol_ready = nullptr;  // caller-owned: recorded after the mvd_volume_from_fused that the next readers need

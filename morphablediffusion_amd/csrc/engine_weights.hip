@@ -217,6 +217,10 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   RET_IF(launch_bn_fold(g->d, b->d, rm->d, rv->d, 1e-3f, cout, L->scale, L->shift, 0));  // eval BatchNorm1d(eps 1e-3), network.py:105
   RET_IF(copy_f32(c, bn + ".weight", &L->gamma));
   RET_IF(copy_f32(c, bn + ".bias", &L->beta));
+  if (c->train_mode) {  // the buffers stay resident in a training context (engine_finalize): train-mode forwards update them
+    L->rmean = rm->d;
+    L->rvar = rv->d;
+  }
   return 0;
 }
 

@@ -168,7 +168,8 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 // masks, uses the coalesced form: k_cond_bwd.hip.)
 __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ stats_out) {
+                                                          float* __restrict__ stats_out, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float momentum) {
   __shared__ float s_red[256];
   const int c = blockIdx.x, t = threadIdx.x;
   float a = 0.f;
@@ -196,6 +197,10 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
   if (stats_out && t == 0) {
     stats_out[c] = mean;
     stats_out[C + c] = rstd;
+  }
+  if (rmean && t == 0) {  // nn.BatchNorm1d in train mode: running statistics, the variance as the unbiased estimate
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (s_red[0] / (float)(n > 1 ? n - 1 : 1));
   }
   for (int r = t; r < n; r += 256) y[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
 }
@@ -358,10 +363,11 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* mean, con
   return 0;
 }
 // y (may be x) = relu(batchnorm(x)); stats_out: optional [2][C] (mean | rstd)
+// rmean / rvar (optional): running statistics, updated with `momentum` as nn.BatchNorm1d does in train mode
 int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gamma, const float* beta, float eps, float* stats_out,
-                        hipStream_t s) {
+                        hipStream_t s, float* rmean, float* rvar, float momentum) {
   if (n <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out);
+  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -122,7 +122,39 @@ class Engine:
         self._loaded = True
         if self.train_mode:
             self._adopt_arenas()
+            # what a checkpoint written after training must carry besides the masters (export_state_dict): references to the
+            # tensors the training step does not change (first stage, CLIP, schedule buffers, ...) -- no copies
+            self._loaded_sd = dict(sd)
         return IncompatibleKeys(missing, unexpected)
+
+    def get_tensor(self, key):
+        """Current value of a resident tensor of a training context (a master parameter or a BatchNorm running statistic)."""
+        ref = self._loaded_sd[key]
+        out = torch.empty(tuple(ref.shape), device=self.device, dtype=torch.float32)
+        L.check(self.lib.mvd_train_get_tensor(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))
+        return out
+
+    def export_state_dict(self):
+        """The loaded state_dict with every trained tensor replaced by its current value: master parameters from the arena, the
+        sparse CNN's BatchNorm running statistics as the train-mode forwards left them (momentum 0.01, network.py:105),
+        ``num_batches_tracked`` advanced by the number of those forwards.  Same keys, shapes and dtypes as what was loaded --
+        the reference's ``torch.save({'state_dict': model.state_dict()})`` of a fine-tuned model."""
+        if not self.train_mode or not self._loaded:
+            raise L.MvdError("export_state_dict needs a training context with loaded weights")
+        out = collections.OrderedDict()
+        calls = int(self.lib.mvd_train_bn_calls(self._ctx))
+        for k, v in self._loaded_sd.items():
+            if not torch.is_tensor(v):
+                out[k] = v
+            elif k in self.param_table:
+                out[k] = self.param_view(k).detach().clone().to(dtype=v.dtype)
+            elif k.startswith("spatial_volume.") and k.endswith((".running_mean", ".running_var")):
+                out[k] = self.get_tensor(k).to(dtype=v.dtype)
+            elif k.startswith("spatial_volume.") and k.endswith(".num_batches_tracked"):
+                out[k] = v.detach().clone() + calls
+            else:
+                out[k] = v
+        return out
 
     # ---- stages --------------------------------------------------------------------------------
     def unet_forward(self, x, timesteps, context, source_dict, n_ctx: Optional[int] = None):

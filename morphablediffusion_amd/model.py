@@ -369,6 +369,13 @@ class SyncMultiviewDiffusion(nn.Module):
         self.model.diffusion_model._keep_trainable(state_dict, "model.diffusion_model.")
         return inc
 
+    def state_dict(self, *args, **kwargs):
+        """Training mode: the checkpoint of the fine-tuned model under the reference's keys (Engine.export_state_dict) -- what
+        Lightning's ModelCheckpoint saves and generate_face.py / the reference itself loads.  Otherwise nn.Module's."""
+        if getattr(self.engine, "train_mode", False) and getattr(self.engine, "_loaded", False):
+            return self.engine.export_state_dict()
+        return super().state_dict(*args, **kwargs)
+
     def get_viewpoint_embedding(self, batch):
         d_e = torch.deg2rad(batch["target_elevation"]) - torch.deg2rad(batch["input_elevation"])
         d_a = torch.deg2rad(batch["target_azimuth"]) - torch.deg2rad(batch["input_azimuth"])

@@ -346,11 +346,19 @@ def fuse_views(W, feats, p="spatial_volume.smpl_feature_extractor."):
     return y.reshape(B, N, -1, Nv).mean(1).permute(0, 2, 1)
 
 
-def _bn_relu(W, p, x, train=False):
-    """BatchNorm1d(eps 1e-3) over the active rows + ReLU.  eval: running statistics; train (the module is in train mode
-    during training_step): statistics of this sample's active rows, biased variance (running buffers are not updated here)."""
+def _bn_relu(W, p, x, train=False, bn_update=None):
+    """BatchNorm1d(eps 1e-3, momentum 0.01: network.py:105) over the active rows + ReLU.  eval: running statistics; train (the
+    module is in train mode during training_step): statistics of this sample's active rows, biased variance.  bn_update (a
+    dict, optional): receives the running buffers as nn.BatchNorm1d leaves them after this call -- running = 0.99 running +
+    0.01 batch statistic, the variance as the unbiased estimate -- chained over calls (a later call starts from the dict)."""
     if train:
         mean, var = x.mean(0), x.var(0, unbiased=False)
+        if bn_update is not None:
+            n = x.shape[0]
+            rm = bn_update.get(p + ".running_mean", W[p + ".running_mean"])
+            rv = bn_update.get(p + ".running_var", W[p + ".running_var"])
+            bn_update[p + ".running_mean"] = 0.99 * rm + 0.01 * mean
+            bn_update[p + ".running_var"] = 0.99 * rv + 0.01 * var * (n / max(n - 1, 1))
     else:
         mean, var = W[p + ".running_mean"], W[p + ".running_var"]
     y = (x - mean) / torch.sqrt(var + 1e-3) * W[p + ".weight"] + W[p + ".bias"]
@@ -404,7 +412,7 @@ def _strided_conv(feats, coords, shape, weight):
     return out, ocoords, oshape
 
 
-def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", train=False):
+def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", train=False, bn_update=None):
     """SparseConvNet.forward network.py:85-96 (double_conv :109, stride_conv :152, triple_conv :127),
     eval-mode BatchNorm1d(eps 1e-3).  feats [Nv,16], coords [Nv,3] (z,y,x) int; returns the
     dense [1,64,D/4,H/4,W/4] volume.  PARITY UNPINNED (spconv absent) -- see module header.
@@ -430,7 +438,7 @@ def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", trai
                 x, coords, shape = _strided_conv(x, coords, shape, w)
             else:
                 x = _subm_conv(x, coords, shape, w)
-            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x, train)
+            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x, train, bn_update)
     dense = torch.zeros([x.shape[1]] + shape)
     dense[:, coords[:, 0], coords[:, 1], coords[:, 2]] = x.t()
     return dense[None]
@@ -448,14 +456,14 @@ def latent_volume(vcfg, feature_volume, bounds_min_xyz, out_sh):
     return sample_zeros_align(feature_volume, g[None]).reshape(1, -1, V, V, V)
 
 
-def construct_spatial_volume(W, vcfg, x_noisy, t_embed, v_embed, batch, train=False):
+def construct_spatial_volume(W, vcfg, x_noisy, t_embed, v_embed, batch, train=False, bn_update=None):
     """SpatialVolumeNet.construct_spatial_volume, morphable_diffusion.py:182-263 (use_spatial_volume False).
     train: the sparse CNN's BatchNorm layers use batch statistics (module in train mode)."""
     B = x_noisy.shape[0]
     fused = fuse_views(W, vertex_features(W, vcfg, x_noisy, t_embed, v_embed, batch))  # B,Nv,16
     vols = []
     for bi in range(B):
-        fv = sparse_conv_net(W, fused[bi], batch["coord"][bi], batch["out_sh"][bi], train=train)
+        fv = sparse_conv_net(W, fused[bi], batch["coord"][bi], batch["out_sh"][bi], train=train, bn_update=bn_update)
         vols.append(latent_volume(vcfg, fv, batch["bounds"][bi, 0], batch["out_sh"][bi])[0])
     return torch.stack(vols)
 

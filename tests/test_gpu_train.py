@@ -440,3 +440,61 @@ def test_training_step_conditioner_gradients_vs_reference():
     print(f"[parity] conditioner gradients in the full step: {len(rows)} tensors, worst {rows[0][0]:.2e}, median {rows[len(rows) // 2][0]:.2e}")
     assert rows[0][0] <= 6e-2, rows[0]
     m.engine.close()
+
+
+def test_checkpoint_export_tracks_batchnorm_and_reloads_bit_identically():
+    """What a fine-tuning run saves: ``state_dict()`` of a training-mode model = the loaded checkpoint with the masters and the
+    sparse CNN's BatchNorm running statistics as training left them (nn.BatchNorm1d(momentum=0.01), network.py:105: one update
+    per sample and train-mode forward).  Checked: untouched before training; running statistics after one training step against
+    the oracle's chained update; loading the export into a fresh inference model reproduces the trained model's eval forward
+    bit for bit."""
+    from morphablediffusion_amd.model import SyncMultiviewDiffusion
+    from oracle import mvd_oracle as O
+    g, dev, prepared, draws = _inputs()
+    N = int(g["N"])
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    W = gi.full_weights(ucfg, vcfg)
+    m = make_train_model(ucfg, vcfg, N, loss_scale=65536.0, recompute=True)
+    sd0 = m.state_dict()
+    assert list(sd0) == list(W) and all(torch.equal(sd0[k].cpu().float(), W[k].float()) for k in W)
+    m.learning_rate = 5e-5
+    (opt,), _ = m.configure_optimizers()
+    opt.zero_grad()
+    m.training_step(dev, prepared=prepared, **draws)
+    opt.step()
+    sd1 = m.state_dict()
+    assert list(sd1) == list(W) and all(sd1[k].shape == W[k].shape and sd1[k].dtype == W[k].dtype for k in W)
+    changed = [k for k in W if not torch.equal(sd1[k].cpu(), W[k])]
+    assert any(k.startswith(P) for k in changed) and any(k.startswith("spatial_volume.") and k.endswith(".weight") for k in changed)
+    # running statistics: the oracle's train-mode forward on the same noisy latents, B samples in sequence
+    x0, ts, noise = prepared[0].cpu(), draws["time_steps"], draws["noise"]
+    x_noisy = m.add_noise(x0.cuda(), ts.cuda(), noise.cuda())[0].cpu()
+    batch = {k: v.cpu() for k, v in dev.items()}
+    upd = {}
+    O.construct_spatial_volume(W, vcfg, x_noisy, m.embed_time(ts.cuda()).cpu(), m.get_viewpoint_embedding(batch), batch, train=True,
+                               bn_update=upd)
+    assert len(upd) == 18  # nine BatchNorm layers
+    worst = 0.0
+    for k, want in upd.items():
+        got = sd1[k].cpu()
+        assert not torch.equal(got, W[k])
+        step = (want - W[k]).abs().max().item()  # the size of the update itself: the error is measured against it
+        worst = max(worst, (got - want).abs().max().item() / step)
+    print(f"[parity] BatchNorm running statistics after one training step ({x_noisy.shape[0]} samples): worst error / update = {worst:.2e}")
+    assert worst <= 2e-3
+    assert int(m.engine.lib.mvd_train_bn_calls(m.engine._ctx)) == x_noisy.shape[0]
+    # a fresh inference model loaded from the export == the trained model in eval mode (re-packed in place), bit for bit
+    m.eval()
+    v_embed, t_embed = m.get_viewpoint_embedding(dev), m.embed_time(ts.cuda())
+    sv_a = m.spatial_volume.construct_spatial_volume(x_noisy.cuda(), t_embed, v_embed, dev)
+    x, t, ctx, sdict = gi.unet_inputs(ucfg, Bv=2)
+    sdc = {k: v.cuda() for k, v in sdict.items()}
+    out_a = m.engine.unet_forward(x.cuda(), t.cuda(), ctx.cuda(), sdc)
+    m2 = make_train_model(ucfg, vcfg, N, train_mode=False)
+    m2.load_state_dict({k: v.cpu() for k, v in sd1.items()})
+    m2.eval()
+    sv_b = m2.spatial_volume.construct_spatial_volume(x_noisy.cuda(), t_embed, v_embed, dev)
+    out_b = m2.engine.unet_forward(x.cuda(), t.cuda(), ctx.cuda(), sdc)
+    assert torch.equal(sv_a, sv_b) and torch.equal(out_a, out_b)
+    m.engine.close()
+    m2.engine.close()
