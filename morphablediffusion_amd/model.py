@@ -553,6 +553,25 @@ class SyncMultiviewDiffusion(nn.Module):
             save_image_grid(x_sample, batch_, str(out / f"{self.global_step}.jpg"))
             return x_sample
 
+    def log_image(self, x_sample, batch, step, output_dir):
+        """morphable_diffusion.py:589-599: one row per sample -- the input view followed by the N generated views -- as
+        <output_dir>/<step>.jpg."""
+        from pathlib import Path
+        from .batch import save_image_grid
+        save_image_grid(x_sample, batch, str(Path(output_dir) / f"{step}.jpg"))
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx):
+        """morphable_diffusion.py:619-625: sample the batch, write <outdir>/<batch_idx>.jpg (``outdir`` is set by the caller, as
+        the reference's trainer script does)."""
+        from pathlib import Path
+        self.eval()
+        x_sample = self.sample(self.sampler, batch, self.cfg_scale, self.batch_view_num)
+        out = Path(getattr(self, "outdir", "."))
+        out.mkdir(exist_ok=True, parents=True)
+        self.log_image(x_sample, batch, batch_idx, output_dir=out)
+        return x_sample
+
     def get_target_view_feats(self, x_input, spatial_volume, clip_embed, t_embed, v_embed, target_index, batch):
         B, _, H, W = x_input.shape
         TN = target_index.shape[1]

@@ -142,6 +142,19 @@ def test_checkpoint_file_yaml_and_eval_style_batch(tmp_path):
     assert imgs.shape == (2, N, 3, 256, 256) and torch.isfinite(imgs).all()
     strip = BT.views_to_uint8(imgs, data["input_image"])
     assert strip.shape == (2 * 256, (N + 1) * 256, 3) and strip.dtype == np.uint8
+    # the LightningModule's own callers of the same path (morphable_diffusion.py:589-625): test_step / validation_step write the
+    # grid the trainer script looks at
+    from PIL import Image
+    model.sampler, model.outdir, model.image_dir = sampler, str(tmp_path / "test_out"), str(tmp_path)
+    model.cfg_scale, model.batch_view_num, model.output_num = 2.0, 4, 1
+    torch.manual_seed(6033)
+    got = model.test_step(data, 7)
+    assert torch.equal(got, imgs)  # same seed, same path
+    im = np.asarray(Image.open(tmp_path / "test_out" / "7.jpg"))
+    assert im.shape == strip.shape  # the JPEG of the same strip (random-weight images are noise: no pixel comparison after JPEG)
+    model.global_rank, model.global_step = 0, 12
+    model.validation_step(data, 0)
+    assert np.asarray(Image.open(tmp_path / "images" / "val" / "12.jpg")).shape == (256, (N + 1) * 256, 3)  # output_num = 1 sample
     model.engine.close()
 
 
