@@ -358,3 +358,22 @@ def test_rulebook_host_build_matches_reference_restatement(force_hash):
     bad = coord.clone()
     bad[3, 2] = out_sh[2]
     assert lib.mvd_rulebook_build(L.ptr(bad), L.ptr(out_sh), bad.shape[0], force_hash, n_sites, lens) != 0
+
+
+def test_bench_reads_roofline_traffic_from_the_pmc_summary(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from the JSON tools/pmc_traffic.py writes out of the rocprofv3 --pmc passes -- for the
+    same workload only, null otherwise; never a constant in the script."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps({"config": "headline", "bytes_per_launch": {"gemm_dma_kernel<128,0>": 1.25e8}}))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
+    assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "headline") == 1.25e8
+    assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "n8") is None      # a summary of another workload
+    assert bench.pmc_traffic("attn_kernel", "headline") is None           # family not in the summary
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "headline") is None
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert committed["config"] == "headline" and "FETCH_SIZE" in committed["source"]
