@@ -220,6 +220,14 @@ int mvd_train_unet_step(mvd_ctx* ctx, const float* x, const int64_t* timesteps, 
 int mvd_train_conditioner_backward(mvd_ctx* ctx, const float* x_noisy, int64_t timestep, const float* v_embed, int n_views,
                                    int target_index, const float* dsrc0, const float* dsrc1, const float* dsrc2, const float* dsrc3,
                                    float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream);
+/* The same for the B samples whose tables sit in slots[0..B) (distinct; uploaded by mvd_set_samples_async): the per-sample
+ * stages run sample by sample, FrustumTV3DNet -- shared weights, same-shaped volumes -- runs once with the samples as its batch.
+ * x_noisy [B,N,4,s,s], v_embed [B,N,view_dim], dsrc{l} [B,C_l,D_l,s_l,s_l] device pointers; timesteps [B] / target_index [B] HOST
+ * arrays; dbg_* only with B = 1.  The active slot is unchanged on return. */
+int mvd_train_conditioner_backward_batch(mvd_ctx* ctx, int B, const int* slots, const float* x_noisy, const int64_t* timesteps,
+                                         const float* v_embed, int n_views, const int* target_index, const float* dsrc0,
+                                         const float* dsrc1, const float* dsrc2, const float* dsrc3, float* dbg_dvolume,
+                                         float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream);
 /* Parity hook: the backward pass of ONE DepthTransformer (attention.py:49-84; cond_index 0 = middle_conditions, 1 + k =
  * output_conditions.k) given its input x [B,dim,H,W], its context volume [B,C_l,D_l,H,W] and dL/d(output) [B,dim,H,W]:
  * dx, dcontext (may be NULL) are written, parameter gradients accumulated into the arena.  depth0 = D of the finest level. */

@@ -523,28 +523,41 @@ int mvd_train_cond_backward(mvd_ctx* c, int cond_index, const float* x, const fl
   return 0;
 }
 
-int mvd_train_conditioner_backward(mvd_ctx* c, const float* x_noisy, int64_t timestep, const float* v_embed, int n_views,
-                                   int target_index, const float* dsrc0, const float* dsrc1, const float* dsrc2, const float* dsrc3,
-                                   float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream) {
+int mvd_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots, const float* x_noisy, const int64_t* timesteps,
+                                         const float* v_embed, int n_views, const int* target_index, const float* dsrc0,
+                                         const float* dsrc1, const float* dsrc2, const float* dsrc3, float* dbg_dvolume,
+                                         float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized || !c->train_mode) return mvd_fail("mvd_train_conditioner_backward: context not finalized in training mode");
-  if (!x_noisy || !v_embed || !dsrc0 || !dsrc1 || !dsrc2 || !dsrc3) return mvd_fail("mvd_train_conditioner_backward: null argument");
+  if (B < 1 || !slots || !x_noisy || !timesteps || !v_embed || !target_index || !dsrc0 || !dsrc1 || !dsrc2 || !dsrc3)
+    return mvd_fail("mvd_train_conditioner_backward: null argument");
+  for (int i = 0; i < B; ++i)
+    if (slots[i] < 0 || slots[i] >= 64) return mvd_fail("mvd_train_conditioner_backward: slot out of range (0..63)");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
   const float* srcs[4] = {dsrc0, dsrc1, dsrc2, dsrc3};
   float* dcl[4];
   int D = c->v.frustum_volume_depth, Sz = c->v.input_image_size / 8;
-  for (int l = 0; l < 4; ++l) {
+  for (int l = 0; l < 4; ++l) {  // NCDHW (the reference's layout) -> channels-last, all samples
     const int C = c->v.frustum_dims[l];
-    const size_t n = (size_t)D * Sz * Sz * C;
+    const size_t n = (size_t)B * D * Sz * Sz * C;
     dcl[l] = ws_alloc<float>(c, n);
     WS_CHECK(dcl[l]);
-    RET_IF(launch_nchw_to_nhwc(srcs[l], 1, C, D * Sz * Sz, dcl[l], C, C, s));
+    RET_IF(launch_nchw_to_nhwc(srcs[l], B, C, D * Sz * Sz, dcl[l], C, C, s));
     D = (D - 1) / 2 + 1;
     Sz = (Sz - 1) / 2 + 1;
   }
-  return engine_train_conditioner_backward(c, x_noisy, timestep, v_embed, n_views, target_index, dcl, dbg_dvolume, dbg_dfused,
-                                           dbg_dfeats, dbg_dtembed, s);
+  return engine_train_conditioner_backward_batch(c, B, slots, x_noisy, timesteps, v_embed, n_views, target_index, dcl, dbg_dvolume,
+                                                 dbg_dfused, dbg_dfeats, dbg_dtembed, s);
+}
+
+int mvd_train_conditioner_backward(mvd_ctx* c, const float* x_noisy, int64_t timestep, const float* v_embed, int n_views,
+                                   int target_index, const float* dsrc0, const float* dsrc1, const float* dsrc2, const float* dsrc3,
+                                   float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, void* stream) {
+  if (!c) return mvd_fail("mvd_train_conditioner_backward: null argument");
+  const int slot = c->cur_slot;
+  return mvd_train_conditioner_backward_batch(c, 1, &slot, x_noisy, &timestep, v_embed, n_views, &target_index, dsrc0, dsrc1, dsrc2, dsrc3,
+                                              dbg_dvolume, dbg_dfused, dbg_dfeats, dbg_dtembed, stream);
 }
 
 int mvd_train_get_grad(mvd_ctx* c, const char* name, float* out, size_t numel, void* stream) {

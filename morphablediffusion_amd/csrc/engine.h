@@ -411,6 +411,9 @@ int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes);         // owned allocat
 int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int64_t timestep, const float* v_embed, int n_views,
                                       int target_idx, float* const dsrc[4], float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats,
                                       float* dbg_dtembed, hipStream_t s);
+int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots, const float* x_noisy_all, const int64_t* timesteps,
+                                            const float* v_embed_all, int n_views, const int* target_idx, float* const dsrc[4],
+                                            float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, hipStream_t s);
 int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const float* ctx_vol, const float* dout, int B, int H, int W,
                                int level, int depth0, float* dx, float* dctx, hipStream_t s);
 int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,

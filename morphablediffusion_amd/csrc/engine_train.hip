@@ -1045,13 +1045,34 @@ int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int64_t timestep, const float* v_embed, int n_views,
-                                      int target_idx, float* const dsrc[4], float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats,
-                                      float* dbg_dtembed, hipStream_t s) {
+namespace {
+// what the per-sample stages of the conditioner's backward hand to each other (all pointers into the call's workspace scope)
+struct CondSample {
+  float *e0, *u1, *e1;
+  int* vidx;
+  float *x8, *pre_e, *cur_e[4], *r1_e[3], *vf;
+  half_t *a1_e[3], *a2_e[3], *af;
+  const float* sp_in[9];
+  float *sp_raw[9], *sp_post[9], *sp_stats[9];
+  const int* sp_nbr[9];
+  int sp_nout[9], sp_nin[9];
+};
+}  // namespace
+
+int engine_select_sample(mvd_ctx* c, int slot);
+
+// Backward of the conditioner for B samples whose tables sit in slots[0..B): the per-sample stages (2-D encoder, gathers, sparse
+// CNN: different meshes, cameras, BatchNorm statistics) run sample by sample, the frustum network between them -- the same
+// weights on same-shaped volumes -- runs ONCE with the samples as its batch (its 8^3 / 4^3 levels are 96- and 768-row GEMMs per
+// sample).  x_noisy [B][N,4,s,s], v_embed [B][N,vd], dsrc[l] [B][vox_l][C_l] channels-last (accumulated in place).
+int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots, const float* x_noisy_all, const int64_t* timesteps,
+                                            const float* v_embed_all, int n_views, const int* target_idx, float* const dsrc[4],
+                                            float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats, float* dbg_dtembed, hipStream_t s) {
   if (!c->finalized || !c->train_mode) return mvd_fail("conditioner backward: context not finalized in training mode");
   if (!c->has_cond || !c->has_step) return mvd_fail("conditioner backward: spatial_volume / time_embed weights not uploaded");
-  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
-  if (n_views != c->v.num_views || target_idx < 0 || target_idx >= n_views) return mvd_fail("conditioner backward: bad view arguments");
+  if (B < 1 || (B > 1 && (dbg_dvolume || dbg_dfused || dbg_dfeats || dbg_dtembed))) return mvd_fail("conditioner backward: bad batch arguments");
+  for (int bi = 0; bi < B; ++bi)
+    if (n_views != c->v.num_views || target_idx[bi] < 0 || target_idx[bi] >= n_views) return mvd_fail("conditioner backward: bad view arguments");
   for (int l = 0; l < 4; ++l)
     if (!dsrc[l]) return mvd_fail("conditioner backward: dL/d(frustum volume) of every level is required");
   WsScope scope(c);
@@ -1065,21 +1086,66 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     fprintf(stderr, "[cond-bwd host] %-28s %7.3f ms\n", what, t - t_last);
     t_last = t;
   };
-  MeshTables& m = c->mesh;
-  const int N = n_views, S = c->u.image_size, HW = S * S, rows = N * HW, td = c->v.time_dim, vd = c->v.view_dim, Nv = m.Nv;
+  const int N = n_views, S = c->u.image_size, HW = S * S, rows = N * HW, td = c->v.time_dim, vd = c->v.view_dim;
   const int V = c->v.spatial_volume_size, persp = c->v.projection == 0;
   const std::string SV = "spatial_volume.", FV = SV + "frustum_volume_feats.";
   auto F = [&](size_t n) { return ws_alloc<float>(c, n); };
   auto H16 = [&](size_t n) { return ws_alloc<half_t>(c, n); };
+  const int* fd = c->v.frustum_dims;
+  int Dl[4], Sl[4];
+  size_t vox[4];
+  for (int l = 0; l < 4; ++l) {
+    Dl[l] = l ? (Dl[l - 1] - 1) / 2 + 1 : c->v.frustum_volume_depth;
+    Sl[l] = l ? (Sl[l - 1] - 1) / 2 + 1 : c->v.input_image_size / 8;
+    vox[l] = (size_t)Dl[l] * Sl[l] * Sl[l];
+  }
+  const int FT = c->film_total;
+  const int back_slot = c->cur_slot;
+  // extended-precision packs of the 2-D encoder's convs, once per call
+  auto xp_pack = [&](const ConvW& w, int cin_src, ConvW* o) -> int {
+    const float* mw = engine_master(c, w.key);
+    if (!mw) return mvd_fail("conditioner backward: encoder master weights missing");
+    *o = w;
+    const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
+    o->xp = 1;
+    o->cin_l = Cl;
+    o->Cin = 3 * Cl;
+    o->wT = nullptr;
+    o->w = H16((size_t)w.taps * w.N * 3 * Cl);
+    WS_CHECK(o->w);
+    return launch_pack_weight(mw, w.N, 3 * Cl, w.taps, 0, 0, o->w, s, cin_src, 1);
+  };
+  ConvW x_init, x_c1[3], x_c2[3], x_final;
+  RET_IF(xp_pack(c->enc_init, 4, &x_init));
+  for (int i = 0; i < 3; ++i) {
+    RET_IF(xp_pack(c->enc_blocks[i].c1, 16, &x_c1[i]));
+    RET_IF(xp_pack(c->enc_blocks[i].c2, 16, &x_c2[i]));
+  }
+  RET_IF(xp_pack(c->enc_final, 16, &x_final));
+  // what crosses the stages, for all samples
+  float *t_emb_all = F((size_t)B * td), *d_temb_all = F((size_t)B * td), *vt_all = F((size_t)B * vd), *pre_f_all = F((size_t)B * FT);
+  half_t* gath_all = H16((size_t)B * vox[0] * 64);
+  float* d_gath_all = F((size_t)B * vox[0] * 64);
+  WS_CHECK(t_emb_all && d_temb_all && vt_all && pre_f_all && gath_all && d_gath_all);
+  HIP_CHECK_RET(hipMemsetAsync(d_temb_all, 0, (size_t)B * td * sizeof(float), s));
+  std::vector<CondSample> st(B);
+
+  // ---------------- stage 1, per sample: forward up to the gathered frustum features ----------------
+  auto stage1 = [&](int bi) -> int {
+  if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
+  MeshTables& m = c->mesh;
+  const int Nv = m.Nv;
+  const float* x_noisy = x_noisy_all + (size_t)bi * N * 4 * HW;
+  const float* v_embed = v_embed_all + (size_t)bi * N * vd;
   // ================= forward, every intermediate kept =================
   // step embedding (morphable_diffusion.py:491-494): t_emb = W2 silu(W0 temb(t) + b0) + b2
   int64_t* t_dev = (int64_t*)c->ws.alloc(sizeof(int64_t));
-  float *e0 = F(td), *u1 = F(td), *e1 = F(td), *t_emb = F(td);
+  float *e0 = F(td), *u1 = F(td), *e1 = F(td), *t_emb = t_emb_all + (size_t)bi * td;
   int* vidx = (int*)c->ws.alloc(sizeof(int) * (N + 1));
   WS_CHECK(t_dev && e0 && u1 && e1 && t_emb && vidx);
-  hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, t_dev, timestep);
+  hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, t_dev, timesteps[bi]);
   hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx, N, 0);
-  hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx + N, 1, target_idx);
+  hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx + N, 1, target_idx[bi]);
   HIP_CHECK_RET(hipGetLastError());
   RET_IF(launch_timestep_embedding(t_dev, 1, td, e0, s));
   RET_IF(launch_small_linear(e0, td, 1, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, u1, td, 0, s));
@@ -1101,29 +1167,9 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     WS_CHECK(r1_e[i] && a1_e[i] && a2_e[i]);
   }
   WS_CHECK(x8 && pre_e && feats && af && x8s && cur_e[0] && cur_e[1] && cur_e[2] && cur_e[3]);
-  auto xp_pack = [&](const ConvW& w, int cin_src, ConvW* o) -> int {
-    const float* mw = engine_master(c, w.key);
-    if (!mw) return mvd_fail("conditioner backward: encoder master weights missing");
-    *o = w;
-    const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
-    o->xp = 1;
-    o->cin_l = Cl;
-    o->Cin = 3 * Cl;
-    o->wT = nullptr;
-    o->w = H16((size_t)w.taps * w.N * 3 * Cl);
-    WS_CHECK(o->w);
-    return launch_pack_weight(mw, w.N, 3 * Cl, w.taps, 0, 0, o->w, s, cin_src, 1);
-  };
-  ConvW x_init, x_c1[3], x_c2[3], x_final;
-  RET_IF(xp_pack(c->enc_init, 4, &x_init));
-  for (int i = 0; i < 3; ++i) {
-    RET_IF(xp_pack(c->enc_blocks[i].c1, 16, &x_c1[i]));
-    RET_IF(xp_pack(c->enc_blocks[i].c2, 16, &x_c2[i]));
-  }
-  RET_IF(xp_pack(c->enc_final, 16, &x_final));
   RET_IF(launch_small_linear(t_emb, td, -N, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre_e, 48, 0, s));
   RET_IF(launch_small_linear(v_embed, vd, N, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre_e, 48, 1, s));
-  RET_IF(launch_nchw_to_nhwc(x_noisy_nchw, N, 4, HW, x8, 8, 8, s));
+  RET_IF(launch_nchw_to_nhwc(x_noisy, N, 4, HW, x8, 8, 8, s));
   RET_IF(launch_rows_f32_to_f16_split(x8, 8, rows, 8, x8s, s));
   GemmArgs g;
   g.a = x8s; g.lda = 24; g.w = &x_init; g.out = cur_e[0]; g.ldc = 16; g.force_splitk = 1;
@@ -1184,80 +1230,90 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   WS_CHECK(volume);
   RET_IF(launch_latent_gather(sp_post[8], m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
                               c->v.spatial_volume_length, volume, s));
-  // frustum gather + FrustumTV3DNet (network.py:313-347) for the target view
-  const int* fd = c->v.frustum_dims;
-  int Dl[4], Sl[4];
-  size_t vox[4];
-  for (int l = 0; l < 4; ++l) {
-    Dl[l] = l ? (Dl[l - 1] - 1) / 2 + 1 : c->v.frustum_volume_depth;
-    Sl[l] = l ? (Sl[l - 1] - 1) / 2 + 1 : c->v.input_image_size / 8;
-    vox[l] = (size_t)Dl[l] * Sl[l] * Sl[l];
+  RET_IF(launch_frustum_gather(volume, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp,
+                               gath_all + (size_t)bi * vox[0] * 64, s));
+  float* pre_row = pre_f_all + (size_t)bi * FT;
+  RET_IF(launch_small_linear(t_emb, td, 1, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre_row, FT, 0, s));
+  RET_IF(launch_small_linear(v_embed + (size_t)target_idx[bi] * vd, vd, 1, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre_row, FT, 1, s));
+  HIP_CHECK_RET(hipMemcpyAsync(vt_all + (size_t)bi * vd, v_embed + (size_t)target_idx[bi] * vd, vd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  CondSample& P = st[bi];
+  P.e0 = e0, P.u1 = u1, P.e1 = e1, P.vidx = vidx, P.x8 = x8, P.pre_e = pre_e, P.af = af, P.vf = vf;
+  for (int i = 0; i < 4; ++i) P.cur_e[i] = cur_e[i];
+  for (int i = 0; i < 3; ++i) P.r1_e[i] = r1_e[i], P.a1_e[i] = a1_e[i], P.a2_e[i] = a2_e[i];
+  for (int i = 0; i < 9; ++i)
+    P.sp_in[i] = sp_in[i], P.sp_raw[i] = sp_raw[i], P.sp_post[i] = sp_post[i], P.sp_stats[i] = sp_stats[i], P.sp_nbr[i] = sp_nbr[i],
+    P.sp_nout[i] = sp_nout[i], P.sp_nin[i] = sp_nin[i];
+  return 0;
+  };
+  for (int bi = 0; bi < B; ++bi) {
+    RET_IF(engine_select_sample(c, slots[bi]));
+    RET_IF(stage1(bi));
   }
-  const int FT = c->film_total;
-  half_t* gath = H16(vox[0] * 64);
-  float* pre_f = F(FT);
+
+  // ---------------- stage 2: FrustumTV3DNet forward + backward, the samples as its batch (chunks of at most 16: 32-bit operand
+  // offsets of the level-0 weight-gradient GEMM) ----------------
+  for (int b0 = 0; b0 < B; b0 += 16) {
+  const size_t Bc = (size_t)std::min(16, B - b0);
+  WsScope chunk_scope(c, WS_BLOCK);
+  half_t* gath = gath_all + (size_t)b0 * vox[0] * 64;
+  float* pre_f = pre_f_all + (size_t)b0 * FT;
+  GemmArgs g;
   float *xd[4], *xf[4], *tmp_f[3];
   half_t *a1_f[3], *a2_f[3], *au_f[3];
   for (int l = 0; l < 4; ++l) {
-    xd[l] = F(vox[l] * fd[l]);
-    xf[l] = F(vox[l] * fd[l]);
+    xd[l] = F(Bc * vox[l] * fd[l]);
+    xf[l] = F(Bc * vox[l] * fd[l]);
     WS_CHECK(xd[l] && xf[l]);
   }
   for (int l = 0; l < 3; ++l) {
-    tmp_f[l] = F(vox[l + 1] * fd[l + 1]);
-    a1_f[l] = H16(vox[l] * fd[l]);
-    a2_f[l] = H16(vox[l + 1] * fd[l + 1]);
-    au_f[l] = H16(vox[l + 1] * fd[l + 1]);
+    tmp_f[l] = F(Bc * vox[l + 1] * fd[l + 1]);
+    a1_f[l] = H16(Bc * vox[l] * fd[l]);
+    a2_f[l] = H16(Bc * vox[l + 1] * fd[l + 1]);
+    au_f[l] = H16(Bc * vox[l + 1] * fd[l + 1]);
     WS_CHECK(tmp_f[l] && a1_f[l] && a2_f[l] && au_f[l]);
   }
-  WS_CHECK(gath && pre_f);
-  RET_IF(launch_frustum_gather(volume, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp, gath, s));
   g = GemmArgs();
   g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = xd[0]; g.ldc = fd[0];
-  RET_IF(run_conv3d(c, g, 1, Dl[0], Sl[0], Sl[0], 1, s));
-  RET_IF(launch_small_linear(t_emb, td, 1, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre_f, FT, 0, s));
-  RET_IF(launch_small_linear(v_embed + (size_t)target_idx * vd, vd, 1, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre_f, FT, 1, s));
+  RET_IF(run_conv3d(c, g, (int)Bc, Dl[0], Sl[0], Sl[0], 1, s));
   for (int l = 0; l < 3; ++l) {
     const FrustumBlockW& b1 = c->fr_blocks[2 * l];
     const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
-    RET_IF(run_group_norm(c, xd[l], fd[l], 1, (int)vox[l], b1.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l], a1_f[l], fd[l], s, FT));
+    RET_IF(run_group_norm(c, xd[l], fd[l], (int)Bc, (int)vox[l], b1.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l], a1_f[l], fd[l], s, FT));
     g = GemmArgs();
     g.a = a1_f[l]; g.lda = fd[l]; g.w = &b1.conv; g.out = tmp_f[l]; g.ldc = fd[l + 1];
-    RET_IF(run_conv3d(c, g, 1, Dl[l], Sl[l], Sl[l], 2, s));
-    RET_IF(run_group_norm(c, tmp_f[l], fd[l + 1], 1, (int)vox[l + 1], b2.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l + 1], a2_f[l],
+    RET_IF(run_conv3d(c, g, (int)Bc, Dl[l], Sl[l], Sl[l], 2, s));
+    RET_IF(run_group_norm(c, tmp_f[l], fd[l + 1], (int)Bc, (int)vox[l + 1], b2.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[2 * l + 1], a2_f[l],
                           fd[l + 1], s, FT));
     g = GemmArgs();
     g.a = a2_f[l]; g.lda = fd[l + 1]; g.w = &b2.conv; g.out = xd[l + 1]; g.ldc = fd[l + 1];
-    RET_IF(run_conv3d(c, g, 1, Dl[l + 1], Sl[l + 1], Sl[l + 1], 1, s));
+    RET_IF(run_conv3d(c, g, (int)Bc, Dl[l + 1], Sl[l + 1], Sl[l + 1], 1, s));
   }
-  HIP_CHECK_RET(hipMemcpyAsync(xf[3], xd[3], vox[3] * fd[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_CHECK_RET(hipMemcpyAsync(xf[3], xd[3], Bc * vox[3] * fd[3] * sizeof(float), hipMemcpyDeviceToDevice, s));
   for (int l = 2; l >= 0; --l) {
     const FrustumBlockW& u = c->fr_up[2 - l];
-    RET_IF(run_group_norm(c, xf[l + 1], fd[l + 1], 1, (int)vox[l + 1], u.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[6 + (2 - l)], au_f[l],
+    RET_IF(run_group_norm(c, xf[l + 1], fd[l + 1], (int)Bc, (int)vox[l + 1], u.gn, 8, 1e-5f, ACT_SILU, pre_f + c->film_off[6 + (2 - l)], au_f[l],
                           fd[l + 1], s, FT));
     g = GemmArgs();
     g.a = au_f[l]; g.lda = fd[l + 1]; g.w = &u.conv; g.out = xf[l]; g.ldc = fd[l]; g.resid = xd[l]; g.ldr = fd[l];
-    RET_IF(run_convT3d(c, g, 1, Dl[l + 1], Sl[l + 1], Sl[l + 1], s));
+    RET_IF(run_convT3d(c, g, (int)Bc, Dl[l + 1], Sl[l + 1], Sl[l + 1], s));
   }
-  mark("fwd: volume, frustum net");
-  // ================= backward =================
-  Fwd f{c, s, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  mark("fwd: frustum net");
+  Fwd f{c, s, (int)Bc, (int)Bc, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
   TrainTape tape;
-  Bwd b{c, s, 1, &f, &tape};
-  float* d_pre_f = F(FT);
-  float* d_temb = F(td);
-  WS_CHECK(d_pre_f && d_temb);
-  HIP_CHECK_RET(hipMemsetAsync(d_pre_f, 0, FT * sizeof(float), s));
-  HIP_CHECK_RET(hipMemsetAsync(d_temb, 0, td * sizeof(float), s));
-  float* gl[4] = {dsrc[0], dsrc[1], dsrc[2], dsrc[3]};  // dL/d x_l, accumulated in place
+  Bwd b{c, s, (int)Bc, &f, &tape};
+  float* d_pre_f = F(Bc * FT);
+  WS_CHECK(d_pre_f);
+  HIP_CHECK_RET(hipMemsetAsync(d_pre_f, 0, Bc * FT * sizeof(float), s));
   half_t* dy16;
+  float* gl[4];
+  for (int l = 0; l < 4; ++l) gl[l] = dsrc[l] + (size_t)b0 * vox[l] * fd[l];  // dL/d x_l, accumulated in place
   // up path (forward order l = 2, 1, 0): x_l = xd_l + convT(silu(GN(xf_{l+1} + film)))
   for (int l = 0; l <= 2; ++l) {
     WsScope sc(c, WS_BLOCK);
     const FrustumBlockW& u = c->fr_up[2 - l];
-    float* d_au = F(vox[l + 1] * fd[l + 1]);
+    float* d_au = F(Bc * vox[l + 1] * fd[l + 1]);
     WS_CHECK(d_au);
-    RET_IF(grad16(c, gl[l], fd[l], (long)vox[l], fd[l], &dy16, s));
+    RET_IF(grad16(c, gl[l], fd[l], (long)(Bc * vox[l]), fd[l], &dy16, s));
     RET_IF(dgrad_conv3d(b, u.conv, 2, dy16, d_au, fd[l + 1], Dl[l], Sl[l], Sl[l], false));
     RET_IF(wgrad_convT3d(b, u.conv, gl[l], fd[l], au_f[l], 0, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1]));
     RET_IF(gn_backward(b, u.gn, 8, 1e-5f, ACT_SILU, xf[l + 1], fd[l + 1], d_au, fd[l + 1], (int)vox[l + 1], gl[l + 1], fd[l + 1], true,
@@ -1269,14 +1325,14 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
     WsScope sc(c, WS_BLOCK);
     const FrustumBlockW& b1 = c->fr_blocks[2 * l];
     const FrustumBlockW& b2 = c->fr_blocks[2 * l + 1];
-    float *d_a2 = F(vox[l + 1] * fd[l + 1]), *d_tmp = F(vox[l + 1] * fd[l + 1]), *d_a1 = F(vox[l] * fd[l]);
+    float *d_a2 = F(Bc * vox[l + 1] * fd[l + 1]), *d_tmp = F(Bc * vox[l + 1] * fd[l + 1]), *d_a1 = F(Bc * vox[l] * fd[l]);
     WS_CHECK(d_a2 && d_tmp && d_a1);
-    RET_IF(grad16(c, gl[l + 1], fd[l + 1], (long)vox[l + 1], fd[l + 1], &dy16, s));
+    RET_IF(grad16(c, gl[l + 1], fd[l + 1], (long)(Bc * vox[l + 1]), fd[l + 1], &dy16, s));
     RET_IF(dgrad_conv3d(b, b2.conv, 0, dy16, d_a2, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1], false));
     RET_IF(wgrad_conv3d(b, b2.conv, gl[l + 1], fd[l + 1], a2_f[l], 0, fd[l + 1], Dl[l + 1], Sl[l + 1], Sl[l + 1], fd[l + 1], 1));
     RET_IF(gn_backward(b, b2.gn, 8, 1e-5f, ACT_SILU, tmp_f[l], fd[l + 1], d_a2, fd[l + 1], (int)vox[l + 1], d_tmp, fd[l + 1], false,
                        pre_f + c->film_off[2 * l + 1], FT, d_pre_f + c->film_off[2 * l + 1], FT));
-    RET_IF(grad16(c, d_tmp, fd[l + 1], (long)vox[l + 1], fd[l + 1], &dy16, s));
+    RET_IF(grad16(c, d_tmp, fd[l + 1], (long)(Bc * vox[l + 1]), fd[l + 1], &dy16, s));
     RET_IF(dgrad_conv3d(b, b1.conv, 1, dy16, d_a1, fd[l], Dl[l + 1], Sl[l + 1], Sl[l + 1], false));
     RET_IF(wgrad_conv3d(b, b1.conv, d_tmp, fd[l + 1], a1_f[l], 0, fd[l], Dl[l], Sl[l], Sl[l], fd[l], 2));
     RET_IF(gn_backward(b, b1.gn, 8, 1e-5f, ACT_SILU, xd[l], fd[l], d_a1, fd[l], (int)vox[l], gl[l], fd[l], true,
@@ -1284,27 +1340,49 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   }
   mark("bwd: frustum down path");
   // conv0 on the gathered frustum features
-  float* d_gath = F(vox[0] * 64);
-  WS_CHECK(d_gath);
-  RET_IF(grad16(c, gl[0], fd[0], (long)vox[0], fd[0], &dy16, s));
+  float* d_gath = d_gath_all + (size_t)b0 * vox[0] * 64;
+  RET_IF(grad16(c, gl[0], fd[0], (long)(Bc * vox[0]), fd[0], &dy16, s));
   RET_IF(dgrad_conv3d(b, c->fr_conv0, 0, dy16, d_gath, 64, Dl[0], Sl[0], Sl[0], false));
   RET_IF(wgrad_conv3d(b, c->fr_conv0, gl[0], fd[0], gath, 0, 64, Dl[0], Sl[0], Sl[0], 64, 1));
   // FiLM projections of the nine frustum blocks: film = t_conv(t_emb) + v_conv(v_embed[target])
   for (int i = 0; i < 9; ++i) {
     const FrustumBlockW& fb = i < 6 ? c->fr_blocks[i] : c->fr_up[i - 6];
     const float* dp = d_pre_f + c->film_off[i];
-    RET_IF(lin_wgrad(c, fb.t_conv.key, dp, FT, t_emb, td, 1, fb.cin, td, s));
-    RET_IF(lin_wgrad(c, fb.v_conv.key, dp, FT, v_embed + (size_t)target_idx * vd, vd, 1, fb.cin, vd, s));
+    RET_IF(lin_wgrad(c, fb.t_conv.key, dp, FT, t_emb_all + (size_t)b0 * td, td, (int)Bc, fb.cin, td, s));
+    RET_IF(lin_wgrad(c, fb.v_conv.key, dp, FT, vt_all + (size_t)b0 * vd, vd, (int)Bc, fb.cin, vd, s));
   }
-  RET_IF(cbwd_small_linear_bwd(d_pre_f, FT, 1, FT, c->film_t.w, td, d_temb, td, 1, s));
-  mark("bwd: conv0 + FiLM");
+  RET_IF(cbwd_small_linear_bwd(d_pre_f, FT, (int)Bc, FT, c->film_t.w, td, d_temb_all + (size_t)b0 * td, td, 1, s));
+  mark("bwd: frustum net, conv0 + FiLM");
+  }
+
+  // ---------------- stage 3, per sample: scatters, sparse CNN, view fusion, 2-D encoder, step MLP ----------------
+  auto stage3 = [&](int bi) -> int {
+  WsScope sample_scope(c, WS_BLOCK);
+  MeshTables& m = c->mesh;
+  const int Nv = m.Nv;
+  const float* v_embed = v_embed_all + (size_t)bi * N * vd;
+  CondSample& P = st[bi];
+  float *e0 = P.e0, *u1 = P.u1, *e1 = P.e1, *t_emb = t_emb_all + (size_t)bi * td, *d_temb = d_temb_all + (size_t)bi * td;
+  int* vidx = P.vidx;
+  float *x8 = P.x8, *pre_e = P.pre_e, *vf = P.vf;
+  float** cur_e = P.cur_e;
+  float** r1_e = P.r1_e;
+  half_t **a1_e = P.a1_e, **a2_e = P.a2_e, *af = P.af;
+  const float** sp_in = P.sp_in;
+  float **sp_raw = P.sp_raw, **sp_stats = P.sp_stats;
+  const int** sp_nbr = P.sp_nbr;
+  int *sp_nout = P.sp_nout, *sp_nin = P.sp_nin;
+  Fwd f{c, s, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  TrainTape tape;
+  Bwd b{c, s, 1, &f, &tape};
+  half_t* dy16;
   // frustum gather, latent-code gather: scatter adjoints
   float* d_vol = F((size_t)V * V * V * 64);
   float* d_cur = F((size_t)sp_nout[8] * 64);
   WS_CHECK(d_vol && d_cur);
   HIP_CHECK_RET(hipMemsetAsync(d_vol, 0, (size_t)V * V * V * 64 * sizeof(float), s));
   HIP_CHECK_RET(hipMemsetAsync(d_cur, 0, (size_t)sp_nout[8] * 64 * sizeof(float), s));
-  RET_IF(cbwd_frustum_scatter(d_gath, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp, d_vol, s));
+  RET_IF(cbwd_frustum_scatter(d_gath_all + (size_t)bi * vox[0] * 64, c->cams, vidx + N, 1, Dl[0], Sl[0], V, c->v.spatial_volume_length, persp, d_vol, s));
   if (dbg_dvolume) RET_IF(launch_nhwc_to_nchw(d_vol, 64, 1, 64, V * V * V, dbg_dvolume, s));
   RET_IF(cbwd_latent_scatter(d_vol, m.grid2, m.shape[2][0], m.shape[2][1], m.shape[2][2], m.min_xyz, m.out_sh, c->v.voxel_size, V,
                              c->v.spatial_volume_length, d_cur, s));
@@ -1391,4 +1469,19 @@ int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int
   RET_IF(bwd_silu_inplace(d_e1, u1, td, s));
   RET_IF(lin_wgrad(c, c->step_te0.key, d_e1, td, e0, td, 1, td, td, s));
   return 0;
+  };
+  for (int bi = 0; bi < B; ++bi) {
+    RET_IF(engine_select_sample(c, slots[bi]));
+    RET_IF(stage3(bi));
+  }
+  return engine_select_sample(c, back_slot);
+}
+
+// one sample: the active slot (parity hook with the debug outputs; dsrc as above with B = 1)
+int engine_train_conditioner_backward(mvd_ctx* c, const float* x_noisy_nchw, int64_t timestep, const float* v_embed, int n_views,
+                                      int target_idx, float* const dsrc[4], float* dbg_dvolume, float* dbg_dfused, float* dbg_dfeats,
+                                      float* dbg_dtembed, hipStream_t s) {
+  const int slot = c->cur_slot;
+  return engine_train_conditioner_backward_batch(c, 1, &slot, x_noisy_nchw, &timestep, v_embed, n_views, &target_idx, dsrc, dbg_dvolume,
+                                                 dbg_dfused, dbg_dfeats, dbg_dtembed, s);
 }

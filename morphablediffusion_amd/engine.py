@@ -380,6 +380,21 @@ class Engine:
                                                         L.ptr(dbg[0]), L.ptr(dbg[1]), L.ptr(dbg[2]), L.ptr(dbg[3]), _stream()))
         return dbg if debug else None
 
+    def train_conditioner_backward_batch(self, slots, x_noisy, timesteps, v_embed, target_index, dsrc):
+        """mvd_train_conditioner_backward_batch: the conditioner's backward for the samples resident in ``slots`` -- x_noisy
+        [B,N,4,s,s], timesteps / target_index host ints [B], v_embed [B,N,4], dsrc {res: [B,C,D,res,res]} (loss-scaled).  The frustum
+        network runs once with the samples as its batch; everything mesh-specific per sample."""
+        dev = self.device
+        x, ve = _f32(x_noisy, dev), _f32(v_embed, dev)
+        B = x.shape[0]
+        s = self.vcfg.input_image_size // 8
+        ds = [_f32(dsrc[s >> lvl], dev) for lvl in range(4)]
+        assert len(slots) == B == len(timesteps) == len(target_index) and all(d.shape[0] == B for d in ds)
+        L.check(self.lib.mvd_train_conditioner_backward_batch(
+            self._ctx, B, (C.c_int * B)(*[int(v) for v in slots]), L.ptr(x), (C.c_int64 * B)(*[int(v) for v in timesteps]), L.ptr(ve),
+            x.shape[1], (C.c_int * B)(*[int(v) for v in target_index]), L.ptr(ds[0]), L.ptr(ds[1]), L.ptr(ds[2]), L.ptr(ds[3]),
+            None, None, None, None, _stream()))
+
     def get_grad(self, key: str, shape):
         out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
         L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))

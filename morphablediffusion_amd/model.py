@@ -500,10 +500,16 @@ class SyncMultiviewDiffusion(nn.Module):
         if self.train_conditioner:  # spatial_volume.* / time_embed.*: per sample, from dL/d(its frustum volumes)
             hs = [int(v) for v in time_steps.tolist()]
             ti = [int(v) for v in target_index[:, 0].tolist()]
-            for bi in range(B):
-                self.spatial_volume._set_sample(batch, bi)
-                self.engine.train_conditioner_backward(x_noisy[bi], hs[bi], v_embed[bi], ti[bi],
-                                                       {k: v[bi:bi + 1] for k, v in dsrc.items()})
+            from .engine import MAX_SAMPLE_SLOTS
+            if B <= MAX_SAMPLE_SLOTS:  # every sample's tables are resident (slot = sample index): one call, the frustum
+                for bi in range(B):    # network batched over the samples
+                    self.spatial_volume._set_sample(batch, bi)
+                self.engine.train_conditioner_backward_batch(list(range(B)), x_noisy, hs, v_embed, ti, dsrc)
+            else:
+                for bi in range(B):
+                    self.spatial_volume._set_sample(batch, bi)
+                    self.engine.train_conditioner_backward(x_noisy[bi], hs[bi], v_embed[bi], ti[bi],
+                                                           {k: v[bi:bi + 1] for k, v in dsrc.items()})
         return loss
 
     # ---- optimiser surface (morphable_diffusion.py:627-646, train_morphable_diffusion.py:302-321) --------------------

@@ -62,7 +62,12 @@ for it in range(2 if os.environ.get('PROFILE_COND') else 4):
     def cb():
         for bi in range(B):
             m.spatial_volume._set_sample(batch, bi)
-            m.engine.train_conditioner_backward(x_noisy[bi], int(ts[bi]), v_embed[bi], int(ti[bi, 0]), {k: v[bi:bi + 1] for k, v in dsrc.items()})
+        if os.environ.get("PER_SAMPLE"):  # the one-sample entry, sample by sample (the frustum network at batch 1)
+            for bi in range(B):
+                m.spatial_volume._set_sample(batch, bi)
+                m.engine.train_conditioner_backward(x_noisy[bi], int(ts[bi]), v_embed[bi], int(ti[bi, 0]), {k: v[bi:bi + 1] for k, v in dsrc.items()})
+        else:
+            m.engine.train_conditioner_backward_batch(list(range(B)), x_noisy, ts.tolist(), v_embed, ti[:, 0].tolist(), dsrc)
     tick("cond bwd", cb)
     tick("adamw", lambda: m.engine.lib.mvd_train_adamw_step(m.engine._ctx, *[__import__("ctypes").c_float(v) for v in (1e-6, 1e-5, 0.9, 0.999, 1e-8, 0.01)], it + 1, __import__("ctypes").c_float(1.0 / m.loss_scale), 1, None, None))
     tick("repack", m.engine.repack)
