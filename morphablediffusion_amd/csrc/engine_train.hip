@@ -1048,10 +1048,8 @@ int engine_train_cond_backward(mvd_ctx* c, int cond_idx, const float* x, const f
 namespace {
 // what the per-sample stages of the conditioner's backward hand to each other (all pointers into the call's workspace scope)
 struct CondSample {
-  float *e0, *u1, *e1;
   int* vidx;
-  float *x8, *pre_e, *cur_e[4], *r1_e[3], *vf;
-  half_t *a1_e[3], *a2_e[3], *af;
+  float* vf;
   const float* sp_in[9];
   float *sp_raw[9], *sp_post[9], *sp_stats[9];
   const int* sp_nbr[9];
@@ -1126,70 +1124,80 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   float *t_emb_all = F((size_t)B * td), *d_temb_all = F((size_t)B * td), *vt_all = F((size_t)B * vd), *pre_f_all = F((size_t)B * FT);
   half_t* gath_all = H16((size_t)B * vox[0] * 64);
   float* d_gath_all = F((size_t)B * vox[0] * 64);
-  WS_CHECK(t_emb_all && d_temb_all && vt_all && pre_f_all && gath_all && d_gath_all);
+  float *feats_all = F((size_t)B * rows * 16), *d_feats_all = F((size_t)B * rows * 16);
+  WS_CHECK(t_emb_all && d_temb_all && vt_all && pre_f_all && gath_all && d_gath_all && feats_all && d_feats_all);
+  HIP_CHECK_RET(hipMemsetAsync(d_feats_all, 0, (size_t)B * rows * 16 * sizeof(float), s));
   HIP_CHECK_RET(hipMemsetAsync(d_temb_all, 0, (size_t)B * td * sizeof(float), s));
   std::vector<CondSample> st(B);
+
+  // ---------------- stage 0, all samples at once: step embedding MLP and the 2-D encoder (B * N views as its batch) ----------------
+  // step embedding (morphable_diffusion.py:491-494): t_emb = W2 silu(W0 temb(t) + b0) + b2
+  const int BN = B * N;
+  const size_t rows_all = (size_t)BN * HW;
+  int64_t* t_dev = (int64_t*)c->ws.alloc(sizeof(int64_t) * B);
+  float *e0 = F((size_t)B * td), *u1 = F((size_t)B * td), *e1 = F((size_t)B * td);
+  WS_CHECK(t_dev && e0 && u1 && e1);
+  for (int bi = 0; bi < B; ++bi) hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, t_dev + bi, timesteps[bi]);
+  HIP_CHECK_RET(hipGetLastError());
+  RET_IF(launch_timestep_embedding(t_dev, B, td, e0, s));
+  RET_IF(launch_small_linear(e0, td, B, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, u1, td, 0, s));
+  RET_IF(bwd_silu_fwd(u1, e1, (size_t)B * td, s));
+  RET_IF(launch_small_linear(e1, td, B, td, c->step_te2.w, c->step_te2.bias, td, ACT_NONE, t_emb_all, td, 0, s));
+  // 2-D encoder (NoisyTargetViewEncoder, network.py:181-207), layer by layer and in EXTENDED precision (hi/lo operand split on
+  // packs made here from the master weights; 16 channels: the cost is nothing): the sparse CNN behind it has nine BatchNorm +
+  // ReLU layers whose masks are re-derived from these features -- an fp16-rounded encoder moves the gradients upstream of them
+  // by 4-10e-2 (measured), the extended-precision one by 1e-3.  No split-K: a view's features do not depend on the batch.
+  float *x8 = F(rows_all * 8), *pre_e = F((size_t)BN * 48);
+  float* cur_e[4];
+  float* r1_e[3];
+  half_t *a1_e[3], *a2_e[3], *af = H16(rows_all * 48), *x8s = H16(rows_all * 24);
+  for (int i = 0; i < 4; ++i) cur_e[i] = F(rows_all * 16);
+  for (int i = 0; i < 3; ++i) {
+    r1_e[i] = F(rows_all * 16);
+    a1_e[i] = H16(rows_all * 48);
+    a2_e[i] = H16(rows_all * 48);
+    WS_CHECK(r1_e[i] && a1_e[i] && a2_e[i]);
+  }
+  WS_CHECK(x8 && pre_e && af && x8s && cur_e[0] && cur_e[1] && cur_e[2] && cur_e[3]);
+  for (int bi = 0; bi < B; ++bi)  // pre[b, v] = time_embed_i(t_emb[b]) + view_embed_i(v_embed[b, v]), the three blocks side by side
+    RET_IF(launch_small_linear(t_emb_all + (size_t)bi * td, td, -N, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre_e + (size_t)bi * N * 48, 48, 0, s));
+  RET_IF(launch_small_linear(v_embed_all, vd, BN, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre_e, 48, 1, s));
+  RET_IF(launch_nchw_to_nhwc(x_noisy_all, BN, 4, HW, x8, 8, 8, s));
+  RET_IF(launch_rows_f32_to_f16_split(x8, 8, (long)rows_all, 8, x8s, s));
+  {
+    GemmArgs g;
+    g.a = x8s; g.lda = 24; g.w = &x_init; g.out = cur_e[0]; g.ldc = 16; g.force_splitk = 1;
+    RET_IF(run_conv2d(c, g, BN, S, S, 1, 0, s));
+    for (int i = 0; i < 3; ++i) {
+      const EncBlockW& e = c->enc_blocks[i];
+      RET_IF(run_group_norm(c, cur_e[i], 16, BN, HW, e.n1, 8, 1e-5f, ACT_SILU, pre_e + 16 * i, a1_e[i], 48, s, 48, 1));
+      g = GemmArgs();
+      g.a = a1_e[i]; g.lda = 48; g.w = &x_c1[i]; g.out = r1_e[i]; g.ldc = 16; g.force_splitk = 1;
+      RET_IF(run_conv2d(c, g, BN, S, S, 1, 0, s));
+      RET_IF(run_group_norm(c, r1_e[i], 16, BN, HW, e.n2, 8, 1e-5f, ACT_SILU, nullptr, a2_e[i], 48, s, 0, 1));
+      g = GemmArgs();
+      g.a = a2_e[i]; g.lda = 48; g.w = &x_c2[i]; g.out = cur_e[i + 1]; g.ldc = 16; g.resid = cur_e[i]; g.ldr = 16; g.force_splitk = 1;
+      RET_IF(run_conv2d(c, g, BN, S, S, 1, 0, s));
+    }
+    RET_IF(run_group_norm(c, cur_e[3], 16, BN, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, af, 48, s, 0, 1));
+    g = GemmArgs();
+    g.a = af; g.lda = 48; g.w = &x_final; g.out = feats_all; g.ldc = 16; g.force_splitk = 1;
+    RET_IF(run_conv2d(c, g, BN, S, S, 1, 0, s));
+  }
+  mark("fwd: step mlp + 2-D encoder");
 
   // ---------------- stage 1, per sample: forward up to the gathered frustum features ----------------
   auto stage1 = [&](int bi) -> int {
   if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
   MeshTables& m = c->mesh;
   const int Nv = m.Nv;
-  const float* x_noisy = x_noisy_all + (size_t)bi * N * 4 * HW;
   const float* v_embed = v_embed_all + (size_t)bi * N * vd;
-  // ================= forward, every intermediate kept =================
-  // step embedding (morphable_diffusion.py:491-494): t_emb = W2 silu(W0 temb(t) + b0) + b2
-  int64_t* t_dev = (int64_t*)c->ws.alloc(sizeof(int64_t));
-  float *e0 = F(td), *u1 = F(td), *e1 = F(td), *t_emb = t_emb_all + (size_t)bi * td;
   int* vidx = (int*)c->ws.alloc(sizeof(int) * (N + 1));
-  WS_CHECK(t_dev && e0 && u1 && e1 && t_emb && vidx);
-  hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, t_dev, timesteps[bi]);
+  WS_CHECK(vidx);
   hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx, N, 0);
   hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(64), 0, s, vidx + N, 1, target_idx[bi]);
   HIP_CHECK_RET(hipGetLastError());
-  RET_IF(launch_timestep_embedding(t_dev, 1, td, e0, s));
-  RET_IF(launch_small_linear(e0, td, 1, td, c->step_te0.w, c->step_te0.bias, td, ACT_NONE, u1, td, 0, s));
-  RET_IF(bwd_silu_fwd(u1, e1, td, s));
-  RET_IF(launch_small_linear(e1, td, 1, td, c->step_te2.w, c->step_te2.bias, td, ACT_NONE, t_emb, td, 0, s));
-  // 2-D encoder (NoisyTargetViewEncoder, network.py:181-207), layer by layer and in EXTENDED precision (hi/lo operand split on
-  // packs made here from the master weights; 16 channels: the cost is nothing): the sparse CNN behind it has nine BatchNorm +
-  // ReLU layers whose masks are re-derived from these features -- an fp16-rounded encoder moves the gradients upstream of them
-  // by 4-10e-2 (measured), the extended-precision one by 1e-3
-  float *x8 = F((size_t)rows * 8), *pre_e = F((size_t)N * 48), *feats = F((size_t)rows * 16);
-  float* cur_e[4];
-  float* r1_e[3];
-  half_t *a1_e[3], *a2_e[3], *af = H16((size_t)rows * 48), *x8s = H16((size_t)rows * 24);
-  for (int i = 0; i < 4; ++i) cur_e[i] = F((size_t)rows * 16);
-  for (int i = 0; i < 3; ++i) {
-    r1_e[i] = F((size_t)rows * 16);
-    a1_e[i] = H16((size_t)rows * 48);
-    a2_e[i] = H16((size_t)rows * 48);
-    WS_CHECK(r1_e[i] && a1_e[i] && a2_e[i]);
-  }
-  WS_CHECK(x8 && pre_e && feats && af && x8s && cur_e[0] && cur_e[1] && cur_e[2] && cur_e[3]);
-  RET_IF(launch_small_linear(t_emb, td, -N, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre_e, 48, 0, s));
-  RET_IF(launch_small_linear(v_embed, vd, N, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre_e, 48, 1, s));
-  RET_IF(launch_nchw_to_nhwc(x_noisy, N, 4, HW, x8, 8, 8, s));
-  RET_IF(launch_rows_f32_to_f16_split(x8, 8, rows, 8, x8s, s));
-  GemmArgs g;
-  g.a = x8s; g.lda = 24; g.w = &x_init; g.out = cur_e[0]; g.ldc = 16; g.force_splitk = 1;
-  RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
-  for (int i = 0; i < 3; ++i) {
-    const EncBlockW& e = c->enc_blocks[i];
-    RET_IF(run_group_norm(c, cur_e[i], 16, N, HW, e.n1, 8, 1e-5f, ACT_SILU, pre_e + 16 * i, a1_e[i], 48, s, 48, 1));
-    g = GemmArgs();
-    g.a = a1_e[i]; g.lda = 48; g.w = &x_c1[i]; g.out = r1_e[i]; g.ldc = 16; g.force_splitk = 1;
-    RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
-    RET_IF(run_group_norm(c, r1_e[i], 16, N, HW, e.n2, 8, 1e-5f, ACT_SILU, nullptr, a2_e[i], 48, s, 0, 1));
-    g = GemmArgs();
-    g.a = a2_e[i]; g.lda = 48; g.w = &x_c2[i]; g.out = cur_e[i + 1]; g.ldc = 16; g.resid = cur_e[i]; g.ldr = 16; g.force_splitk = 1;
-    RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
-  }
-  RET_IF(run_group_norm(c, cur_e[3], 16, N, HW, c->enc_final_norm, 8, 1e-5f, ACT_SILU, nullptr, af, 48, s, 0, 1));
-  g = GemmArgs();
-  g.a = af; g.lda = 48; g.w = &x_final; g.out = feats; g.ldc = 16; g.force_splitk = 1;
-  RET_IF(run_conv2d(c, g, N, S, S, 1, 0, s));
-  mark("fwd: step mlp + 2-D encoder");
+  const float *t_emb = t_emb_all + (size_t)bi * td, *feats = feats_all + (size_t)bi * rows * 16;
   // vertex features, view fusion
   float *vf = F((size_t)N * Nv * 16), *fused = F((size_t)Nv * 16);
   WS_CHECK(vf && fused);
@@ -1237,9 +1245,7 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   RET_IF(launch_small_linear(v_embed + (size_t)target_idx[bi] * vd, vd, 1, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre_row, FT, 1, s));
   HIP_CHECK_RET(hipMemcpyAsync(vt_all + (size_t)bi * vd, v_embed + (size_t)target_idx[bi] * vd, vd * sizeof(float), hipMemcpyDeviceToDevice, s));
   CondSample& P = st[bi];
-  P.e0 = e0, P.u1 = u1, P.e1 = e1, P.vidx = vidx, P.x8 = x8, P.pre_e = pre_e, P.af = af, P.vf = vf;
-  for (int i = 0; i < 4; ++i) P.cur_e[i] = cur_e[i];
-  for (int i = 0; i < 3; ++i) P.r1_e[i] = r1_e[i], P.a1_e[i] = a1_e[i], P.a2_e[i] = a2_e[i];
+  P.vidx = vidx, P.vf = vf;
   for (int i = 0; i < 9; ++i)
     P.sp_in[i] = sp_in[i], P.sp_raw[i] = sp_raw[i], P.sp_post[i] = sp_post[i], P.sp_stats[i] = sp_stats[i], P.sp_nbr[i] = sp_nbr[i],
     P.sp_nout[i] = sp_nout[i], P.sp_nin[i] = sp_nin[i];
@@ -1360,22 +1366,13 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   WsScope sample_scope(c, WS_BLOCK);
   MeshTables& m = c->mesh;
   const int Nv = m.Nv;
-  const float* v_embed = v_embed_all + (size_t)bi * N * vd;
   CondSample& P = st[bi];
-  float *e0 = P.e0, *u1 = P.u1, *e1 = P.e1, *t_emb = t_emb_all + (size_t)bi * td, *d_temb = d_temb_all + (size_t)bi * td;
   int* vidx = P.vidx;
-  float *x8 = P.x8, *pre_e = P.pre_e, *vf = P.vf;
-  float** cur_e = P.cur_e;
-  float** r1_e = P.r1_e;
-  half_t **a1_e = P.a1_e, **a2_e = P.a2_e, *af = P.af;
+  float* vf = P.vf;
   const float** sp_in = P.sp_in;
   float **sp_raw = P.sp_raw, **sp_stats = P.sp_stats;
   const int** sp_nbr = P.sp_nbr;
   int *sp_nout = P.sp_nout, *sp_nin = P.sp_nin;
-  Fwd f{c, s, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
-  TrainTape tape;
-  Bwd b{c, s, 1, &f, &tape};
-  half_t* dy16;
   // frustum gather, latent-code gather: scatter adjoints
   float* d_vol = F((size_t)V * V * V * 64);
   float* d_cur = F((size_t)sp_nout[8] * 64);
@@ -1417,62 +1414,67 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   float* d_fused = d_cur;  // [Nv][16]
   if (dbg_dfused) HIP_CHECK_RET(hipMemcpyAsync(dbg_dfused, d_fused, (size_t)Nv * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
   // view fusion, vertex gather
-  float *d_vf = F((size_t)N * Nv * 16), *d_feats = F((size_t)rows * 16);
-  WS_CHECK(d_vf && d_feats);
+  float *d_vf = F((size_t)N * Nv * 16), *d_feats = d_feats_all + (size_t)bi * rows * 16;
+  WS_CHECK(d_vf);
   RET_IF(cbwd_fuse(d_fused, vf, c->fuse_w, N, Nv, N, d_vf, engine_grad(c, SV + "smpl_feature_extractor.conv0.weight"),
                    engine_grad(c, SV + "smpl_feature_extractor.conv0.bias"), s));
-  HIP_CHECK_RET(hipMemsetAsync(d_feats, 0, (size_t)rows * 16 * sizeof(float), s));
   RET_IF(cbwd_vertex_scatter(d_vf, c->cams, vidx, N, m.verts, Nv, V, c->v.spatial_volume_length, S, persp, d_feats, s));
   if (dbg_dfeats) RET_IF(launch_nhwc_to_nchw(d_feats, 16, N, 16, HW, dbg_dfeats, s));
   mark("bwd: fuse + vertex scatter");
-  // 2-D encoder, the N views as the batch
-  b.B = N;
-  float *d_a = F((size_t)rows * 16), *d_r = F((size_t)rows * 16), *d_x = F((size_t)rows * 16), *d_nxt = F((size_t)rows * 16);
-  float* d_pre_e = F((size_t)N * 48);
-  WS_CHECK(d_a && d_r && d_x && d_nxt && d_pre_e);
-  RET_IF(grad16(c, d_feats, 16, rows, 16, &dy16, s));
-  RET_IF(dgrad_conv3(b, c->enc_final, dy16, d_a, 16, S, S, false));
-  RET_IF(wgrad_conv3(b, c->enc_final, d_feats, 16, af, 0, 48, S, S, 16, 1, 0));
-  RET_IF(gn_backward(b, c->enc_final_norm, 8, 1e-5f, ACT_SILU, cur_e[3], 16, d_a, 16, HW, d_nxt, 16, false));
-  for (int i = 2; i >= 0; --i) {
-    const EncBlockW& e = c->enc_blocks[i];
-    RET_IF(grad16(c, d_nxt, 16, rows, 16, &dy16, s));
-    RET_IF(dgrad_conv3(b, e.c2, dy16, d_a, 16, S, S, false));
-    RET_IF(wgrad_conv3(b, e.c2, d_nxt, 16, a2_e[i], 0, 48, S, S, 16, 1, 0));
-    RET_IF(gn_backward(b, e.n2, 8, 1e-5f, ACT_SILU, r1_e[i], 16, d_a, 16, HW, d_r, 16, false));
-    RET_IF(grad16(c, d_r, 16, rows, 16, &dy16, s));
-    RET_IF(dgrad_conv3(b, e.c1, dy16, d_a, 16, S, S, false));
-    RET_IF(wgrad_conv3(b, e.c1, d_r, 16, a1_e[i], 0, 48, S, S, 16, 1, 0));
-    RET_IF(gn_backward(b, e.n1, 8, 1e-5f, ACT_SILU, cur_e[i], 16, d_a, 16, HW, d_x, 16, false, pre_e + 16 * i, 48, d_pre_e + 16 * i, 48));
-    RET_IF(bwd_add_views(d_x, 16, d_nxt, 16, nullptr, 0, rows, 16, 1, s));  // + the residual branch
-    std::swap(d_x, d_nxt);
-  }
-  RET_IF(wgrad_conv3(b, c->enc_init, d_nxt, 16, x8, 1, 8, S, S, 4, 1, 0));  // 4 latent channels (the pack pads them to 8)
-  {  // FiLM of the three encoder blocks: pre[v] = time_embed_i(t_emb) + view_embed_i(v_embed[v])
-    float* dsum = F(48);
-    WS_CHECK(dsum);
-    RET_IF(bwd_sum_rows_add(d_pre_e, N, 48, 48, dsum, 0, s));
-    for (int i = 0; i < 3; ++i) {
-      const EncBlockW& e = c->enc_blocks[i];
-      RET_IF(lin_wgrad(c, e.t.key, dsum + 16 * i, 48, t_emb, td, 1, 16, td, s));
-      RET_IF(lin_wgrad(c, e.v.key, d_pre_e + 16 * i, 48, v_embed, vd, N, 16, vd, s));
-    }
-    RET_IF(cbwd_small_linear_bwd(dsum, 48, 1, 48, c->enc_t.w, td, d_temb, td, 1, s));
-  }
-  mark("bwd: 2-D encoder + FiLM");
-  if (dbg_dtembed) HIP_CHECK_RET(hipMemcpyAsync(dbg_dtembed, d_temb, td * sizeof(float), hipMemcpyDeviceToDevice, s));
-  // step MLP
-  RET_IF(lin_wgrad(c, c->step_te2.key, d_temb, td, e1, td, 1, td, td, s));
-  float* d_e1 = F(td);
-  WS_CHECK(d_e1);
-  RET_IF(cbwd_small_linear_bwd(d_temb, td, 1, td, c->step_te2.w, td, d_e1, td, 0, s));
-  RET_IF(bwd_silu_inplace(d_e1, u1, td, s));
-  RET_IF(lin_wgrad(c, c->step_te0.key, d_e1, td, e0, td, 1, td, td, s));
   return 0;
   };
   for (int bi = 0; bi < B; ++bi) {
     RET_IF(engine_select_sample(c, slots[bi]));
     RET_IF(stage3(bi));
+  }
+
+  // ---------------- stage 4, all samples at once: 2-D encoder backward (B * N views as its batch), FiLM projections, step MLP ----------------
+  {
+  Fwd f{c, s, BN, BN, 0, nullptr, nullptr, nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  TrainTape tape;
+  Bwd b{c, s, BN, &f, &tape};
+  half_t* dy16;
+  float *d_a = F(rows_all * 16), *d_r = F(rows_all * 16), *d_x = F(rows_all * 16), *d_nxt = F(rows_all * 16);
+  float* d_pre_e = F((size_t)BN * 48);
+  WS_CHECK(d_a && d_r && d_x && d_nxt && d_pre_e);
+  RET_IF(grad16(c, d_feats_all, 16, (long)rows_all, 16, &dy16, s));
+  RET_IF(dgrad_conv3(b, c->enc_final, dy16, d_a, 16, S, S, false));
+  RET_IF(wgrad_conv3(b, c->enc_final, d_feats_all, 16, af, 0, 48, S, S, 16, 1, 0));
+  RET_IF(gn_backward(b, c->enc_final_norm, 8, 1e-5f, ACT_SILU, cur_e[3], 16, d_a, 16, HW, d_nxt, 16, false));
+  for (int i = 2; i >= 0; --i) {
+    const EncBlockW& e = c->enc_blocks[i];
+    RET_IF(grad16(c, d_nxt, 16, (long)rows_all, 16, &dy16, s));
+    RET_IF(dgrad_conv3(b, e.c2, dy16, d_a, 16, S, S, false));
+    RET_IF(wgrad_conv3(b, e.c2, d_nxt, 16, a2_e[i], 0, 48, S, S, 16, 1, 0));
+    RET_IF(gn_backward(b, e.n2, 8, 1e-5f, ACT_SILU, r1_e[i], 16, d_a, 16, HW, d_r, 16, false));
+    RET_IF(grad16(c, d_r, 16, (long)rows_all, 16, &dy16, s));
+    RET_IF(dgrad_conv3(b, e.c1, dy16, d_a, 16, S, S, false));
+    RET_IF(wgrad_conv3(b, e.c1, d_r, 16, a1_e[i], 0, 48, S, S, 16, 1, 0));
+    RET_IF(gn_backward(b, e.n1, 8, 1e-5f, ACT_SILU, cur_e[i], 16, d_a, 16, HW, d_x, 16, false, pre_e + 16 * i, 48, d_pre_e + 16 * i, 48));
+    RET_IF(bwd_add_views(d_x, 16, d_nxt, 16, nullptr, 0, (long)rows_all, 16, 1, s));  // + the residual branch
+    std::swap(d_x, d_nxt);
+  }
+  RET_IF(wgrad_conv3(b, c->enc_init, d_nxt, 16, x8, 1, 8, S, S, 4, 1, 0));  // 4 latent channels (the pack pads them to 8)
+  {  // FiLM of the three encoder blocks: pre[b, v] = time_embed_i(t_emb[b]) + view_embed_i(v_embed[b, v])
+    float* dsum = F((size_t)B * 48);
+    WS_CHECK(dsum);
+    RET_IF(bwd_colsum_samples(d_pre_e, 1, 48, B, N, 48, dsum, 48, s));  // per sample: its N views
+    for (int i = 0; i < 3; ++i) {
+      const EncBlockW& e = c->enc_blocks[i];
+      RET_IF(lin_wgrad(c, e.t.key, dsum + 16 * i, 48, t_emb_all, td, B, 16, td, s));
+      RET_IF(lin_wgrad(c, e.v.key, d_pre_e + 16 * i, 48, v_embed_all, vd, BN, 16, vd, s));
+    }
+    RET_IF(cbwd_small_linear_bwd(dsum, 48, B, 48, c->enc_t.w, td, d_temb_all, td, 1, s));
+  }
+  mark("bwd: 2-D encoder + FiLM");
+  if (dbg_dtembed) HIP_CHECK_RET(hipMemcpyAsync(dbg_dtembed, d_temb_all, td * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // step MLP
+  RET_IF(lin_wgrad(c, c->step_te2.key, d_temb_all, td, e1, td, B, td, td, s));
+  float* d_e1 = F((size_t)B * td);
+  WS_CHECK(d_e1);
+  RET_IF(cbwd_small_linear_bwd(d_temb_all, td, B, td, c->step_te2.w, td, d_e1, td, 0, s));
+  RET_IF(bwd_silu_inplace(d_e1, u1, (size_t)B * td, s));
+  RET_IF(lin_wgrad(c, c->step_te0.key, d_e1, td, e0, td, B, td, td, s));
   }
   return engine_select_sample(c, back_slot);
 }
