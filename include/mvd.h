@@ -253,6 +253,12 @@ int mvd_set_volume(mvd_ctx* ctx, const float* volume, void* stream);
  * volume held in the context.  out_l: [TN,C_l,D_l,s_l,s_l] fp32 (reference layout), any may be NULL. */
 int mvd_frustum_volumes(mvd_ctx* ctx, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
                         float* out0, float* out1, float* out2, float* out3, void* stream);
+/* The same for ONE target view of each of B samples (the training step, morphable_diffusion.py:496-518 with TN = 1): sample b's
+ * frustum is gathered from volumes[b] [64,V,V,V] with the cameras of slot slots[b], then FrustumTV3DNet runs once with the B
+ * volumes as its batch.  t_embed [B,time_dim], v_rows [B,view_dim] (the target view's embedding), view_idx [B] int32 -- device
+ * pointers; out_l [B,C_l,D_l,s_l,s_l].  The active slot is unchanged on return. */
+int mvd_frustum_volumes_batch(mvd_ctx* ctx, int B, const int* slots, const float* volumes, const float* t_embed, const float* v_rows,
+                              const int32_t* view_idx, float* out0, float* out1, float* out2, float* out3, void* stream);
 
 /* The per-view part of SyncDDIMSampler.denoise_apply (morphable_diffusion.py:721-738) for TN views, fully on
  * the device without leaving the library's layouts: frustum volumes -> CFG-batched UNet

@@ -656,6 +656,31 @@ int mvd_frustum_volumes(mvd_ctx* c, const float* t_embed, const float* v_embed, 
   return 0;
 }
 
+int mvd_frustum_volumes_batch(mvd_ctx* c, int B, const int* slots, const float* volumes, const float* t_embed, const float* v_rows,
+                              const int32_t* view_idx, float* out0, float* out1, float* out2, float* out3, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (B < 1 || !slots || !volumes || !t_embed || !v_rows || !view_idx) return mvd_fail("mvd_frustum_volumes_batch: bad argument");
+  for (int i = 0; i < B; ++i)
+    if (slots[i] < 0 || slots[i] >= 64) return mvd_fail("mvd_frustum_volumes_batch: slot out of range (0..63)");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const int V = c->v.spatial_volume_size;
+  float* vcl = ws_alloc<float>(c, (size_t)B * V * V * V * 64);  // NCDHW -> channels-last, all samples
+  WS_CHECK(vcl);
+  RET_IF(launch_nchw_to_nhwc(volumes, B, 64, V * V * V, vcl, 64, 64, s));
+  FrustumOut fo;
+  RET_IF(engine_frustum_batch(c, B, slots, vcl, t_embed, v_rows, view_idx, &fo, s));
+  float* outs[4] = {out0, out1, out2, out3};
+  int D = c->v.frustum_volume_depth, Sz = c->v.input_image_size / 8;
+  for (int l = 0; l < 4; ++l) {
+    if (outs[l]) RET_IF(launch_nhwc_to_nchw(fo.lvl[l], c->v.frustum_dims[l], B, c->v.frustum_dims[l], D * Sz * Sz, outs[l], s));
+    D = (D - 1) / 2 + 1;
+    Sz = (Sz - 1) / 2 + 1;
+  }
+  return 0;
+}
+
 int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, const float* clip, int64_t timestep,
                       const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
                       const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,

@@ -438,6 +438,8 @@ struct FrustumOut {
 };
 int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
                    FrustumOut* out, hipStream_t s, bool half0 = false);
+int engine_frustum_batch(mvd_ctx* c, int B, const int* slots, const float* volumes, const float* t_embed, const float* v_rows,
+                         const int32_t* view_idx_dev, FrustumOut* out, hipStream_t s);
 
 // helpers shared by the executors
 struct GemmArgs {

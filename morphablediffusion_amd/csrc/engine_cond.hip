@@ -604,13 +604,12 @@ int engine_volume_from_fused(mvd_ctx* c, const float* fused, hipStream_t s, bool
 
 // construct_view_frustum_volume (morphable_diffusion.py:265-320): frustum gather + FrustumTV3DNet
 // (network.py:313-347).  Outputs stay channels-last fp32 in the workspace (caller owns the mark).
-int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
-                   FrustumOut* out, hipStream_t s, bool half0) {
-  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
-  if (!c->volume || !c->cams) return mvd_fail("volume / cameras not set");
-  // the volume may have been produced on another stream (mvd_set_volume_ready_event): its first reader waits here
-  if (c->vol_ready) HIP_CHECK_RET(hipStreamWaitEvent(s, c->vol_ready, 0));
-  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
+// FrustumTV3DNet (network.py:313-347) on TN gathered frustum volumes; the caller fills `gath` [TN][D0*S0*S0][64] fp16 through
+// `gather` and `pre` [TN][film_total] (x + t_conv(t) + v_conv(v) of all nine blocks) through `film`.  The launch order --
+// gather, conv0, FiLM projections -- is the one the side-stream determinism runs of DESIGN section 4 were made with.
+template <typename Gather, typename Film>
+static int frustum_net(mvd_ctx* c, int TN, FrustumOut* out, hipStream_t s, bool half0, Gather&& gather, Film&& film) {
+  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8;
   const int* fd = c->v.frustum_dims;
   int D[4], S[4];
   for (int l = 0; l < 4; ++l) {
@@ -640,8 +639,7 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   float* pre = ws_alloc<float>(c, (size_t)TN * c->film_total);
   float* up = ws_alloc<float>(c, vox(0) * fd[0]);
   WS_CHECK(gath && tmp && a && pre && up);
-  RET_IF(launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
-                               c->v.spatial_volume_length, c->v.projection == 0, gath, s));
+  RET_IF(gather(gath));
   static const bool dbg_sum = getenv("MVD_DEBUG_SUM") != nullptr;
   if (dbg_sum) {
     const int V = c->v.spatial_volume_size;
@@ -655,11 +653,8 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
   GemmArgs g;
   g.a = gath; g.lda = 64; g.w = &c->fr_conv0; g.out = x[0]; g.ldc = fd[0];
   RET_IF(run_conv3d(c, g, TN, D0, S0, S0, 1, s));
-  // x + t_conv(t) + v_conv(v) (network.py:294,308) of all nine blocks in two launches: a per-(view, channel)
-  // constant that the GroupNorm kernels fold in (pre[v][film_off[i] + c])
   const int FT = c->film_total;
-  RET_IF(launch_small_linear(t_embed, td, -TN, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre, FT, 0, s));
-  RET_IF(launch_small_linear(v_embed, vd, TN, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre, FT, 1, s));
+  RET_IF(film(pre));
   // down path: conv{1,3,5} stride 2, conv{2,4,6} stride 1
   for (int l = 0; l < 3; ++l) {
     const FrustumBlockW& b1 = c->fr_blocks[2 * l];
@@ -689,4 +684,51 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
     RET_IF(run_convT3d(c, g, TN, D[l + 1], S[l + 1], S[l + 1], s));
   }
   return 0;
+}
+
+int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
+                   FrustumOut* out, hipStream_t s, bool half0) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (!c->volume || !c->cams) return mvd_fail("volume / cameras not set");
+  // the volume may have been produced on another stream (mvd_set_volume_ready_event): its first reader waits here
+  if (c->vol_ready) HIP_CHECK_RET(hipStreamWaitEvent(s, c->vol_ready, 0));
+  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
+  return frustum_net(c, TN, out, s, half0, [&](half_t* gath) -> int {
+    return launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
+                                 c->v.spatial_volume_length, c->v.projection == 0, gath, s);
+  }, [&](float* pre) -> int {
+    // x + t_conv(t) + v_conv(v) (network.py:294,308) of all nine blocks in two launches: a per-(view, channel)
+    // constant that the GroupNorm kernels fold in (pre[v][film_off[i] + c])
+    const int FT = c->film_total;
+    RET_IF(launch_small_linear(t_embed, td, -TN, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre, FT, 0, s));
+    return launch_small_linear(v_embed, vd, TN, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre, FT, 1, s);
+  });
+}
+
+int engine_select_sample(mvd_ctx* c, int slot);
+// One target view for each of B samples (training_step: morphable_diffusion.py:496-518 with TN = 1): every sample's frustum is
+// gathered from ITS 32^3 volume with ITS cameras (slots[b]), then the network runs once with the B volumes as its batch.
+// volumes: channels-last [B][V^3][64]; t_embed [B][time_dim]; v_rows [B][view_dim] (the target view's embedding); view_idx_dev [B]
+int engine_frustum_batch(mvd_ctx* c, int B, const int* slots, const float* volumes, const float* t_embed, const float* v_rows,
+                         const int32_t* view_idx_dev, FrustumOut* out, hipStream_t s) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
+  const int V = c->v.spatial_volume_size;
+  const int back = c->cur_slot;
+  const int r = frustum_net(c, B, out, s, false, [&](half_t* gath) -> int {
+    const size_t per = (size_t)D0 * S0 * S0 * 64;
+    for (int b = 0; b < B; ++b) {
+      RET_IF(engine_select_sample(c, slots[b]));
+      if (!c->cams) return mvd_fail("mvd_frustum_volumes_batch: a slot has no cameras");
+      RET_IF(launch_frustum_gather(volumes + (size_t)b * V * V * V * 64, c->cams, view_idx_dev + b, 1, D0, S0, V,
+                                   c->v.spatial_volume_length, c->v.projection == 0, gath + (size_t)b * per, s));
+    }
+    return 0;
+  }, [&](float* pre) -> int {
+    const int FT = c->film_total;
+    RET_IF(launch_small_linear(t_embed, td, B, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pre, FT, 0, s));
+    return launch_small_linear(v_rows, vd, B, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pre, FT, 1, s);
+  });
+  const int r2 = engine_select_sample(c, back);
+  return r ? r : r2;
 }

@@ -432,6 +432,23 @@ class Engine:
         L.check(self.lib.mvd_mse_loss(self._ctx, L.ptr(a), L.ptr(b), C.c_size_t(a.numel()), L.ptr(out), _stream()))
         return out[0]
 
+    def frustum_volumes_batch(self, slots, volumes, t_embed, v_rows, view_idx):
+        """mvd_frustum_volumes_batch: one target view per sample -- volumes [B,64,V,V,V], t_embed [B,time_dim], v_rows [B,view_dim],
+        view_idx [B]; the samples' cameras are resident in ``slots``.  Returns {res: [B,C,D,res,res]}."""
+        dev = self.device
+        vol, te, vr = _f32(volumes, dev), _f32(t_embed, dev), _f32(v_rows, dev)
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        B = vol.shape[0]
+        D, S = self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size
+        outs, ptrs = {}, []
+        for lvl in range(4):
+            o = torch.empty(B, self.vcfg.frustum_dims[lvl], D >> lvl, S >> lvl, S >> lvl, device=dev, dtype=torch.float32)
+            outs[S >> lvl] = o
+            ptrs.append(L.ptr(o))
+        L.check(self.lib.mvd_frustum_volumes_batch(self._ctx, B, (C.c_int * B)(*[int(v) for v in slots]), L.ptr(vol), L.ptr(te), L.ptr(vr),
+                                                   L.ptr(vi), *ptrs, _stream()))
+        return outs
+
     def frustum_volumes(self, t_embed, v_embed, view_idx):
         dev = self.device
         vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()

@@ -291,6 +291,13 @@ class SpatialVolumeNet(nn.Module):
         """B == 1 uses the volume held by the engine from the last construct_spatial_volume of the same sample; B > 1 (the
         training step: one target view per sample) re-uploads each sample's ``spatial_volume[bi]`` first."""
         B, TN = target_indices.shape
+        from .engine import MAX_SAMPLE_SLOTS
+        if 1 < B <= MAX_SAMPLE_SLOTS and TN == 1:  # the training step: the frustum network once, the samples as its batch
+            for bi in range(B):
+                self._set_sample(batch, bi)  # (tables resident, slot = sample index)
+            idx = target_indices[:, 0].to(v_embed.device)
+            v_rows = v_embed[torch.arange(B, device=v_embed.device), idx]
+            return self._engine.frustum_volumes_batch(list(range(B)), spatial_volume, t_embed, v_rows, idx), None
         outs = []
         for bi in range(B):
             self._set_sample(batch, bi)
