@@ -1098,7 +1098,11 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
     vox[l] = (size_t)Dl[l] * Sl[l] * Sl[l];
   }
   const int FT = c->film_total;
-  const int back_slot = c->cur_slot;
+  struct SlotGuard {  // the active slot is the caller's again on every exit path
+    mvd_ctx* c;
+    int slot;
+    ~SlotGuard() { engine_select_sample(c, slot); }
+  } slot_guard{c, c->cur_slot};
   // extended-precision packs of the 2-D encoder's convs, once per call
   auto xp_pack = [&](const ConvW& w, int cin_src, ConvW* o) -> int {
     const float* mw = engine_master(c, w.key);
@@ -1476,7 +1480,7 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   RET_IF(bwd_silu_inplace(d_e1, u1, (size_t)B * td, s));
   RET_IF(lin_wgrad(c, c->step_te0.key, d_e1, td, e0, td, B, td, td, s));
   }
-  return engine_select_sample(c, back_slot);
+  return 0;
 }
 
 // one sample: the active slot (parity hook with the debug outputs; dsrc as above with B = 1)
