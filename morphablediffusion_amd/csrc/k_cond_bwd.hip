@@ -440,7 +440,7 @@ int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)vertex_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(n_views, 8), dim3(1024), lds, s, d_out, cams, view_idx, verts, Nv, V, vol_len, S, persp,
+  hipLaunchKernelGGL(vertex_scatter_kernel, dim3(n_views, 16), dim3(1024), lds, s, d_out, cams, view_idx, verts, Nv, V, vol_len, S, persp,
                      d_feats);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
