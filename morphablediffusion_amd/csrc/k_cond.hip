@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
   __shared__ float s_red[256];
   const int c = blockIdx.x, t = threadIdx.x;
   float a = 0.f;
+#pragma unroll 8
   for (int r = t; r < n; r += 256) a += x[(long)r * C + c];
   s_red[t] = a;
   __syncthreads();
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
   const float mean = s_red[0] / (float)n;
   __syncthreads();
   float q = 0.f;
+#pragma unroll 8
   for (int r = t; r < n; r += 256) {
     const float d = x[(long)r * C + c] - mean;
     q += d * d;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (s_red[0] / (float)(n > 1 ? n - 1 : 1));
   }
+#pragma unroll 8
   for (int r = t; r < n; r += 256) y[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
 }
 

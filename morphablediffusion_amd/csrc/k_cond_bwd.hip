@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_sums_kernel(const float* __re
   float s1 = 0.f, s2 = 0.f;
   if (rl < RL) {
     const float mean = stats[c], rstd = stats[C + c], g = gamma[c], b = beta[c];
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += RL) {
       const float xh = (xraw[(long)r * C + c] - mean) * rstd;
       const float du = (g * xh + b) > 0.f ? dy[(long)r * C + c] : 0.f;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __r
   }
   __syncthreads();
   const long e0 = (long)blockIdx.x * BNB_CH * C, e1 = min((long)n * C, e0 + (long)BNB_CH * C);
+#pragma unroll 8
   for (long e = e0 + t; e < e1; e += 256) {
     const int c = (int)(e % C);
     const float rstd = stats[C + c], g = gamma[c];
