@@ -24,7 +24,8 @@
 #include "engine.h"
 
 // k_bwd.hip
-int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split = 0);
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split = 0, half_t* rows16 = nullptr,
+              int Cp = 0);
 int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int C, int stride, int ups, half_t* dst, int Rp, hipStream_t s);
 int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split = 0);
 int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s, int flip = 1);
@@ -257,12 +258,18 @@ inline Opnd F32(const float* p, long ld, int trans) { return Opnd{p, 1, ld, tran
 inline Opnd F16(const half_t* p, long ld, int trans) { return Opnd{p, 0, ld, trans}; }
 
 // dense fp16 [rows][up8(C)] copy of an fp32 gradient (the A operand of a dgrad GEMM)
-int grad16(mvd_ctx* c, const float* g, long ld, long rows, int C, half_t** out, hipStream_t s) {
+int grad16(mvd_ctx* c, const float* g, long ld, long rows, int C, half_t** out, hipStream_t s, half_t** outT = nullptr) {
   half_t* d = ws_alloc<half_t>(c, (size_t)rows * up8(C));
   WS_CHECK(d);
-  RET_IF(bwd_cast_rows(g, ld, rows, C, up8(C), d, s));
   *out = d;
-  return 0;
+  if (outT) {  // also the K-contiguous image [C][up64(rows)] for the layer's weight-gradient GEMM, from the same read
+    const int Rp = up64((int)rows);
+    half_t* t = ws_alloc<half_t>(c, (size_t)C * Rp);
+    WS_CHECK(t);
+    *outT = t;
+    return bwd_tcast(g, 1, ld, (int)rows, C, t, Rp, s, 0, d, up8(C));
+  }
+  return bwd_cast_rows(g, ld, rows, C, up8(C), d, s);
 }
 
 // dX[rows][cin] (lddx) (+)= dY16[rows][Np] wT   (Linear / 1x1 conv adjoint on the forward GEMM kernels)
@@ -315,15 +322,21 @@ int wgrad_gemm(Bwd& b, const half_t* dyT, int N, const half_t* colT, int K2, int
   return run_linear(b.c, g, 1, N, b.s);
 }
 // weight + bias gradient of a Linear / 1x1 conv: dy fp32 [rows][N] (ld), x [rows][K] (fp16 or fp32)
-int wgrad_linear(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int rows, int K) {
+int wgrad_linear(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int rows, int K,
+                 const half_t* dyT_pre = nullptr) {
   mvd_ctx* c = b.c;
   WsScope scope(c, WS_TEMP);
   const int Rp = up64(rows), N = w.N;
   if (float* G = engine_grad(c, w.key)) {
-    half_t* dyT = ws_alloc<half_t>(c, (size_t)N * Rp);
+    const half_t* dyT = dyT_pre;
+    if (!dyT) {
+      half_t* t = ws_alloc<half_t>(c, (size_t)N * Rp);
+      WS_CHECK(t);
+      RET_IF(bwd_tcast(dy, 1, ldy, rows, N, t, Rp, b.s));
+      dyT = t;
+    }
     half_t* xT = ws_alloc<half_t>(c, (size_t)K * Rp);
-    WS_CHECK(dyT && xT);
-    RET_IF(bwd_tcast(dy, 1, ldy, rows, N, dyT, Rp, b.s));
+    WS_CHECK(xT);
     RET_IF(bwd_tcast(x, x_f32, ldx, rows, K, xT, Rp, b.s));
     RET_IF(wgrad_gemm(b, dyT, N, xT, K, Rp, G));
   }
@@ -337,16 +350,21 @@ int wgrad_linear(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* 
 }
 // weight + bias gradient of a 3x3 conv (stride / nearest-upsampled input as in the forward): x [B,H,W,K] physical
 int wgrad_conv3(Bwd& b, const ConvW& w, const float* dy, long ldy, const void* x, int x_f32, long ldx, int H, int W, int K, int stride,
-                int ups) {
+                int ups, const half_t* dyT_pre = nullptr) {
   mvd_ctx* c = b.c;
   WsScope scope(c, WS_TEMP);
   const int Ho = ((H << ups) - 1) / stride + 1, Wo = ((W << ups) - 1) / stride + 1;
   const int rows = b.B * Ho * Wo, Rp = up64(rows), N = w.N;
   if (float* G = engine_grad(c, w.key)) {
-    half_t* dyT = ws_alloc<half_t>(c, (size_t)N * Rp);
+    const half_t* dyT = dyT_pre;
+    if (!dyT) {
+      half_t* t = ws_alloc<half_t>(c, (size_t)N * Rp);
+      WS_CHECK(t);
+      RET_IF(bwd_tcast(dy, 1, ldy, rows, N, t, Rp, b.s));
+      dyT = t;
+    }
     half_t* colT = ws_alloc<half_t>(c, (size_t)K * 9 * Rp);
-    WS_CHECK(dyT && colT);
-    RET_IF(bwd_tcast(dy, 1, ldy, rows, N, dyT, Rp, b.s));
+    WS_CHECK(colT);
     RET_IF(bwd_im2colT(x, x_f32, ldx, b.B, H, W, K, stride, ups, colT, Rp, b.s));
     RET_IF(wgrad_gemm(b, dyT, N, colT, K * 9, Rp, G));
   }
@@ -416,11 +434,11 @@ int bwd_res(Bwd& b, const ResW& r, const ResSaved& sv, View in, View dout, View 
   float* d_h1 = ws_alloc<float>(c, (size_t)rows * cout);
   float* d_a1 = ws_alloc<float>(c, (size_t)rows * cin);
   WS_CHECK(d_a2 && d_h1 && d_a1);
-  half_t* dy16;
-  RET_IF(grad16(c, dout.p, dout.ld, rows, cout, &dy16, b.s));
+  half_t *dy16, *dyT, *dhT;
+  RET_IF(grad16(c, dout.p, dout.ld, rows, cout, &dy16, b.s, &dyT));
   // out = conv2(a2) + b2 + skip(x)
   RET_IF(dgrad_conv3(b, r.c2, dy16, d_a2, cout, H, W, false));
-  RET_IF(wgrad_conv3(b, r.c2, dout.p, dout.ld, sv.a2, 0, sv.ld2, H, W, cout, 1, 0));
+  RET_IF(wgrad_conv3(b, r.c2, dout.p, dout.ld, sv.a2, 0, sv.ld2, H, W, cout, 1, 0, dyT));
   // a2 = silu(GN2(h1))
   RET_IF(gn_backward(b, r.n2, 32, 1e-5f, ACT_SILU, sv.h1, cout, d_a2, cout, HW, d_h1, cout, false));
   // h1 = conv1(a1) + b1 + emb[b]: the per-sample sums of d_h1 are the gradient of this block's slice of the stacked emb
@@ -428,18 +446,18 @@ int bwd_res(Bwd& b, const ResW& r, const ResSaved& sv, View in, View dout, View 
   RET_IF(bwd_colsum_samples(d_h1, 1, cout, b.B, HW, cout, b.demb + r.emb_off, c->emb_total, b.s));
   if (float* Gb = engine_grad(c, r.c1.bkey)) RET_IF(bwd_sum_rows_add(b.demb + r.emb_off, b.B, cout, c->emb_total, Gb, 1, b.s));
   half_t* dh16;
-  RET_IF(grad16(c, d_h1, cout, rows, cout, &dh16, b.s));
+  RET_IF(grad16(c, d_h1, cout, rows, cout, &dh16, b.s, &dhT));
   RET_IF(dgrad_conv3(b, r.c1, dh16, d_a1, cin, H, W, false));
   {
     ConvW w1 = r.c1;
     w1.bkey.clear();  // the bias gradient was taken from the emb sums above
-    RET_IF(wgrad_conv3(b, w1, d_h1, cout, sv.a1, 0, sv.ld1, H, W, cin, 1, 0));
+    RET_IF(wgrad_conv3(b, w1, d_h1, cout, sv.a1, 0, sv.ld1, H, W, cin, 1, 0, dhT));
   }
   // a1 = silu(GN1(x))
   RET_IF(gn_backward(b, r.n1, 32, 1e-5f, ACT_SILU, in.p, in.ld, d_a1, cin, HW, din.p, din.ld, accum));
   if (r.has_skip) {
     RET_IF(dgrad_linear(b, r.skip, dy16, up8(cout), din.p, din.ld, 1, rows, true));
-    RET_IF(wgrad_linear(b, r.skip, dout.p, dout.ld, in.p, 1, in.ld, rows, cin));
+    RET_IF(wgrad_linear(b, r.skip, dout.p, dout.ld, in.p, 1, in.ld, rows, cin, dyT));
   } else {
     RET_IF(bwd_add_views(din.p, din.ld, dout.p, dout.ld, nullptr, 0, rows, cout, 1, b.s));
   }
@@ -464,15 +482,15 @@ int bwd_st(Bwd& b, const STW& t, const STSaved& sv, View in, View dout, View din
   float* part = ws_alloc<float>(c, (size_t)b.B * 8 * C);
   WS_CHECK(d_t && d_gg && pre16 && dpre16 && d_l && d_ao16 && dqkv16 && lse && delta && tmpW && part);
   const std::string tb = t.key + ".transformer_blocks.0";
-  half_t* g16;
+  half_t *g16, *gT;
   // out = proj_out(t3) + x
-  RET_IF(grad16(c, dout.p, dout.ld, rows, C, &g16, b.s));
+  RET_IF(grad16(c, dout.p, dout.ld, rows, C, &g16, b.s, &gT));
   RET_IF(dgrad_linear(b, t.proj_out, g16, C, d_t, C, 1, rows, false));
-  RET_IF(wgrad_linear(b, t.proj_out, dout.p, dout.ld, sv.t3, 0, sv.ldt3, rows, C));
+  RET_IF(wgrad_linear(b, t.proj_out, dout.p, dout.ld, sv.t3, 0, sv.ldt3, rows, C, gT));
   // t3 = t2 + ff2(gg)
-  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s, &gT));
   RET_IF(dgrad_linear(b, t.ff2, g16, C, d_gg, 4 * C, 1, rows, false));
-  RET_IF(wgrad_linear(b, t.ff2, d_t, C, sv.gg, 0, 4 * C, rows, 4 * C));
+  RET_IF(wgrad_linear(b, t.ff2, d_t, C, sv.gg, 0, 4 * C, rows, 4 * C, gT));
   // gg = GEGLU(ff1(l3)): the pre-activations are re-computed (packed column order), never stored by the forward pass
   {
     GemmArgs g;
@@ -502,12 +520,12 @@ int bwd_st(Bwd& b, const STW& t, const STSaved& sv, View in, View dout, View din
   // l3 = LN3(t2)
   RET_IF(ln_backward(b, t.ln3, sv.t2, C, d_l, C, rows, d_t, C, true));
   // t2 = t0 + to_out(ao) + b_o + attn2[b]
-  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s, &gT));
   RET_IF(dgrad_linear(b, t.attn_out, g16, C, d_ao16, C, 0, rows, false));
   {
     ConvW wo = t.attn_out;
     wo.bkey.clear();
-    RET_IF(wgrad_linear(b, wo, d_t, C, sv.ao, 0, C, rows, C));
+    RET_IF(wgrad_linear(b, wo, d_t, C, sv.ao, 0, C, rows, C, gT));
     // per-sample token sums of d_t2: gradient of the attn2 output (a per-sample constant) and, summed, of attn1's output bias
     RET_IF(bwd_colsum_samples(d_t, 1, C, b.B, T, C, b.da2 + t.a2_off, c->a2_total, b.s));
     if (float* Gb = engine_grad(c, t.attn_out.bkey)) RET_IF(bwd_sum_rows_add(b.da2 + t.a2_off, b.B, C, c->a2_total, Gb, 1, b.s));
@@ -532,9 +550,9 @@ int bwd_st(Bwd& b, const STW& t, const STSaved& sv, View in, View dout, View din
   // l1 = LN1(t0)
   RET_IF(ln_backward(b, t.ln1, sv.t0, C, d_l, C, rows, d_t, C, true));
   // t0 = proj_in(n0) + b
-  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s));
+  RET_IF(grad16(c, d_t, C, rows, C, &g16, b.s, &gT));
   RET_IF(dgrad_linear(b, t.proj_in, g16, C, d_l, C, 1, rows, false));
-  RET_IF(wgrad_linear(b, t.proj_in, d_t, C, sv.n0, 0, sv.ldn0, rows, C));
+  RET_IF(wgrad_linear(b, t.proj_in, d_t, C, sv.n0, 0, sv.ldn0, rows, C, gT));
   // n0 = GN(x) (eps 1e-6, no activation); out also carries x itself
   RET_IF(gn_backward(b, t.norm, 32, 1e-6f, ACT_NONE, in.p, in.ld, d_l, C, T, din.p, din.ld, accum));
   RET_IF(bwd_add_views(din.p, din.ld, dout.p, dout.ld, nullptr, 0, rows, C, 1, b.s));

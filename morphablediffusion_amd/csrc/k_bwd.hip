@@ -26,15 +26,19 @@ __device__ __forceinline__ float ldf(const half_t* p) { return (float)*p; }
 // split != 0 (fp32 sources): every dst row holds three Rp-long segments -- split 1: [hi | lo | hi], split 2: [hi | hi | lo]
 // with hi = fp16(x), lo = fp16(x - hi) -- the two operand images of an extended-precision GEMM (a_hi b_hi + a_lo b_hi +
 // a_hi b_lo by concatenation along K, the forward pass's ConvW::xp trick).
+// rows16 (optional): the row-major fp16 image [R][Cp] of the same tile as well (columns C..Cp zero) -- the A operand of the
+// dgrad GEMM that accompanies the wgrad GEMM of a layer: one read of the fp32 gradient instead of two kernels
 template <typename T>
 __global__ __launch_bounds__(256) void tcast_kernel(const T* __restrict__ src, long ld, int R, int C, half_t* __restrict__ dst, int Rp,
-                                                    int split) {
+                                                    int split, half_t* __restrict__ rows16, int Cp) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int rr = i >> 6, cc = i & 63;
     const int r = r0 + rr, c = c0 + cc;
-    tile[rr][cc] = (r < R && c < C) ? ldf(src + (long)r * ld + c) : 0.f;
+    const float v = (r < R && c < C) ? ldf(src + (long)r * ld + c) : 0.f;
+    tile[rr][cc] = v;
+    if (rows16 && r < R && c < Cp) rows16[(long)r * Cp + c] = (half_t)v;
   }
   __syncthreads();
   const long rowlen = split ? 3L * Rp : Rp;
@@ -975,12 +979,13 @@ int launch_attn_bwd_t(const half_t* qkv, int ld3, const half_t* o, const half_t*
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
-int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split) {
+int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, int Rp, hipStream_t s, int split, half_t* rows16, int Cp) {
   if (R <= 0 || C <= 0 || Rp < R) return mvd_fail("bwd_tcast: bad shape");
   if (split && !src_f32) return mvd_fail("bwd_tcast: the split layout needs an fp32 source");
+  if (rows16 && (Cp < C || Cp > 64 * cdiv(C, 64))) return mvd_fail("bwd_tcast: bad row-image width");
   dim3 grid(cdiv(Rp, 64), cdiv(C, 64));
-  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split);
-  else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp, 0);
+  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split, rows16, Cp);
+  else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp, 0, rows16, Cp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
