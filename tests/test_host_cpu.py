@@ -27,6 +27,39 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(lib.SYMBOLS) == declared
 
 
+def test_library_has_no_crossed_packed_f32_multiply(tmp_path):
+    """ISA lint of the built library.  On MI355X a ``v_pk_mul_f32`` whose low result takes the HIGH half of a VGPR operand
+    (``op_sel:[0,1]``; the SLP vectoriser emits it for 3x4 camera transforms) returns 0 in the low half of lanes 48-63
+    whenever the wave shares a SIMD with ``conv3_dma_kernel`` waves of another stream -- the "lost 128-byte lines" of the
+    frustum gather (tools/race_probe.hip reproduces it with the single instruction).  The two
+    kernels that had it are built with -fno-slp-vectorize; nothing in the library may (re)acquire the form."""
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    so = os.path.join(ROOT, "morphablediffusion_amd", "libmvd_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(so)):
+        pytest.skip("llvm-objdump or the built library is missing")
+    work = tmp_path / "lint"
+    work.mkdir()
+    shutil.copy(so, work / "libmvd_hip.so")
+    subprocess.run([objdump, "--offloading", "libmvd_hip.so"], cwd=work, check=True, capture_output=True)
+    bundles = sorted(f for f in os.listdir(work) if f.endswith("gfx950"))
+    assert bundles, "no gfx950 code objects found in libmvd_hip.so"
+    bad, kernels, cur = [], 0, "?"
+    for b in bundles:
+        dis = subprocess.run([objdump, "-d", b], cwd=work, check=True, capture_output=True, text=True).stdout
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+            if m:
+                cur = m.group(1)
+                kernels += 1
+                continue
+            if re.search(r"\bv_pk_(mul|fma|add)_f32\b", line) and re.search(r"op_sel:\[0,1", line) and \
+                    not re.search(r"v_pk_\w+ v\[\d+:\d+\], s\[", line):
+                bad.append((cur, line.split("//")[0].strip()))
+    assert kernels > 100, "disassembly looks empty"
+    assert not bad, f"crossed packed-f32 arithmetic on VGPR operands: {bad[:4]}"
+
+
 def test_no_cpu_fallback_without_gpu():
     """The product path must fail loudly when there is no GPU / extension (never route through the oracle)."""
     if torch.cuda.is_available():
