@@ -93,8 +93,15 @@ def pick_cpu_threads():
         seen[n] = round(dt, 3)
         if best_t is None or dt < best_t:
             best_n, best_t = n, dt
-        elif dt > 1.5 * best_t:
-            break  # past the knee: more threads only thrash
+        elif dt > 1.5 * best_t and n != ncpu:
+            # past the knee: more threads only thrash -- skip the points in between, but always time os.cpu_count() threads
+            # too, so the line carries the all-cores figure next to the best one
+            torch.set_num_threads(ncpu)
+            with torch.no_grad():
+                t0 = time.time()
+                O.unet_forward(W, plan, x[:2], t[:2], ctx[:2], {k: v[:2] for k, v in sd.items()})
+                seen[ncpu] = round((time.time() - t0) * (x.shape[0] / 2.0), 3)  # quarter of the batch, scaled: it can be very slow
+            break
     return best_n, seen
 
 
@@ -133,6 +140,10 @@ def cpu_baseline_main():
     print(json.dumps({
         "value": 1.0 / dt16, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "thread_calibration_s": calib,
+        "all_threads": {"threads": os.cpu_count(), "reduced_width_unet_s": calib.get(os.cpu_count()),
+                        "best_threads_reduced_width_unet_s": min(calib.values()) if calib else None,
+                        "note": "the headline-width step is only run at the best thread count: with every hardware thread "
+                                "eager PyTorch is slower by the ratio of these two figures (and did not finish in 20 minutes)"},
         "sample": f"ONE full denoise_apply of the headline configuration (N={N_VIEWS}, CFG 2.0, full-width UNet, "
                   f"5023-vertex mesh, fp32 eager): {dt16:.1f} s; plus configs[0] (one view, 64x64 latent, first DDIM "
                   f"step, full width): {dt1:.1f} s.  Thread count = the fastest of 16, 32, ... os.cpu_count() on a "
@@ -154,6 +165,25 @@ def cpu_baseline(timeout_s=420):
                 "sample": f"the CPU oracle did not finish one step within {timeout_s} s on this host"}
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks of ONE node ourselves, exactly as the driver does
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1).  Rank 0 of the child prints the JSON line on our
+    stdout.  Fails loudly -- a JSON error line and a non-zero exit -- when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "MVD_FORCE_DEVICE" not in os.environ:
+        print(json.dumps({"error": f"--gpus {n} requested but this node has {have} visible GPU(s)"}))
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def train_main(args):
     """``--config train`` (NOT the headline metric): BASELINE.json configs[3]'s unit of work -- one training step of
     SyncMultiviewDiffusion (training_step morphable_diffusion.py:520-549 on B samples per GPU, N = 16 views, finetune_unet) =
@@ -168,6 +198,9 @@ def train_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("MVD_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if args.gpus != world:
+        os.write(real_stdout, (json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE is {world}"}) + "\n").encode())
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -294,6 +327,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_main()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     if args.config == "train":
         return train_main(args)
 
@@ -311,12 +346,17 @@ def main():
     backend = os.environ.get("MVD_DIST_BACKEND", "nccl")
     if "MVD_FORCE_DEVICE" in os.environ:
         local = int(os.environ["MVD_FORCE_DEVICE"])
+    if args.gpus != world:
+        # never a silent single-rank run labelled n_gpus = 1: the launcher and --gpus must agree
+        os.write(real_stdout, (json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
+                                                    f"torch.distributed.run --nproc-per-node {args.gpus} (or plain "
+                                                    f"`python bench.py --gpus {args.gpus}`, which spawns the ranks itself)"}) + "\n").encode())
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group(backend)  # "nccl" = RCCL over xGMI
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+        assert dist.get_world_size() == args.gpus, f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}"
     dev = f"cuda:{local}"
 
     from morphablediffusion_amd import synthetic
@@ -499,7 +539,10 @@ def main():
             "families": fam_rows,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "dist_backend": dist.get_backend() if world > 1 else None,
-            "step_tflops": 433.9e9 * N_VIEWS / (dt / args.steps) / 1e12,
+            # algorithmic FLOPs of one step as the engine books them launch by launch (survey pass, all families), not a
+            # constant: the SURVEY figure 433.9 GFLOP x N holds for the 32 x 32 latents of the headline only
+            "step_gflop": sum(f["flops"] for f in families) / 2.0 / 1e9,
+            "step_tflops": sum(f["flops"] for f in families) / 2.0 / (dt / args.steps) / 1e12,
             "ddim50_wall_s": extras["ddim50_wall_s"], "vae_decode_ms_local_views": extras["vae_decode_ms"],
         }
         if args.simulate_gpus:

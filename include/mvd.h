@@ -86,6 +86,18 @@ int mvd_finalize_weights(mvd_ctx* ctx);
 int mvd_unet_forward(mvd_ctx* ctx, const float* x, const int64_t* timesteps, const float* context, int Bv, int n_ctx,
                      const float* src0, const float* src1, const float* src2, const float* src3, int depth0, float* out,
                      void* stream);
+/* ONE block of DepthWiseAttention on its own input, through the production block code (same plans and kernels as
+ * mvd_unet_forward): `path` is the reference module path below model.diffusion_model --
+ *   "input_blocks.I.J" / "middle_block.J" / "output_blocks.I.J": ResBlock._forward (openaimodel.py:256-276; needs timesteps [B]),
+ *      SpatialTransformer.forward (modules/attention.py:325-336; needs context [B,1,context_dim]), Downsample / Upsample /
+ *      the input convolution (openaimodel.py:100-157);
+ *   "middle_conditions" / "output_conditions.K": DepthTransformer.forward (ldm/models/diffusion/attention.py:78-84; needs
+ *      volume [B,C_l,D,H,W], every sample conditional).
+ * x [B,C,H,W] at a UNet resolution (image_size >> level); out receives [B,Cout,Ho,Wo] (at most out_capacity floats) and
+ * out_shape[4] its shape.  Used by the block-level parity tests. */
+int mvd_unet_block(mvd_ctx* ctx, const char* path, const float* x, int B, int C, int H, int W, const int64_t* timesteps,
+                   const float* context, const float* volume, int D, float* out, int out_capacity, int* out_shape, void* stream);
+
 
 /* SyncMultiviewDiffusion.embed_time -- morphable_diffusion.py:491-494. t [B] int64 -> out [B,time_dim] */
 int mvd_embed_time(mvd_ctx* ctx, const int64_t* t, int B, float* out, void* stream);

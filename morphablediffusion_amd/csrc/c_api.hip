@@ -304,6 +304,37 @@ int mvd_unet_forward(mvd_ctx* c, const float* x, const int64_t* timesteps, const
   return 0;
 }
 
+int mvd_unet_block(mvd_ctx* c, const char* path, const float* x, int B, int C, int H, int W, const int64_t* timesteps,
+                   const float* context, const float* volume, int D, float* out, int out_capacity, int* out_shape, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || !c->finalized || !path || !x || !out || !out_shape || B <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0)
+    return mvd_fail("mvd_unet_block: bad argument");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const int HW = H * W;
+  float* xn = ws_alloc<float>(c, (size_t)B * HW * C);
+  // any block's output fits: an Upsample quadruples the pixels, no block is wider than 8 * model_channels
+  float* on = ws_alloc<float>(c, (size_t)B * HW * 4 * (size_t)(c->u.model_channels * 8));
+  WS_CHECK(xn && on);
+  RET_IF(launch_nchw_to_nhwc(x, B, C, HW, xn, C, C, s));
+  float* vn = nullptr;
+  if (volume) {
+    int level = 0;
+    for (int r = c->u.image_size; r > H; r >>= 1) ++level;
+    if (level > 3 || D <= 0) return mvd_fail("mvd_unet_block: bad volume");
+    const int Cc = c->u.volume_dims[level];
+    vn = ws_alloc<float>(c, (size_t)B * D * HW * Cc);
+    WS_CHECK(vn);
+    RET_IF(launch_nchw_to_nhwc(volume, B, Cc, D * HW, vn, Cc, Cc, s));
+  }
+  int Co = 0, Ho = 0;
+  RET_IF(engine_unet_block(c, path, xn, B, C, H, W, timesteps, context, vn, D, on, &Co, &Ho, s));
+  if ((size_t)B * Co * Ho * Ho > (size_t)out_capacity) return mvd_fail("mvd_unet_block: output buffer too small");
+  RET_IF(launch_nhwc_to_nchw(on, Co, B, Co, Ho * Ho, out, s));
+  out_shape[0] = B; out_shape[1] = Co; out_shape[2] = Ho; out_shape[3] = Ho;
+  return 0;
+}
+
 int mvd_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed,
                         const int32_t* view_idx, int n_local, int add_bias, float* fused_out, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");

@@ -386,6 +386,10 @@ struct Fwd {
   bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
   bool train = false;     // training forward: no deferred split-K slabs, LN1 / LN3 outputs in separate buffers
 };
+int unet_embeddings(mvd_ctx* c, const int64_t* t, const float* context, int Bv, hipStream_t s, float** e0_out, float** e1_out,
+                    float** e2_out, float** ea_out, float** a2_out);
+int engine_unet_block(mvd_ctx* c, const char* path, const float* x_nhwc, int B, int C, int H, int W, const int64_t* t,
+                      const float* context, const float* vol_ndhwc, int D, float* out_nhwc, int* Cout, int* Hout, hipStream_t s);
 int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv = nullptr);
 int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv = nullptr);
 int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1);

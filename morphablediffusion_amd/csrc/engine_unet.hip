@@ -670,6 +670,50 @@ int out_res_of(const std::vector<UOp>& ops, int H) {
 
 }  // namespace
 
+// Per-sample constants of a forward: the timestep embedding through the time_embed MLP and every ResBlock's emb projection
+// (openaimodel.py:728-729, 264-269: [Bv][emb_total]) and the folded attn2 output of every SpatialTransformer for the single CLIP
+// token ([Bv][a2_total]).  Allocated in the caller's workspace scope.  t / context may be null (the part is skipped).
+int unet_embeddings(mvd_ctx* c, const int64_t* t, const float* context, int Bv, hipStream_t s, float** e0_out, float** e1_out,
+                    float** e2_out, float** ea_out, float** a2_out) {
+  const mvd_unet_config& u = c->u;
+  const int mc = u.model_channels, temb = 4 * mc;
+  if (t) {
+    float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
+    float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);
+    float* e2 = ws_alloc<float>(c, (size_t)Bv * temb);
+    float* ea = ws_alloc<float>(c, (size_t)Bv * c->emb_total);
+    WS_CHECK(e0 && e1 && e2 && ea);
+    RET_IF(launch_timestep_embedding(t, Bv, mc, e0, s));
+    // time_embed MLP and every ResBlock's emb projection as three weight-streaming GEMMs (M = Bv rows)
+    ConvW w0, w2, wa;
+    w0.w = c->te0.w; w0.bias = c->te0.bias; w0.N = temb; w0.Cin = mc;
+    w2.w = c->te2.w; w2.bias = c->te2.bias; w2.N = temb; w2.Cin = temb;
+    wa.w = c->emb_all.w; wa.bias = c->emb_all.bias; wa.N = c->emb_total; wa.Cin = temb;
+    GemmArgs g;
+    g.a = e0; g.a_f32 = 1; g.lda = mc; g.w = &w0; g.out = e1; g.ldc = temb; g.act = ACT_SILU;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    g = GemmArgs();
+    g.a = e1; g.a_f32 = 1; g.lda = temb; g.w = &w2; g.out = e2; g.ldc = temb; g.act = ACT_SILU;  // emb is only used as silu(emb)
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    g = GemmArgs();
+    g.a = e2; g.a_f32 = 1; g.lda = temb; g.w = &wa; g.out = ea; g.ldc = c->emb_total;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    if (e0_out) *e0_out = e0;
+    if (e1_out) *e1_out = e1;
+    if (e2_out) *e2_out = e2;
+    *ea_out = ea;
+  }
+  if (context) {
+    float* a2 = ws_alloc<float>(c, (size_t)Bv * c->a2_total);
+    WS_CHECK(a2);
+    GemmArgs g;
+    g.a = context; g.a_f32 = 1; g.lda = u.context_dim; g.w = &c->a2_all; g.out = a2; g.ldc = c->a2_total;
+    RET_IF(run_linear(c, g, Bv, Bv, s));
+    *a2_out = a2;
+  }
+  return 0;
+}
+
 int engine_side_init(mvd_ctx* c) {
   if (c->side) return 0;
   HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -684,7 +728,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
   if (tape && (produce || n_ctx != Bv)) return mvd_fail("engine_unet: the training forward takes every sample's context volumes");
   const mvd_unet_config& u = c->u;
-  const int mc = u.model_channels, temb = 4 * mc;
+  const int mc = u.model_channels;
   WsScope ws_scope0(c);
   Fwd f{c, s, Bv, n_ctx, depth0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
   f.train = tape != nullptr;
@@ -775,40 +819,14 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   };
   if (!produce) RET_IF(fork_ctx());
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
-  float* e0 = ws_alloc<float>(c, (size_t)Bv * mc);
-  float* e1 = ws_alloc<float>(c, (size_t)Bv * temb);
-  float* e2 = ws_alloc<float>(c, (size_t)Bv * temb);
-  float* ea = ws_alloc<float>(c, (size_t)Bv * c->emb_total);
-  WS_CHECK(e0 && e1 && e2 && ea);
-  RET_IF(launch_timestep_embedding(t, Bv, mc, e0, s));
-  {  // time_embed MLP and every ResBlock's emb projection as three weight-streaming GEMMs (M = Bv rows)
-    ConvW w0, w2, wa;
-    w0.w = c->te0.w; w0.bias = c->te0.bias; w0.N = temb; w0.Cin = mc;
-    w2.w = c->te2.w; w2.bias = c->te2.bias; w2.N = temb; w2.Cin = temb;
-    wa.w = c->emb_all.w; wa.bias = c->emb_all.bias; wa.N = c->emb_total; wa.Cin = temb;
-    GemmArgs g;
-    g.a = e0; g.a_f32 = 1; g.lda = mc; g.w = &w0; g.out = e1; g.ldc = temb; g.act = ACT_SILU;
-    RET_IF(run_linear(c, g, Bv, Bv, s));
-    g = GemmArgs();
-    g.a = e1; g.a_f32 = 1; g.lda = temb; g.w = &w2; g.out = e2; g.ldc = temb; g.act = ACT_SILU;  // emb is only used as silu(emb)
-    RET_IF(run_linear(c, g, Bv, Bv, s));
-    g = GemmArgs();
-    g.a = e2; g.a_f32 = 1; g.lda = temb; g.w = &wa; g.out = ea; g.ldc = c->emb_total;
-    RET_IF(run_linear(c, g, Bv, Bv, s));
-  }
+  float *e0 = nullptr, *e1 = nullptr, *e2 = nullptr, *ea = nullptr, *a2 = nullptr;
+  RET_IF(unet_embeddings(c, t, context, Bv, s, &e0, &e1, &e2, &ea, &a2));
   f.emb_all = ea;
+  f.a2_all = a2;
   if (tape) {
     tape->e0 = e0; tape->e1 = e1; tape->e2 = e2; tape->ea = ea; tape->context = context;
     tape->Bv = Bv; tape->depth0 = depth0; tape->src = src;
-  }
-  {
-    float* a2 = ws_alloc<float>(c, (size_t)Bv * c->a2_total);
-    WS_CHECK(a2);
-    GemmArgs g;
-    g.a = context; g.a_f32 = 1; g.lda = u.context_dim; g.w = &c->a2_all; g.out = a2; g.ldc = c->a2_total;
-    RET_IF(run_linear(c, g, Bv, Bv, s));
-    f.a2_all = a2;
-    if (tape) tape->a2 = a2;
+    tape->a2 = a2;
   }
 
   // shapes of the concat buffers
@@ -962,5 +980,66 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     fprintf(stderr, " final=%016llx eps=%016llx\n", sum(final_h, (size_t)Bv * u.image_size * u.image_size * mc * 4),
             sum(eps_nhwc, (size_t)Bv * u.image_size * u.image_size * u.out_channels * 4));
   }
+  return 0;
+}
+
+// One block of the UNet on its own input (include/mvd.h: mvd_unet_block): the block-level parity tests of SURVEY section 8
+// rows a19-a22 run the production block code -- same plans, same kernels -- against the reference's block goldens.
+int engine_unet_block(mvd_ctx* c, const char* path, const float* x_nhwc, int B, int C, int H, int W, const int64_t* t,
+                      const float* context, const float* vol_ndhwc, int D, float* out_nhwc, int* Cout, int* Hout, hipStream_t s) {
+  if (!c->finalized || !c->has_unet) return mvd_fail("UNet weights not uploaded / finalized");
+  const mvd_unet_config& u = c->u;
+  int level = 0;
+  for (int r = u.image_size; r > H; r >>= 1) ++level;
+  if (H != W || level > 3 || (u.image_size >> level) != H) return mvd_fail("mvd_unet_block: the resolution is not a UNet level");
+  const std::string p(path);
+  const UOp* op = nullptr;
+  const CondW* cond = nullptr;
+  int cond_idx = -1;
+  {
+    int i = -1, j = -1;
+    if (p == "middle_conditions") cond_idx = 0;
+    else if (sscanf(path, "output_conditions.%d", &i) == 1) cond_idx = i >= 3 ? 1 + (i - 3) : -1;
+    else if (sscanf(path, "input_blocks.%d.%d", &i, &j) == 2 && i >= 0 && i < (int)c->in_blocks.size() && j >= 0 &&
+             j < (int)c->in_blocks[i].size()) op = &c->in_blocks[i][j];
+    else if (sscanf(path, "middle_block.%d", &j) == 1 && j >= 0 && j < (int)c->mid_block.size()) op = &c->mid_block[j];
+    else if (sscanf(path, "output_blocks.%d.%d", &i, &j) == 2 && i >= 0 && i < (int)c->out_blocks.size() && j >= 0 &&
+             j < (int)c->out_blocks[i].size()) op = &c->out_blocks[i][j];
+    if (cond_idx >= 0 && cond_idx < (int)c->conds.size()) cond = &c->conds[cond_idx];
+    if (!op && !cond) return mvd_fail("mvd_unet_block: no such block");
+  }
+  WsScope ws_scope(c);
+  Ctx5 src[4];
+  Fwd f{c, s, B, cond ? B : 0, cond ? D << level : 0, nullptr, context, nullptr, src, {nullptr, nullptr, nullptr, nullptr}};
+  View in, out;
+  in.p = const_cast<float*>(x_nhwc); in.ld = C; in.C = C;
+  out.p = out_nhwc;
+  if (cond) {
+    if (C != cond->dim) return mvd_fail("mvd_unet_block: channel count does not match the DepthTransformer");
+    if (!vol_ndhwc || D <= 0) return mvd_fail("mvd_unet_block: a DepthTransformer needs its context volume");
+    src[level].p = vol_ndhwc;
+    src[level].f32 = 1;
+    const size_t n = (size_t)B * D * H * W * cond->Cc;
+    half_t* h = ws_alloc<half_t>(c, n);  // the forward's fp16 view of the context volume (engine_unet: fork_ctx)
+    WS_CHECK(h);
+    RET_IF(launch_f32_to_f16(vol_ndhwc, h, n, s));
+    f.src16[level] = h;
+    out.ld = out.C = cond->dim;
+    *Cout = cond->dim;
+    *Hout = H;
+    return unet_do_cond(f, *cond, in, out, H, W, level, -1);
+  }
+  if (C != op->cin) return mvd_fail("mvd_unet_block: channel count does not match the block");
+  if (op->kind == OP_RES && !t) return mvd_fail("mvd_unet_block: a ResBlock needs the timesteps");
+  if (op->kind == OP_ST && !context) return mvd_fail("mvd_unet_block: a SpatialTransformer needs the context");
+  float *ea = nullptr, *a2 = nullptr;
+  RET_IF(unet_embeddings(c, op->kind == OP_RES ? t : nullptr, op->kind == OP_ST ? context : nullptr, B, s, nullptr, nullptr, nullptr, &ea, &a2));
+  f.emb_all = ea;
+  f.a2_all = a2;
+  out.ld = out.C = op->cout;
+  *Cout = op->cout;
+  int Ho = H, Wo = W;
+  RET_IF(unet_do_op(f, *op, in, out, Ho, Wo, nullptr));
+  *Hout = Ho;
   return 0;
 }

@@ -182,6 +182,24 @@ class Engine:
                                           L.ptr(srcs[1]), L.ptr(srcs[2]), L.ptr(srcs[3]), depth0, L.ptr(out), _stream()))
         return out
 
+    def unet_block(self, path, x, timesteps=None, context=None, volume=None):
+        """One block of DepthWiseAttention through the production block code: ``path`` is the reference module path below
+        ``model.diffusion_model`` ("input_blocks.4.0", "output_blocks.8.2", "middle_conditions", "output_conditions.8", ...);
+        ResBlocks take ``timesteps`` [B], SpatialTransformers ``context`` [B,1,768], DepthTransformers ``volume`` [B,C,D,H,W]."""
+        dev = self.device
+        x = _f32(x, dev)
+        B, C, H, W = x.shape
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous() if timesteps is not None else None
+        ctx = _f32(context, dev) if context is not None else None
+        vol = _f32(volume, dev) if volume is not None else None
+        cap = B * H * W * 4 * self.ucfg.model_channels * 8
+        out = torch.empty(cap, device=dev, dtype=torch.float32)
+        shape = (C.c_int * 4)()
+        L.check(self.lib.mvd_unet_block(self._ctx, path.encode(), L.ptr(x), B, C, H, W, L.ptr(t), L.ptr(ctx), L.ptr(vol),
+                                        vol.shape[2] if vol is not None else 0, L.ptr(out), cap, shape, _stream()))
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        return out[:n].view(shape[0], shape[1], shape[2], shape[3]).clone()
+
     def embed_time(self, t):
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         out = torch.empty(t.shape[0], self.vcfg.time_dim, device=self.device, dtype=torch.float32)
@@ -404,12 +422,7 @@ class Engine:
                    check=True):
         """torch.optim.AdamW on the arena (two learning-rate groups, morphable_diffusion.py:627-646) + in-place re-pack of the
         fp16 weights.  Returns True when the update was skipped because a gradient was inf / nan (check=False: not read back)."""
-        if self.flat_m is None:
-            self.flat_m = torch.zeros_like(self.flat_params)
-            self.flat_v = torch.zeros_like(self.flat_params)
-            n = self.flat_params.numel()
-            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 2, L.ptr(self.flat_m), C.c_int64(n)))
-            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 3, L.ptr(self.flat_v), C.c_int64(n)))
+        self.ensure_moments()
         skipped = C.c_int(0)
         L.check(self.lib.mvd_train_adamw_step(self._ctx, C.c_float(lr), C.c_float(lr_aux), C.c_float(betas[0]),
                                               C.c_float(betas[1]), C.c_float(eps), C.c_float(weight_decay), int(step),
@@ -417,6 +430,15 @@ class Engine:
                                               C.byref(skipped) if check else None, _stream()))
         self.repack()
         return bool(skipped.value)
+
+    def ensure_moments(self):
+        """The two Adam moment arenas (zero until the first update), adopted by the library like the master / gradient arenas."""
+        if self.flat_m is None:
+            self.flat_m = torch.zeros_like(self.flat_params)
+            self.flat_v = torch.zeros_like(self.flat_params)
+            n = self.flat_params.numel()
+            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 2, L.ptr(self.flat_m), C.c_int64(n)))
+            L.check(self.lib.mvd_train_adopt_arena(self._ctx, 3, L.ptr(self.flat_v), C.c_int64(n)))
 
     def repack(self):
         """Re-derive every packed fp16 weight from the master parameters (after they changed), in place."""

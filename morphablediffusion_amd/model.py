@@ -653,6 +653,7 @@ class ArenaAdamW(torch.optim.Optimizer):
         else:
             self.steps_done += 1
             self._clean += 1
+            m.global_step = getattr(m, "global_step", 0) + 1  # what Lightning's loop advances per optimiser step
             if self._clean >= self.growth_interval:
                 self._clean = 0
                 m.loss_scale = min(m.loss_scale * 2.0, 2.0 ** 24)
@@ -660,6 +661,34 @@ class ArenaAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self.model.engine.zero_grad()  # the .grad views stay attached to the (now zero) arena
+
+    # The Adam moments live in the engine's flat arenas, not in torch's per-parameter ``state``: without these two methods a
+    # Lightning / torch checkpoint would carry an EMPTY optimiser state and a resumed run would restart with zero moments,
+    # bias-correction step 1 and the initial loss scale (torch.optim.AdamW round-trips all of that, morphable_diffusion.py:642).
+    def state_dict(self):
+        sd = super().state_dict()  # param_groups (learning rates as the scheduler left them); ``state`` is empty
+        eng = self.model.engine
+        eng.ensure_moments()
+        sd["arena"] = {"exp_avg": eng.flat_m.detach().clone(), "exp_avg_sq": eng.flat_v.detach().clone(),
+                       "step": self.steps_done, "steps_skipped": self.steps_skipped, "clean_steps": self._clean,
+                       "loss_scale": float(self.model.loss_scale), "numel": int(eng.flat_params.numel())}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        arena = state_dict.get("arena")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "arena"})
+        if arena is None:
+            raise KeyError("ArenaAdamW.load_state_dict: the checkpoint has no 'arena' entry (moments, step, loss scale)")
+        eng = self.model.engine
+        eng.ensure_moments()
+        if int(arena["numel"]) != eng.flat_params.numel():
+            raise ValueError(f"ArenaAdamW: checkpoint arena has {arena['numel']} elements, the engine {eng.flat_params.numel()}")
+        eng.flat_m.copy_(arena["exp_avg"].to(eng.flat_m.device))  # in place: the library holds these pointers
+        eng.flat_v.copy_(arena["exp_avg_sq"].to(eng.flat_v.device))
+        self.steps_done = int(arena["step"])
+        self.steps_skipped = int(arena.get("steps_skipped", 0))
+        self._clean = int(arena.get("clean_steps", 0))
+        self.model.loss_scale = float(arena["loss_scale"])
 
 
 class LambdaLinearScheduler:

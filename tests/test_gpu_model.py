@@ -89,6 +89,42 @@ def test_unet_small_vs_golden_and_oracle():
     assert rl2 <= REL_L2
 
 
+def test_unet_blocks_small_vs_golden():
+    """SURVEY section 8 rows a19-a22 block by block: the production ResBlock / SpatialTransformer / Downsample / Upsample /
+    DepthTransformer code (mvd_unet_block: same plans and kernels as the whole forward) on the inputs the reference's own
+    blocks were run on by tools/make_goldens.py (openaimodel.py:256-276, modules/attention.py:325-336,
+    ldm/models/diffusion/attention.py:78-84).  Until round 4 these fixtures were compared with the oracle only."""
+    from morphablediffusion_amd.model import DepthWiseAttention
+    cfg = gi.SMALL_UNET
+    g = np.load(os.path.join(G, "unet_small.npz"))
+    W = gi.unet_weights(cfg)
+    net = DepthWiseAttention(volume_dims=cfg.volume_dims, image_size=32, in_channels=8, out_channels=4,
+                             model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                             channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                             transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+    net.load_state_dict({k[len("model.diffusion_model."):]: v for k, v in W.items()})
+    e = net._engine
+    x, t, ctx, sd = gi.unet_inputs(cfg, Bv=2)
+    gen = torch.Generator().manual_seed(5)  # the draws of tools/make_goldens.py / tests/test_oracle_golden.py
+    h64 = torch.randn(2, 64, 32, 32, generator=gen)
+    h128 = torch.randn(2, 128, 16, 16, generator=gen)
+    h256 = torch.randn(2, 256, 8, 8, generator=gen)
+    compare(e.unet_block("input_blocks.1.0", h64, timesteps=t), g, "res_same")
+    compare(e.unet_block("input_blocks.4.0", h64[:, :, ::2, ::2].contiguous(), timesteps=t), g, "res_skip")
+    compare(e.unet_block("input_blocks.1.1", h64, context=ctx), g, "st32")
+    compare(e.unet_block("input_blocks.4.1", h128, context=ctx), g, "st16")
+    compare(e.unet_block("input_blocks.7.1", h256, context=ctx), g, "st8")
+    compare(e.unet_block("input_blocks.3.0", h64), g, "down")
+    compare(e.unet_block("output_blocks.8.2", h128), g, "up")
+    compare(e.unet_block("output_conditions.8", h64, volume=sd[32]), g, "cond8")
+    compare(e.unet_block("output_conditions.3", h128, volume=sd[16]), g, "cond3")
+    compare(e.unet_block("middle_conditions", h256[:, :, ::2, ::2].contiguous(), volume=sd[4]), g, "cond_mid")
+    with pytest.raises(Exception):
+        e.unet_block("input_blocks.99.0", h64, timesteps=t)
+    with pytest.raises(Exception):
+        e.unet_block("input_blocks.1.0", h64)  # a ResBlock without its timesteps
+
+
 def test_unet_full_vs_golden():
     from morphablediffusion_amd.model import DepthWiseAttention
     cfg = gi.FULL_UNET

@@ -302,6 +302,52 @@ def test_adamw_step_and_repack():
     m2.engine.close()
 
 
+def test_optimizer_state_round_trip_resumes_bit_identically():
+    """the Adam moments, the bias-correction step and the loss scale live outside torch's Optimizer.state -- a
+    checkpoint made of model.state_dict() + optimizer.state_dict() must resume so that update N+1 is the one an uninterrupted
+    run makes, bit for bit (torch.optim.AdamW round-trips its state the same way, morphable_diffusion.py:642)."""
+    import io
+    g, dev, prepared, draws = _inputs()
+    N = int(g["N"])
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        m.training_step(dev, prepared=prepared, **draws)
+        opt.step()
+
+    m = make_train_model(ucfg, vcfg, N, loss_scale=65536.0, recompute=True)
+    m.learning_rate = 5e-5
+    (opt,), _ = m.configure_optimizers()
+    one_step(m, opt)
+    one_step(m, opt)
+    m.loss_scale = 16384.0  # as if two overflows had happened: must survive the round trip
+    buf = io.BytesIO()
+    torch.save({"state_dict": m.state_dict(), "optimizer": opt.state_dict()}, buf)
+    assert m.global_step == 2
+    one_step(m, opt)  # update 3 of the uninterrupted run
+    want = m.engine.flat_params.clone()
+    m.engine.close()
+    # resume in a fresh model / engine / optimiser from the checkpoint bytes
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    assert ck["optimizer"]["arena"]["step"] == 2 and ck["optimizer"]["arena"]["exp_avg"].abs().max() > 0
+    m2 = make_train_model(ucfg, vcfg, N, loss_scale=65536.0, recompute=True)
+    m2.load_state_dict(ck["state_dict"])
+    m2.learning_rate = 5e-5
+    (opt2,), _ = m2.configure_optimizers()
+    opt2.load_state_dict(ck["optimizer"])
+    assert opt2.steps_done == 2 and m2.loss_scale == 16384.0
+    one_step(m2, opt2)
+    hi = _unet_range(m2.engine)
+    assert torch.equal(m2.engine.flat_params[:hi], want[:hi]), "update 3 after the resume differs from the uninterrupted run"
+    # (the conditioner's scatter adjoints use hardware fp32 atomics: its parameters agree to rounding, not bit for bit)
+    assert torch.allclose(m2.engine.flat_params[hi:], want[hi:], rtol=1e-5, atol=1e-7)
+    with pytest.raises(KeyError):
+        opt2.load_state_dict({k: v for k, v in ck["optimizer"].items() if k != "arena"})
+    m2.engine.close()
+
+
 def test_training_step_default_prepare_path():
     """training_step(batch) with no overrides: prepare() VAE-encodes the target views itself, time steps are drawn
     before it, sampling afterwards still works on the same context."""
