@@ -129,7 +129,8 @@ bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo);
 // split != 0: out rows hold [hi | lo | hi] (3C halfs, ldo >= 3C), see IGemm::out_split
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split = 0,
-                    int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr);
+                    int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr, const float* resid = nullptr, int ldr = 0,
+                    float* mat = nullptr, int ldm = 0);
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                      half_t* out, hipStream_t s);
 int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,

@@ -386,14 +386,18 @@ struct Fwd {
   bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
   bool train = false;     // training forward: no deferred split-K slabs, LN1 / LN3 outputs in separate buffers
 };
+struct Carry;
 int unet_embeddings(mvd_ctx* c, const int64_t* t, const float* context, int Bv, hipStream_t s, float** e0_out, float** e1_out,
                     float** e2_out, float** ea_out, float** a2_out);
 int engine_unet_block(mvd_ctx* c, const char* path, const float* x_nhwc, int B, int C, int H, int W, const int64_t* t,
                       const float* context, const float* vol_ndhwc, int D, float* out_nhwc, int* Cout, int* Hout, hipStream_t s);
-int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv = nullptr);
-int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv = nullptr);
+int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv = nullptr, Carry* in_carry = nullptr,
+                Carry* out_carry = nullptr);
+int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv = nullptr, Carry* in_carry = nullptr,
+               Carry* out_carry = nullptr);
 int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx = -1);
-int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec = nullptr);
+int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec = nullptr, Carry* in_carry = nullptr,
+               Carry* out_carry = nullptr);
 // engine_weights.hip: re-derive the packed weights of the UNet / step embedding / conditioner from the master parameters
 int engine_repack(mvd_ctx* c);
 // engine_train.hip
@@ -475,6 +479,24 @@ struct GemmArgs {
   float* slabs = nullptr;
   size_t slabs_cap = 0;
   int* sk_used = nullptr;
+  // with `slabs`: the deferral may also leave the bias and an fp32 residual to the consumer (run_group_norm: bias2 / resid);
+  // without this flag a GEMM with a residual always reduces its slabs itself
+  bool defer_epilogue = false;
+};
+// A block's output left as the split-K slabs of its last GEMM: the NEXT block's first GroupNorm sums them, adds the bias and
+// the residual, writes the finished tensor to its own input view (for the later readers: residual adds, skip connections)
+// and normalises it -- the GEMM's reduce pass and the GroupNorm in one launch (engine_unet.hip: run_chain).
+struct Carry {
+  float* slabs = nullptr;  // storage provided by the caller; outlives the producing block
+  size_t cap = 0;          // floats
+  float* aux = nullptr;    // storage for a residual operand that must outlive the producing block (the skip conv's result)
+  size_t aux_cap = 0;
+  // filled by the producer; sk == 1: nothing was deferred, the output view holds the finished tensor
+  int sk = 1;
+  size_t stride = 0;       // floats between slabs (rows * N)
+  const float* bias = nullptr;
+  const float* resid = nullptr;
+  int ldr = 0;
 };
 // plain GEMM / 1x1 conv over `rows` rows grouped in `B` samples (rows % B == 0)
 int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s);
@@ -492,7 +514,8 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 // and the pre-add, is the tensor to normalise (GemmArgs::slabs)
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
                    int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld = 0, int split = 0,
-                   int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr);
+                   int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr, const float* resid = nullptr, int ldr = 0,
+                   float* mat = nullptr, int ldm = 0);
 // restores the workspace bump pointer when the scope is left, on the error returns too (a failed call must not leak
 // workspace into the calls that follow it)
 enum { WS_CHAIN = 0, WS_BLOCK = 1, WS_TEMP = 2 };

@@ -7,6 +7,8 @@
 //     channel slice of the buffer the matching output block will read (row stride = concatenated width).
 #include <string.h>
 
+#include <algorithm>
+
 #include "engine.h"
 
 namespace {
@@ -157,8 +159,9 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
   g.partial = nullptr;
   bool deferred = false;  // the caller's consumer adds the slabs (GemmArgs::slabs): no reduce pass
   if (sk > 1) {
-    if (defer && defer->slabs && defer->sk_used && sk <= 4 && (size_t)sk * M * g.N <= defer->slabs_cap && !g.geglu && !g.resid &&
-        g.act == 0 && g.alpha == 1.0f) {
+    if (defer && defer->slabs && defer->sk_used && sk <= 16 && (size_t)sk * M * g.N <= defer->slabs_cap && !g.geglu &&
+        (!g.resid || (defer->defer_epilogue && g.resid_f32)) && g.act == 0 && g.alpha == 1.0f && g.out_linear && g.out_f32 &&
+        !g.out_split) {
       g.partial = defer->slabs;
       deferred = true;
     } else {
@@ -230,7 +233,7 @@ int run_linear(mvd_ctx* c, const GemmArgs& ga, int B, int rows, hipStream_t s) {
   g.IX = g.X;
   g.PX = g.X;
   g.ntaps = 1;
-  return igemm_go(c, g, ga.force_splitk, s);
+  return igemm_go(c, g, ga.force_splitk, s, &ga);
 }
 
 int run_conv2d(mvd_ctx* c, const GemmArgs& ga, int B, int H, int W, int stride, int ups, hipStream_t s) {
@@ -394,14 +397,14 @@ int run_convT3d(mvd_ctx* c, const GemmArgs& ga, int B, int D, int H, int W, hipS
 
 int run_group_norm(mvd_ctx* c, const float* x, int ld, int B, int rows_per_sample, const NormW& n, int groups, float eps,
                    int act, const float* preadd, half_t* out, int ldo, hipStream_t s, int preadd_ld, int split, int nslab,
-                   size_t slab_stride, const float* bias2) {
+                   size_t slab_stride, const float* bias2, const float* resid, int ldr, float* mat, int ldm) {
   // algorithmic: x read once (fp32), fp16 result written once
   ProbeScope ps(c, s, "group_norm", 0.0, (double)B * rows_per_sample * n.C * 6.0);
   static const bool two_pass = getenv("MVD_GN_TWO_PASS") != nullptr;
   if (!two_pass && gn_group_eligible(ld, rows_per_sample, n.C, groups, preadd ? (preadd_ld ? preadd_ld : n.C) : 0, ldo))
     return launch_gn_group(x, ld, B, rows_per_sample, n.C, groups, preadd, preadd_ld ? preadd_ld : n.C, n.g, n.b, eps, act, out,
-                           ldo, s, split, nslab, slab_stride, bias2);
-  if (nslab > 1) return mvd_fail("run_group_norm: slab input needs the single-pass form");
+                           ldo, s, split, nslab, slab_stride, bias2, resid, ldr, mat, ldm);
+  if (nslab > 1 || resid || mat) return mvd_fail("run_group_norm: slab input needs the single-pass form");
   WsScope ws_scope(c, WS_TEMP);
   float* partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
   WS_CHECK(partial);
@@ -417,7 +420,7 @@ namespace {
 }  // namespace
 
 // ResBlock._forward, openaimodel.py:256-276
-int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv) {
+int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved* sv, Carry* in_carry, Carry* out_carry) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c, WS_BLOCK);
   const int rows = f.Bv * H * W;
@@ -427,7 +430,11 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
   half_t* a2 = ws_alloc<half_t>(c, (size_t)rows * r.cout * w2);
   WS_CHECK(a1 && h1 && a2);
-  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp));
+  if (in_carry && in_carry->sk > 1)  // the previous block's last GEMM left its split-K slabs: sum + bias + residual -> in, then normalise
+    RET_IF(run_group_norm(c, in_carry->slabs, r.cin, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp,
+                          in_carry->sk, in_carry->stride, in_carry->bias, in_carry->resid, in_carry->ldr, in.p, in.ld));
+  else
+    RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp));
   GemmArgs g1;
   g1.a = a1; g1.lda = r.cin * w1; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
   g1.rowbias = f.emb_all + r.emb_off; g1.rb_ld = c->emb_total;
@@ -437,8 +444,9 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   int sk1 = 1;
   const size_t slab_elems = (size_t)rows * r.cout;
   if (!no_defer && !f.train && gn_group_eligible(r.cout, H * W, r.cout, 32, c->emb_total, r.cout * w2)) {
-    g1.slabs = ws_alloc<float>(c, 4 * slab_elems);
-    g1.slabs_cap = g1.slabs ? 4 * slab_elems : 0;
+    const size_t nsl = rows > 8192 ? 4 : 16;  // the 4 x 4 level's convolutions split K twelve ways; full resolution never splits
+    g1.slabs = ws_alloc<float>(c, nsl * slab_elems);
+    g1.slabs_cap = g1.slabs ? nsl * slab_elems : 0;
     g1.sk_used = &sk1;
   }
   RET_IF(run_conv2d(c, g1, f.Bv, H, W, 1, 0, f.s));
@@ -450,7 +458,9 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   const float* resid = in.p;
   int ldr = in.ld;
   if (r.has_skip) {
-    float* sk = ws_alloc<float>(c, (size_t)rows * r.cout);
+    // (a deferred conv2 hands the residual to the NEXT block's GroupNorm: the skip conv's result then lives in the carry)
+    float* sk = (out_carry && out_carry->aux && out_carry->aux_cap >= (size_t)rows * r.cout) ? out_carry->aux
+                                                                                              : ws_alloc<float>(c, (size_t)rows * r.cout);
     WS_CHECK(sk);
     GemmArgs gs;
     gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
@@ -466,7 +476,18 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   }
   GemmArgs g2;
   g2.a = a2; g2.lda = r.cout * w2; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
+  int sk2 = 1;
+  if (out_carry && out_carry->slabs) {
+    g2.slabs = out_carry->slabs; g2.slabs_cap = out_carry->cap; g2.sk_used = &sk2; g2.defer_epilogue = true;
+  }
   RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));
+  if (out_carry) {
+    out_carry->sk = sk2;
+    out_carry->stride = (size_t)rows * r.cout;
+    out_carry->bias = r.c2.bias;
+    out_carry->resid = resid;
+    out_carry->ldr = ldr;
+  }
   if (sv) {
     sv->a1 = a1; sv->ld1 = r.cin * w1; sv->h1 = h1; sv->a2 = a2; sv->ld2 = r.cout * w2;
   }
@@ -474,7 +495,7 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
 }
 
 // SpatialTransformer.forward modules/attention.py:325-336, BasicTransformerBlock._forward :265-269
-int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv) {
+int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* sv, Carry* in_carry, Carry* out_carry) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c, WS_BLOCK);
   const int C = t.C, T = H * W, rows = f.Bv * T;
@@ -489,7 +510,11 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
   half_t* l3 = f.train ? ws_alloc<half_t>(c, (size_t)rows * C) : l1;  // the backward pass needs both LayerNorm outputs
   WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3 && l3);
-  RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
+  if (in_carry && in_carry->sk > 1)
+    RET_IF(run_group_norm(c, in_carry->slabs, C, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp,
+                          in_carry->sk, in_carry->stride, in_carry->bias, in_carry->resid, in_carry->ldr, in.p, in.ld));
+  else
+    RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
   g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
@@ -524,7 +549,18 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   g = GemmArgs();
   g.a = t3; g.lda = C * wo; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
+  int skp = 1;
+  if (out_carry && out_carry->slabs) {
+    g.slabs = out_carry->slabs; g.slabs_cap = out_carry->cap; g.sk_used = &skp; g.defer_epilogue = true;
+  }
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  if (out_carry) {
+    out_carry->sk = skp;
+    out_carry->stride = (size_t)rows * C;
+    out_carry->bias = t.proj_out.bias;
+    out_carry->resid = in.p;
+    out_carry->ldr = in.ld;
+  }
   if (sv) {
     sv->n0 = n0; sv->ldn0 = C * wi; sv->t0 = t0; sv->l1 = l1; sv->qkv = qkv; sv->ao = ao; sv->t2 = t2; sv->l3 = l3; sv->gg = gg;
     sv->t3 = t3; sv->ldt3 = C * wo;
@@ -627,18 +663,24 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
   return 0;
 }
 
-int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec) {
+int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec, Carry* in_carry, Carry* out_carry) {
   mvd_ctx* c = f.c;
   const bool keep = rec && c->ws.hold == 2;  // keep-all tape: the block's intermediates stay valid
   if (rec) rec->have_saved = keep;
   switch (op.kind) {
-    case OP_RES: return unet_do_res(f, c->res[op.idx], in, out, H, W, keep ? &rec->rs : nullptr);
-    case OP_ST: return unet_do_st(f, c->st[op.idx], in, out, H, W, keep ? &rec->ss : nullptr);
+    case OP_RES: return unet_do_res(f, c->res[op.idx], in, out, H, W, keep ? &rec->rs : nullptr, in_carry, out_carry);
+    case OP_ST: return unet_do_st(f, c->st[op.idx], in, out, H, W, keep ? &rec->ss : nullptr, in_carry, out_carry);
     case OP_CONV_IN:
     case OP_DOWN:
     case OP_UP: {
+      if (in_carry && in_carry->sk > 1) return mvd_fail("unet_do_op: a convolution cannot take a deferred input");
       GemmArgs g;
       g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &c->convs[op.idx]; g.out = out.p; g.ldc = out.ld;
+      int skc = 1;
+      const bool can_defer = out_carry && out_carry->slabs && op.kind == OP_DOWN && !c->convs[op.idx].xp;
+      if (can_defer) {
+        g.slabs = out_carry->slabs; g.slabs_cap = out_carry->cap; g.sk_used = &skc; g.defer_epilogue = true;
+      }
       const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
       WsScope ws_scope(c, WS_BLOCK);
       if (c->convs[op.idx].xp) {  // extended precision (conv_in): fp32 source -> [hi | lo | hi] copy
@@ -652,6 +694,13 @@ int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRe
       if (ups && c->convs[op.idx].w_up && f.Bv * H * W >= 2048) RET_IF(run_upconv2d(c, g, f.Bv, H, W, f.s));
       else RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
       if (op.kind == OP_DOWN) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
+      if (out_carry) {
+        out_carry->sk = skc;
+        out_carry->stride = (size_t)f.Bv * H * W * op.cout;
+        out_carry->bias = c->convs[op.idx].bias;
+        out_carry->resid = nullptr;
+        out_carry->ldr = 0;
+      }
       if (op.kind == OP_UP) { H *= 2; W *= 2; }
       return 0;
     }
@@ -857,10 +906,40 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   }
   int chain_id = 0;
 
-  auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W) -> int {
-    WsScope ws_scope(c);
+  // A block whose first layer is a single-pass GroupNorm over exactly the previous block's output can take that output as
+  // split-K slabs (Carry): the previous block's reduce pass and this GroupNorm become one launch.
+  static const bool no_carry = getenv("MVD_NO_CARRY") != nullptr;
+  auto takes_carry = [&](const UOp& nx, int Hn) -> bool {
+    if (no_carry || tape || (long)Bv * Hn * Hn > 8192) return false;  // (full resolution never splits K)
+    const int C = nx.cin;
+    if (nx.kind == OP_RES) return gn_group_eligible(C, Hn * Hn, C, 32, 0, C * (c->res[nx.idx].c1.xp ? 3 : 1));
+    if (nx.kind == OP_ST) return gn_group_eligible(C, Hn * Hn, C, 32, 0, C * (c->st[nx.idx].proj_in.xp ? 3 : 1));
+    return false;
+  };
+  auto carry_storage = [&](Carry& cy, size_t elems) {  // may leave the pointers null (no workspace): then nothing is deferred
+    cy = Carry();
+    cy.slabs = ws_alloc<float>(c, 16 * elems);
+    cy.cap = cy.slabs ? 16 * elems : 0;
+    cy.aux = cy.slabs ? ws_alloc<float>(c, elems) : nullptr;
+    cy.aux_cap = cy.aux ? elems : 0;
+  };
+  // in_carry: the chain's input was left as slabs by the previous chain; out_carry: the chain's last block may leave its
+  // output as slabs for the next chain's first block (the caller checked takes_carry).  keep_temps: the chain's
+  // intermediate tensors stay allocated after it returns (a carried output's residual operand may be one of them).
+  auto run_chain = [&](const std::vector<UOp>& ops, const CondW* cond, View in, View dst, int& H, int& W, Carry* in_carry,
+                       Carry* out_carry, bool keep_temps) -> int {
+    struct OptScope {
+      mvd_ctx* c;
+      size_t mark;
+      bool on;
+      ~OptScope() {
+        if (on && !c->ws.hold) c->ws.off = mark;
+      }
+    } ws_scope{c, c->ws.off, !keep_temps};
     View cur = in;
     const int nstage = (int)ops.size() + (cond ? 1 : 0);
+    Carry local[2];
+    Carry* prev = in_carry;
     for (int k = 0; k < nstage; ++k) {
       const bool last = k == nstage - 1;
       const bool is_cond = cond && k == (int)ops.size();
@@ -882,16 +961,32 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       rec.H = H;
       rec.W = W;
       for (int r = u.image_size; r > H; r >>= 1) ++rec.level;
+      Carry* oc = nullptr;
       if (is_cond) {
+        if (prev && prev->sk > 1) return mvd_fail("run_chain: a DepthTransformer cannot take a deferred input");
         rec.kind = OP_COND;
         rec.idx = (int)(cond - c->conds.data());
         RET_IF(unet_do_cond(f, *cond, cur, o, H, W, rec.level, rec.idx));
       } else {
+        if (!last) {
+          const bool next_is_cond = cond && k + 1 == (int)ops.size();
+          if (!next_is_cond && takes_carry(ops[k + 1], Ho)) {
+            oc = &local[k & 1];
+            carry_storage(*oc, (size_t)Bv * Ho * Ho * cout);
+          }
+        } else if (out_carry) {
+          oc = out_carry;
+        }
+        if (oc) {
+          oc->sk = 1;
+          oc->resid = oc->bias = nullptr;
+        }
         rec.kind = ops[k].kind;
         rec.idx = ops[k].idx;
         rec.in.C = ops[k].cin;
-        RET_IF(unet_do_op(f, ops[k], cur, o, H, W, tape ? &rec : nullptr));
+        RET_IF(unet_do_op(f, ops[k], cur, o, H, W, tape ? &rec : nullptr, prev, oc));
       }
+      prev = oc;
       if (tape) tape->stages.push_back(rec);
       cur = o;
     }
@@ -903,6 +998,19 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   cur.p = const_cast<float*>(x_nhwc);
   cur.ld = x_ld;
   cur.C = u.in_channels;
+  // input blocks: one block's output goes to the next block only (its other reader, the skip connection, reads the finished
+  // tensor much later), so the carry crosses the chain boundaries here; two storages alternate
+  Carry xcarry[2];
+  {
+    size_t emax = 0;
+    for (int j = 0; j < nb; ++j)
+      if ((long)Bv * in_res[j] * in_res[j] <= 8192) emax = std::max(emax, (size_t)Bv * in_res[j] * in_res[j] * in_ch[j]);
+    if (emax && !tape && !no_carry) {
+      carry_storage(xcarry[0], emax);
+      carry_storage(xcarry[1], emax);
+    }
+  }
+  Carry* prev_carry = nullptr;
   for (int j = 0; j < nb; ++j) {
     const int i = nb - 1 - j;
     View dst;
@@ -910,7 +1018,10 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.ld = cat_C[i];
     dst.C = in_ch[j];
     chain_id = j;
-    RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W));
+    const std::vector<UOp>& next_ops = j + 1 < nb ? c->in_blocks[j + 1] : c->mid_block;
+    Carry* outc = (xcarry[j & 1].slabs && !next_ops.empty() && takes_carry(next_ops[0], in_res[j])) ? &xcarry[j & 1] : nullptr;
+    RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W, prev_carry, outc, true));
+    prev_carry = outc;
     cur = dst;
     if (!forked && (H < u.image_size || j == nb - 1)) RET_IF(fork_ctx());
   }
@@ -919,7 +1030,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     dst.p = cat[0];
     dst.ld = cat_C[0];
     chain_id = nb;
-    RET_IF(run_chain(c->mid_block, &c->conds[0], cur, dst, H, W));
+    RET_IF(run_chain(c->mid_block, &c->conds[0], cur, dst, H, W, prev_carry, nullptr, false));
   }
   for (int i = 0; i < nb; ++i) {
     View in;
@@ -936,7 +1047,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     }
     const CondW* cond = i >= 3 ? &c->conds[1 + (i - 3)] : nullptr;  // attention.py:100
     chain_id = nb + 1 + i;
-    RET_IF(run_chain(c->out_blocks[i], cond, in, dst, H, W));
+    RET_IF(run_chain(c->out_blocks[i], cond, in, dst, H, W, nullptr, nullptr, false));
   }
   // out: GroupNorm32 + SiLU + zero-init conv (openaimodel.py:717-721)
   {
@@ -999,7 +1110,7 @@ int engine_unet_block(mvd_ctx* c, const char* path, const float* x_nhwc, int B, 
   {
     int i = -1, j = -1;
     if (p == "middle_conditions") cond_idx = 0;
-    else if (sscanf(path, "output_conditions.%d", &i) == 1) cond_idx = i >= 3 ? 1 + (i - 3) : -1;
+    else if (sscanf(path, "output_conditions.%d", &i) == 1) cond_idx = i >= 0 ? 1 + i : -1;  // ModuleList index (attention.py:98-113)
     else if (sscanf(path, "input_blocks.%d.%d", &i, &j) == 2 && i >= 0 && i < (int)c->in_blocks.size() && j >= 0 &&
              j < (int)c->in_blocks[i].size()) op = &c->in_blocks[i][j];
     else if (sscanf(path, "middle_block.%d", &j) == 1 && j >= 0 && j < (int)c->mid_block.size()) op = &c->mid_block[j];

@@ -253,13 +253,19 @@ __device__ unsigned long long mvd_gn_tl[8 * 4096];
 // (register tiles of up to 10 pairs are held to 64 VGPRs = 2048 resident threads per CU: the 1024-thread variant compiled to
 // 70, i.e. one workgroup per CU and four rounds for the 1024 slices of a 32-sample batch)
 // NS > 1: x is NS split-K slabs (slab_stride floats apart) of the producing conv; their sum + bias2[c] + the pre-add is the
-// tensor to normalise (the conv's reduce pass never runs: GemmArgs::slabs)
+// tensor to normalise (the conv's reduce pass never runs: GemmArgs::slabs).  NS == 0: the slab count is the run-time `nslab`
+// (5 ... 16 slabs: the 4 x 4 level's convolutions split K twelve ways); the slabs are added in slab order either way.
+// resid (optional, row stride ldr): added to the sum like the reduce pass's residual epilogue.  mat (optional, row stride
+// ldm): the summed tensor is ALSO written there in fp32 -- the materialised output of the producing GEMM for its later
+// readers (residual adds, skip connections), which makes this kernel the GEMM's reduce pass and the next block's first
+// GroupNorm in one launch.
 template <int NT, int MAXE, int NS>
 __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(const float* __restrict__ x, int ld, int rows, int C, int G,
                                                       const float* __restrict__ preadd, int pld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, int act, half_t* __restrict__ out, int ldo, int split,
-                                                      long slab_stride, const float* __restrict__ bias2) {
+                                                      long slab_stride, const float* __restrict__ bias2, int nslab,
+                                                      const float* __restrict__ resid, int ldr, float* __restrict__ mat, int ldm) {
   __shared__ float s_red[NT / 64];
   // the group's gain, bias and pre-add in LDS: as global loads inside the store loop (4 loads per 4-byte store, each
   // iteration waiting on its own) they made "normalise + store" 9 of the workgroup's 13.7 us (tools/gn_timeline.py)
@@ -291,9 +297,22 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
     if (e < n2) {
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
       v[i] = *(const float2*)(xb + (long)row * ld + 2 * j);
+      if constexpr (NS == 0) {
+        for (int sl = 1; sl < nslab; ++sl) {
+          const float2 q2 = *(const float2*)(xb + sl * slab_stride + (long)row * ld + 2 * j);
+          v[i].x += q2.x;
+          v[i].y += q2.y;
+        }
+      } else {
 #pragma unroll
-      for (int sl = 1; sl < NS; ++sl) {
-        const float2 q2 = *(const float2*)(xb + sl * slab_stride + (long)row * ld + 2 * j);
+        for (int sl = 1; sl < NS; ++sl) {
+          const float2 q2 = *(const float2*)(xb + sl * slab_stride + (long)row * ld + 2 * j);
+          v[i].x += q2.x;
+          v[i].y += q2.y;
+        }
+      }
+      if (resid) {
+        const float2 q2 = *(const float2*)(resid + ((long)b * rows + row) * ldr + g * cpg + 2 * j);
         v[i].x += q2.x;
         v[i].y += q2.y;
       }
@@ -309,6 +328,17 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
         const float2 p = *(const float2*)(&s_par[2][2 * j]);
         v[i].x += p.x;
         v[i].y += p.y;
+      }
+    }
+  }
+  if (mat) {
+    float* mb = mat + (long)b * rows * ldm + g * cpg;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int e = t + i * NT;
+      if (e < n2) {
+        const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
+        *(float2*)(mb + (long)row * ldm + 2 * j) = v[i];
       }
     }
   }
@@ -556,20 +586,22 @@ bool gn_group_eligible(int ld, int rows, int C, int G, int pld, int ldo) {
 
 int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const float* preadd, int pld, const float* gamma,
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split, int nslab,
-                    size_t slab_stride, const float* bias2) {
+                    size_t slab_stride, const float* bias2, const float* resid, int ldr, float* mat, int ldm) {
   const int n2 = rows * (C / G) / 2;
   if (split && ldo < 3 * C) return mvd_fail("gn_group: a split output needs ldo >= 3C");
-  if (nslab < 1 || nslab > 4) return mvd_fail("gn_group: 1 to 4 slabs");
+  if (nslab < 1 || nslab > 64) return mvd_fail("gn_group: 1 to 64 slabs");
+  if ((resid && (ldr & 1)) || (mat && (ldm & 1))) return mvd_fail("gn_group: residual / materialised rows must be 8-byte aligned");
   const dim3 grid(B * G);
 #define MVD_GN1(NT, ME, NS_)                                                                                                     \
   hipLaunchKernelGGL((gn_group_kernel<NT, ME, NS_>), grid, dim3(NT), 0, s, x, ld, rows, C, G, preadd, pld, gamma, beta, eps, act, \
-                     out, ldo, split, (long)slab_stride, bias2)
+                     out, ldo, split, (long)slab_stride, bias2, nslab, resid, ldr, mat, ldm)
 #define MVD_GN(NT, ME)                      \
   do {                                      \
     if (nslab == 1) MVD_GN1(NT, ME, 1);     \
     else if (nslab == 2) MVD_GN1(NT, ME, 2); \
     else if (nslab == 3) MVD_GN1(NT, ME, 3); \
-    else MVD_GN1(NT, ME, 4);                \
+    else if (nslab == 4) MVD_GN1(NT, ME, 4); \
+    else MVD_GN1(NT, ME, 0);                \
   } while (0)
   // the smallest register tile that holds the group (unused slots still cost predicated loop iterations), 512-thread
   // workgroups up to 8192 pairs: swept on the UNet's shapes (tools/gn_bench.py), e.g. C=320 @32x32: 35 -> 27 us

@@ -188,14 +188,14 @@ class Engine:
         ResBlocks take ``timesteps`` [B], SpatialTransformers ``context`` [B,1,768], DepthTransformers ``volume`` [B,C,D,H,W]."""
         dev = self.device
         x = _f32(x, dev)
-        B, C, H, W = x.shape
+        B, Cx, H, W = x.shape
         t = timesteps.to(device=dev, dtype=torch.int64).contiguous() if timesteps is not None else None
         ctx = _f32(context, dev) if context is not None else None
         vol = _f32(volume, dev) if volume is not None else None
         cap = B * H * W * 4 * self.ucfg.model_channels * 8
         out = torch.empty(cap, device=dev, dtype=torch.float32)
         shape = (C.c_int * 4)()
-        L.check(self.lib.mvd_unet_block(self._ctx, path.encode(), L.ptr(x), B, C, H, W, L.ptr(t), L.ptr(ctx), L.ptr(vol),
+        L.check(self.lib.mvd_unet_block(self._ctx, path.encode(), L.ptr(x), B, Cx, H, W, L.ptr(t), L.ptr(ctx), L.ptr(vol),
                                         vol.shape[2] if vol is not None else 0, L.ptr(out), cap, shape, _stream()))
         n = shape[0] * shape[1] * shape[2] * shape[3]
         return out[:n].view(shape[0], shape[1], shape[2], shape[3]).clone()

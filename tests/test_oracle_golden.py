@@ -336,3 +336,116 @@ def test_training_step_loss_and_gradients():
         assert abs(float(W[n].grad.double().norm()) - want_norm) <= 2e-3 * want_norm, n
     m_clip, m_vol, m_cat = O.drop_masks(dr)
     assert m_clip.tolist() == [0, 1, 1, 1] and m_vol.tolist() == [0, 0, 1, 1] and m_cat.tolist() == [0, 1, 0, 1]
+
+
+# ---- a11: the sparse voxel CNN on three independent derivations -----------------------------------------------------------
+def _hashmap_sparse_conv(feats, coords, shape, weight, stride):
+    """spconv's own formulation (get_indice_pairs + gather - GEMM - scatter-add), written from its documented algorithm and
+    independent of both the oracle's index-grid gather and the dense-masked emulation the goldens come from: every ACTIVE
+    INPUT proposes, for each kernel offset, the output site it contributes to; a hash map (a dict) assigns output rows;
+    per offset the (input row, output row) pairs are gathered, multiplied by that offset's [Cin, Cout] matrix and
+    scatter-added.  stride 1 = SubMConv3d (output sites are exactly the input sites: pairs whose output voxel is not active
+    are dropped), stride 2 = SparseConv3d(k3, s2, p1) (every proposed site inside the output extent becomes active)."""
+    inp = {tuple(c): i for i, c in enumerate(coords.tolist())}
+    oshape = list(shape) if stride == 1 else [(s - 1) // 2 + 1 for s in shape]
+    if stride == 1:
+        out_index = dict(inp)
+    else:
+        sites = set()
+        for (z, y, x) in inp:
+            for kz in range(3):
+                for ky in range(3):
+                    for kx in range(3):
+                        nz, ny, nx = z + 1 - kz, y + 1 - ky, x + 1 - kx  # out * 2 - pad + k = in
+                        if nz % 2 or ny % 2 or nx % 2:
+                            continue
+                        o = (nz // 2, ny // 2, nx // 2)
+                        if all(0 <= o[a] < oshape[a] for a in range(3)):
+                            sites.add(o)
+        out_index = {o: i for i, o in enumerate(sorted(sites))}
+    out = torch.zeros(len(out_index), weight.shape[0], dtype=torch.float64)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                pin, pout = [], []
+                for (z, y, x), i in inp.items():
+                    nz, ny, nx = z + 1 - kz, y + 1 - ky, x + 1 - kx
+                    if stride == 2:
+                        if nz % 2 or ny % 2 or nx % 2:
+                            continue
+                        o = (nz // 2, ny // 2, nx // 2)
+                    else:
+                        o = (nz, ny, nx)
+                    j = out_index.get(o)
+                    if j is not None:
+                        pin.append(i)
+                        pout.append(j)
+                if pin:
+                    out.index_add_(0, torch.tensor(pout), feats[pin].double() @ weight[:, :, kz, ky, kx].t().double())
+    ocoords = torch.tensor(sorted(out_index, key=out_index.get), dtype=torch.long).reshape(-1, 3)
+    return out.float(), ocoords, oshape
+
+
+@pytest.mark.parametrize("case", ["odd extents", "duplicates", "border sites"])
+def test_sparse_cnn_three_derivations_agree(case):
+    """SURVEY section 8 row a11 (network.py:74-161; spconv is not importable, requirements.txt:18): the oracle's index-grid
+    rule book, spconv's pair-list algorithm restated with a hash map, and the dense-masked emulation behind the goldens must
+    give the same network output on meshes the goldens do not cover -- odd voxel extents at every level, several vertices in
+    one voxel (first one wins), active sites on the grid border."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ref_import as RI
+    from morphablediffusion_amd.spec import full_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    g = torch.Generator().manual_seed({"odd extents": 3, "duplicates": 4, "border sites": 5}[case])
+    shape = {"odd extents": [37, 45, 27], "duplicates": [24, 32, 28], "border sites": [20, 20, 20]}[case]
+    n = 900
+    coords = torch.stack([torch.randint(0, s, (n,), generator=g) for s in shape], 1)
+    if case == "border sites":
+        coords[:200, 0] = 0
+        coords[200:400, 1] = shape[1] - 1
+        coords[400:500, 2] = torch.where(torch.rand(100, generator=g) < 0.5, 0, shape[2] - 1)
+    key = (coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]
+    if case == "duplicates":
+        coords = torch.cat([coords, coords[:300]], 0)  # 300 voxels hold two vertices with DIFFERENT features
+    else:  # unique voxels
+        _, first = np.unique(key.numpy(), return_index=True)
+        coords = coords[np.sort(first)]
+    feats = torch.randn(coords.shape[0], 16, generator=g)
+    vcfg = VolumeConfig()
+    W = {k: v for k, v in seeded_state_dict(full_manifest(gi.SMALL_UNET, vcfg), 7).items() if k.startswith("spatial_volume.xyzc_net.")}
+    P = "spatial_volume.xyzc_net."
+    want = O.sparse_conv_net(W, feats, coords, shape)[0]  # derivation 1: the oracle
+    # the representative of a voxel is its FIRST vertex (what the oracle and the engine implement)
+    key = ((coords[:, 0] * shape[1] + coords[:, 1]) * shape[2] + coords[:, 2]).numpy()
+    _, first = np.unique(key, return_index=True)
+    keep = np.sort(first)
+    uc, uf = coords[keep], feats[keep]
+    # derivation 2: hash-map pair lists
+    x, c2, sh2 = uf, uc, list(shape)
+    for blk, nconv in (("conv0", 2), ("down0", 1), ("conv1", 2), ("down1", 1), ("conv2", 3)):
+        for i in range(nconv):
+            x, c2, sh2 = _hashmap_sparse_conv(x, c2, sh2, W[f"{P}{blk}.{3 * i}.weight"], 2 if blk.startswith("down") else 1)
+            x = O._bn_relu(W, f"{P}{blk}.{3 * i + 1}", x)
+    got2 = torch.zeros([x.shape[1]] + sh2)
+    got2[:, c2[:, 0], c2[:, 1], c2[:, 2]] = x.t()
+    # derivation 3: the dense-masked emulation (conv3d * mask), layers assembled as network.py:98-161 does
+    t = RI._make_sparse_conv_tensor(uf, torch.cat([torch.zeros(len(uc), 1, dtype=torch.long), uc], 1), shape, 1)
+    with torch.no_grad():
+        for blk, nconv in (("conv0", 2), ("down0", 1), ("conv1", 2), ("down1", 1), ("conv2", 3)):
+            for i in range(nconv):
+                w = W[f"{P}{blk}.{3 * i}.weight"]
+                conv = RI._SparseConv3d(w.shape[1], w.shape[0], 3, 2, padding=1) if blk.startswith("down") else RI._SubMConv3d(w.shape[1], w.shape[0], 3)
+                conv.weight.data.copy_(w)
+                bn = torch.nn.BatchNorm1d(w.shape[0], eps=1e-3, momentum=0.01).eval()
+                q = f"{P}{blk}.{3 * i + 1}"
+                bn.weight.data.copy_(W[q + ".weight"]); bn.bias.data.copy_(W[q + ".bias"])
+                bn.running_mean.copy_(W[q + ".running_mean"]); bn.running_var.copy_(W[q + ".running_var"])
+                t = RI._SparseSequential(conv, bn, torch.nn.ReLU())(t)
+    got3 = t.dense()[0]
+    assert list(want.shape) == list(got2.shape) == list(got3.shape), (want.shape, got2.shape, got3.shape)
+    assert want.abs().max() > 0
+    for name, got in (("hash-map pair lists", got2), ("dense-masked emulation", got3)):
+        err = ((got - want).abs().max() / want.abs().max()).item()
+        assert (got != 0).eq(want != 0).all(), f"{case}: active sites differ ({name})"
+        assert err <= 2e-5, f"{case}: {name} vs oracle {err:.2e}"
