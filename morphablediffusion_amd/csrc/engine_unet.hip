@@ -159,7 +159,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
   g.partial = nullptr;
   bool deferred = false;  // the caller's consumer adds the slabs (GemmArgs::slabs): no reduce pass
   if (sk > 1) {
-    if (defer && defer->slabs && defer->sk_used && sk <= 16 && (size_t)sk * M * g.N <= defer->slabs_cap && !g.geglu &&
+    static const int defer_max = getenv("MVD_DEFER_MAX") ? atoi(getenv("MVD_DEFER_MAX")) : 16;  // A/B: 4 = the round-3 limit
+    if (defer && defer->slabs && defer->sk_used && sk <= defer_max && (size_t)sk * M * g.N <= defer->slabs_cap && !g.geglu &&
         (!g.resid || (defer->defer_epilogue && g.resid_f32)) && g.act == 0 && g.alpha == 1.0f && g.out_linear && g.out_f32 &&
         !g.out_split) {
       g.partial = defer->slabs;

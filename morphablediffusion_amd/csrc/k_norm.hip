@@ -298,10 +298,19 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
       const int row = (int)(((float)e + 0.5f) * inv_h), j = e - row * h;
       v[i] = *(const float2*)(xb + (long)row * ld + 2 * j);
       if constexpr (NS == 0) {
-        for (int sl = 1; sl < nslab; ++sl) {
-          const float2 q2 = *(const float2*)(xb + sl * slab_stride + (long)row * ld + 2 * j);
-          v[i].x += q2.x;
-          v[i].y += q2.y;
+        // four slab loads in flight per step (a load -> add -> load chain would pay the L2 latency once per slab); the slabs
+        // are still added in slab order
+        const float* xs = xb + (long)row * ld + 2 * j;
+        for (int s0 = 1; s0 < nslab; s0 += 4) {
+          float2 q4[4];
+#pragma unroll
+          for (int u2 = 0; u2 < 4; ++u2) q4[u2] = *(const float2*)(xs + (long)min(s0 + u2, nslab - 1) * slab_stride);
+#pragma unroll
+          for (int u2 = 0; u2 < 4; ++u2)
+            if (s0 + u2 < nslab) {
+              v[i].x += q4[u2].x;
+              v[i].y += q4[u2].y;
+            }
         }
       } else {
 #pragma unroll
