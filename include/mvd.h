@@ -57,6 +57,9 @@ int mvd_create(const mvd_unet_config* ucfg, const mvd_volume_config* vcfg, int d
                mvd_ctx** out);
 void mvd_destroy(mvd_ctx* ctx);
 const char* mvd_last_error(void);
+/* "f16" (libmvd_hip.so) or "bf16" (libmvd_hip_bf16.so: the same sources built with bfloat16 MFMA operands and storage, the
+ * training dtype BASELINE configs[3] names; the reference trainer's `precision` key, configs/facescape.yaml:65). */
+const char* mvd_compute_dtype(void);
 
 /* Replaces load_state_dict (reference generate_face.py:75-76): one call per state_dict entry, keyed by the
  * reference's own names.  data is fp32, contiguous, reference layout; on_device

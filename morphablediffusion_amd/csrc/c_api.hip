@@ -98,6 +98,7 @@ int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* d
 extern "C" {
 
 const char* mvd_last_error(void) { return g_err.c_str(); }
+const char* mvd_compute_dtype(void) { return MVD_DTYPE_NAME; }
 
 int mvd_create(const mvd_unet_config* ucfg, const mvd_volume_config* vcfg, int device, size_t workspace_bytes,
                mvd_ctx** out) {

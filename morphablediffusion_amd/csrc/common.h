@@ -4,10 +4,24 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+// The 16-bit MFMA operand type of the whole library.  Default build: IEEE fp16 (11-bit significand: what the inference parity
+// bounds are stated for).  -DMVD_BF16 (make bf16 -> libmvd_hip_bf16.so, selected with MVD_DTYPE=bf16): bfloat16 operands and
+// storage, fp32 accumulation and master weights -- BASELINE configs[3]'s training dtype (fp32 range: no loss scaling needed;
+// same MFMA rate on gfx950).  Every kernel is written against `half_t` and the two MFMA macros only.
+#ifdef MVD_BF16
+typedef __bf16 half_t;
+#define MVD_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MVD_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MVD_DTYPE_NAME "bf16"
+#else
 typedef _Float16 half_t;
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#define MVD_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MVD_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MVD_DTYPE_NAME "f16"
+#endif
+typedef half_t h8 __attribute__((ext_vector_type(8)));
+typedef half_t h4 __attribute__((ext_vector_type(4)));
+typedef half_t h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+        s[f] = MVD_MFMA_32x32x16(kf, qf[ks], s[f], 0, 0, 0);
       }
     }
     // online softmax over the key axis (rows of S^T).  The running maximum is tracked on the scaled scores; the
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
         h8 va;
         va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
         va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
-        o[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[f], 0, 0, 0);
+        o[f] = MVD_MFMA_32x32x16(va, pb, o[f], 0, 0, 0);
       }
     }
   }

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const half_t* __restri
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+        s[f] = MVD_MFMA_32x32x16(kf, qf[ks], s[f], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -788,9 +788,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const half_t* __restri
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const h8 kf = *(const h8*)(sK + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[f], 0, 0, 0);
+        s[f] = MVD_MFMA_32x32x16(kf, qf[ks], s[f], 0, 0, 0);
         const h8 vf = *(const h8*)(sV + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, dof[ks], dp[f], 0, 0, 0);
+        dp[f] = MVD_MFMA_32x32x16(vf, dof[ks], dp[f], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const half_t* __restri
         h8 va;
         va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
         va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
-        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, acc[f], 0, 0, 0);
+        acc[f] = MVD_MFMA_32x32x16(va, pb, acc[f], 0, 0, 0);
       }
     }
   }
@@ -892,9 +892,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const half_t* __restr
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const h8 qa = *(const h8*)(sQ + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        s[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s[f], 0, 0, 0);
+        s[f] = MVD_MFMA_32x32x16(qa, kf[ks], s[f], 0, 0, 0);
         const h8 da = *(const h8*)(sdO + (f * 32 + lq) * KLD + ks * 16 + hh * 8);
-        dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(da, vf[ks], dp[f], 0, 0, 0);
+        dp[f] = MVD_MFMA_32x32x16(da, vf[ks], dp[f], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -920,14 +920,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const half_t* __restr
         h8 va;
         va[0] = a0[0]; va[1] = a0[1]; va[2] = a0[2]; va[3] = a0[3];
         va[4] = a1[0]; va[5] = a1[1]; va[6] = a1[2]; va[7] = a1[3];
-        dv[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, dv[f], 0, 0, 0);
+        dv[f] = MVD_MFMA_32x32x16(va, pb, dv[f], 0, 0, 0);
         const half_t* r2 = sQT + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
         const h4 b0 = *(const h4*)(r2);
         const h4 b1 = *(const h4*)(r2 + 8);
         h8 vb;
         vb[0] = b0[0]; vb[1] = b0[1]; vb[2] = b0[2]; vb[3] = b0[3];
         vb[4] = b1[0]; vb[5] = b1[1]; vb[6] = b1[2]; vb[7] = b1[3];
-        dk[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb, sb, dk[f], 0, 0, 0);
+        dk[f] = MVD_MFMA_32x32x16(vb, sb, dk[f], 0, 0, 0);
       }
     }
   }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3_dma_kernel(const IGemm g) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
+        acc[j] = MVD_MFMA_32x32x16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
       // issue order within the kk block: one LDS read of kk+1 between consecutive MFMAs of kk, so the eight waves
       // (in lockstep after the step barrier) do not hit the LDS with 48 reads at once
       if (kk < 3) {

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(ENT) void target_encoder_kernel(const float* __rest
         if (tap > 8) tap = 8;  // the padding tap: zero weights, any finite operand
         const int dy = tap / 3, dx = tap - dy * 3;  // tile coordinates are image coordinates + 1
         const h8 af = *(const h8*)(tile + ((y + dy) * ETS + x0 + n + dx) * EPS + (q & 1) * 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[ks], acc, 0, 0, 0);
+        acc = MVD_MFMA_16x16x32(af, bf[ks], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[t][r] = acc[r] + b + (resid ? resid[t][r] : 0.f);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
       if (kk < 3) read_frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
+        acc[j] = MVD_MFMA_32x32x16(af[kk & 1], bf[kk & 1][j], acc[j], 0, 0, 0);
       // issue order within the kk block: one LDS read of kk+1 between consecutive MFMAs of kk (the eight waves run in
       // lockstep after the step barrier; a burst of 8 x (FN+1) reads would queue in the LDS while the MFMA pipe idles)
       if (kk < 3) {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IGemm g) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = MVD_MFMA_32x32x16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_tiles(cur ^ 1);

@@ -7,11 +7,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MVD_LIB_PATH: A/B timing of two builds of the same ABI (development aid)
-LIB_PATH = os.environ.get("MVD_LIB_PATH", os.path.join(_HERE, "libmvd_hip.so"))
+# MVD_DTYPE (read once, at the first load): "f16" (default) -> libmvd_hip.so, "bf16" -> libmvd_hip_bf16.so, the same sources
+# built with bfloat16 MFMA operands and storage (csrc/common.h MVD_BF16; `make -C csrc bf16`): the training dtype of BASELINE
+# configs[3].  One process uses one of them.  MVD_LIB_PATH: A/B timing of two builds of the same ABI (development aid).
+DTYPE = os.environ.get("MVD_DTYPE", "f16")
+if DTYPE not in ("f16", "bf16"):
+    raise ValueError(f"MVD_DTYPE must be f16 or bf16, not {DTYPE!r}")
+LIB_PATH = os.environ.get("MVD_LIB_PATH", os.path.join(_HERE, "libmvd_hip.so" if DTYPE == "f16" else "libmvd_hip_bf16.so"))
 
 SYMBOLS = [
-    "mvd_create", "mvd_destroy", "mvd_last_error", "mvd_upload_weight", "mvd_set_precision_level", "mvd_set_vae_precision", "mvd_finalize_weights", "mvd_unet_forward", "mvd_unet_block",
+    "mvd_create", "mvd_destroy", "mvd_last_error", "mvd_compute_dtype", "mvd_upload_weight", "mvd_set_precision_level", "mvd_set_vae_precision", "mvd_finalize_weights", "mvd_unet_forward", "mvd_unet_block",
     "mvd_embed_time", "mvd_select_sample", "mvd_set_mesh", "mvd_set_cameras", "mvd_set_mesh_async", "mvd_set_cameras_async", "mvd_set_samples_async", "mvd_rulebook_build", "mvd_rulebook_table", "mvd_vertex_features", "mvd_vertex_view_features", "mvd_fuse_vertex_features",
     "mvd_stage_target_encoder", "mvd_stage_sparse_dense", "mvd_set_volume_ready_event", "mvd_volume_from_fused", "mvd_volume_from_fused_train", "mvd_mse_loss", "mvd_set_volume", "mvd_train_enable", "mvd_train_param_count", "mvd_train_param_info", "mvd_train_arena_size", "mvd_train_adopt_arena", "mvd_train_zero_grad", "mvd_train_unet_step", "mvd_train_get_grad", "mvd_train_get_tensor", "mvd_train_bn_calls", "mvd_train_cond_backward", "mvd_train_conditioner_backward", "mvd_train_conditioner_backward_batch", "mvd_train_adamw_step", "mvd_train_repack",
     "mvd_frustum_volumes", "mvd_frustum_volumes_batch", "mvd_denoise_views", "mvd_op_conv", "mvd_op_linear", "mvd_op_group_norm",
@@ -51,15 +56,18 @@ def load():
                        f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     lib.mvd_last_error.restype = C.c_char_p
+    lib.mvd_compute_dtype.restype = C.c_char_p
     lib.mvd_destroy.restype = None
     for name in SYMBOLS:
         if not hasattr(lib, name):
             raise MvdError(f"libmvd_hip.so does not export {name}")
     for name in SYMBOLS:
-        if name not in ("mvd_last_error", "mvd_destroy"):
+        if name not in ("mvd_last_error", "mvd_destroy", "mvd_compute_dtype"):
             getattr(lib, name).restype = C.c_int
     lib.mvd_train_arena_size.restype = C.c_int64
     lib.mvd_train_bn_calls.restype = C.c_int64
+    if "MVD_LIB_PATH" not in os.environ and lib.mvd_compute_dtype().decode() != DTYPE:
+        raise MvdError(f"{LIB_PATH} computes in {lib.mvd_compute_dtype().decode()}, MVD_DTYPE asks for {DTYPE}")
     _lib = lib
     return lib
 

@@ -42,6 +42,10 @@ def test_library_has_no_crossed_packed_f32_multiply(tmp_path):
     work.mkdir()
     shutil.copy(so, work / "libmvd_hip.so")
     subprocess.run([objdump, "--offloading", "libmvd_hip.so"], cwd=work, check=True, capture_output=True)
+    so16 = os.path.join(ROOT, "morphablediffusion_amd", "libmvd_hip_bf16.so")  # the bfloat16 build of the same sources
+    if os.path.exists(so16):
+        shutil.copy(so16, work / "libmvd_hip_bf16.so")
+        subprocess.run([objdump, "--offloading", "libmvd_hip_bf16.so"], cwd=work, check=True, capture_output=True)
     bundles = sorted(f for f in os.listdir(work) if f.endswith("gfx950"))
     assert bundles, "no gfx950 code objects found in libmvd_hip.so"
     bad, kernels, cur = [], 0, "?"
