@@ -218,8 +218,12 @@ def train_main(args):
     model = SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
         scheduler_config=sched_cfg, finetune_unet=True, view_num=N, image_size=256, cfg_scale=2.0, device=dev, workspace_gb=96.0,
-        train_mode=True, recompute=not args.keep_activations)
+        train_mode=True, recompute=not args.keep_activations,
+        loss_scale=1.0 if args.dtype == "bf16" else 65536.0)  # bf16 has fp32's exponent range: no loss scaling
     model.load_state_dict(W)
+    from morphablediffusion_amd import lib as mvd_lib
+    lib_dtype = mvd_lib.load().mvd_compute_dtype().decode()
+    assert lib_dtype == args.dtype, (lib_dtype, args.dtype)
     (opt,), (sched,) = model.configure_optimizers()
     # Every step sees a NEW batch, as a training loop does: per sample another mesh (a pool of 2B synthetic meshes, cycled) and
     # another camera order, in fresh device tensors -- so the per-sample tables (sparse-conv rule book, cameras) are rebuilt
@@ -280,7 +284,9 @@ def train_main(args):
                          "finetune_unet training step, full-width UNet)",
                "value": B * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f16 operands / f32 accumulate and master weights (the configuration names bf16)", "data": "synthetic",
+               "dtype": lib_dtype, "dtype_detail": f"{lib_dtype} MFMA operands and activation / weight storage, f32 accumulation, f32 master "
+                                                   f"weights and Adam moments" + ("" if lib_dtype == "bf16" else ", dynamic loss scale"),
+               "data": "synthetic",
                "config": {"workload": f"training step, {B} samples per GPU x {N} views (seeded latents instead of VAE/CLIP on "
                                       f"images; a NEW {NV}-vertex mesh and camera order per sample and step: the sparse-conv rule book "
                                       f"and camera tables are rebuilt inside the step), full-width UNet (916.9M params, random init), "
@@ -290,7 +296,6 @@ def train_main(args):
                           "mesh_vertices_after_voxel_dedup": int(nv_min), "parallelism": f"data-parallel x{world}" if world > 1 else "single GPU"},
                "unet_tflops": per_sample * B * world / (dt / args.steps) / 1e12,
                "loss_first_last": [lv[0], lv[-1]], "loss_scale": model.loss_scale, "optimizer_steps_skipped": opt.steps_skipped,
-               "not_built": "bf16 storage (fp16 operands + loss scale instead)",
                "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
@@ -314,6 +319,10 @@ def main():
     ap.add_argument("--keep-activations", action="store_true",
                     help="--config train: keep every activation of the forward pass instead of re-running each block before its "
                          "backward (the reference's use_checkpoint: True is the default)")
+    ap.add_argument("--dtype", default=None, choices=["f16", "bf16"],
+                    help="MFMA operand / storage type = which build of the library is loaded (MVD_DTYPE).  Default: f16 for the "
+                         "denoising configurations (north_star's parity bound is stated for fp16), bf16 for --config train "
+                         "(BASELINE configs[3] names bf16)")
     ap.add_argument("--config", default="headline", choices=["headline", "n8", "smplx32", "train"],
                     help="headline = BASELINE.json's metric configuration (N=16, 256^2: configs[2], the default the driver "
                          "runs); n8 = configs[1] (N=8, 256^2); smplx32 = configs[4] (SMPL-X-sized mesh, N=32 views, 512^2 -> "
@@ -327,6 +336,9 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_main()
+    if args.dtype is None:
+        args.dtype = os.environ.get("MVD_DTYPE") or ("bf16" if args.config == "train" else "f16")
+    os.environ["MVD_DTYPE"] = args.dtype  # read by morphablediffusion_amd.lib at its first import (below, in every rank)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
     if args.config == "train":
@@ -509,7 +521,7 @@ def main():
                            f"(N={N_VIEWS} views, {CFG['size']}x{CFG['size']}, CFG 2.0)",
             "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"synthetic sample ({'FaceScape-FLAME' if CFG['nverts'] == 5023 else 'SMPL-X'}-sized mesh, "
                                    f"{CFG['nverts']} vertices before voxel de-duplication): N={N_VIEWS} target views, "
                                    f"{CFG['size']}x{CFG['size']} (latent {lat}x{lat}), {CFG['proj']} cameras, full-width UNet "

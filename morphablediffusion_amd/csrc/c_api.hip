@@ -629,7 +629,9 @@ int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float 
       c->arena_owned[a == &c->arena_m ? 2 : 3] = true;
     }
   HIP_CHECK_RET(hipMemsetAsync(c->found_inf, 0, sizeof(int), s));
-  RET_IF(bwd_finite_check(c->arena_g, c->arena_n, c->found_inf, s));
+  // The overflow check (a 3.7 GB read: ~1 ms) belongs to loss scaling -- GradScaler's "skip the step, halve the scale".  Without
+  // a loss scale (inv_scale == 1: the bfloat16 build) the step is torch.optim.AdamW's own, which checks nothing.
+  if (inv_scale != 1.0f) RET_IF(bwd_finite_check(c->arena_g, c->arena_n, c->found_inf, s));
   // the reference's parameter groups (morphable_diffusion.py:627-646): the UNet (all of it with finetune_unet, else the
   // DepthTransformers: attention.py:140-142) at lr; time_embed and spatial_volume at 10 lr (passed in as lr_aux).
   // Consecutive parameters of one group are updated by one launch.

@@ -636,6 +636,9 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.steps_skipped = 0
         self.growth_interval = 2000  # torch.cuda.amp.GradScaler's defaults: x2 after 2000 clean steps, x0.5 on overflow
         self._clean = 0
+        # loss_scale == 1 (the bfloat16 build: fp32 exponent range) means NO loss scaling: no overflow check, no read-back of
+        # the "skipped" flag (a stream synchronisation per step), no scale growth -- torch.optim.AdamW's own behaviour
+        self.dynamic_scale = float(model.loss_scale) != 1.0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -645,7 +648,7 @@ class ArenaAdamW(torch.optim.Optimizer):
         m = self.model
         skipped = m.engine.adamw_step(g0["lr"], aux, self.steps_done + 1, betas=g0["betas"], eps=g0["eps"],
                                       weight_decay=g0["weight_decay"], inv_scale=1.0 / m.loss_scale,
-                                      finetune_unet=m.finetune_unet)
+                                      finetune_unet=m.finetune_unet, check=self.dynamic_scale)
         if skipped:  # torch.cuda.amp.GradScaler's rule: back off and try again
             self.steps_skipped += 1
             self._clean = 0
@@ -654,7 +657,7 @@ class ArenaAdamW(torch.optim.Optimizer):
             self.steps_done += 1
             self._clean += 1
             m.global_step = getattr(m, "global_step", 0) + 1  # what Lightning's loop advances per optimiser step
-            if self._clean >= self.growth_interval:
+            if self.dynamic_scale and self._clean >= self.growth_interval:
                 self._clean = 0
                 m.loss_scale = min(m.loss_scale * 2.0, 2.0 ** 24)
         return loss

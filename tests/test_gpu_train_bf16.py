@@ -4,11 +4,13 @@ and storage (csrc/common.h MVD_BF16), fp32 accumulation, fp32 master weights / m
 exponent range); MVD_DTYPE=bf16 selects it per process, hence the subprocess.
 
 Bounds.  bf16 carries an 8-bit significand against fp16's 11: every operand rounding is 8x coarser (2^-9 = 2.0e-3 against 2.4e-4),
-so each fp16 bound of tests/test_gpu_train.py is taken x8: loss 8e-3, prediction 1.6e-2, trunk gradients (worst) 8e-2.  The
-DepthTransformer tensors re-derive three ReLU masks and a near-uniform softmax from an input that carries the forward pass's
-rounding (x8 amplification in the reference arithmetic itself, tests/test_host_cpu.py::test_depth_transformer_gradient_sensitivity):
-their per-tensor bound is 0.4 (median 0.12) and what is asserted beside it is the direction of the whole gradient (cosine >= 0.995
-to the reference's) and that an optimisation run descends.  The fp16 library runs the same script as the control."""
+and the measured errors are 8x the fp16 ones throughout (profiles/r04_b_train_dtype_check.txt: prediction 5.5e-3 / 7.0e-4, trunk
+gradients worst 3.7e-2 / 4.6e-3, median 1.7e-2 / 2.4e-3, DepthTransformer gradients worst 1.2e-1 / 3.9e-2).  Asserted: loss 2e-3,
+prediction 1.2e-2, trunk gradients worst 8e-2 (= 8 x the fp16 bound) median 4e-2, DepthTransformer tensors (three ReLU masks and a
+near-uniform softmax re-derived from a rounded input: tests/test_host_cpu.py::test_depth_transformer_gradient_sensitivity) worst
+0.3 median 0.1, the direction of the WHOLE gradient (cosine >= 0.9995 to the reference's; measured 0.99997), bit-reproducibility,
+no skipped optimiser step at loss scale 1, and that six AdamW steps descend like the fp16 run.  The fp16 library runs the same
+script as the control."""
 import json
 import os
 import subprocess
@@ -41,10 +43,10 @@ def test_training_step_bf16_vs_reference_and_fp16_control():
               f"6 steps: {d['losses'][0]:.4f} -> {d['losses'][-1]:.4f}")
     assert b["dtype"] == "bf16" and f["dtype"] == "f16" and b["loss_scale"] == 1.0
     assert b["finite"] and b["bit_reproducible"] and b["steps_skipped"] == 0
-    assert b["loss_rel_err"] <= 8e-3 and b["pred_rel_l2"] <= 1.6e-2
+    assert b["loss_rel_err"] <= 2e-3 and b["pred_rel_l2"] <= 1.2e-2
     assert b["grad_trunk_worst"] <= 8e-2 and b["grad_trunk_median"] <= 4e-2
-    assert b["grad_dt_worst"] <= 0.4 and b["grad_dt_median"] <= 0.12
-    assert b["grad_cosine"] >= 0.995 and f["grad_cosine"] >= 0.9999
+    assert b["grad_dt_worst"] <= 0.3 and b["grad_dt_median"] <= 0.1
+    assert b["grad_cosine"] >= 0.9995 and f["grad_cosine"] >= 0.9999
     assert b["losses"][-1] < 0.9 * b["losses"][0], b["losses"]
     # the control keeps the fp16 bounds of tests/test_gpu_train.py
     assert f["loss_rel_err"] <= 1e-3 and f["pred_rel_l2"] <= 2e-3 and f["grad_trunk_worst"] <= 1e-2
