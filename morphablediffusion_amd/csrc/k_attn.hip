@@ -55,44 +55,53 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
   // K / V tiles are register-staged one tile ahead: the global loads of tile i+1 are in flight behind the MFMAs and the
   // softmax of tile i.  V arrives row-major ([token][head*d + dv], the third block of the fused q|k|v projection) and is
   // transposed by the LDS write pass (eight 2-byte stores per 16-byte load) into the V^T image the second MFMA reads.
-  constexpr int KSLOTS = (64 * (DK / 8) + 255) / 256, VSLOTS = (64 * (D / 8) + 255) / 256;
-  h8 kreg[KSLOTS], vreg[VSLOTS];
+  // A thread's slots -- (key, 8-channel chunk) pairs, D/8 chunks per key for K and for V -- its source pointers and its LDS
+  // addresses are fixed for the whole kernel: they are derived ONCE here and the loop only advances the pointers by 64 rows
+  // (round 4: with the index arithmetic and the bounds tests inside the loop they were ~180 of the ~450 VALU instructions
+  // per key tile of this VALU-bound kernel).  The padding chunk of K (d = D .. DK-1) is zeroed once and never rewritten.
+  constexpr int CH = D / 8, NSLOT = (64 * CH + 255) / 256;
+  h8 kreg[NSLOT], vreg[NSLOT];
+  const half_t *gk[NSLOT], *gv[NSLOT];
+  int skey[NSLOT], sch[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int idx = tid + i * 256;
+    const bool ok = idx < 64 * CH;
+    const int key = ok ? idx / CH : 0, ch = ok ? idx - key * CH : 0;
+    skey[i] = ok ? key : -1;
+    sch[i] = ch;
+    gk[i] = qk + (tok0 + key) * ldqk + C + head * D + ch * 8;
+    gv[i] = v + (tok0 + key) * ldv + head * D + ch * 8;
+  }
   auto load_tiles = [&](int k0) {
+    const bool full = k0 + 64 <= T;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < KSLOTS; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx / (DK / 8), ch = idx - key * (DK / 8);
+    for (int i = 0; i < NSLOT; ++i) {
       kreg[i] = (h8)(half_t)0;
-      if (idx < 64 * (DK / 8) && k0 + key < T && ch * 8 < D)
-        kreg[i] = *(const h8*)(qk + (tok0 + k0 + key) * ldqk + C + head * D + ch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < VSLOTS; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx / (D / 8), ch = idx - key * (D / 8);
       vreg[i] = (h8)(half_t)0;  // keys >= T must be zeros: their P is 0, but 0 x garbage could be NaN
-      if (idx < 64 * (D / 8) && k0 + key < T) vreg[i] = *(const h8*)(v + (tok0 + k0 + key) * ldv + head * D + ch * 8);
+      if (skey[i] >= 0 && (full || k0 + skey[i] < T)) {
+        kreg[i] = *(const h8*)gk[i];
+        vreg[i] = *(const h8*)gv[i];
+      }
+      gk[i] += 64 * (long)ldqk;
+      gv[i] += 64 * (long)ldv;
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < KSLOTS; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx / (DK / 8), ch = idx - key * (DK / 8);
-      if (idx < 64 * (DK / 8)) *(h8*)(sK + key * KLD + ch * 8) = kreg[i];
-    }
+    for (int i = 0; i < NSLOT; ++i) {
+      if (skey[i] >= 0) {
+        *(h8*)(sK + skey[i] * KLD + sch[i] * 8) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < VSLOTS; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx / (D / 8), ch = idx - key * (D / 8);
-      if (idx < 64 * (D / 8)) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sV[(ch * 8 + e) * VLD + key] = vreg[i][e];
+        for (int e = 0; e < 8; ++e) sV[(sch[i] * 8 + e) * VLD + skey[i]] = vreg[i][e];
       }
     }
   };
-  // rows D..DVP-1 of the V^T image are padding of the last 32-row fragment: zeroed once, never rewritten
+  // rows D..DVP-1 of the V^T image are padding of the last 32-row fragment, columns D..DK-1 of the K image padding of the last
+  // k-step: zeroed once, never rewritten
   for (int idx = tid; idx < (DVP - D) * 64; idx += 256) sV[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
+  if constexpr (DK > D)
+    for (int idx = tid; idx < 64 * (DK - D); idx += 256) sK[(idx / (DK - D)) * KLD + D + idx % (DK - D)] = (half_t)0;
   load_tiles(0);
   for (int k0 = 0; k0 < T; k0 += 64) {
     __syncthreads();  // every wave is done reading the previous tile
