@@ -285,6 +285,17 @@ int mvd_denoise_views(mvd_ctx* ctx, const float* x_noisy, const float* x_input, 
                       const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
                       const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
                       float sigma, float* eps_out, float* x_prev, void* stream);
+/* The same step for B samples in ONE UNet pass (batch 2 * B * TN with guidance): the reference's own batching of
+ * eval/generate_all_facescape.py:106-108,128-129,184-187, where denoise_apply (morphable_diffusion.py:701-739) receives B > 1.
+ * slots[b]: the sample slot (mvd_select_sample) that holds sample b's mesh tables, cameras AND 32^3 volume (the volume built
+ * by mvd_volume_from_fused while that slot was active); x_noisy / noise / eps_out / x_prev [B,TN,4,h,w]; x_input [B,4,h,w];
+ * clip [B,context_dim]; timesteps [B] (host); t_embed [B,time_dim]; v_embed [B,TN,view_dim]; view_idx [TN] (the same views
+ * of every sample).  B == 1 with slots == NULL is mvd_denoise_views.  Per sample the result equals the single-sample call to
+ * fp16 operand rounding (the larger batch changes tile plans, i.e. fp32 summation orders), not bit for bit. */
+int mvd_denoise_views_batch(mvd_ctx* ctx, int B, const int* slots, const float* x_noisy, const float* x_input, const float* clip,
+                            const int64_t* timesteps, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
+                            float cfg_scale, const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev,
+                            float dir_coef, float sigma, float* eps_out, float* x_prev, void* stream);
 
 /* ---- single-kernel hooks used by the parity tests (tests/test_gpu_ops.py) ---- */
 int mvd_op_conv(mvd_ctx* ctx, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,

@@ -43,7 +43,10 @@ __global__ void pack_qkv_rows_kernel(const float* q, const float* k, const float
 }
 // UNetWrapper.predict_with_unconditional_scale input assembly (morphable_diffusion.py:133-146), channels-last:
 // rows [0,TN) = [x | x_input / 0.18215], rows [TN,2TN) = [x | 0]
-__global__ void build_cfg_input_kernel(const float* x_noisy, const float* x_input, int TN, int HW, int copies, float* out) {
+// UNet input of one sample's TN views: rows [0, TN) of `out` = the conditional copies, rows [half_off, half_off + TN) the
+// unconditional ones (copies == 2); half_off = TN for a single sample, B * TN when B samples share the UNet pass
+__global__ void build_cfg_input_kernel(const float* x_noisy, const float* x_input, int TN, int HW, int copies, float* out,
+                                       long half_off) {
   const long total = (long)copies * TN * HW * 8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i & 7);
@@ -53,15 +56,17 @@ __global__ void build_cfg_input_kernel(const float* x_noisy, const float* x_inpu
     float val;
     if (ch < 4) val = x_noisy[((long)v * 4 + ch) * HW + p];
     else val = half == 0 ? x_input[(long)(ch - 4) * HW + p] / 0.18215f : 0.f;
-    out[i] = val;
+    out[(((long)half * half_off + v) * HW + p) * 8 + ch] = val;
   }
 }
-__global__ void build_cfg_context_kernel(const float* clip, int TN, int dim, int copies, float* ctx, int64_t* t, int64_t step) {
+__global__ void build_cfg_context_kernel(const float* clip, int TN, int dim, int copies, float* ctx, int64_t* t, int64_t step,
+                                         long half_off) {
   const int total = copies * TN * dim;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int b = i / dim, j = i - b * dim;
-    ctx[i] = b < TN ? clip[j] : 0.f;
-    if (j == 0) t[b] = step;
+    const long row = (long)(b / TN) * half_off + (b % TN);
+    ctx[row * dim + j] = b < TN ? clip[j] : 0.f;
+    if (j == 0) t[row] = step;
   }
 }
 __global__ void fill_pattern_f16_kernel(half_t* p, size_t n, unsigned seed) {
@@ -142,6 +147,7 @@ void mvd_destroy(mvd_ctx* c) {
     mesh_free(sl.mesh);
     hipFree(sl.cams);
     free_stage(sl.cam_stage);
+    hipFree(sl.volume);
   }
   hipFree(c->volume);
   hipFree(c->ws.base);
@@ -715,25 +721,28 @@ int mvd_frustum_volumes_batch(mvd_ctx* c, int B, const int* slots, const float* 
   return 0;
 }
 
-int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, const float* clip, int64_t timestep,
-                      const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
-                      const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
-                      float sigma, float* eps_out, float* x_prev, void* stream) {
+int mvd_denoise_views_batch(mvd_ctx* c, int B, const int* slots, const float* x_noisy, const float* x_input, const float* clip,
+                            const int64_t* timesteps, const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN,
+                            float cfg_scale, const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev,
+                            float dir_coef, float sigma, float* eps_out, float* x_prev, void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !c->finalized) return mvd_fail("weights not finalized");
+  if (B < 1 || TN < 1 || (B > 1 && !slots) || !timesteps) return mvd_fail("mvd_denoise_views_batch: bad argument");
   hipStream_t s = S(stream);
   const mvd_unet_config& u = c->u;
   if (u.in_channels != 8 || u.out_channels != 4) return mvd_fail("denoise_views: expects the 8-in / 4-out latent UNet");
   WsScope ws_scope(c);
   const int HW = u.image_size * u.image_size;
   const bool cfg = cfg_scale != 1.0f;
-  const int copies = cfg ? 2 : 1, Bv = copies * TN;
+  const int copies = cfg ? 2 : 1, Bv = copies * B * TN;
+  const int td = c->v.time_dim, vd = c->v.view_dim;
   // The frustum network feeds the DepthTransformers only (middle block onwards): engine_unet enqueues it (through this
   // producer) on its side stream after the full-resolution input blocks, beside the lower-resolution ones.
   FrustumOut fo;
   Ctx5 cl[4];
   const CtxProducer produce = [&](hipStream_t ps) -> int {
-    RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, ps, /*half0=*/true));
+    if (B == 1 && !slots) RET_IF(engine_frustum(c, t_embed, v_embed, view_idx, TN, &fo, ps, /*half0=*/true));
+    else RET_IF(engine_frustum_multi(c, B, slots, t_embed, v_embed, view_idx, TN, &fo, ps, /*half0=*/true));
     for (int l = 0; l < 4; ++l) {
       cl[l].p = fo.lvl[l];
       cl[l].f32 = 1;
@@ -750,17 +759,33 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
   float* eps = ws_alloc<float>(c, (size_t)Bv * HW * 4);
   float* eps_nchw = ws_alloc<float>(c, (size_t)Bv * HW * 4);
   WS_CHECK(xin && ctx && tt && eps && eps_nchw);
-  hipLaunchKernelGGL(build_cfg_input_kernel, dim3(nblk((size_t)Bv * HW * 8)), dim3(256), 0, s, x_noisy, x_input, TN, HW,
-                     copies, xin);
-  hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)Bv * u.context_dim)), dim3(256), 0, s, clip, TN,
-                     u.context_dim, copies, ctx, tt, timestep);
+  // UNet batch order (morphable_diffusion.py:133-147): every conditional row first -- sample by sample, view by view --, then
+  // the unconditional copies in the same order
+  const long half_off = (long)B * TN;
+  for (int b = 0; b < B; ++b) {
+    hipLaunchKernelGGL(build_cfg_input_kernel, dim3(nblk((size_t)copies * TN * HW * 8)), dim3(256), 0, s,
+                       x_noisy + (size_t)b * TN * 4 * HW, x_input + (size_t)b * 4 * HW, TN, HW, copies, xin + (size_t)b * TN * HW * 8,
+                       half_off);
+    hipLaunchKernelGGL(build_cfg_context_kernel, dim3(nblk((size_t)copies * TN * u.context_dim)), dim3(256), 0, s,
+                       clip + (size_t)b * u.context_dim, TN, u.context_dim, copies, ctx + (size_t)b * TN * u.context_dim,
+                       tt + (size_t)b * TN, timesteps[b], half_off);
+  }
   HIP_CHECK_RET(hipGetLastError());
-  RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, TN, c->v.frustum_volume_depth, cl, eps, s, &produce));
+  (void)td; (void)vd;
+  RET_IF(engine_unet(c, xin, 8, tt, ctx, Bv, B * TN, c->v.frustum_volume_depth, cl, eps, s, &produce));
   RET_IF(launch_nhwc_to_nchw(eps, 4, Bv, 4, HW, eps_nchw, s));
-  const size_t n = (size_t)TN * 4 * HW;
+  const size_t n = (size_t)B * TN * 4 * HW;
   RET_IF(launch_cfg_ddim(eps_nchw, cfg ? eps_nchw + n : nullptr, cfg_scale, x_noisy, noise, sqrt_one_minus_at, sqrt_at,
                          sqrt_aprev, dir_coef, sigma, eps_out, x_prev, n, s));
   return 0;
+}
+
+int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, const float* clip, int64_t timestep,
+                      const float* t_embed, const float* v_embed, const int32_t* view_idx, int TN, float cfg_scale,
+                      const float* noise, float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef,
+                      float sigma, float* eps_out, float* x_prev, void* stream) {
+  return mvd_denoise_views_batch(c, 1, nullptr, x_noisy, x_input, clip, &timestep, t_embed, v_embed, view_idx, TN, cfg_scale, noise,
+                                 sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma, eps_out, x_prev, stream);
 }
 
 // ------------------------------------------------------------------------------------------ test hooks

@@ -306,6 +306,7 @@ struct mvd_ctx {
     ViewCam* cams = nullptr;
     int n_cams = 0;
     CamStage cam_stage;
+    float* volume = nullptr;  // the slot's 32^3 latent volume (mvd_denoise_views_batch reads one per sample)
   };
   std::vector<SampleSlot> slots;
   long bn_train_calls = 0;  // train-mode forwards of the sparse CNN since the weights were loaded (num_batches_tracked)
@@ -446,6 +447,10 @@ struct FrustumOut {
 };
 int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const int32_t* view_idx_dev, int TN,
                    FrustumOut* out, hipStream_t s, bool half0 = false);
+// construct_view_frustum_volume for TN views of EACH of B samples (slots[b]: that sample's cameras and 32^3 volume), the network
+// once over the B * TN volumes; t_embed [B][time_dim], v_embed [B][TN][view_dim], view_idx_dev [TN] (the same views per sample)
+int engine_frustum_multi(mvd_ctx* c, int B, const int* slots, const float* t_embed, const float* v_embed,
+                         const int32_t* view_idx_dev, int TN, FrustumOut* out, hipStream_t s, bool half0);
 int engine_frustum_batch(mvd_ctx* c, int B, const int* slots, const float* volumes, const float* t_embed, const float* v_rows,
                          const int32_t* view_idx_dev, FrustumOut* out, hipStream_t s);
 

@@ -449,11 +449,13 @@ int engine_select_sample(mvd_ctx* c, int slot) {
   cur.cams = c->cams;
   cur.n_cams = c->n_cams;
   cur.cam_stage = c->cam_stage;
+  cur.volume = c->volume;
   mvd_ctx::SampleSlot& nxt = c->slots[slot];
   c->mesh = nxt.mesh;
   c->cams = nxt.cams;
   c->n_cams = nxt.n_cams;
   c->cam_stage = nxt.cam_stage;
+  c->volume = nxt.volume;
   nxt = mvd_ctx::SampleSlot();  // the active copy is the owner now
   c->cur_slot = slot;
   return 0;
@@ -706,6 +708,33 @@ int engine_frustum(mvd_ctx* c, const float* t_embed, const float* v_embed, const
 }
 
 int engine_select_sample(mvd_ctx* c, int slot);
+int engine_frustum_multi(mvd_ctx* c, int B, const int* slots, const float* t_embed, const float* v_embed,
+                         const int32_t* view_idx_dev, int TN, FrustumOut* out, hipStream_t s, bool half0) {
+  if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
+  if (c->vol_ready) HIP_CHECK_RET(hipStreamWaitEvent(s, c->vol_ready, 0));
+  const int D0 = c->v.frustum_volume_depth, S0 = c->v.input_image_size / 8, td = c->v.time_dim, vd = c->v.view_dim;
+  const int back = c->cur_slot;
+  const int r = frustum_net(c, B * TN, out, s, half0, [&](half_t* gath) -> int {
+    const size_t per = (size_t)TN * D0 * S0 * S0 * 64;
+    for (int b = 0; b < B; ++b) {
+      RET_IF(engine_select_sample(c, slots[b]));
+      if (!c->cams || !c->volume) return mvd_fail("mvd_denoise_views_batch: a slot has no cameras / no volume");
+      RET_IF(launch_frustum_gather(c->volume, c->cams, view_idx_dev, TN, D0, S0, c->v.spatial_volume_size,
+                                   c->v.spatial_volume_length, c->v.projection == 0, gath + (size_t)b * per, s));
+    }
+    return 0;
+  }, [&](float* pre) -> int {
+    const int FT = c->film_total;
+    for (int b = 0; b < B; ++b) {  // the step embedding is shared by the views of a sample
+      float* pb = pre + (size_t)b * TN * FT;
+      RET_IF(launch_small_linear(t_embed + (size_t)b * td, td, -TN, td, c->film_t.w, c->film_t.bias, FT, ACT_NONE, pb, FT, 0, s));
+      RET_IF(launch_small_linear(v_embed + (size_t)b * TN * vd, vd, TN, vd, c->film_v.w, c->film_v.bias, FT, ACT_NONE, pb, FT, 1, s));
+    }
+    return 0;
+  });
+  const int r2 = engine_select_sample(c, back);
+  return r ? r : r2;
+}
 // One target view for each of B samples (training_step: morphable_diffusion.py:496-518 with TN = 1): every sample's frustum is
 // gathered from ITS 32^3 volume with ITS cameras (slots[b]), then the network runs once with the B volumes as its batch.
 // volumes: channels-last [B][V^3][64]; t_embed [B][time_dim]; v_rows [B][view_dim] (the target view's embedding); view_idx_dev [B]

@@ -504,6 +504,27 @@ class Engine:
             L.ptr(eps), L.ptr(x_prev), _stream()))
         return (x_prev, eps) if want_eps else x_prev
 
+    def denoise_views_batch(self, slots, x_noisy, x_input, clip, timesteps, t_embed, v_embed, view_idx, cfg_scale, noise, coef,
+                            want_eps=False):
+        """B samples in one UNet pass (mvd_denoise_views_batch): x_noisy / noise [B,TN,4,h,w], x_input [B,4,h,w], clip [B,768],
+        timesteps: B python ints, t_embed [B,td], v_embed [B,TN,vd]; slots[b] holds sample b's tables, cameras and volume."""
+        dev = self.device
+        x = _f32(x_noisy, dev)
+        B, TN = x.shape[:2]
+        vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
+        assert vi.shape[0] == TN and len(slots) == B and len(timesteps) == B
+        x_prev = torch.empty_like(x)
+        eps = torch.empty_like(x) if want_eps else None
+        nz = None if noise is None else _f32(noise, dev)
+        xi, cl, te, ve = _f32(x_input, dev), _f32(clip, dev), _f32(t_embed, dev), _f32(v_embed, dev)
+        sl = (C.c_int * B)(*[int(v) for v in slots])
+        ts = (C.c_int64 * B)(*[int(v) for v in timesteps])
+        L.check(self.lib.mvd_denoise_views_batch(
+            self._ctx, B, sl, L.ptr(x), L.ptr(xi), L.ptr(cl), ts, L.ptr(te), L.ptr(ve), L.ptr(vi), TN, C.c_float(cfg_scale),
+            L.ptr(nz), C.c_float(coef[0]), C.c_float(coef[1]), C.c_float(coef[2]), C.c_float(coef[3]), C.c_float(coef[4]),
+            L.ptr(eps), L.ptr(x_prev), _stream()))
+        return (x_prev, eps) if want_eps else x_prev
+
     # ---- single-kernel hooks (parity tests) -------------------------------------------------------
     def op_conv(self, x, w, bias=None, stride=1, upsample=0, resid=None, force_splitk=0):
         dev = self.device

@@ -777,6 +777,9 @@ class SyncDDIMSampler:
         self.exchange = exchange
         import os
         self.overlap = overlap and not os.environ.get("MVD_NO_COMM_OVERLAP")
+        # B > 1 (the eval driver): "batched" = all samples share each UNet pass (batch 2 * B * views with guidance), like the
+        # reference's own batching; "loop" = samples one by one (each then equals its single-sample run bit for bit)
+        self.sample_batching = os.environ.get("MVD_SAMPLE_BATCHING", "batched")
         self.simulate_world = 0  # timing aid (bench.py --simulate-gpus): run ONE rank's share without a process group
         self._comm = None  # (stream, event after the vertex features, event after the volume), created on first use
         self._bufs = {}    # persistent exchange buffers: never handed back to the allocator while the side stream uses them
@@ -830,6 +833,27 @@ class SyncDDIMSampler:
         local_idx = self._idx_dev
         if host_steps is None:  # one read for the whole call (none at all when the caller passes host_steps)
             host_steps = [int(v) for v in time_steps.tolist()]
+        from .engine import MAX_SAMPLE_SLOTS
+        if B > 1 and self.sample_batching == "batched" and B <= MAX_SAMPLE_SLOTS:
+            # All samples share each UNet pass (batch 2 * B * views with guidance), as the reference's own batching does
+            # (eval/generate_all_facescape.py:106-108,128-129); every sample's volume is built first, into its slot.
+            for bi in range(B):
+                m.spatial_volume._set_sample(batch, bi)
+                self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N,
+                                   tag=f".{bi}" if bi else "")
+            slots = [bi % MAX_SAMPLE_SLOTS for bi in range(B)]
+            for ni in range(0, NL, batch_view_num):
+                sl = slice(ni, min(NL, ni + batch_view_num))
+                idx = local_idx[sl]
+                r = eng.denoise_views_batch(
+                    slots, x_target_noisy[:, sl], x_input, clip_embed.reshape(B, -1), host_steps, t_embed,
+                    v_embed[:, lo + sl.start:lo + sl.stop], idx, float(unconditional_scale),
+                    None if is_step0 else noise[:, sl], coef, want_eps=return_eps)
+                if return_eps:
+                    out[:, sl], eps_out[:, sl] = r
+                else:
+                    out[:, sl] = r
+            return (out, eps_out) if return_eps else out
         for bi in range(B):
             m.spatial_volume._set_sample(batch, bi)
             self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N)
@@ -853,9 +877,11 @@ class SyncDDIMSampler:
             self._bufs[name] = t
         return t
 
-    def _build_volume(self, x_local, t_embed, v_embed_local, local_idx, rank, world, N):
+    def _build_volume(self, x_local, t_embed, v_embed_local, local_idx, rank, world, N, tag=""):
         """2-D encoder + vertex gather for this rank's views (caller's stream), then exchange -> view fusion -> sparse voxel
-        CNN -> lattice gather on the communication stream; leaves the 32^3 volume in the engine, guarded by an event."""
+        CNN -> lattice gather on the communication stream; leaves the 32^3 volume in the engine (in the ACTIVE sample slot),
+        guarded by an event.  ``tag``: suffix of the persistent exchange buffers -- consecutive builds of different samples
+        (batched denoise_apply) must not share them, the communication stream still reads the previous sample's."""
         import torch.distributed as dist
         eng = self.model.engine
         dev = x_local.device
@@ -870,14 +896,14 @@ class SyncDDIMSampler:
         if self.exchange == "all_gather":
             Nv = eng.num_vertices
             if dev.type == "cuda":
-                vf_all = self._buf("vf_all", (N, Nv, 16), dev)
+                vf_all = self._buf("vf_all" + tag, (N, Nv, 16), dev)
                 lo = rank * NL if world > 1 else 0
-                vf_loc = vf_all[lo:lo + NL] if not real else self._buf("vf_loc", (NL, Nv, 16), dev)
+                vf_loc = vf_all[lo:lo + NL] if not real else self._buf("vf_loc" + tag, (NL, Nv, 16), dev)
                 eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx, out=vf_loc)
             else:  # CPU stand-ins of the engine (tests)
                 vf_loc = eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx)
                 vf_all = vf_loc if world == 1 else torch.empty((N,) + tuple(vf_loc.shape[1:]), dtype=vf_loc.dtype)
-            fused_buf = self._buf("fused", (Nv, 16), dev) if dev.type == "cuda" else None
+            fused_buf = self._buf("fused" + tag, (Nv, 16), dev) if dev.type == "cuda" else None
 
             def tail():
                 if real:
@@ -889,7 +915,7 @@ class SyncDDIMSampler:
         else:
             fused = eng.vertex_features(x_local, t_embed, v_embed_local, local_idx, add_bias=(rank == 0))
             if dev.type == "cuda":  # persistent: the communication stream reads it after this call returns
-                fused = self._buf("fused", tuple(fused.shape), dev).copy_(fused)
+                fused = self._buf("fused" + tag, tuple(fused.shape), dev).copy_(fused)
 
             def tail():
                 if real:
