@@ -211,7 +211,10 @@ int mvd_mse_loss(mvd_ctx* ctx, const float* a, const float* b, size_t n, float* 
  *                                   time_embed.* and spatial_volume.* at `lr_aux` (the reference: 10 lr); gradients are
  *                                   multiplied by inv_scale first.  `step` counts from 1.  If any gradient is inf / nan the
  *                                   whole update is skipped (*skipped_out = 1; reading it back synchronises the stream; NULL
- *                                   = no read-back).  With inv_scale == 1 (no loss scaling: the bfloat16 build) the overflow
+ *                                   = no read-back).  A group no backward call has written to since the last
+ *                                   mvd_train_zero_grad is left alone -- parameters AND moments -- as torch.optim.AdamW skips
+ *                                   parameters whose .grad is None (e.g. spatial_volume.* when only mvd_train_unet_step ran).
+ *                                   With inv_scale == 1 (no loss scaling: the bfloat16 build) the overflow
  *                                   check is not run -- torch.optim.AdamW's own behaviour -- and *skipped_out stays 0.
  *   mvd_train_repack                after the parameters changed: re-derive every packed fp16 weight in place. */
 int mvd_train_enable(mvd_ctx* ctx, int on);

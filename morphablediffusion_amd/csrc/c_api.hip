@@ -481,6 +481,7 @@ int mvd_train_zero_grad(mvd_ctx* c, void* stream) {
   if (!c || !c->train_mode || !c->finalized) return mvd_fail("mvd_train_zero_grad: context not finalized in training mode");
   HIP_CHECK_RET(hipSetDevice(c->device));
   HIP_CHECK_RET(hipMemsetAsync(c->arena_g, 0, c->arena_n * sizeof(float), S(stream)));
+  c->grad_touched[1] = c->grad_touched[2] = false;
   return 0;
 }
 
@@ -523,6 +524,7 @@ int mvd_train_unet_step(mvd_ctx* c, const float* x, const int64_t* timesteps, co
     }
   }
   RET_IF(engine_train_step(c, xn, cin, timesteps, context, B, depth0, cl, tgt, loss_scale, recompute, eps, loss_out, dcl, s));
+  c->grad_touched[1] = true;
   RET_IF(launch_nhwc_to_nchw(eps, oc, B, oc, HW, pred_out, s));
   for (int l = 0; l < 4; ++l)
     if (douts[l]) {
@@ -556,6 +558,7 @@ int mvd_train_cond_backward(mvd_ctx* c, int cond_index, const float* x, const fl
   RET_IF(launch_nchw_to_nhwc(context, B, cd.Cc, D * HW, cn, cd.Cc, cd.Cc, s));
   HIP_CHECK_RET(hipMemsetAsync(gc, 0, (size_t)B * D * HW * cd.Cc * sizeof(float), s));
   RET_IF(engine_train_cond_backward(c, cond_index, xn, cn, dn, B, H, W, level, depth0, gx, gc, s));
+  c->grad_touched[1] = true;
   RET_IF(launch_nhwc_to_nchw(gx, cd.dim, B, cd.dim, HW, dx, s));
   if (dcontext) RET_IF(launch_nhwc_to_nchw(gc, cd.Cc, B, cd.Cc, D * HW, dcontext, s));
   return 0;
@@ -585,6 +588,7 @@ int mvd_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots, co
     D = (D - 1) / 2 + 1;
     Sz = (Sz - 1) / 2 + 1;
   }
+  c->grad_touched[2] = true;
   return engine_train_conditioner_backward_batch(c, B, slots, x_noisy, timesteps, v_embed, n_views, target_index, dcl, dbg_dvolume,
                                                  dbg_dfused, dbg_dfeats, dbg_dtembed, s);
 }
@@ -654,7 +658,7 @@ int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float 
     const int grp = group_of(c->params[i].key);
     size_t j = i;
     while (j + 1 < c->params.size() && group_of(c->params[j + 1].key) == grp) ++j;
-    if (grp) {
+    if (grp && c->grad_touched[grp]) {  // a group no backward pass wrote to since zero_grad keeps its parameters AND its moments
       const size_t off = c->params[i].off, end = c->params[j].off + ((c->params[j].numel + 63) & ~(size_t)63);
       RET_IF(bwd_adamw(c->arena_p + off, c->arena_g + off, c->arena_m + off, c->arena_v + off, end - off, grp == 1 ? lr : lr_aux, beta1,
                        beta2, eps, weight_decay, step, inv_scale, c->found_inf, s));

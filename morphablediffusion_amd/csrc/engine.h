@@ -266,6 +266,9 @@ struct mvd_ctx {
   // key, so the reference's optimiser groups are contiguous ranges); `raw` keeps pointing into it, gradients / Adam moments
   // live in arenas of the same layout, and engine_repack re-derives every packed fp16 weight from the masters in place.
   bool train_mode = false;
+  // which optimiser groups received a gradient since the last mvd_train_zero_grad (1: the UNet, 2: time_embed / spatial_volume):
+  // mvd_train_adamw_step leaves the others alone, as torch.optim.AdamW skips parameters whose .grad is None
+  bool grad_touched[3] = {false, false, false};
   bool repacking = false;
   size_t repack_cursor = 0, sec_begin = 0, sec_end = 0;  // the `owned` allocations [sec_begin, sec_end) belong to the re-packable sections
   std::vector<size_t> owned_bytes;

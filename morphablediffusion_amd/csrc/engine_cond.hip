@@ -91,8 +91,10 @@ struct VoxelMap {
 // ----------------------------------------------------------------------------------------------------
 // mvd_set_cameras: construct_project_matrix (utils.py:46-69), the inverse used by create_target_volume
 // (utils.py:79-153) and near/far from the camera distance (morphable_diffusion.py:281-299), once per sample.
-int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipStream_t s) {
-  std::vector<ViewCam> cams(N);
+// (two halves: cams_build validates and converts on the host -- nothing of the context changes --, cams_commit uploads; a batch
+//  of samples validates ALL of its samples before the first commit: engine_set_samples)
+static int cams_build(mvd_ctx* c, const float* K, const float* RT, int N, std::vector<ViewCam>& cams) {
+  cams.assign(N, ViewCam());
   const double ratio = (double)(c->v.input_image_size / 8) / (double)c->v.input_image_size;
   for (int i = 0; i < N; ++i) {
     const float* k = K + i * 16;
@@ -133,6 +135,10 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipSt
     v.near_ = (float)dist - c->v.frustum_volume_length;
     v.far_ = (float)dist + c->v.frustum_volume_length;
   }
+  return 0;
+}
+static int cams_commit(mvd_ctx* c, const std::vector<ViewCam>& cams, hipStream_t s) {
+  const int N = (int)cams.size();
   // upload: pinned host image -> device table by ONE stream-ordered copy; both grow only when N does
   mvd_ctx::CamStage& st = c->cam_stage;
   if (N > st.cap) {
@@ -156,6 +162,11 @@ int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipSt
   HIP_CHECK_RET(hipEventRecord(st.staged, s));
   c->n_cams = N;
   return 0;
+}
+int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipStream_t s) {
+  std::vector<ViewCam> cams;
+  RET_IF(cams_build(c, K, RT, N, cams));
+  return cams_commit(c, cams, s);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -423,14 +434,21 @@ int engine_set_samples(mvd_ctx* c, int B, const int* slots, const float* const* 
   }
   for (int i = 0; i < B; ++i)
     if (rc[i]) return i ? mvd_fail(err[i].c_str()) : rc[i];
+  // every sample's cameras are validated and converted before the first slot is touched (a singular K / RT in sample 3 must not
+  // leave samples 0-2 committed), and the caller's slot is active again on every exit path
+  std::vector<std::vector<ViewCam>> cams(B);
+  for (int i = 0; i < B; ++i) RET_IF(cams_build(c, K[i], RT[i], N, cams[i]));
   const auto t1 = std::chrono::steady_clock::now();
-  const int back = c->cur_slot;
+  struct SlotGuard {
+    mvd_ctx* c;
+    int slot;
+    ~SlotGuard() { engine_select_sample(c, slot); }
+  } guard{c, c->cur_slot};
   for (int i = 0; i < B; ++i) {
     RET_IF(engine_select_sample(c, slots[i]));
     RET_IF(mesh_commit(c, hp[i], vertices[i], out_sh[i], bounds[i], Nv[i], s));
-    RET_IF(engine_set_cameras(c, K[i], RT[i], N, s));
+    RET_IF(cams_commit(c, cams[i], s));
   }
-  RET_IF(engine_select_sample(c, back));
   if (timing)
     fprintf(stderr, "[set_samples] %d samples: build (threads) %.2f ms, commit %.2f ms\n", B,
             std::chrono::duration<double, std::milli>(t1 - t0).count(),

@@ -22,6 +22,16 @@ IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "
 MAX_SAMPLE_SLOTS = 64  # per-sample mesh / camera tables kept resident in the context (mvd_select_sample)
 
 
+def _level_dims(d, s):
+    """(depth, size) of the four frustum levels: stride-2 convolutions with padding 1 (network.py:320-333), i.e. (x - 1) // 2 + 1
+    per level -- the same rule csrc/engine_cond.hip uses (x >> level only agrees for multiples of 8)."""
+    out = []
+    for _ in range(4):
+        out.append((d, s))
+        d, s = (d - 1) // 2 + 1, (s - 1) // 2 + 1
+    return out
+
+
 class Engine:
     def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0,
                  precision_level: int = 2, train: bool = False, vae_exact: bool = False):
@@ -461,11 +471,10 @@ class Engine:
         vol, te, vr = _f32(volumes, dev), _f32(t_embed, dev), _f32(v_rows, dev)
         vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
         B = vol.shape[0]
-        D, S = self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size
         outs, ptrs = {}, []
-        for lvl in range(4):
-            o = torch.empty(B, self.vcfg.frustum_dims[lvl], D >> lvl, S >> lvl, S >> lvl, device=dev, dtype=torch.float32)
-            outs[S >> lvl] = o
+        for lvl, (Dl, Sl) in enumerate(_level_dims(self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size)):
+            o = torch.empty(B, self.vcfg.frustum_dims[lvl], Dl, Sl, Sl, device=dev, dtype=torch.float32)
+            outs[Sl] = o
             ptrs.append(L.ptr(o))
         L.check(self.lib.mvd_frustum_volumes_batch(self._ctx, B, (C.c_int * B)(*[int(v) for v in slots]), L.ptr(vol), L.ptr(te), L.ptr(vr),
                                                    L.ptr(vi), *ptrs, _stream()))
@@ -475,12 +484,11 @@ class Engine:
         dev = self.device
         vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
         TN = vi.shape[0]
-        D, S = self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size
         outs = {}
         ptrs = []
-        for lvl in range(4):
-            o = torch.empty(TN, self.vcfg.frustum_dims[lvl], D >> lvl, S >> lvl, S >> lvl, device=dev, dtype=torch.float32)
-            outs[S >> lvl] = o
+        for lvl, (Dl, Sl) in enumerate(_level_dims(self.vcfg.frustum_volume_depth, self.vcfg.frustum_volume_size)):
+            o = torch.empty(TN, self.vcfg.frustum_dims[lvl], Dl, Sl, Sl, device=dev, dtype=torch.float32)
+            outs[Sl] = o
             ptrs.append(L.ptr(o))
         te, ve = _f32(t_embed, dev), _f32(v_embed, dev)
         L.check(self.lib.mvd_frustum_volumes(self._ctx, L.ptr(te), L.ptr(ve), L.ptr(vi), TN, *ptrs, _stream()))
