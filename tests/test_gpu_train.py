@@ -149,6 +149,37 @@ def test_training_step_every_unet_gradient_vs_reference():
 
 
 @pytest.mark.parametrize("cond_index,res_", [(0, 4), (2, 8), (5, 16), (9, 32)])
+def test_training_step_full_width_gradients_vs_reference():
+    """The FULL-WIDTH training step (916.9 M-parameter UNet, B = 2) against the reference's own training_step + loss.backward()
+    run on the CPU (tools/make_goldens.py --only-train-full -> tests/golden/train_full.npz): loss, prediction and a sample of 26
+    gradient tensors -- every block kind, every resolution level, both ends of the network, six DepthTransformer tensors.  Same
+    bounds as at reduced width (until round 4 the full-width step was only property-tested)."""
+    path = os.path.join(G, "train_full.npz")
+    g = np.load(path)
+    batch, x0, x_in, clip, ts, noise, ti, dr = _train_inputs(g)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    prepared = (x0.cuda(), clip.cuda(), {"x": x_in.cuda()})
+    N = int(g["N"])
+    m = make_train_model(gi.FULL_UNET, VolumeConfig(num_views=N), N, workspace_gb=40.0, loss_scale=65536.0, recompute=True)
+    m.train_conditioner = False  # the golden holds UNet gradients (frustum volumes as leaves)
+    m.engine.zero_grad()
+    loss = m.training_step(dev, prepared=prepared, time_steps=ts, noise=noise, target_index=ti, drop_random=dr)
+    want = float(np.asarray(g["loss.full"])[0])
+    rl = abs(float(loss) - want) / want
+    print(f"[parity] full-width training loss {float(loss):.6f} vs reference {want:.6f}: rel {rl:.2e}")
+    assert rl <= 1e-3
+    compare(m.last_noise_predict, g, "noise_predict", rel=2e-3, mx=1e-2)
+    rows = sorted(_grad_report(m, g, m.loss_scale), reverse=True)
+    for rl_, nr, n in rows:
+        print(f"[parity] full-width grad {n}: relL2={rl_:.2e} norm err {nr:.2e}")
+    cond = [r for r in rows if r[2].startswith(("middle_conditions.", "output_conditions."))]
+    rest = [r for r in rows if not r[2].startswith(("middle_conditions.", "output_conditions."))]
+    assert len(cond) == 6 and len(rest) == 20
+    assert max(r[0] for r in cond) <= 5e-2, cond[0]
+    assert max(r[0] for r in rest) <= 1e-2, rest[0]
+    m.engine.close()
+
+
 def test_depth_transformer_backward_exact_inputs(cond_index, res_):
     """One DepthTransformer's backward with the SAME input, context volume and output gradient on both sides (oracle autograd
     in fp32 on the CPU vs mvd_train_cond_backward): no forward-pass rounding in the inputs, so no mask flips -- what is left is

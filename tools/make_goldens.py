@@ -346,8 +346,21 @@ def gold_trained(ns, full=True):
         gold_step(ns, "step_full_trained.npz", gi.FULL_UNET, 16, "perspective", 20, True, 5023, 16, style="trained")
 
 
-def gold_train(ns):
-    """f2: the reference's training_step (morphable_diffusion.py:520-549) at reduced width, run with
+FULL_TRAIN_TENSORS = (  # the sample of tools/make_goldens.py --only-train-full: every block kind, every level, both ends
+    "input_blocks.0.0.weight", "input_blocks.1.0.in_layers.2.weight", "input_blocks.1.0.emb_layers.1.weight",
+    "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight", "input_blocks.2.1.transformer_blocks.0.ff.net.0.proj.weight",
+    "input_blocks.3.0.op.weight", "input_blocks.4.0.skip_connection.weight", "input_blocks.5.1.proj_in.weight",
+    "input_blocks.7.1.transformer_blocks.0.attn1.to_out.0.weight", "input_blocks.8.0.out_layers.3.weight",
+    "input_blocks.10.0.in_layers.2.weight", "middle_block.1.transformer_blocks.0.ff.net.2.weight", "middle_block.2.out_layers.0.weight",
+    "middle_conditions.proj_in.0.weight", "middle_conditions.depth_attn.to_k.weight", "output_conditions.2.proj_out.3.weight",
+    "output_conditions.5.depth_attn.to_q.weight", "output_conditions.8.proj_context.0.weight", "output_conditions.8.proj_out.5.weight",
+    "output_blocks.2.1.conv.weight", "output_blocks.5.1.transformer_blocks.0.norm1.weight", "output_blocks.8.0.in_layers.2.weight",
+    "output_blocks.11.0.out_layers.3.bias", "output_blocks.11.1.proj_out.weight", "out.2.weight", "time_embed.2.weight")
+
+
+def gold_train(ns, ucfg=None, B=4, out="train_small.npz", only=None, drops=(0.03, 0.12, 0.07, 0.6), with_conditioner=True):
+    """(ucfg / B / out / only: the full-width variant stores loss, prediction and the gradients of the tensors named in `only`.)
+    f2: the reference's training_step (morphable_diffusion.py:520-549) at reduced width, run with
     the reference's own methods in the reference's own order -- time steps, add_noise (:551-565), random target view,
     construct_spatial_volume on all noisy views, one frustum volume per sample, UNetWrapper.forward(is_train=True) with
     condition dropout (:95-130), MSE -- then loss.backward().  ``prepare`` (VAE / CLIP) is replaced by seeded latents.
@@ -355,8 +368,8 @@ def gold_train(ns):
     (torch.rand patched for that one call) so that all four branches of get_drop_scheme (:84-93) occur in a batch of 4.
     Stored: loss, noise_predict, dL/dpred, the gradient of EVERY UNet parameter (sample + norm; the 170 DepthTransformer
     tensors with larger samples) and the gradient w.r.t. the four frustum volumes."""
-    B, N = 4, 4
-    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    N = 4
+    ucfg, vcfg = ucfg or gi.SMALL_UNET, VolumeConfig(num_views=N)
     model, _ = build_full_model(ns, ucfg, vcfg, N)
     model.model.drop_conditions = True
     model.train()
@@ -370,7 +383,7 @@ def gold_train(ns):
     x0 = torch.randn(B, N, 4, 32, 32, generator=g) * 0.8           # target latents (what prepare() returns as x)
     x_in = torch.randn(B, 4, 32, 32, generator=g) * 0.18215
     clip = torch.randn(B, 1, 768, generator=g)
-    drop_random = torch.tensor([0.03, 0.12, 0.07, 0.6])            # drop all | drop volume | drop concat | keep everything
+    drop_random = torch.tensor(list(drops)[:B])                    # drop all | drop volume | drop concat | keep everything
     torch.manual_seed(4242)
     time_steps = torch.randint(0, model.num_timesteps, (B,)).long()
     x_noisy, noise = model.add_noise(x0, time_steps)
@@ -402,6 +415,8 @@ def gold_train(ns):
     # sample + the L2 norm of each gradient
     names, norms = [], []
     for n_, p_ in model.model.diffusion_model.named_parameters():
+        if only is not None and n_ not in only:
+            continue
         if p_.grad is None:  # attn2.to_q / to_k / norm2 see a single context token: autograd may leave them untouched
             g_ = torch.zeros_like(p_)
         else:
@@ -413,6 +428,12 @@ def gold_train(ns):
     # gradient w.r.t. the frustum volumes BEFORE the condition dropout: where the conditioner's backward starts
     for k_, v_ in vf_pre.items():
         packs[f"dsrc.{k_}"] = gi.pack(v_.grad, limit=2048, target=4096)
+    if not with_conditioner:
+        print("train golden:", out, "loss", float(loss), "pred std", float(pred.std()), "UNet grads stored:", len(names))
+        save(out, packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(), "target_index": target_index.numpy(),
+                          "drop_random": drop_random.numpy(), "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names),
+                          "grad_norms": np.array(norms)})
+        return
     # second pass with the FULL graph (frustum volumes attached to the conditioner): the gradients of spatial_volume.* and of
     # the step-embedding MLP time_embed.* (the reference's second and third optimiser groups, morphable_diffusion.py:639-640)
     model.zero_grad()
@@ -437,7 +458,7 @@ def gold_train(ns):
     print("train golden: loss", float(loss), "pred std", float(pred.std()), "UNet grads:", len(names), "zero-norm:",
           [n for n, v in zip(names, norms) if v == 0.0][:8], "| conditioner grads:", len(cnames), "zero-norm:",
           [n for n, v in zip(cnames, cnorms) if v == 0.0][:6])
-    save("train_small.npz", packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
+    save(out, packs, {"B": B, "N": N, "nverts_in": 500, "time_steps": time_steps.numpy(),
                                     "target_index": target_index.numpy(), "drop_random": drop_random.numpy(),
                                     "seed_latents": 77, "seed_draws": 4242, "grad_names": np.array(names),
                                     "grad_norms": np.array(norms), **extra_c})
@@ -487,6 +508,7 @@ def main():
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
     ap.add_argument("--only-train", action="store_true", help="only the training-step golden (loss + gradients)")
+    ap.add_argument("--only-train-full", action="store_true", help="only the FULL-WIDTH training-step golden (loss, prediction, a sample of 26 gradient tensors)")
     ap.add_argument("--only-traj", action="store_true", help="only the multi-step trajectory golden")
     ap.add_argument("--only-trained", action="store_true", help="only the goldens on the trained-like weight set")
     ap.add_argument("--only-cameras", action="store_true", help="only the camera-trajectory golden (ast-extracted from generate_face.py)")
@@ -512,6 +534,10 @@ def main():
         return
     if args.only_train:
         gold_train(ns)
+        return
+    if args.only_train_full:
+        gold_train(ns, ucfg=gi.FULL_UNET, B=2, out="train_full.npz", only=set(FULL_TRAIN_TENSORS), drops=(0.6, 0.12),
+                   with_conditioner=False)
         return
     if args.only_trained:
         gold_trained(ns, not args.skip_full)
