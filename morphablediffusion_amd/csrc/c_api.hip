@@ -153,7 +153,7 @@ void mvd_destroy(mvd_ctx* c) {
   hipFree(c->ws.base);
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
-  for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx})
+  for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
   if (c->side) hipStreamDestroy(c->side);
   delete c;

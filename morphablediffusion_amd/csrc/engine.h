@@ -208,7 +208,7 @@ struct mvd_ctx {
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
   // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr, ev_emb0 = nullptr, ev_emb = nullptr;
   std::vector<hipEvent_t> ev_cond;
   // in-situ per-kernel-family timing (bench.py's roofline object): HIP events on the launch stream around launches, keyed
   // by the kernel's template instance.  mode 0 off; 1 every launch of every family; 2 only family `probe_only`, a

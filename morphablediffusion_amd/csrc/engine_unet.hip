@@ -767,7 +767,8 @@ int unet_embeddings(mvd_ctx* c, const int64_t* t, const float* context, int Bv, 
 int engine_side_init(mvd_ctx* c) {
   if (c->side) return 0;
   HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (hipEvent_t* ev : {&c->ev_fork, &c->ev_join, &c->ev_join2, &c->ev_ctx}) HIP_CHECK_RET(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  for (hipEvent_t* ev : {&c->ev_fork, &c->ev_join, &c->ev_join2, &c->ev_ctx, &c->ev_emb0, &c->ev_emb})
+    HIP_CHECK_RET(hipEventCreateWithFlags(ev, hipEventDisableTiming));
   c->ev_cond.resize(c->conds.size());
   for (auto& ev : c->ev_cond) HIP_CHECK_RET(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   return 0;
@@ -869,8 +870,27 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   };
   if (!produce) RET_IF(fork_ctx());
   // timestep embedding -> MLP -> every ResBlock's emb projection in one pass
+  // Nothing before the first ResBlock reads them (the input convolution does not), and they are five weight-streaming GEMMs
+  // of Bv rows on a few CUs: on the side stream they run beside the input convolution instead of in front of it (the caller's
+  // stream waits for them behind the first input block).  Their split-K scratch is freed by host scopes while the side
+  // stream may still use it: held, like the context producer's (Workspace::hold).
   float *e0 = nullptr, *e1 = nullptr, *e2 = nullptr, *ea = nullptr, *a2 = nullptr;
-  RET_IF(unet_embeddings(c, t, context, Bv, s, &e0, &e1, &e2, &ea, &a2));
+  static const bool side_emb_off = getenv("MVD_NO_SIDE_EMB") != nullptr;
+  const bool side_emb = use_side && produce && !side_emb_off && c->in_blocks.size() > 1 && c->ws.hold == 0;  // (without a producer the side stream is already busy with the context folds)
+  if (side_emb) {
+    RET_IF(engine_side_init(c));
+    HIP_CHECK_RET(hipEventRecord(c->ev_emb0, s));  // t / context were written on the caller's stream
+    HIP_CHECK_RET(hipStreamWaitEvent(c->side, c->ev_emb0, 0));
+    join.side = c->side;
+    join.ev = c->ev_join;
+    c->ws.hold = 1;
+    const int r = unet_embeddings(c, t, context, Bv, c->side, &e0, &e1, &e2, &ea, &a2);
+    c->ws.hold = 0;
+    RET_IF(r);
+    HIP_CHECK_RET(hipEventRecord(c->ev_emb, c->side));
+  } else {
+    RET_IF(unet_embeddings(c, t, context, Bv, s, &e0, &e1, &e2, &ea, &a2));
+  }
   f.emb_all = ea;
   f.a2_all = a2;
   if (tape) {
@@ -1021,6 +1041,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     chain_id = j;
     const std::vector<UOp>& next_ops = j + 1 < nb ? c->in_blocks[j + 1] : c->mid_block;
     Carry* outc = (xcarry[j & 1].slabs && !next_ops.empty() && takes_carry(next_ops[0], in_res[j])) ? &xcarry[j & 1] : nullptr;
+    if (side_emb && j == 1) HIP_CHECK_RET(hipStreamWaitEvent(s, c->ev_emb, 0));  // the first ResBlock needs the embeddings
     RET_IF(run_chain(c->in_blocks[j], nullptr, cur, dst, H, W, prev_carry, outc, true));
     prev_carry = outc;
     cur = dst;

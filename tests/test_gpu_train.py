@@ -148,7 +148,6 @@ def test_training_step_every_unet_gradient_vs_reference():
     m.engine.close()
 
 
-@pytest.mark.parametrize("cond_index,res_", [(0, 4), (2, 8), (5, 16), (9, 32)])
 def test_training_step_full_width_gradients_vs_reference():
     """The FULL-WIDTH training step (916.9 M-parameter UNet, B = 2) against the reference's own training_step + loss.backward()
     run on the CPU (tools/make_goldens.py --only-train-full -> tests/golden/train_full.npz): loss, prediction and a sample of 26
@@ -180,6 +179,7 @@ def test_training_step_full_width_gradients_vs_reference():
     m.engine.close()
 
 
+@pytest.mark.parametrize("cond_index,res_", [(0, 4), (2, 8), (5, 16), (9, 32)])
 def test_depth_transformer_backward_exact_inputs(cond_index, res_):
     """One DepthTransformer's backward with the SAME input, context volume and output gradient on both sides (oracle autograd
     in fp32 on the CPU vs mvd_train_cond_backward): no forward-pass rounding in the inputs, so no mask flips -- what is left is
