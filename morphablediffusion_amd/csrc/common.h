@@ -195,8 +195,11 @@ int launch_vertex_gather(const float* feats, const ViewCam* cams, const int* vie
                          float vol_len, int fsize, int persp, float* out, hipStream_t s);
 int launch_fuse_views(const float* vf, int n_views, int Nv, int total_views, const float* w, const float* b,
                       float* out, int accumulate, hipStream_t s);
-int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w,
-                       const float* scale, const float* shift, float* out, hipStream_t s);
+// w: [27][Cin][Cout]; wp: the same weights as matrix-core B fragments (launch_sparse_w_frag) or null -> one-site-per-workgroup kernel
+int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w, const float* wp,
+                       const float* scale, const float* shift, float* out, hipStream_t s, int mask_nonrep = 0);
+bool sparse_mfma_takes(int Cin, int Cout);
+int launch_sparse_w_frag(const float* w, int Cl_in, int Cl_out, int transposed, int flip, float* dst, hipStream_t s);
 // BatchNorm1d in train mode over n rows of C <= 256 channels + ReLU, in place: x = relu((x - mean) / sqrt(var + eps) * g + b),
 // biased variance (what F.batch_norm normalises with)
 int launch_sparse_w_pack(const float* src, int Cin, int Cout, int layout, float* dst, hipStream_t s);

@@ -141,6 +141,8 @@ struct SparseLayerW {
   std::string wkey, bnkey;  // state_dict keys of the conv weight / of its BatchNorm1d (prefix)
   int layout = 0;           // layout of the uploaded weight (build_sparse_layer): the gradient goes back in the same one
   float* w = nullptr;      // [27][Cin][Cout] fp32
+  float* wp = nullptr;     // the same as B fragments of sparse_mfma_kernel (k_cond.hip); null: channel counts it does not take
+  float* wd = nullptr;     // training contexts: fragments of the data-gradient's layer (transposed; tap-flipped when submanifold)
   float* scale = nullptr;  // folded eval BatchNorm
   float* shift = nullptr;
   float* gamma = nullptr;  // BatchNorm weight / bias themselves (train mode: batch statistics, engine_volume_from_fused)

@@ -599,10 +599,10 @@ int engine_sparse_net(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_bat
     }
     float* out = m.feat[pp];
     if (bn_batch_stats) {  // train mode: raw conv, then BatchNorm1d(eps 1e-3) on the statistics of the active rows + ReLU
-      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, nullptr, nullptr, out, s));
+      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.wp, nullptr, nullptr, out, s));
       RET_IF(launch_bn_rows_relu(out, out, n_out, L.cout, L.gamma, L.beta, 1e-3f, nullptr, s, L.rmean, L.rvar, 0.01f));
     } else {
-      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.scale, L.shift, out, s));
+      RET_IF(launch_sparse_conv(in, nbr, n_out, L.cin, L.cout, L.w, L.wp, L.scale, L.shift, out, s));
     }
     in = out;
     pp ^= 1;

@@ -71,6 +71,10 @@ int cbwd_sparse_wgrad_chunks(int n_out);
 int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, const float* w, float* d_in,
                      float* dw_packed, float* dw_part, hipStream_t s);
 int cbwd_sparse_w_unpack_add(const float* pk, int Cin, int Cout, int layout, float* dst, hipStream_t s);
+int cbwd_sparse_wgrad_mfma(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, float* dw_packed,
+                           float* dw_part, hipStream_t s);
+int cbwd_sparse_inverse_table(const int* nbr_down, int n_out, int n_in, int* inv, hipStream_t s);
+int cbwd_sparse_fold_dups(float* d, const int* nbr, int n, int C, hipStream_t s);
 int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, int W, int C, int stride, half_t* dst, int Rp, hipStream_t s);
 int cbwd_small_linear_bwd(const float* g, long ldg, int rows, int N, const half_t* w, int K, float* out, long ldo, int accum, hipStream_t s);
 // k_train.hip
@@ -1249,7 +1253,7 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
       WS_CHECK(sp_raw[i] && sp_post[i]);
       sp_stats[i] = F((size_t)2 * L.cout);
       WS_CHECK(sp_stats[i]);
-      RET_IF(launch_sparse_conv(in, sp_nbr[i], sp_nout[i], L.cin, L.cout, L.w, nullptr, nullptr, sp_raw[i], s));
+      RET_IF(launch_sparse_conv(in, sp_nbr[i], sp_nout[i], L.cin, L.cout, L.w, L.wp, nullptr, nullptr, sp_raw[i], s));
       RET_IF(launch_bn_rows_relu(sp_raw[i], sp_post[i], sp_nout[i], L.cout, L.gamma, L.beta, 1e-3f, sp_stats[i], s));
       in = sp_post[i];
       n_in = sp_nout[i];
@@ -1422,8 +1426,29 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
     float* dwp = F((size_t)27 * L.cin * L.cout);
     float* d_in = F((size_t)sp_nin[i] * L.cin);
     WS_CHECK(dwp && d_in);
-    HIP_CHECK_RET(hipMemsetAsync(d_in, 0, (size_t)sp_nin[i] * L.cin * sizeof(float), s));
-    {
+    if (L.wp && L.wd) {
+      // matrix-core form (k_cond.hip / k_cond_bwd.hip): gather-form data gradient through the layer's own table with the tap
+      // flipped (submanifold) or through the inverse table (strided) -- no atomics, no zero fill.  At level 0 the gradients of
+      // duplicate vertices' rows are folded into their representatives' first (the table is symmetric over those only).
+      const bool lvl0_subm = !L.strided && sp_nbr[i] == m.nbr_subm[0];
+      if (lvl0_subm) RET_IF(cbwd_sparse_fold_dups(d_cur, sp_nbr[i], sp_nout[i], L.cout, s));
+      {
+        WsScope sc(c, WS_TEMP);
+        float* dw_part = F((size_t)cbwd_sparse_wgrad_chunks(sp_nout[i]) * 27 * L.cin * L.cout);
+        WS_CHECK(dw_part);
+        RET_IF(cbwd_sparse_wgrad_mfma(sp_in[i], sp_nbr[i], d_cur, sp_nout[i], L.cin, L.cout, dwp, dw_part, s));
+      }
+      const int* table = sp_nbr[i];
+      WsScope sc(c, WS_TEMP);
+      if (L.strided) {
+        int* inv = (int*)F((size_t)sp_nin[i] * 27);
+        WS_CHECK(inv);
+        RET_IF(cbwd_sparse_inverse_table(sp_nbr[i], sp_nout[i], sp_nin[i], inv, s));
+        table = inv;
+      }
+      RET_IF(launch_sparse_conv(d_cur, table, sp_nin[i], L.cout, L.cin, nullptr, L.wd, nullptr, nullptr, d_in, s, lvl0_subm ? 1 : 0));
+    } else {
+      HIP_CHECK_RET(hipMemsetAsync(d_in, 0, (size_t)sp_nin[i] * L.cin * sizeof(float), s));
       WsScope sc(c, WS_TEMP);
       float* dw_part = F((size_t)cbwd_sparse_wgrad_chunks(sp_nout[i]) * 27 * L.cin * L.cout);
       WS_CHECK(dw_part);

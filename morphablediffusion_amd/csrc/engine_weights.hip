@@ -214,6 +214,17 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   RET_IF(dmalloc(c, (void**)&L->scale, cout * 4));
   RET_IF(dmalloc(c, (void**)&L->shift, cout * 4));
   RET_IF(launch_sparse_w_pack(w->d, cin, cout, layout, L->w, 0));                       // -> [27][cin][cout]
+  // MVD_SPARSE_VALU=1 (A/B switch, read when the weights are built): the one-site-per-workgroup kernels and the scatter-form
+  // data gradient instead -- tests/test_gpu_train.py holds the two forms against each other
+  const bool valu_only = getenv("MVD_SPARSE_VALU") != nullptr && getenv("MVD_SPARSE_VALU")[0] == '1';
+  if (sparse_mfma_takes(cin, cout) && !valu_only) {  // B fragments of the matrix-core kernel; the data-gradient's in a training context
+    RET_IF(dmalloc(c, (void**)&L->wp, w->numel * 4));
+    RET_IF(launch_sparse_w_frag(L->w, cin, cout, 0, 0, L->wp, 0));
+    if (c->train_mode) {
+      RET_IF(dmalloc(c, (void**)&L->wd, w->numel * 4));
+      RET_IF(launch_sparse_w_frag(L->w, cout, cin, 1, strided ? 0 : 1, L->wd, 0));
+    }
+  }
   RET_IF(launch_bn_fold(g->d, b->d, rm->d, rv->d, 1e-3f, cout, L->scale, L->shift, 0));  // eval BatchNorm1d(eps 1e-3), network.py:105
   RET_IF(copy_f32(c, bn + ".weight", &L->gamma));
   RET_IF(copy_f32(c, bn + ".bias", &L->beta));

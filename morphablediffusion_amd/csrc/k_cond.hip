@@ -143,6 +143,117 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same layer as a tiled gather-GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an exact fp32 fma chain, so the
+// layer stays fp32 -- the conditioner's BatchNorm / ReLU masks depend on it).  A workgroup owns 16 output sites x all Cout;
+// its four waves split the 27 taps (tap t -> wave t & 3) and combine through LDS in wave order (fixed summation order).
+// Per tap a lane gathers ONE 16-byte piece of its neighbour row -- lane (m = lane & 15, q = lane >> 4) holds channels
+// 4q .. 4q+3 of site m, which is the A operand of four consecutive MFMAs (k index of MFMA j = channel 16 cb + 4q + j) -- and the
+// weights come pre-ordered as B fragments (sparse_w_frag_kernel: one coalesced 16-byte load per lane and fragment).  A tap none
+// of the 16 sites has is skipped (wave-uniform); the operands of the next tap are in flight while the current one multiplies.
+// Also the layer's data-gradient (dgrad): a sparse conv of d_out with the transposed weights through the same table read with
+// the tap flipped (submanifold: nbr[s][k] = s' <=> nbr[s'][26-k] = s) or through the inverse table (strided), see k_cond_bwd.hip.
+// NBW: 16-channel output blocks per workgroup (grid.y = Cout / 16 / NBW): the 64-channel layers have few sites (one or two
+// thousand voxels after two strided layers), so their output blocks go to separate workgroups.
+template <int CIN, int COUT, int NBW>
+__global__ __launch_bounds__(256) void sparse_mfma_kernel(const float* __restrict__ in, const int* __restrict__ nbr, int n_out,
+                                                          const float* __restrict__ wp, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int mask_nonrep, float* __restrict__ out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CB = CIN / 16, NBT = COUT / 16, NB = NBW, CW = 16 * NBW;  // CW: output channels of this workgroup
+  __shared__ int s_nb[16 * 27];
+  __shared__ float s_red[4][16 * CW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s0 = blockIdx.x * 16, b0 = blockIdx.y * NBW;
+  for (int i = tid; i < 16 * 27; i += 256) s_nb[i] = s0 + i / 27 < n_out ? nbr[(long)s0 * 27 + i] : -1;
+  __syncthreads();
+  const int m = lane & 15, q = lane >> 4;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // taps of this wave that at least one of the 16 sites has (bit i: tap wave + 4 i)
+  unsigned act = 0;
+  int nbs[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int t = wave + 4 * i;
+    nbs[i] = t < 27 ? s_nb[m * 27 + t] : -1;
+    if (__ballot(nbs[i] >= 0) != 0ull) act |= 1u << i;
+  }
+  f32x4 a0[CB], a1[CB], w0[CB * NB], w1[CB * NB];
+  auto load = [&](int i, f32x4 (&a)[CB], f32x4 (&w)[CB * NB]) {
+    int nb = -1;  // nbs[i] with a wave-uniform i: selected without dynamic register indexing
+#pragma unroll
+    for (int j = 0; j < 7; ++j) nb = i == j ? nbs[j] : nb;
+    const int t = wave + 4 * i;
+    const float* row = in + (long)(nb < 0 ? 0 : nb) * CIN + 4 * q;
+    const float* wt = wp + (((long)t * CB * NBT + b0) * 64 + lane) * 4;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      a[cb] = nb >= 0 ? *(const f32x4*)(row + cb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NB; ++b) w[cb * NB + b] = *(const f32x4*)(wt + (long)(cb * NBT + b) * 256);
+    }
+  };
+  auto compute = [&](const f32x4 (&a)[CB], const f32x4 (&w)[CB * NB]) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][j], w[cb * NB + b][j], acc[b], 0, 0, 0);
+  };
+  auto next = [&]() -> int {  // lowest remaining active tap slot, or -1
+    if (!act) return -1;
+    const int i = __builtin_ctz(act);
+    act &= act - 1;
+    return i;
+  };
+  int i0 = next(), i1 = -1;
+  if (i0 >= 0) load(i0, a0, w0);
+  while (i0 >= 0) {
+    i1 = next();
+    if (i1 >= 0) load(i1, a1, w1);
+    compute(a0, w0);
+    if (i1 < 0) break;
+    i0 = next();
+    if (i0 >= 0) load(i0, a0, w0);
+    compute(a1, w1);
+  }
+  // D fragment: lane holds sites 4q .. 4q+3 (register r) x output channel 16 b + m
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wave][(4 * q + r) * CW + b * 16 + m] = acc[b][r];
+  __syncthreads();
+  for (int e = tid; e < 16 * CW; e += 256) {
+    const int sl = e / CW, co = b0 * 16 + e - sl * CW, site = s0 + sl;
+    if (site >= n_out) break;
+    float v = ((s_red[0][e] + s_red[1][e]) + s_red[2][e]) + s_red[3][e];
+    if (scale) v = fmaxf(v * scale[co] + shift[co], 0.f);
+    if (mask_nonrep && s_nb[sl * 27 + 13] != site) v = 0.f;  // a duplicate vertex's row: nothing reads it
+    out[(long)site * COUT + co] = v;
+  }
+#endif
+}
+
+// w_src -> B fragments of sparse_mfma_kernel: dst[t][cb][b][lane][j] = W(t, in = 16 cb + 4 (lane >> 4) + j, out = 16 b + (lane & 15)).
+// transposed == 0: W(t, in, out) = w[t][in][out] of the forward pack [27][Cin][Cout] (Cl_in = Cin, Cl_out = Cout).
+// transposed == 1: the data-gradient's layer (its inputs are the forward outputs): W(t, in, out) = w[flip ? 26 - t : t][out][in].
+__global__ void sparse_w_frag_kernel(const float* __restrict__ w, int Cl_in, int Cl_out, int transposed, int flip, float* __restrict__ dst) {
+  const long total = (long)27 * Cl_in * Cl_out;
+  const int CB = Cl_in / 16, NB = Cl_out / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long f = i >> 8;
+    const int b = (int)(f % NB);
+    f /= NB;
+    const int cb = (int)(f % CB), t = (int)(f / CB);
+    const int ci = cb * 16 + 4 * (lane >> 4) + j, co = b * 16 + (lane & 15);
+    dst[i] = transposed ? w[((long)(flip ? 26 - t : t) * Cl_out + co) * Cl_in + ci] : w[((long)t * Cl_in + ci) * Cl_out + co];
+  }
+}
+
 __global__ void sparse_w_pack_kernel(const float* __restrict__ src, int Cin, int Cout, int layout, float* __restrict__ dst) {
   const long total = (long)27 * Cin * Cout;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -342,11 +453,34 @@ int launch_fuse_views(const float* vf, int n_views, int Nv, int total_views, con
   return 0;
 }
 
-int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w, const float* scale,
-                       const float* shift, float* out, hipStream_t s) {
+// wp: the layer's B-fragment pack (launch_sparse_w_frag) or null; channel counts the matrix-core kernel does not take (not
+// multiples of 16, more than 64) go through the one-site-per-workgroup kernel on `w` ([27][Cin][Cout]).
+int launch_sparse_conv(const float* in, const int* nbr, int n_out, int Cin, int Cout, const float* w, const float* wp, const float* scale,
+                       const float* shift, float* out, hipStream_t s, int mask_nonrep) {
   if (Cout > 256 || n_out <= 0) return n_out <= 0 ? 0 : mvd_fail("sparse_conv: Cout > 256");
+  const dim3 blk(256);
+#define MVD_SP(CI, CO, NBW)                                                                                                   \
+  if (wp && Cin == CI && Cout == CO) {                                                                                        \
+    hipLaunchKernelGGL((sparse_mfma_kernel<CI, CO, NBW>), dim3(cdiv(n_out, 16), CO / 16 / NBW), blk, 0, s, in, nbr, n_out, wp, scale, \
+                       shift, mask_nonrep, out);                                                                              \
+    HIP_CHECK_RET(hipGetLastError());                                                                                        \
+    return 0;                                                                                                                \
+  }
+  MVD_SP(16, 16, 1) MVD_SP(16, 32, 2) MVD_SP(32, 16, 1) MVD_SP(32, 32, 2) MVD_SP(32, 64, 1) MVD_SP(64, 32, 1) MVD_SP(64, 64, 1)
+#undef MVD_SP
+  if (mask_nonrep || !w) return mvd_fail("sparse_conv: no matrix-core kernel for these channel counts");
   hipLaunchKernelGGL(sparse_conv_kernel, dim3(n_out), dim3(256), 0, s, in, nbr, n_out, Cin, Cout, w,
                      scale, shift, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+bool sparse_mfma_takes(int Cin, int Cout) {
+  return (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 16 || Cout == 32 || Cout == 64) && !(Cin == 16 && Cout == 64) &&
+         !(Cin == 64 && Cout == 16);
+}
+int launch_sparse_w_frag(const float* w, int Cl_in, int Cl_out, int transposed, int flip, float* dst, hipStream_t s) {
+  const long total = (long)27 * Cl_in * Cl_out;
+  hipLaunchKernelGGL(sparse_w_frag_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, w, Cl_in, Cl_out, transposed, flip, dst);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

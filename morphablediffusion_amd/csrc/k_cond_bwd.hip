@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void sparse_conv_dgrad_kernel(const float* __r
 // Only ~30 % of a surface mesh's (site, tap) pairs are active: each wave first compacts the active pairs of its quarter of the
 // chunk into LDS (ballot + prefix popcount: site order is kept, so the sum order is fixed), then every thread walks the four
 // lists -- a third of the iterations, none of them a skipped one, four independent loads in flight.
-constexpr int SP_CHUNK = 512;
+constexpr int SP_CHUNK = 256;
 __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
                                                                 const float* __restrict__ d_out, int n_out, int Cin, int Cout,
                                                                 float* __restrict__ part) {
@@ -350,6 +350,90 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   }
   part[(((long)chunk * 27 + k) * Cin + ci) * Cout + co] = acc;
 }
+// The same weight gradient on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): a wave owns one tap of one chunk of
+// SP_CHUNK output sites and the whole Cin x Cout tile; the K dimension of the MFMA is the list of ACTIVE (site, neighbour) pairs of
+// that tap (compacted with ballot + prefix popcount: site order is kept, so the summation order is fixed), four pairs per
+// instruction: lane (m = lane & 15, q = lane >> 4) supplies in[nbr of pair q][16 a + m] as A and d_out[site of pair q][16 b + m] as
+// B -- both are 64-byte row segments, no transposes.  Partials per chunk as before, summed in chunk order by the reduce kernel.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sparse_wgrad_mfma_kernel(const float* __restrict__ in, const int* __restrict__ nbr,
+                                                                const float* __restrict__ d_out, int n_out, float* __restrict__ part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CA = CIN / 16, CB = COUT / 16, G = 4;  // G groups of four pairs in flight
+  __shared__ int s_i[4][SP_CHUNK], s_o[4][SP_CHUNK];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = blockIdx.x * 4 + wave, chunk = blockIdx.y, s0 = chunk * SP_CHUNK;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < SP_CHUNK / 64; ++j) {
+    const int site = s0 + j * 64 + lane;
+    const int nb = (k < 27 && site < n_out) ? nbr[(long)site * 27 + k] : -1;
+    const unsigned long long mk = __ballot(nb >= 0);
+    if (nb >= 0) {
+      const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+      s_i[wave][pos] = nb;
+      s_o[wave][pos] = site;
+    }
+    cnt += __popcll(mk);
+  }
+  __syncthreads();
+  if (k >= 27) return;
+  const int m = lane & 15, q = lane >> 4;
+  f32x4 acc[CA][CB];
+#pragma unroll
+  for (int a = 0; a < CA; ++a)
+#pragma unroll
+    for (int b = 0; b < CB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < cnt; base += 4 * G) {
+    float av[G][CA], bv[G][CB];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int p = base + 4 * g + q;
+      const bool ok = p < cnt;
+      const int i = ok ? s_i[wave][p] : 0, o = ok ? s_o[wave][p] : 0;
+#pragma unroll
+      for (int a = 0; a < CA; ++a) av[g][a] = ok ? in[(long)i * CIN + a * 16 + m] : 0.f;
+#pragma unroll
+      for (int b = 0; b < CB; ++b) bv[g][b] = ok ? d_out[(long)o * COUT + b * 16 + m] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int a = 0; a < CA; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][a], bv[g][b], acc[a][b], 0, 0, 0);
+  }
+  float* dst = part + ((long)chunk * 27 + k) * CIN * COUT;
+#pragma unroll
+  for (int a = 0; a < CA; ++a)
+#pragma unroll
+    for (int b = 0; b < CB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(long)(a * 16 + 4 * q + r) * COUT + b * 16 + m] = acc[a][b][r];
+#endif
+}
+
+// inverse of a strided layer's table: inv[i][k] = the output site that reads input row i at tap k (at most one), else -1
+__global__ void sparse_inverse_table_kernel(const int* __restrict__ nbr_down, int n_out, int* __restrict__ inv) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)n_out * 27; e += (long)gridDim.x * blockDim.x) {
+    const int i = nbr_down[e];
+    if (i >= 0) inv[(long)i * 27 + (int)(e % 27)] = (int)(e / 27);
+  }
+}
+// Several vertices in one voxel: the later ones' rows equal the representative's (the one every neighbour lookup returns, the
+// centre tap included), so their output gradients belong to the representative's row.  After this the level's table is symmetric
+// over the rows that carry gradient, which is what the gather-form data-gradient needs.
+__global__ void sparse_fold_dups_kernel(float* __restrict__ d, const int* __restrict__ nbr, int n, int C) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)n * C; e += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(e / C), c = (int)(e - (long)s * C);
+    const int r = nbr[(long)s * 27 + 13];
+    if (r != s && r >= 0) {
+      unsafeAtomicAdd(d + (long)r * C + c, d[e]);
+      d[e] = 0.f;
+    }
+  }
+}
+
 __global__ void sparse_wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long n, float* __restrict__ dw) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float a = 0.f;
@@ -480,6 +564,36 @@ int cbwd_sparse_conv(const float* in, const int* nbr, const float* d_out, int n_
                        dw_part);
     hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(gridn((size_t)n)), dim3(256), 0, s, dw_part, nchunk, n, dw_packed);
   }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// Matrix-core form (channel counts sparse_mfma_takes): weight gradient only; the data gradient is launch_sparse_conv on the
+// layer's transposed fragments (SparseLayerW::wd) -- no atomics, no zero fill.
+int cbwd_sparse_wgrad_mfma(const float* in, const int* nbr, const float* d_out, int n_out, int Cin, int Cout, float* dw_packed,
+                           float* dw_part, hipStream_t s) {
+  if (n_out <= 0) return 0;
+  const int nchunk = cdiv(n_out, SP_CHUNK);
+  const long n = (long)27 * Cin * Cout;
+  const dim3 grid(7, nchunk), blk(256);
+#define MVD_SPW(CI, CO)                                                                                                    \
+  if (Cin == CI && Cout == CO)                                                                                             \
+    hipLaunchKernelGGL((sparse_wgrad_mfma_kernel<CI, CO>), grid, blk, 0, s, in, nbr, d_out, n_out, dw_part);               \
+  else
+  MVD_SPW(16, 16) MVD_SPW(16, 32) MVD_SPW(32, 32) MVD_SPW(32, 64) MVD_SPW(64, 64)
+  return mvd_fail("sparse wgrad: no matrix-core kernel for these channel counts");
+#undef MVD_SPW
+  hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(gridn((size_t)n)), dim3(256), 0, s, dw_part, nchunk, n, dw_packed);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_sparse_inverse_table(const int* nbr_down, int n_out, int n_in, int* inv, hipStream_t s) {
+  HIP_CHECK_RET(hipMemsetAsync(inv, 0xFF, (size_t)n_in * 27 * sizeof(int), s));
+  if (n_out > 0) hipLaunchKernelGGL(sparse_inverse_table_kernel, dim3(gridn((size_t)n_out * 27)), dim3(256), 0, s, nbr_down, n_out, inv);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int cbwd_sparse_fold_dups(float* d, const int* nbr, int n, int C, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(sparse_fold_dups_kernel, dim3(gridn((size_t)n * C)), dim3(256), 0, s, d, nbr, n, C);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -346,15 +346,18 @@ def fuse_views(W, feats, p="spatial_volume.smpl_feature_extractor."):
     return y.reshape(B, N, -1, Nv).mean(1).permute(0, 2, 1)
 
 
-def _bn_relu(W, p, x, train=False, bn_update=None):
+def _bn_relu(W, p, x, train=False, bn_update=None, rows=None):
     """BatchNorm1d(eps 1e-3, momentum 0.01: network.py:105) over the active rows + ReLU.  eval: running statistics; train (the
     module is in train mode during training_step): statistics of this sample's active rows, biased variance.  bn_update (a
     dict, optional): receives the running buffers as nn.BatchNorm1d leaves them after this call -- running = 0.99 running +
-    0.01 batch statistic, the variance as the unbiased estimate -- chained over calls (a later call starts from the dict)."""
+    0.01 batch statistic, the variance as the unbiased estimate -- chained over calls (a later call starts from the dict).
+    rows (optional, train mode): index of x's row for every row of the layer's feature matrix -- several vertices in one voxel
+    keep a feature row each (copies of the voxel's representative), and BatchNorm1d's batch statistics run over all of them."""
     if train:
-        mean, var = x.mean(0), x.var(0, unbiased=False)
+        xs = x if rows is None else x[rows]
+        mean, var = xs.mean(0), xs.var(0, unbiased=False)
         if bn_update is not None:
-            n = x.shape[0]
+            n = xs.shape[0]
             rm = bn_update.get(p + ".running_mean", W[p + ".running_mean"])
             rv = bn_update.get(p + ".running_var", W[p + ".running_var"])
             bn_update[p + ".running_mean"] = 0.99 * rm + 0.01 * mean
@@ -428,7 +431,12 @@ def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", trai
         if k not in seen:
             seen.add(k)
             keep.append(i)
+    rows0 = None
     if len(keep) != coords.shape[0]:
+        first = {}
+        for j, i in enumerate(keep):
+            first[key[i].item()] = j
+        rows0 = torch.tensor([first[k] for k in key.tolist()])  # feature row of every vertex = its voxel's representative
         coords, feats = coords[keep], feats[keep]
     x = feats
     for blk, n in (("conv0", 2), ("down0", 1), ("conv1", 2), ("down1", 1), ("conv2", 3)):
@@ -438,7 +446,7 @@ def sparse_conv_net(W, feats, coords, out_sh, p="spatial_volume.xyzc_net.", trai
                 x, coords, shape = _strided_conv(x, coords, shape, w)
             else:
                 x = _subm_conv(x, coords, shape, w)
-            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x, train, bn_update)
+            x = _bn_relu(W, f"{p}{blk}.{3 * i + 1}", x, train, bn_update, rows=rows0 if blk == "conv0" else None)
     dense = torch.zeros([x.shape[1]] + shape)
     dense[:, coords[:, 0], coords[:, 1], coords[:, 2]] = x.t()
     return dense[None]
