@@ -263,6 +263,21 @@ int64_t mvd_train_bn_calls(mvd_ctx* ctx);
 int mvd_train_adamw_step(mvd_ctx* ctx, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
                          float inv_scale, int finetune_unet, int* skipped_out, void* stream);
 int mvd_train_repack(mvd_ctx* ctx);
+/* DDP's bucketed, overlapped gradient averaging (train_morphable_diffusion.py:302-303: Lightning wraps the module in
+ * DistributedDataParallel, whose reducer all-reduces a bucket as soon as its gradients are ready).  mvd_train_unet_step leaves
+ * its UNet gradients as buckets in the order they become final during the backward pass -- one per chain of blocks (output
+ * blocks 11..0, middle block, input blocks 11..0), then one for what completes at the end (the stacked emb_layers / attn2
+ * projections, the head, time_embed) -- each a list of gradient-arena ranges (floats) plus an event recorded behind the last
+ * kernel that writes them; together they cover model.diffusion_model.* exactly once.
+ *   mvd_train_grad_bucket_count   buckets of the last step (0 before the first).
+ *   mvd_train_grad_bucket         ranges of bucket k (offs / lens NULL: only *n_ranges).
+ *   mvd_train_grad_bucket_wait    makes `stream` (the caller's communication stream) wait for bucket k's event.
+ *   mvd_train_set_bucket_snapshot test hook: while set, every bucket's ranges are copied into `arena` (gradient-arena layout,
+ *                                 device memory) right behind its event -- equal to the final gradients iff the ranges were final. */
+int mvd_train_grad_bucket_count(mvd_ctx* ctx);
+int mvd_train_grad_bucket(mvd_ctx* ctx, int k, int max_ranges, int64_t* offs, int64_t* lens, int* n_ranges);
+int mvd_train_grad_bucket_wait(mvd_ctx* ctx, int k, void* stream);
+int mvd_train_set_bucket_snapshot(mvd_ctx* ctx, float* arena);
 /* Puts a volume [64,V,V,V] (reference layout, e.g. one sample of construct_spatial_volume's [B,64,V,V,V] result) back into
  * the context for mvd_frustum_volumes / mvd_denoise_views: with B > 1 samples per step (training_step) the per-sample
  * volumes are built first and the frustum stage runs afterwards (morphable_diffusion.py:531-533). */

@@ -152,6 +152,8 @@ void mvd_destroy(mvd_ctx* c) {
   hipFree(c->volume);
   hipFree(c->ws.base);
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
+  for (auto& gb : c->buckets)
+    if (gb.ev) hipEventDestroy(gb.ev);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
@@ -675,6 +677,31 @@ int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float 
 int mvd_train_repack(mvd_ctx* c) {
   if (!c) return mvd_fail("null context");
   return engine_repack(c);
+}
+
+int mvd_train_grad_bucket_count(mvd_ctx* c) { return c ? c->n_buckets : 0; }
+int mvd_train_grad_bucket(mvd_ctx* c, int k, int max_ranges, int64_t* offs, int64_t* lens, int* n_ranges) {
+  if (!c || k < 0 || k >= c->n_buckets || !n_ranges) return mvd_fail("mvd_train_grad_bucket: no such bucket");
+  const mvd_ctx::GradBucket& b = c->buckets[k];
+  *n_ranges = (int)b.off.size();
+  if (!offs || !lens) return 0;  // count only
+  if (max_ranges < (int)b.off.size()) return mvd_fail("mvd_train_grad_bucket: range arrays too small");
+  for (size_t r = 0; r < b.off.size(); ++r) {
+    offs[r] = (int64_t)b.off[r];
+    lens[r] = (int64_t)b.len[r];
+  }
+  return 0;
+}
+int mvd_train_grad_bucket_wait(mvd_ctx* c, int k, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c || k < 0 || k >= c->n_buckets || !c->buckets[k].ev) return mvd_fail("mvd_train_grad_bucket_wait: no such bucket");
+  HIP_CHECK_RET(hipStreamWaitEvent(S(stream), c->buckets[k].ev, 0));
+  return 0;
+}
+int mvd_train_set_bucket_snapshot(mvd_ctx* c, float* arena) {
+  if (!c) return mvd_fail("null context");
+  c->bucket_snapshot = arena;
+  return 0;
 }
 
 int mvd_mse_loss(mvd_ctx* c, const float* a, const float* b, size_t n, float* out, void* stream) {

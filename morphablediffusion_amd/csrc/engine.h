@@ -285,6 +285,19 @@ struct mvd_ctx {
   float *arena_p = nullptr, *arena_g = nullptr, *arena_m = nullptr, *arena_v = nullptr;
   bool arena_owned[4] = {false, false, false, false};  // hipMalloc'ed here (true) or adopted from the caller (mvd_train_adopt_arena)
   int* found_inf = nullptr;  // device flag of the last gradient finite-check
+  // Gradient buckets of the last mvd_train_unet_step, in the order their gradients become final during the backward pass (one per
+  // chain of UNet blocks, then one for everything that completes at the end: the stacked embedding / attn2 projections, the
+  // head): arena ranges + an event recorded behind the last kernel that writes them.  The caller starts one all-reduce per
+  // bucket on its communication stream as soon as the event allows (DDP's bucketed overlap, train_morphable_diffusion.py:302-303).
+  struct GradBucket {
+    hipEvent_t ev = nullptr;
+    std::vector<size_t> off, len;
+  };
+  std::vector<GradBucket> buckets;
+  int n_buckets = 0;
+  bool buckets_cached = false;        // the ranges are a property of the loaded weights: built during the first step
+  std::vector<char> bucket_done;      // per parameter: already in a bucket (while the ranges are being built)
+  float* bucket_snapshot = nullptr;   // test hook: every bucket's ranges are copied here right behind its event
 
   struct DbgBuf {
     std::string name;

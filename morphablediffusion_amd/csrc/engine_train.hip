@@ -897,6 +897,53 @@ __global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __r
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Closes gradient bucket number c->n_buckets behind what is enqueued on `s` so far.  prefixes: state_dict prefixes of the blocks
+// whose backward just finished; their parameters are final EXCEPT the ones the stacked end-of-step kernels write (emb_layers.*
+// through bwd_emb, attn2.* through bwd_attn2).  final: everything of model.diffusion_model.* not in a bucket yet.
+static int bucket_close(mvd_ctx* c, const std::vector<std::string>& prefixes, bool final, hipStream_t s) {
+  const int k = c->n_buckets;
+  if ((int)c->buckets.size() <= k) c->buckets.resize(k + 1);
+  mvd_ctx::GradBucket& b = c->buckets[k];
+  if (!b.ev) HIP_CHECK_RET(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  if (!c->buckets_cached) {
+    b.off.clear();
+    b.len.clear();
+    if (c->bucket_done.size() != c->params.size()) c->bucket_done.assign(c->params.size(), 0);
+    static const std::string U = "model.diffusion_model.";
+    for (size_t i = 0; i < c->params.size(); ++i) {
+      if (c->bucket_done[i]) continue;
+      const std::string& key = c->params[i].key;
+      if (key.rfind(U, 0) != 0) continue;
+      bool take = final;
+      if (!take && key.find(".emb_layers.") == std::string::npos && key.find(".attn2.") == std::string::npos)
+        for (const std::string& p : prefixes)
+          if (!p.empty() && key.rfind(p, 0) == 0) {
+            take = true;
+            break;
+          }
+      if (!take) continue;
+      c->bucket_done[i] = 1;
+      const size_t off = c->params[i].off, len = (c->params[i].numel + 63) & ~(size_t)63;
+      if (!b.off.empty() && b.off.back() + b.len.back() == off) b.len.back() += len;
+      else {
+        b.off.push_back(off);
+        b.len.push_back(len);
+      }
+    }
+  }
+  if (c->bucket_snapshot)
+    for (size_t r = 0; r < b.off.size(); ++r)
+      HIP_CHECK_RET(hipMemcpyAsync(c->bucket_snapshot + b.off[r], c->arena_g + b.off[r], b.len[r] * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_CHECK_RET(hipEventRecord(b.ev, s));
+  ++c->n_buckets;
+  return 0;
+}
+static std::string dot(const std::string& k) { return k.empty() || k.back() == '.' ? k : k + "."; }
+static std::string strip_leaf(const std::string& k) {  // "a.b.weight" -> "a.b."
+  const size_t p = k.rfind('.');
+  return p == std::string::npos ? std::string() : k.substr(0, p + 1);
+}
+
 int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, const float* context, int B, int depth0,
                       const Ctx5 src[4], const float* target_nhwc, float loss_scale, int recompute, float* pred_nhwc, float* loss_out,
                       float* const dsrc[4], hipStream_t s) {
@@ -925,6 +972,7 @@ int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* 
     HIP_CHECK_RET(hipGetLastError());
   }
   // ---------------- backward ----------------
+  c->n_buckets = 0;
   Fwd f{c, s, B, B, depth0, tape.ea, context, tape.a2, src, {nullptr, nullptr, nullptr, nullptr}};
   f.train = true;
   for (int l = 0; l < 4; ++l) f.src16[l] = nullptr;
@@ -999,6 +1047,20 @@ int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* 
       RET_IF(rr);
       g_out = g_in;
     }
+    {  // the chain's parameter gradients are final: one bucket
+      std::vector<std::string> pre;
+      if (!c->buckets_cached)
+        for (int id : ids) {
+          const StageRec& st = tape.stages[id];
+          switch (st.kind) {
+            case OP_RES: pre.push_back(dot(c->res[st.idx].key)); break;
+            case OP_ST: pre.push_back(dot(c->st[st.idx].key)); break;
+            case OP_COND: pre.push_back(dot(c->conds[st.idx].key)); break;
+            default: pre.push_back(strip_leaf(c->convs[st.idx].key)); break;
+          }
+        }
+      RET_IF(bucket_close(c, pre, false, s));
+    }
     return 0;
   };
   auto skip_view = [&](int i) {  // gradient of input block (nb-1-i)'s output
@@ -1040,6 +1102,8 @@ int engine_train_step(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* 
   }
   RET_IF(bwd_emb(b));
   RET_IF(bwd_attn2(b));
+  RET_IF(bucket_close(c, {}, true, s));  // the stacked projections, the head, whatever no chain owns
+  c->buckets_cached = true;
   return 0;
 }
 

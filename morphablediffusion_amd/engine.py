@@ -428,6 +428,27 @@ class Engine:
         L.check(self.lib.mvd_train_get_grad(self._ctx, key.encode(), L.ptr(out), C.c_size_t(out.numel()), _stream()))
         return out
 
+    def grad_buckets(self):
+        """Gradient buckets of the last train_unet_step (mvd_train_grad_bucket*): a list, in the order the gradients become final
+        during the backward pass, of lists of (offset, length) ranges of ``flat_grads``; together model.diffusion_model.* once."""
+        out = []
+        for k in range(int(self.lib.mvd_train_grad_bucket_count(self._ctx))):
+            n = C.c_int(0)
+            L.check(self.lib.mvd_train_grad_bucket(self._ctx, k, 0, None, None, C.byref(n)))
+            offs, lens = (C.c_int64 * max(1, n.value))(), (C.c_int64 * max(1, n.value))()
+            L.check(self.lib.mvd_train_grad_bucket(self._ctx, k, n.value, offs, lens, C.byref(n)))
+            out.append([(int(offs[i]), int(lens[i])) for i in range(n.value)])
+        return out
+
+    def grad_bucket_wait(self, k, stream):
+        """Makes ``stream`` (a torch.cuda.Stream: the communication stream) wait until bucket k's gradients are final."""
+        L.check(self.lib.mvd_train_grad_bucket_wait(self._ctx, int(k), C.c_void_p(stream.cuda_stream)))
+
+    def set_bucket_snapshot(self, arena):
+        """Test hook (mvd_train_set_bucket_snapshot): ``arena`` = a float32 device tensor shaped like ``flat_grads``, or None."""
+        L.check(self.lib.mvd_train_set_bucket_snapshot(self._ctx, L.ptr(arena)))
+        self._bucket_snapshot = arena  # keep it alive while the engine writes to it
+
     def adamw_step(self, lr, lr_aux, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, inv_scale=1.0, finetune_unet=True,
                    check=True):
         """torch.optim.AdamW on the arena (two learning-rate groups, morphable_diffusion.py:627-646) + in-place re-pack of the

@@ -336,6 +336,9 @@ class SyncMultiviewDiffusion(nn.Module):
         self.loss_scale = float(loss_scale)
         self.recompute = bool(recompute)
         self.global_step = 0
+        self.overlap_grad_sync = True  # DDP: bucketed all-reduces started by training_step (False: one flat all-reduce in sync_gradients)
+        self._grad_sync = None
+        self._grad_comm = None
         self.global_rank = 0
         self.image_dir = "."
         self.view_num = view_num
@@ -504,6 +507,7 @@ class SyncMultiviewDiffusion(nn.Module):
         pred, loss, dsrc = self.model.train_step(x_t, time_steps, clip_, vf, xc, target, drop_random=drop_random,
                                                  loss_scale=self.loss_scale, recompute=self.recompute)
         self.last_noise_predict, self.last_dsrc = pred, dsrc
+        self._start_grad_sync()  # DDP: the UNet's buckets are reduced while the rest of the backward runs
         if self.train_conditioner:  # spatial_volume.* / time_embed.*: per sample, from dL/d(its frustum volumes)
             hs = [int(v) for v in time_steps.tolist()]
             ti = [int(v) for v in target_index[:, 0].tolist()]
@@ -545,9 +549,45 @@ class SyncMultiviewDiffusion(nn.Module):
 
     def sync_gradients(self):
         """DDP's gradient averaging (train_morphable_diffusion.py:302-303: Lightning wraps the module in
-        DistributedDataParallel) as ONE all-reduce on the flat gradient arena -- RCCL over xGMI when the process group's
-        backend is nccl.  No-op without an initialised process group."""
+        DistributedDataParallel) -- RCCL over xGMI when the process group's backend is nccl.  With ``overlap_grad_sync`` (default)
+        training_step has already started the bucketed all-reduces on the communication stream, behind the events the backward
+        pass recorded (UNet buckets while the backward and the conditioner's backward still run); this call starts the rest,
+        joins the stream and applies the 1 / world_size.  Otherwise ONE all-reduce on the flat gradient arena.  No-op without an
+        initialised process group."""
+        if self._grad_sync is not None:
+            return self._grad_sync.finish()
         return sync_flat_gradients(self.engine.flat_grads)
+
+    def no_sync(self):
+        """DistributedDataParallel.no_sync(): inside the context training_step starts no gradient all-reduce (gradient
+        accumulation over several batches: only the last one, outside the context, is followed by the averaging)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.overlap_grad_sync
+            self.overlap_grad_sync = None  # neither bucketed nor (by mistake) a flat one through a stale object
+            try:
+                yield
+            finally:
+                self.overlap_grad_sync = old
+        return ctx()
+
+    def _start_grad_sync(self):
+        """Called by training_step right after the UNet's forward + backward is enqueued."""
+        self._grad_sync = None
+        if not self.overlap_grad_sync or not _dist_world() > 1:
+            return
+        eng = self.engine
+        dev = eng.flat_grads.device
+        if dev.type == "cuda":
+            if getattr(self, "_grad_comm", None) is None:
+                self._grad_comm = torch.cuda.Stream(device=dev)
+            self._grad_sync = BucketedGradSync(eng.flat_grads, eng.grad_buckets(), comm=self._grad_comm,
+                                               wait=lambda k: eng.grad_bucket_wait(k, self._grad_comm))
+        else:  # CPU stand-ins of the engine (tests): no streams, the buckets are reduced in order
+            self._grad_sync = BucketedGradSync(eng.flat_grads, eng.grad_buckets())
+        self._grad_sync.start()
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx):
@@ -611,6 +651,65 @@ class SyncMultiviewDiffusion(nn.Module):
                    for ni in range(0, N, inter_view_interval)]
             return x_sample, torch.stack(res, 1)
         return x_sample
+
+
+def _dist_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class BucketedGradSync:
+    """DDP's reducer on the flat gradient arena: ``buckets`` = lists of (offset, length) ranges in the order their gradients
+    become final; ``start()`` enqueues one all-reduce per range on the communication stream ``comm``, each bucket behind
+    ``wait(k)`` (which makes ``comm`` wait for the event of bucket k); ``finish()`` reduces every range of the arena no bucket
+    covered (the conditioner's parameters, written after the UNet's backward), makes the caller's stream wait for ``comm`` and
+    scales by 1 / world_size.  The arithmetic per element is the flat all-reduce's: sum over ranks, then the scale."""
+
+    def __init__(self, flat, buckets, comm=None, wait=None):
+        self.flat, self.buckets, self.comm, self.wait = flat, buckets, comm, wait
+        self.done = False
+
+    def _ctx(self):
+        import contextlib
+        return torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
+
+    def start(self):
+        import torch.distributed as dist
+        with self._ctx():
+            for k, ranges in enumerate(self.buckets):
+                if self.wait is not None:
+                    self.wait(k)
+                for off, n in ranges:
+                    dist.all_reduce(self.flat[off:off + n])
+
+    def uncovered(self):
+        """Ranges of the arena outside every bucket, ascending."""
+        spans = sorted((o, o + n) for r in self.buckets for o, n in r)
+        out, pos = [], 0
+        for a, b in spans:
+            if a < pos:
+                raise RuntimeError("gradient buckets overlap")
+            if a > pos:
+                out.append((pos, a - pos))
+            pos = b
+        if pos < self.flat.numel():
+            out.append((pos, self.flat.numel() - pos))
+        return out
+
+    def finish(self):
+        import torch.distributed as dist
+        if self.done:
+            return True
+        if self.comm is not None:
+            self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))  # the conditioner's backward wrote the rest
+        with self._ctx():
+            for off, n in self.uncovered():
+                dist.all_reduce(self.flat[off:off + n])
+        if self.comm is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        self.flat.mul_(1.0 / dist.get_world_size())
+        self.done = True
+        return True
 
 
 def sync_flat_gradients(flat_grads):

@@ -98,3 +98,60 @@ def test_exchange_on_side_stream_equals_inline():
     for _ in range(30):
         assert torch.equal(_step(m, *args), ref)
     m.engine.close()
+
+
+def _train_rank_main(rank, world, port, outdir):
+    """One rank of a 2-rank data-parallel training step (different draws per rank): the bucketed, overlapped gradient averaging
+    training_step starts, against the flat all-reduce of the same local gradients."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from morphablediffusion_amd.spec import VolumeConfig
+        from tests import golden_inputs as gi
+        from tests.test_gpu_train import _inputs as train_inputs, _unet_range, make_train_model
+        g, dev, prepared, draws = train_inputs()
+        N = int(g["N"])
+        gen = torch.Generator().manual_seed(1234 + rank)  # every rank its own noise: different local gradients
+        draws = dict(draws, noise=torch.randn(draws["noise"].shape, generator=gen))
+        m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, recompute=True)
+        eng = m.engine
+        res = {}
+        for mode in ("bucketed", "flat"):
+            m.overlap_grad_sync = mode == "bucketed"
+            eng.zero_grad()
+            m.training_step(dev, prepared=prepared, **draws)
+            assert (m._grad_sync is not None) == (mode == "bucketed")
+            assert m.sync_gradients() is True
+            torch.cuda.synchronize()
+            res[mode] = eng.flat_grads.detach().cpu().clone()
+        hi = _unet_range(eng)
+        torch.save({"hi": hi, "n_buckets": len(eng.grad_buckets()), **res}, os.path.join(outdir, f"train{rank}.pt"))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_bucketed_sync_equals_flat():
+    """DDP's gradient averaging (train_morphable_diffusion.py:302-303) on two ranks: training_step starts one all-reduce per
+    gradient bucket on the communication stream behind the events the backward pass records (UNet buckets while the backward and
+    the conditioner's backward still run), sync_gradients() reduces the rest and joins.  Element for element the flat
+    all-reduce's arithmetic: the UNet range is bit-identical (its local gradients are bit-reproducible), the conditioner's
+    parameters to rounding (their scatter adjoints use unordered atomics); both ranks end with the same averaged gradients."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_train_rank_main, args=(2, port, d), nprocs=2, join=True)
+        parts = [torch.load(os.path.join(d, f"train{r}.pt")) for r in range(2)]
+    for p in parts:
+        hi = p["hi"]
+        assert p["n_buckets"] >= 20 and torch.isfinite(p["bucketed"]).all() and p["bucketed"][:hi].abs().max() > 0
+        assert torch.equal(p["bucketed"][:hi], p["flat"][:hi]), "bucketed UNet gradients differ from the flat all-reduce's"
+        aux = ((p["bucketed"][hi:] - p["flat"][hi:]).norm() / p["flat"][hi:].norm()).item()
+        assert aux <= 1e-3, aux
+    assert torch.equal(parts[0]["bucketed"], parts[1]["bucketed"])  # every rank holds the same averaged gradients
+    print(f"[property] 2-rank training step: {parts[0]['n_buckets']} gradient buckets, bucketed == flat on the UNet range, "
+          f"conditioner range within {aux:.1e}")

@@ -557,6 +557,37 @@ def test_sparse_cnn_matrix_core_form_equals_site_form(monkeypatch):
     assert max(e) <= 1e-3 and errs[0][0] <= 5e-3, (e, errs[:3])
 
 
+def test_gradient_buckets_cover_the_unet_once_and_are_final_at_their_events():
+    """mvd_train_grad_bucket*: the UNet's gradients as buckets in the order the backward pass completes them (one per chain of
+    blocks + one for what the stacked end-of-step kernels write).  Their ranges cover model.diffusion_model.* exactly once, and
+    every range is FINAL when its event is recorded: with the snapshot hook the engine copies each bucket right behind its event,
+    and the copy equals the gradients at the end of the step bit for bit (a range written after its event would differ).
+    Checked on the step that builds the ranges and on the next one (cached ranges)."""
+    g, dev, prepared, draws = _inputs()
+    N = int(g["N"])
+    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, recompute=True)
+    eng = m.engine
+    hi = _unet_range(eng)
+    for rep in range(2):
+        eng.zero_grad()
+        snap = torch.full_like(eng.flat_grads, float("nan"))
+        eng.set_bucket_snapshot(snap)
+        m.training_step(dev, prepared=prepared, **draws)
+        torch.cuda.synchronize()
+        eng.set_bucket_snapshot(None)
+        buckets = eng.grad_buckets()
+        spans = sorted((o, o + n) for b in buckets for o, n in b)
+        assert spans[0][0] == 0 and spans[-1][1] == hi, (spans[0], spans[-1], hi)
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "gaps or overlaps between bucket ranges"
+        assert len(buckets) == 26, [len(b) for b in buckets]  # 12 output chains, the middle block, 12 input chains, the rest
+        final = eng.flat_grads[:hi]
+        assert torch.isfinite(snap[:hi]).all() and final.abs().max() > 0
+        assert torch.equal(snap[:hi], final), f"step {rep}: a bucket was not final at its event"
+        assert torch.isnan(snap[hi:]).all()  # nothing outside the UNet range is in a bucket
+    print(f"[property] gradient buckets: {len(buckets)} buckets, {sum(len(b) for b in buckets)} ranges, final at their events")
+    eng.close()
+
+
 def test_training_step_conditioner_gradients_vs_reference():
     """The complete training step: after the UNet's backward, the conditioner's (per sample, from dL/d(its frustum volumes))
     fills the gradients of spatial_volume.* and time_embed.* -- all 149 tensors against the reference's loss.backward().

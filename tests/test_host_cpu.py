@@ -319,6 +319,54 @@ dist.destroy_process_group()
 '''
 
 
+BUCKET_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from morphablediffusion_amd.model import BucketedGradSync, sync_flat_gradients
+
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+g = torch.Generator().manual_seed(100 + rank)
+local = torch.randn(4096, generator=g)
+# buckets in completion order, ranges out of address order, a late bucket made of scattered pieces; [3000, 4096) is in no
+# bucket (the conditioner's parameters: reduced by finish())
+buckets = [[(1024, 512), (2048, 256)], [(0, 1024)], [(1536, 512), (2304, 696)]]
+waited = []
+flat = local.clone()
+sync = BucketedGradSync(flat, buckets, wait=lambda k: waited.append(k))
+sync.start()
+assert waited == [0, 1, 2]
+assert sync.uncovered() == [(3000, 1096)]
+# after start(): bucket ranges hold the SUM over ranks, the rest is still local
+other = torch.randn(4096, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+assert torch.equal(flat[0:3000], (local + other)[0:3000]) and torch.equal(flat[3000:], local[3000:])
+assert sync.finish() is True and sync.finish() is True       # idempotent
+ref = local.clone()
+sync_flat_gradients(ref)
+assert torch.equal(flat, ref)                                # element for element the flat all-reduce's result
+try:
+    BucketedGradSync(flat, [[(0, 100)], [(50, 100)]]).uncovered()
+    raise SystemExit("overlap not detected")
+except RuntimeError:
+    pass
+print("BUCKET_OK", rank)
+dist.destroy_process_group()
+'''
+
+
+def test_bucketed_gradient_allreduce_equals_flat_two_ranks_gloo(tmp_path):
+    """DDP's bucketed reducer (BucketedGradSync: what training_step starts behind the backward pass's events) against the flat
+    all-reduce: 2 gloo ranks, buckets in completion order with scattered ranges, an uncovered tail reduced by finish()."""
+    script = tmp_path / "bworker.py"
+    script.write_text(BUCKET_WORKER % {"root": ROOT, "port": 29743})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"BUCKET_OK {r}" in o, o[-2000:]
+
+
 def test_flat_gradient_allreduce_two_ranks_gloo(tmp_path):
     """DDP's gradient averaging (train_morphable_diffusion.py:302-303) as ONE all-reduce over the flat gradient arena:
     2 gloo ranks, parameter-shaped views of the buffer see the mean; the LR schedule of configs/facescape.yaml:17-24."""
