@@ -154,6 +154,10 @@ void mvd_destroy(mvd_ctx* c) {
   for (hipEvent_t ev : c->probe_ev) hipEventDestroy(ev);
   for (auto& gb : c->buckets)
     if (gb.ev) hipEventDestroy(gb.ev);
+  for (int i = 0; i < 4; ++i) {
+    if (c->bstreams[i]) hipStreamDestroy(c->bstreams[i]);
+    if (c->bevents[i]) hipEventDestroy(c->bevents[i]);
+  }
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);

@@ -272,6 +272,14 @@ struct mvd_ctx {
   // mvd_train_adamw_step leaves the others alone, as torch.optim.AdamW skips parameters whose .grad is None
   bool grad_touched[3] = {false, false, false};
   bool repacking = false;
+  // Stream of the weight-build launches: 0 for the first build; engine_repack spreads the ~600 small pack / fold launches of
+  // a training step's re-pack over four streams (bs rotates per packed tensor, joins between the sections whose packs read
+  // earlier packs), they are latency- not bandwidth-bound
+  hipStream_t bs = 0;
+  hipStream_t bstreams[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t bevents[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned bs_rr = 0;
+  bool bs_multi = false;
   size_t repack_cursor = 0, sec_begin = 0, sec_end = 0;  // the `owned` allocations [sec_begin, sec_end) belong to the re-packable sections
   std::vector<size_t> owned_bytes;
   struct ParamRec {
@@ -421,6 +429,8 @@ int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRe
 int engine_repack(mvd_ctx* c);
 // engine_train.hip
 int engine_train_setup(mvd_ctx* c);     // finalize, train mode: masters into the arena
+void engine_build_rotate(mvd_ctx* c);  // next build stream (no-op outside a multi-stream re-pack)
+int engine_build_join(mvd_ctx* c);     // every build stream waits for all of them
 bool engine_hot_key(const std::string& k);  // a key of the re-packable sections (UNet / conditioner / step embedding)
 int engine_build_dgrad(mvd_ctx* c);     // adjoint weights of every UNet GEMM (ConvW::wT)
 int engine_build_dgrad_cond(mvd_ctx* c);  // ... of the conditioner's dense convolutions

@@ -352,6 +352,10 @@ int mesh_commit(mvd_ctx* c, HostMesh& h, const float* vertices, const int32_t* o
   const std::vector<int>* src[6] = {&nbr_subm[0], &nbr_subm[1], &nbr_subm[2], &nbr_down[0], &nbr_down[1], &grid};
   for (int i = 0; i < 6; ++i)
     if (!src[i]->empty()) memcpy(m.h_pool + off[i + 1], src[i]->data(), src[i]->size() * sizeof(int));
+  // readers on other streams: the volume build of the caller's communication stream reads these tables; the hand-over event it
+  // registered (mvd_set_volume_ready_event) is recorded behind that build, so the upload waits for it (an upload on
+  // another stream than the one that ran the last step could otherwise overtake the last reader)
+  if (c->vol_ready) HIP_CHECK_RET(hipStreamWaitEvent(s, c->vol_ready, 0));
   HIP_CHECK_RET(hipMemcpyAsync(m.pool, m.h_pool, total * sizeof(int), hipMemcpyHostToDevice, s));
   HIP_CHECK_RET(hipEventRecord(m.staged, s));
   m.Nv = Nv;

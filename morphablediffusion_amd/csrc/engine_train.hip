@@ -156,7 +156,8 @@ int make_wT(mvd_ctx* c, ConvW& w, int flip = 1) {
   const int Cl = w.cin_l > 0 ? w.cin_l : w.Cin;
   w.Np = up8(w.N);
   RET_IF(engine_dmalloc(c, (void**)&w.wT, (size_t)w.taps * Cl * w.Np * sizeof(half_t)));
-  return bwd_pack_dgrad(w.w, w.taps, w.N, w.Cin, Cl, w.Np, w.wT, 0, flip);
+  engine_build_rotate(c);
+  return bwd_pack_dgrad(w.w, w.taps, w.N, w.Cin, Cl, w.Np, w.wT, c->bs, flip);
 }
 }  // namespace
 int engine_build_dgrad(mvd_ctx* c) {

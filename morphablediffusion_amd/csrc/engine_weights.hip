@@ -22,6 +22,21 @@ int engine_dmalloc(mvd_ctx* c, void** p, size_t bytes) {
   return 0;
 }
 
+// Build streams of a multi-stream re-pack (mvd_ctx::bs): the launches of one packed tensor stay on one stream, consecutive
+// tensors go round-robin; a join makes every stream wait for all of them (before packs that read earlier packs: the adjoint
+// weights of engine_build_dgrad*).  Outside engine_repack both are no-ops and bs stays the null stream.
+void engine_build_rotate(mvd_ctx* c) {
+  if (c->bs_multi) c->bs = c->bstreams[(c->bs_rr++) & 3];
+}
+int engine_build_join(mvd_ctx* c) {
+  if (!c->bs_multi) return 0;
+  for (int i = 0; i < 4; ++i) HIP_CHECK_RET(hipEventRecord(c->bevents[i], c->bstreams[i]));
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (i != j) HIP_CHECK_RET(hipStreamWaitEvent(c->bstreams[i], c->bevents[j], 0));
+  return 0;
+}
+
 namespace {
 
 int dmalloc(mvd_ctx* c, void** p, size_t bytes) { return engine_dmalloc(c, p, bytes); }
@@ -46,7 +61,7 @@ int copy_f32(mvd_ctx* c, const std::string& k, float** out, int* n = nullptr) {
     return 0;
   }
   RET_IF(dmalloc(c, (void**)out, r->numel * sizeof(float)));
-  HIP_CHECK_RET(hipMemcpyAsync(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
+  HIP_CHECK_RET(hipMemcpyAsync(*out, r->d, r->numel * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
   if (n) *n = (int)r->numel;
   return 0;
 }
@@ -61,6 +76,7 @@ int load_norm(mvd_ctx* c, const std::string& p, NormW* n) {
 // conv / linear weight -> fp16 [taps][N][Cin(+pad)]
 int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool transposed, bool geglu, ConvW* o,
               int cin_pad = 0, bool xp = false) {
+  engine_build_rotate(c);
   RawTensor* r;
   RET_IF(get_raw(c, wkey, &r));
   if (r->shape.size() < 2) return mvd_fail("pack_conv: weight rank < 2");
@@ -78,13 +94,13 @@ int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool
   o->key = wkey;
   o->bkey = bkey;
   RET_IF(dmalloc(c, (void**)&o->w, (size_t)taps * N * Cin * sizeof(half_t)));
-  RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, 0, cin_src, xp ? 1 : 0));
+  RET_IF(launch_pack_weight(r->d, N, Cin, taps, transposed ? 1 : 0, geglu ? 1 : 0, o->w, c->bs, cin_src, xp ? 1 : 0));
   if (!bkey.empty()) {
     if (geglu) {
       RawTensor* b;
       RET_IF(get_raw(c, bkey, &b));
       RET_IF(dmalloc(c, (void**)&o->bias, (size_t)N * sizeof(float)));
-      RET_IF(launch_permute_geglu_bias(b->d, N, o->bias, 0));
+      RET_IF(launch_permute_geglu_bias(b->d, N, o->bias, c->bs));
     } else {
       RET_IF(copy_f32(c, bkey, &o->bias));
     }
@@ -93,13 +109,14 @@ int pack_conv(mvd_ctx* c, const std::string& wkey, const std::string& bkey, bool
 }
 
 int pack_lin(mvd_ctx* c, const std::string& wkey, const std::string& bkey, LinW* o) {
+  engine_build_rotate(c);
   RawTensor* r;
   RET_IF(get_raw(c, wkey, &r));
   o->N = (int)r->shape[0];
   o->K = (int)(r->numel / r->shape[0]);
   o->key = wkey.size() > 7 ? wkey.substr(0, wkey.size() - 7) : wkey;  // strip ".weight"
   RET_IF(dmalloc(c, (void**)&o->w, r->numel * sizeof(half_t)));
-  RET_IF(launch_f32_to_f16(r->d, o->w, r->numel, 0));
+  RET_IF(launch_f32_to_f16(r->d, o->w, r->numel, c->bs));
   if (!bkey.empty()) RET_IF(copy_f32(c, bkey, &o->bias));
   return 0;
 }
@@ -138,9 +155,9 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   s->qkv.cin_l = C;
   s->qkv.taps = 1;
   RET_IF(dmalloc(c, (void**)&s->qkv.w, (size_t)3 * C * C * sizeof(half_t)));
-  RET_IF(launch_f32_to_f16(q->d, s->qkv.w, (size_t)C * C, 0));
-  RET_IF(launch_f32_to_f16(k->d, s->qkv.w + (size_t)C * C, (size_t)C * C, 0));
-  RET_IF(launch_f32_to_f16(v->d, s->qkv.w + (size_t)2 * C * C, (size_t)C * C, 0));
+  RET_IF(launch_f32_to_f16(q->d, s->qkv.w, (size_t)C * C, c->bs));
+  RET_IF(launch_f32_to_f16(k->d, s->qkv.w + (size_t)C * C, (size_t)C * C, c->bs));
+  RET_IF(launch_f32_to_f16(v->d, s->qkv.w + (size_t)2 * C * C, (size_t)C * C, c->bs));
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
@@ -166,18 +183,18 @@ int build_cond(mvd_ctx* c, const std::string& p, int dim, int Cc, CondW* d) {
   d->wqk.Cin = I;
   d->wqk.taps = 1;
   RET_IF(dmalloc(c, (void**)&d->wqk.w, (size_t)heads * Cc * I * sizeof(half_t)));
-  RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, Cc, I, 1.0f / sqrtf((float)hd), d->wqk.w, 0));
+  RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, Cc, I, 1.0f / sqrtf((float)hd), d->wqk.w, c->bs));
   d->wov.N = I;
   d->wov.Cin = heads * Cc;
   d->wov.taps = 1;
   RET_IF(dmalloc(c, (void**)&d->wov.w, (size_t)heads * Cc * I * sizeof(half_t)));
-  RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, Cc, I, d->wov.w, 0));
+  RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, Cc, I, d->wov.w, c->bs));
   RET_IF(load_norm(c, p + ".proj_out.0", &d->gn_o1));
   RET_IF(pack_conv(c, p + ".proj_out.2.weight", "", false, false, &d->conv1));
   RET_IF(load_norm(c, p + ".proj_out.3", &d->gn_o2));
   RET_IF(pack_conv(c, p + ".proj_out.5.weight", "", false, false, &d->conv2));
   RET_IF(dmalloc(c, (void**)&d->relu_beta, (size_t)heads * Cc * sizeof(half_t)));
-  RET_IF(launch_relu_beta_tile(d->gn_ctx.b, Cc, heads, d->relu_beta, 0));
+  RET_IF(launch_relu_beta_tile(d->gn_ctx.b, Cc, heads, d->relu_beta, c->bs));
   return 0;
 }
 
@@ -213,19 +230,19 @@ int build_sparse_layer(mvd_ctx* c, const std::string& p, const std::string& blk,
   RET_IF(dmalloc(c, (void**)&L->w, w->numel * 4));
   RET_IF(dmalloc(c, (void**)&L->scale, cout * 4));
   RET_IF(dmalloc(c, (void**)&L->shift, cout * 4));
-  RET_IF(launch_sparse_w_pack(w->d, cin, cout, layout, L->w, 0));                       // -> [27][cin][cout]
+  RET_IF(launch_sparse_w_pack(w->d, cin, cout, layout, L->w, c->bs));                       // -> [27][cin][cout]
   // MVD_SPARSE_VALU=1 (A/B switch, read when the weights are built): the one-site-per-workgroup kernels and the scatter-form
   // data gradient instead -- tests/test_gpu_train.py holds the two forms against each other
   const bool valu_only = getenv("MVD_SPARSE_VALU") != nullptr && getenv("MVD_SPARSE_VALU")[0] == '1';
   if (sparse_mfma_takes(cin, cout) && !valu_only) {  // B fragments of the matrix-core kernel; the data-gradient's in a training context
     RET_IF(dmalloc(c, (void**)&L->wp, w->numel * 4));
-    RET_IF(launch_sparse_w_frag(L->w, cin, cout, 0, 0, L->wp, 0));
+    RET_IF(launch_sparse_w_frag(L->w, cin, cout, 0, 0, L->wp, c->bs));
     if (c->train_mode) {
       RET_IF(dmalloc(c, (void**)&L->wd, w->numel * 4));
-      RET_IF(launch_sparse_w_frag(L->w, cout, cin, 1, strided ? 0 : 1, L->wd, 0));
+      RET_IF(launch_sparse_w_frag(L->w, cout, cin, 1, strided ? 0 : 1, L->wd, c->bs));
     }
   }
-  RET_IF(launch_bn_fold(g->d, b->d, rm->d, rv->d, 1e-3f, cout, L->scale, L->shift, 0));  // eval BatchNorm1d(eps 1e-3), network.py:105
+  RET_IF(launch_bn_fold(g->d, b->d, rm->d, rv->d, 1e-3f, cout, L->scale, L->shift, c->bs));  // eval BatchNorm1d(eps 1e-3), network.py:105
   RET_IF(copy_f32(c, bn + ".weight", &L->gamma));
   RET_IF(copy_f32(c, bn + ".bias", &L->beta));
   if (c->train_mode) {  // the buffers stay resident in a training context (engine_finalize): train-mode forwards update them
@@ -294,11 +311,12 @@ int build_vae_attn(mvd_ctx* c, const std::string& p, VaeAttnW* a) {
 
 // CLIP vision tower (openai/CLIP VisionTransformer key names under clip_image_encoder.model.visual.)
 int pack_rows(mvd_ctx* c, const float* src, int N, int Cin, int cin_src, ConvW* o) {
+  engine_build_rotate(c);
   o->N = N;
   o->Cin = Cin;
   o->taps = 1;
   RET_IF(dmalloc(c, (void**)&o->w, (size_t)N * Cin * sizeof(half_t)));
-  return launch_pack_weight(src, N, Cin, 1, 0, 0, o->w, 0, cin_src);
+  return launch_pack_weight(src, N, Cin, 1, 0, 0, o->w, c->bs, cin_src);
 }
 
 int build_clip(mvd_ctx* c) {
@@ -443,7 +461,7 @@ int build_vae(mvd_ctx* c) {
       RET_IF(get_raw(c, L + ".upsample.conv.weight", &r));
       if (!c->vae_exact) {  // the parity-folded form (pre-summed taps) exists for plain fp16 weights only
         RET_IF(dmalloc(c, (void**)&uc.w_up, (size_t)16 * uc.N * uc.Cin * sizeof(half_t)));
-        RET_IF(launch_pack_upconv_weight(r->d, uc.N, uc.Cin, uc.w_up, 0));
+        RET_IF(launch_pack_upconv_weight(r->d, uc.N, uc.Cin, uc.w_up, c->bs));
       }
     }
   }
@@ -501,26 +519,25 @@ int xp_cond(mvd_ctx* c, CondW& d) {
   RET_IF(get_raw(c, d.key + ".depth_attn.to_v.weight", &wv));
   RET_IF(get_raw(c, d.key + ".depth_attn.to_out.weight", &wo));
   const size_t nf = (size_t)heads * d.Cc * d.I;
+  // fold scratch: an allocation of the build like any other (a re-pack replays it: no hipMalloc / hipDeviceSynchronize / hipFree
+  // per training step); both folds and their packs run in stream order
   float* tmp = nullptr;
-  HIP_CHECK_RET(hipMalloc((void**)&tmp, nf * sizeof(float)));
+  RET_IF(dmalloc(c, (void**)&tmp, nf * sizeof(float)));
   auto fold = [&](ConvW& w, int N, int Cl, bool qk) -> int {
-    if (qk) RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, d.Cc, d.I, 1.0f / sqrtf((float)hd), nullptr, 0, tmp));
-    else RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, d.Cc, d.I, nullptr, 0, tmp));
+    if (qk) RET_IF(launch_fold_qk(wq->d, wk->d, heads, hd, d.Cc, d.I, 1.0f / sqrtf((float)hd), nullptr, c->bs, tmp));
+    else RET_IF(launch_fold_ov(wo->d, wv->d, heads, hd, d.Cc, d.I, nullptr, c->bs, tmp));
     w.N = N;
     w.cin_l = Cl;
     w.Cin = 3 * Cl;
     w.xp = 1;
     w.taps = 1;
     RET_IF(dmalloc(c, (void**)&w.w, (size_t)N * 3 * Cl * sizeof(half_t)));
-    return launch_pack_weight(tmp, N, 3 * Cl, 1, 0, 0, w.w, 0, Cl, 1);
+    return launch_pack_weight(tmp, N, 3 * Cl, 1, 0, 0, w.w, c->bs, Cl, 1);
   };
-  int r = fold(d.wqk, heads * d.Cc, d.I, true);
-  if (!r) r = fold(d.wov, d.I, heads * d.Cc, false);
-  hipDeviceSynchronize();
-  hipFree(tmp);
-  RET_IF(r);
+  RET_IF(fold(d.wqk, heads * d.Cc, d.I, true));
+  RET_IF(fold(d.wov, d.I, heads * d.Cc, false));
   RET_IF(dmalloc(c, (void**)&d.relu_beta, (size_t)3 * heads * d.Cc * sizeof(half_t)));
-  return launch_relu_beta_tile(d.gn_ctx.b, d.Cc, heads, d.relu_beta, 0, 1);
+  return launch_relu_beta_tile(d.gn_ctx.b, d.Cc, heads, d.relu_beta, c->bs, 1);
 }
 
 int xp_ops(mvd_ctx* c, const std::vector<UOp>& ops, bool convs3) {
@@ -612,7 +629,7 @@ int build_unet_section(mvd_ctx* c) {
       RawTensor* r;
       RET_IF(get_raw(c, U + wkey + ".weight", &r));
       RET_IF(dmalloc(c, (void**)&w.w_up, (size_t)16 * w.N * w.Cin * sizeof(half_t)));
-      RET_IF(launch_pack_upconv_weight(r->d, w.N, w.Cin, w.w_up, 0));
+      RET_IF(launch_pack_upconv_weight(r->d, w.N, w.Cin, w.w_up, c->bs));
     }
     c->convs.push_back(w);
     ops.push_back({kind, (int)c->convs.size() - 1, cin, cout});
@@ -685,8 +702,8 @@ int build_unet_section(mvd_ctx* c) {
       RawTensor *w, *b;
       RET_IF(get_raw(c, pz.key + ".weight", &w));
       RET_IF(get_raw(c, pz.key + ".bias", &b));
-      RET_IF(launch_f32_to_f16(w->d, c->emb_all.w + (size_t)off * temb, w->numel, 0));
-      HIP_CHECK_RET(hipMemcpyAsync(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice, 0));
+      RET_IF(launch_f32_to_f16(w->d, c->emb_all.w + (size_t)off * temb, w->numel, c->bs));
+      HIP_CHECK_RET(hipMemcpyAsync(c->emb_all.bias + off, b->d, pz.cout * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
       off += pz.cout;
     }
   }
@@ -705,8 +722,8 @@ int build_unet_section(mvd_ctx* c) {
       RET_IF(get_raw(c, k + ".to_out.0.weight", &wo));
       RET_IF(get_raw(c, k + ".to_out.0.bias", &bo));
       const int C = (int)bo->numel;
-      RET_IF(launch_fold_ov(wo->d, wv->d, 1, C, u.context_dim, C, c->a2_all.w + off * u.context_dim, 0));
-      HIP_CHECK_RET(hipMemcpyAsync(c->a2_all.bias + off, bo->d, C * sizeof(float), hipMemcpyDeviceToDevice, 0));
+      RET_IF(launch_fold_ov(wo->d, wv->d, 1, C, u.context_dim, C, c->a2_all.w + off * u.context_dim, c->bs));
+      HIP_CHECK_RET(hipMemcpyAsync(c->a2_all.bias + off, bo->d, C * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
       off += C;
     }
   }
@@ -782,8 +799,8 @@ int build_condnet_section(mvd_ctx* c) {
       RET_IF(dmalloc(c, (void**)&out->bias, (size_t)total * sizeof(float)));
       size_t off = 0;
       for (size_t i = 0; i < ws.size(); ++i) {
-        RET_IF(launch_f32_to_f16(ws[i]->d, out->w + off * K, ws[i]->numel, 0));
-        HIP_CHECK_RET(hipMemcpyAsync(out->bias + off, bs[i]->d, bs[i]->numel * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        RET_IF(launch_f32_to_f16(ws[i]->d, out->w + off * K, ws[i]->numel, c->bs));
+        HIP_CHECK_RET(hipMemcpyAsync(out->bias + off, bs[i]->d, bs[i]->numel * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
         off += ws[i]->shape[0];
       }
       return 0;
@@ -810,11 +827,13 @@ int build_hot_sections(mvd_ctx* c) {
   if (c->has_unet) {
     RET_IF(build_unet_section(c));
     RET_IF(apply_xp_policy(c));
+    RET_IF(engine_build_join(c));  // the adjoint packs read the forward packs
     if (c->train_mode) RET_IF(engine_build_dgrad(c));
   }
   if (c->has_step) RET_IF(build_step_section(c));
   if (c->has_cond) {
     RET_IF(build_condnet_section(c));
+    RET_IF(engine_build_join(c));
     if (c->train_mode) RET_IF(engine_build_dgrad_cond(c));
   }
   return 0;
@@ -866,11 +885,23 @@ int engine_repack(mvd_ctx* c) {
   if (!c->finalized || !c->train_mode) return mvd_fail("engine_repack: the context was not finalized in training mode");
   HIP_CHECK_RET(hipSetDevice(c->device));
   HIP_CHECK_RET(hipDeviceSynchronize());
+  // ~600 pack / fold launches of 5-50 us that do not fill the chip: four streams (MVD_REPACK_STREAMS=1: the null stream)
+  static const bool one_stream = getenv("MVD_REPACK_STREAMS") != nullptr && getenv("MVD_REPACK_STREAMS")[0] == '1';
+  if (!one_stream && !c->bstreams[0])
+    for (int i = 0; i < 4; ++i) {
+      HIP_CHECK_RET(hipStreamCreateWithFlags(&c->bstreams[i], hipStreamNonBlocking));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&c->bevents[i], hipEventDisableTiming));
+    }
+  c->bs_multi = !one_stream;
+  c->bs_rr = 0;
+  engine_build_rotate(c);
   c->repacking = true;
   c->repack_cursor = c->sec_begin;
   const int r = build_hot_sections(c);
   const bool complete = c->repack_cursor == c->sec_end;
   c->repacking = false;
+  c->bs_multi = false;
+  c->bs = 0;
   RET_IF(r);
   if (!complete) return mvd_fail("engine_repack: allocation sequence shorter than the first build");
   HIP_CHECK_RET(hipDeviceSynchronize());
