@@ -263,6 +263,9 @@ int64_t mvd_train_bn_calls(mvd_ctx* ctx);
 int mvd_train_adamw_step(mvd_ctx* ctx, float lr, float lr_aux, float beta1, float beta2, float eps, float weight_decay, int step,
                          float inv_scale, int finetune_unet, int* skipped_out, void* stream);
 int mvd_train_repack(mvd_ctx* ctx);
+/* The same in the order of `stream` (the stream the optimiser update was enqueued on and the next forward will be): no device
+ * synchronisation -- the pack launches wait for an event on `stream`, later work on `stream` waits for them. */
+int mvd_train_repack_async(mvd_ctx* ctx, void* stream);
 /* DDP's bucketed, overlapped gradient averaging (train_morphable_diffusion.py:302-303: Lightning wraps the module in
  * DistributedDataParallel, whose reducer all-reduces a bucket as soon as its gradients are ready).  mvd_train_unet_step leaves
  * its UNet gradients as buckets in the order they become final during the backward pass -- one per chain of blocks (output

@@ -158,6 +158,7 @@ void mvd_destroy(mvd_ctx* c) {
     if (c->bstreams[i]) hipStreamDestroy(c->bstreams[i]);
     if (c->bevents[i]) hipEventDestroy(c->bevents[i]);
   }
+  if (c->bev_after) hipEventDestroy(c->bev_after);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
@@ -681,6 +682,10 @@ int mvd_train_adamw_step(mvd_ctx* c, float lr, float lr_aux, float beta1, float 
 int mvd_train_repack(mvd_ctx* c) {
   if (!c) return mvd_fail("null context");
   return engine_repack(c);
+}
+int mvd_train_repack_async(mvd_ctx* c, void* stream) {
+  if (!c) return mvd_fail("null context");
+  return engine_repack(c, S(stream), true);
 }
 
 int mvd_train_grad_bucket_count(mvd_ctx* c) { return c ? c->n_buckets : 0; }

@@ -278,6 +278,7 @@ struct mvd_ctx {
   hipStream_t bs = 0;
   hipStream_t bstreams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t bevents[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t bev_after = nullptr;  // recorded on the caller's stream: what the re-pack follows
   unsigned bs_rr = 0;
   bool bs_multi = false;
   size_t repack_cursor = 0, sec_begin = 0, sec_end = 0;  // the `owned` allocations [sec_begin, sec_end) belong to the re-packable sections
@@ -426,7 +427,7 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
 int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRec* rec = nullptr, Carry* in_carry = nullptr,
                Carry* out_carry = nullptr);
 // engine_weights.hip: re-derive the packed weights of the UNet / step embedding / conditioner from the master parameters
-int engine_repack(mvd_ctx* c);
+int engine_repack(mvd_ctx* c, hipStream_t after = nullptr, bool have_stream = false);
 // engine_train.hip
 int engine_train_setup(mvd_ctx* c);     // finalize, train mode: masters into the arena
 void engine_build_rotate(mvd_ctx* c);  // next build stream (no-op outside a multi-stream re-pack)

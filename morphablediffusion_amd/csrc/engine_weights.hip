@@ -881,20 +881,30 @@ int engine_finalize(mvd_ctx* c) {
 
 // After an optimiser step changed the master parameters: every packed / folded / stacked fp16 weight of the UNet, the step
 // embedding and the conditioner is re-derived IN PLACE (same allocations, same pointers).
-int engine_repack(mvd_ctx* c) {
+// after: the stream whose enqueued work (the optimiser update) the re-pack must follow and that later work (the next forward)
+// is enqueued on, or null.  With a stream the re-pack is asynchronous: the build streams wait for an event on it and it waits
+// for theirs -- no device synchronisation, the host enqueues the ~600 launches while the AdamW kernels still run.  Without one
+// (mvd_train_repack, arena adoption) the device is synchronised before and after, as before.
+int engine_repack(mvd_ctx* c, hipStream_t after, bool have_stream) {
   if (!c->finalized || !c->train_mode) return mvd_fail("engine_repack: the context was not finalized in training mode");
   HIP_CHECK_RET(hipSetDevice(c->device));
-  HIP_CHECK_RET(hipDeviceSynchronize());
-  // ~600 pack / fold launches of 5-50 us that do not fill the chip: four streams (MVD_REPACK_STREAMS=1: the null stream)
+  // ~600 pack / fold launches of 5-50 us that do not fill the chip: four streams (MVD_REPACK_STREAMS=1: one stream)
   static const bool one_stream = getenv("MVD_REPACK_STREAMS") != nullptr && getenv("MVD_REPACK_STREAMS")[0] == '1';
-  if (!one_stream && !c->bstreams[0])
+  if (!c->bstreams[0])
     for (int i = 0; i < 4; ++i) {
       HIP_CHECK_RET(hipStreamCreateWithFlags(&c->bstreams[i], hipStreamNonBlocking));
       HIP_CHECK_RET(hipEventCreateWithFlags(&c->bevents[i], hipEventDisableTiming));
     }
+  if (!c->bev_after) HIP_CHECK_RET(hipEventCreateWithFlags(&c->bev_after, hipEventDisableTiming));
+  if (have_stream) {
+    HIP_CHECK_RET(hipEventRecord(c->bev_after, after));
+    for (int i = 0; i < 4; ++i) HIP_CHECK_RET(hipStreamWaitEvent(c->bstreams[i], c->bev_after, 0));
+  } else {
+    HIP_CHECK_RET(hipDeviceSynchronize());
+  }
   c->bs_multi = !one_stream;
   c->bs_rr = 0;
-  engine_build_rotate(c);
+  c->bs = c->bstreams[0];  // (one stream: every launch on build stream 0)
   c->repacking = true;
   c->repack_cursor = c->sec_begin;
   const int r = build_hot_sections(c);
@@ -902,8 +912,15 @@ int engine_repack(mvd_ctx* c) {
   c->repacking = false;
   c->bs_multi = false;
   c->bs = 0;
+  if (have_stream) {  // also on the error paths: nothing later on `after` may overtake what was enqueued
+    for (int i = 0; i < 4; ++i) {
+      hipEventRecord(c->bevents[i], c->bstreams[i]);
+      hipStreamWaitEvent(after, c->bevents[i], 0);
+    }
+  } else {
+    hipDeviceSynchronize();
+  }
   RET_IF(r);
   if (!complete) return mvd_fail("engine_repack: allocation sequence shorter than the first build");
-  HIP_CHECK_RET(hipDeviceSynchronize());
   return 0;
 }

@@ -2,6 +2,7 @@
 library by pointer (PyTorch is used for device memory and streams only)."""
 import collections
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -472,8 +473,12 @@ class Engine:
             L.check(self.lib.mvd_train_adopt_arena(self._ctx, 3, L.ptr(self.flat_v), C.c_int64(n)))
 
     def repack(self):
-        """Re-derive every packed fp16 weight from the master parameters (after they changed), in place."""
-        L.check(self.lib.mvd_train_repack(self._ctx))
+        """Re-derive every packed fp16 weight from the master parameters (after they changed), in place, in the order of the
+        current stream (mvd_train_repack_async: behind the optimiser update enqueued on it, ahead of the next forward)."""
+        if os.environ.get("MVD_REPACK_SYNC") == "1":  # A/B switch: the device-synchronising form
+            L.check(self.lib.mvd_train_repack(self._ctx))
+        else:
+            L.check(self.lib.mvd_train_repack_async(self._ctx, _stream()))
 
     def set_volume(self, volume):
         v = _f32(volume, self.device)
