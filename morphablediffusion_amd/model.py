@@ -555,8 +555,9 @@ class SyncMultiviewDiffusion(nn.Module):
         pass recorded (UNet buckets while the backward and the conditioner's backward still run); this call starts the rest,
         joins the stream and applies the 1 / world_size.  Otherwise ONE all-reduce on the flat gradient arena.  No-op without an
         initialised process group."""
-        if self._grad_sync is not None:
-            return self._grad_sync.finish()
+        sync, self._grad_sync = self._grad_sync, None  # one averaging per backward pass, as with the flat all-reduce
+        if sync is not None:
+            return sync.finish()
         return sync_flat_gradients(self.engine.flat_grads)
 
     def no_sync(self):
