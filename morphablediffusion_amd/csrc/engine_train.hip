@@ -62,7 +62,9 @@ int cbwd_latent_scatter(const float* d_vol, const int* grid, int gd, int gh, int
                         int V, float vol_len, float* d_rows, hipStream_t s);
 int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view_idx, int n_views, const float* verts, int Nv, int V,
                         float vol_len, int S, int persp, float* d_feats, hipStream_t s);
+int cbwd_fuse_scratch_floats(int Nv);
 int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views, int Nv, int total_views, float* d_vf, float* dw, float* db,
+              float* part,
               hipStream_t s);
 int cbwd_bn_scratch_floats(int n, int C);
 int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, const float* stats,
@@ -1527,9 +1529,10 @@ int engine_train_conditioner_backward_batch(mvd_ctx* c, int B, const int* slots,
   if (dbg_dfused) HIP_CHECK_RET(hipMemcpyAsync(dbg_dfused, d_fused, (size_t)Nv * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
   // view fusion, vertex gather
   float *d_vf = F((size_t)N * Nv * 16), *d_feats = d_feats_all + (size_t)bi * rows * 16;
-  WS_CHECK(d_vf);
+  float* fuse_part = F((size_t)cbwd_fuse_scratch_floats(Nv));
+  WS_CHECK(d_vf && fuse_part);
   RET_IF(cbwd_fuse(d_fused, vf, c->fuse_w, N, Nv, N, d_vf, engine_grad(c, SV + "smpl_feature_extractor.conv0.weight"),
-                   engine_grad(c, SV + "smpl_feature_extractor.conv0.bias"), s));
+                   engine_grad(c, SV + "smpl_feature_extractor.conv0.bias"), fuse_part, s));
   RET_IF(cbwd_vertex_scatter(d_vf, c->cams, vidx, N, m.verts, Nv, V, c->v.spatial_volume_length, S, persp, d_feats, s));
   if (dbg_dfeats) RET_IF(launch_nhwc_to_nchw(d_feats, 16, N, 16, HW, dbg_dfeats, s));
   mark("bwd: fuse + vertex scatter");

@@ -184,33 +184,51 @@ __global__ void fuse_bwd_dvf_kernel(const float* __restrict__ d_fused, const flo
   acc /= (float)total_views;
   for (int view = 0; view < n_views; ++view) d_vf[((long)view * Nv + v) * 16 + ci] = acc;
 }
-// dw[co][ci] += sum_v d_fused[v][co] mean_view vf[.][v][ci];  db[co] += sum_v d_fused[v][co]: one workgroup per (co, ci)
+// dw[co][ci] += sum_v d_fused[v][co] mean_view vf[.][v][ci];  db[co] += sum_v d_fused[v][co].
+// A workgroup takes FW_CH vertices: their view mean m[v][16] and gradient rows g[v][16] go to LDS with row-contiguous 16-byte
+// loads (the one-workgroup-per-(co, ci) form walked the vertices with a 64-byte stride, 16 views each: 148 us per sample), then
+// thread (co, ci) sums its 256-vertex partial from LDS; partials per chunk, added in chunk order by fuse_bwd_w_reduce_kernel.
+constexpr int FW_CH = 256;
 __global__ __launch_bounds__(256) void fuse_bwd_w_kernel(const float* __restrict__ d_fused, const float* __restrict__ vf, int n_views, int Nv,
-                                                         int total_views, float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ float s_a[256], s_b[256];
-  const int co = blockIdx.x >> 4, ci = blockIdx.x & 15, t = threadIdx.x;
+                                                         int total_views, float* __restrict__ part) {
+  __shared__ float s_m[FW_CH][17], s_g[FW_CH][17];  // (+1: the (co, ci) readers of a row do not share a bank)
+  const int t = threadIdx.x, v0 = blockIdx.x * FW_CH;
+  for (int e = t; e < FW_CH * 4; e += 256) {
+    const int vl = e >> 2, q = e & 3, v = v0 + vl;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), g = m;
+    if (v < Nv) {
+      for (int view = 0; view < n_views; ++view) {
+        const float4 x = *(const float4*)(vf + ((long)view * Nv + v) * 16 + 4 * q);
+        m.x += x.x; m.y += x.y; m.z += x.z; m.w += x.w;
+      }
+      g = *(const float4*)(d_fused + (long)v * 16 + 4 * q);
+    }
+    const float inv = 1.0f / (float)total_views;
+    s_m[vl][4 * q] = m.x * inv; s_m[vl][4 * q + 1] = m.y * inv; s_m[vl][4 * q + 2] = m.z * inv; s_m[vl][4 * q + 3] = m.w * inv;
+    s_g[vl][4 * q] = g.x; s_g[vl][4 * q + 1] = g.y; s_g[vl][4 * q + 2] = g.z; s_g[vl][4 * q + 3] = g.w;
+  }
+  __syncthreads();
+  const int co = t >> 4, ci = t & 15;
   float a = 0.f, b = 0.f;
-  for (int v = t; v < Nv; v += 256) {
-    float m = 0.f;
-    for (int view = 0; view < n_views; ++view) m += vf[((long)view * Nv + v) * 16 + ci];
-    const float g = d_fused[(long)v * 16 + co];
-    a += g * m / (float)total_views;
+#pragma unroll 8
+  for (int vl = 0; vl < FW_CH; ++vl) {
+    const float g = s_g[vl][co];
+    a += g * s_m[vl][ci];
     b += g;
   }
-  s_a[t] = a;
-  s_b[t] = b;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-      s_a[t] += s_a[t + o];
-      s_b[t] += s_b[t + o];
-    }
-    __syncthreads();
+  part[(long)blockIdx.x * 272 + t] = a;
+  if (ci == 0) part[(long)blockIdx.x * 272 + 256 + co] = b;
+}
+__global__ __launch_bounds__(256) void fuse_bwd_w_reduce_kernel(const float* __restrict__ part, int nchunk, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  const int t = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    a += part[(long)c * 272 + t];
+    if (t < 16) b += part[(long)c * 272 + 256 + t];
   }
-  if (t == 0) {
-    dw[co * 16 + ci] += s_a[0];
-    if (ci == 0) db[co] += s_b[0];
-  }
+  dw[t] += a;
+  if (t < 16) db[t] += b;
 }
 
 // ---- sparse voxel CNN, train mode -------------------------------------------------------------------------------------
@@ -531,13 +549,20 @@ int cbwd_vertex_scatter(const float* d_out, const ViewCam* cams, const int* view
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+// part: scratch of cbwd_fuse_scratch_floats(Nv) floats (only read when dw / db are given)
 int cbwd_fuse(const float* d_fused, const float* vf, const float* w, int n_views, int Nv, int total_views, float* d_vf, float* dw, float* db,
-              hipStream_t s) {
+              float* part, hipStream_t s) {
   hipLaunchKernelGGL(fuse_bwd_dvf_kernel, dim3(cdiv(Nv * 16, 256)), dim3(256), 0, s, d_fused, w, n_views, Nv, total_views, d_vf);
-  if (dw && db) hipLaunchKernelGGL(fuse_bwd_w_kernel, dim3(256), dim3(256), 0, s, d_fused, vf, n_views, Nv, total_views, dw, db);
+  if (dw && db) {
+    if (!part) return mvd_fail("fuse backward: scratch for the weight-gradient partials missing");
+    const int nchunk = cdiv(Nv, FW_CH);
+    hipLaunchKernelGGL(fuse_bwd_w_kernel, dim3(nchunk), dim3(256), 0, s, d_fused, vf, n_views, Nv, total_views, part);
+    hipLaunchKernelGGL(fuse_bwd_w_reduce_kernel, dim3(1), dim3(256), 0, s, part, nchunk, dw, db);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+int cbwd_fuse_scratch_floats(int Nv) { return cdiv(Nv, FW_CH) * 272; }
 int cbwd_bn_scratch_floats(int n, int C) { return cdiv(n, BNB_CH) * 2 * C; }
 // stats: [mean | rstd] from launch_bn_rows_relu; scratch: cbwd_bn_scratch_floats(n, C) floats
 int cbwd_bn_rows_relu(const float* xraw, float* dy, int n, int C, const float* gamma, const float* beta, const float* stats,
