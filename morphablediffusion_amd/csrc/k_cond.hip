@@ -319,6 +319,65 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
   for (int r = t; r < n; r += 256) y[(long)r * C + c] = fmaxf((x[(long)r * C + c] - mean) * rstd * g + b, 0.f);
 }
 
+// The same kernel for layers of at most 256 * BN_MAXR rows (every level of a FLAME-sized mesh): a thread's rows are loaded ONCE,
+// all loads in flight together, and stay in registers for the mean, the centred second moment and the apply -- the looped form
+// above reads the column three times in dependent batches of eight strided loads (20 us per launch, 144 launches per training
+// step at 8 samples).  Same partial sums in the same order, same tree: bit-identical statistics and outputs (the masks drawn from
+// them do not move).
+constexpr int BN_MAXR = 24;
+__global__ __launch_bounds__(256) void bn_rows_relu_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ stats_out, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, float momentum) {
+  __shared__ float s_red[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  float v[BN_MAXR];
+#pragma unroll
+  for (int i = 0; i < BN_MAXR; ++i) {
+    const int r = t + 256 * i;
+    v[i] = r < n ? x[(long)r * C + c] : 0.f;
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_MAXR; ++i)
+    if (t + 256 * i < n) a += v[i];
+  s_red[t] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  const float mean = s_red[0] / (float)n;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_MAXR; ++i)
+    if (t + 256 * i < n) {
+      const float d = v[i] - mean;
+      q += d * d;
+    }
+  s_red[t] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s_red[t] += s_red[t + o];
+    __syncthreads();
+  }
+  const float rstd = rsqrtf(s_red[0] / (float)n + eps), g = gamma[c], b = beta[c];
+  if (stats_out && t == 0) {
+    stats_out[c] = mean;
+    stats_out[C + c] = rstd;
+  }
+  if (rmean && t == 0) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (s_red[0] / (float)(n > 1 ? n - 1 : 1));
+  }
+#pragma unroll
+  for (int i = 0; i < BN_MAXR; ++i) {
+    const int r = t + 256 * i;
+    if (r < n) y[(long)r * C + c] = fmaxf((v[i] - mean) * rstd * g + b, 0.f);
+  }
+}
+
 // mean((a - b)^2) of n elements into out[0]: one workgroup, fixed summation order
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
                                                    float* __restrict__ out) {
@@ -504,7 +563,11 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* mean, con
 int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gamma, const float* beta, float eps, float* stats_out,
                         hipStream_t s, float* rmean, float* rvar, float momentum) {
   if (n <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
+  const char* loop_env = getenv("MVD_BN_LOOP");  // A/B + the bit-identity test: the looped form
+  if (n <= 256 * BN_MAXR && !(loop_env && loop_env[0] == '1'))
+    hipLaunchKernelGGL(bn_rows_relu_reg_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
+  else
+    hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

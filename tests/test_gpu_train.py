@@ -510,6 +510,34 @@ def test_conditioner_backward_stages_vs_oracle_autograd(mesh):
     m.engine.close()
 
 
+def test_train_mode_batchnorm_register_form_is_bit_identical(monkeypatch):
+    """The sparse CNN's train-mode BatchNorm1d + ReLU with a thread's rows held in registers (one read of the column, all loads in
+    flight) against the looped three-pass kernel (MVD_BN_LOOP=1): the same partial sums in the same order -- the 32^3 volume
+    built in train mode (nine such layers, masks drawn from their statistics) must be bit for bit the same."""
+    from morphablediffusion_amd import synthetic
+    N = 4
+    ucfg, vcfg = gi.SMALL_UNET, VolumeConfig(num_views=N)
+    m = make_train_model(ucfg, vcfg, N, workspace_gb=8.0)
+    batch = {k: v.cuda() for k, v in synthetic.make_batch(N, "perspective", 5023, mesh_seed=2).items()}
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(1, N, 4, 32, 32, generator=gen) * 0.8).cuda()
+    v_embed = torch.zeros(1, N, 4).cuda()
+    v_embed[..., 2] = 1.0
+    t_embed = m.embed_time(torch.tensor([300]).cuda())
+    m.train()
+    vols = {}
+    for form in ("register", "loop"):
+        if form == "loop":
+            monkeypatch.setenv("MVD_BN_LOOP", "1")
+        else:
+            monkeypatch.delenv("MVD_BN_LOOP", raising=False)
+        m.spatial_volume.invalidate()
+        vols[form] = m.spatial_volume.construct_spatial_volume(x, t_embed, v_embed, batch).cpu().clone()
+    assert torch.isfinite(vols["register"]).all() and vols["register"].abs().max() > 0
+    assert torch.equal(vols["register"], vols["loop"])
+    m.engine.close()
+
+
 def test_sparse_cnn_matrix_core_form_equals_site_form(monkeypatch):
     """The sparse voxel CNN on the fp32 matrix cores (tiled gather-GEMM forward, gather-form data gradient through the flipped /
     inverse tables with duplicate rows folded, pair-list weight gradient) against the one-site-per-workgroup kernels with the
