@@ -254,32 +254,59 @@ __global__ void fill_rows_f16_kernel(half_t* __restrict__ out, int ld, int rows,
 // C[z][m][n] = scale * sum_k A_z(m,k) B_z(k,n) with strided operands (element (m,k) of A at a[z*a_zs + m*a_rs + k*a_cs], ...),
 // fp64 accumulation, 16 x 16 tiles through LDS: the weight folds below (a few GFLOP at finalize / re-pack time; the one-thread-
 // per-output form they replace ran at 1 TFLOP/s and was 40 % of a re-pack)
+// (round 4: 64 x 64 tiles, a 4 x 4 block of outputs per thread -- eight LDS reads per sixteen fp64 fmas instead of two per fma;
+// every output is still the k-ascending fp64 sum of exact fp32 x fp32 products, so the folded weights are bit for bit the same)
 __global__ __launch_bounds__(256) void fold_gemm_kernel(const float* __restrict__ a, long a_zs, long a_rs, long a_cs,
                                                         const float* __restrict__ b, long b_zs, long b_rs, long b_cs, int M, int N, int K,
                                                         float scale, long c_zs, long c_rs, long c_cs, half_t* __restrict__ out,
                                                         float* __restrict__ out32) {
-  __shared__ float sA[16][17], sB[16][17];
+  __shared__ float sA[16][68], sB[16][68];  // [k][m], [k][n]
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, z = blockIdx.z;
-  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const float* az = a + z * a_zs;
   const float* bz = b + z * b_zs;
-  double acc = 0.0;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
   for (int k0 = 0; k0 < K; k0 += 16) {
-    // A tile [m][k]: thread (ty, tx) loads (m = m0 + ty, k = k0 + tx); B tile [k][n]: (k = k0 + ty, n = n0 + tx)
-    const int ka = k0 + tx, kb = k0 + ty;
-    sA[ty][tx] = (m < M && ka < K) ? az[(long)m * a_rs + (long)ka * a_cs] : 0.f;
-    sB[ty][tx] = (kb < K && n < N) ? bz[(long)kb * b_rs + (long)n * b_cs] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // A tile: element (m = m0 + ml, k = k0 + kl); thread t covers ml = (t >> 4) + 16 e, kl = t & 15; B tile: (k = k0 + (t >> 4)
+      // ... ) as before: kl = t >> 4, nl = (t & 15) + 16 e
+      const int ml = ty + 16 * e, ka = k0 + tx;
+      sA[tx][ml] = (m0 + ml < M && ka < K) ? az[(long)(m0 + ml) * a_rs + (long)ka * a_cs] : 0.f;
+      const int nl = tx + 16 * e, kb = k0 + ty;
+      sB[ty][nl] = (kb < K && n0 + nl < N) ? bz[(long)kb * b_rs + (long)(n0 + nl) * b_cs] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc += (double)sA[ty][kk] * (double)sB[kk][tx];
+    for (int kk = 0; kk < 16; ++kk) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = (double)sA[kk][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = (double)sB[kk][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
     __syncthreads();
   }
-  if (m < M && n < N) {
-    const long o = z * c_zs + (long)m * c_rs + (long)n * c_cs;
-    const float v = (float)(acc * (double)scale);
-    if (out32) out32[o] = v;
-    else out[o] = (half_t)v;
-  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+      if (m < M && n < N) {
+        const long o = z * c_zs + (long)m * c_rs + (long)n * c_cs;
+        const float v = (float)(acc[i][j] * (double)scale);
+        if (out32) out32[o] = v;
+        else out[o] = (half_t)v;
+      }
+    }
 }
 
 __global__ void relu_beta_tile_kernel(const float* __restrict__ beta, int Cc, int heads, half_t* __restrict__ out, int split) {
@@ -411,7 +438,7 @@ int launch_fill_rows_f16(half_t* out, int ld, int rows, const half_t* vec, int n
 int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, int I, float scale, half_t* out,
                    hipStream_t s, float* out32) {
   // W_qk[hn*Cc + j][i] = scale * sum_c Wk[hn*hd + c][j] * Wq[hn*hd + c][i]:  per head  C[j][i] = sum_c Wk^T(j,c) Wq(c,i)
-  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(I, 16), cdiv(Cc, 16), heads), dim3(256), 0, s, wk, (long)hd * Cc, 1L, (long)Cc, wq,
+  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(I, 64), cdiv(Cc, 64), heads), dim3(256), 0, s, wk, (long)hd * Cc, 1L, (long)Cc, wq,
                      (long)hd * I, (long)I, 1L, Cc, I, hd, scale, (long)Cc * I, (long)I, 1L, out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -420,7 +447,7 @@ int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, 
 int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s,
                    float* out32) {
   // W_ov[i][hn*Cc + j] = sum_c Wo[i][hn*hd + c] * Wv[hn*hd + c][j]:  per head  C[i][j] = sum_c Wo(i, hn*hd + c) Wv(hn*hd + c, j)
-  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(Cc, 16), cdiv(I, 16), heads), dim3(256), 0, s, wo, (long)hd, (long)I, 1L, wv,
+  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(Cc, 64), cdiv(I, 64), heads), dim3(256), 0, s, wo, (long)hd, (long)I, 1L, wv,
                      (long)hd * Cc, (long)Cc, 1L, I, Cc, hd, 1.0f, (long)Cc, (long)heads * Cc, 1L, out, out32);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
