@@ -59,6 +59,64 @@ __global__ __launch_bounds__(256) void tcast_kernel(const T* __restrict__ src, l
   }
 }
 
+// The same with 16-byte accesses (round 4): a thread loads four consecutive columns (float4 / four halfs), writes the row image as
+// four halfs, and the transposed image as EIGHT consecutive rows of one column (one 16-byte store; eight lanes cover 128
+// contiguous bytes of a dst row).  The element-per-thread form above moved 2 bytes per lane and store instruction and was the
+// largest item of the training step's operand staging (401 launches, 6.4 ms at 8 samples).  Same values.
+// Needs C % 4 == 0, ld % 4 == 0, Rp % 64 == 0, Cp % 4 == 0 and aligned pointers (bwd_tcast checks; otherwise the scalar kernel).
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+  const float4 q = *(const float4*)p;
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void ld4(const half_t* p, float (&v)[4]) {
+  const h4 q = *(const h4*)p;
+  v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tcast_vec_kernel(const T* __restrict__ src, long ld, int R, int C, half_t* __restrict__ dst, int Rp,
+                                                        int split, half_t* __restrict__ rows16, int Cp) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int rr = i >> 4, cc = (i & 15) * 4;
+    const int r = r0 + rr, c = c0 + cc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < C) ld4(src + (long)r * ld + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[rr][cc + e] = v[e];
+    if (rows16 && r < R && c < Cp) {
+      h4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+      *(h4*)(rows16 + (long)r * Cp + c) = hv;
+    }
+  }
+  __syncthreads();
+  const long rowlen = split ? 3L * Rp : Rp;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int cc = i >> 3, g = i & 7;
+    const int c = c0 + cc, r = r0 + g * 8;
+    if (c >= C) continue;
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = tile[g * 8 + k][cc];
+      hi[k] = (half_t)v;
+      lo[k] = (half_t)(v - (float)hi[k]);
+    }
+    half_t* d = dst + (long)c * rowlen + r;
+    *(h8*)d = hi;
+    if (split) {
+      *(h8*)(d + Rp) = split == 1 ? lo : hi;
+      *(h8*)(d + 2L * Rp) = split == 1 ? hi : lo;
+    }
+  }
+}
+
 // dst[(ci * 9 + tap)][r] = fp16(X[b, (yo*s + ky - 1) >> ups, (xo*s + kx - 1) >> ups, ci])  (zero outside the virtual image of
 // (H << ups) x (W << ups) and for r >= R); r = (b*Ho + yo)*Wo + xo.  The row order ci*9 + tap makes the wgrad GEMM's
 // output [Cout][Cin*9] the reference's conv weight layout [Cout][Cin][3][3] itself.
@@ -103,6 +161,30 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long ro
       const half_t lo = (half_t)(v - (float)hi);
       d[Cp] = split == 1 ? lo : hi;
       d[2L * Cp] = split == 1 ? hi : lo;
+    }
+  }
+}
+
+// four columns per thread (float4 in, four halfs out); needs C % 4 == 0, Cp % 4 == 0, ld % 4 == 0, aligned pointers
+__global__ void cast_rows_vec_kernel(const float* __restrict__ src, long ld, long rows, int C, int Cp, half_t* __restrict__ dst, int split) {
+  const int q = Cp >> 2;
+  const long total = rows * q;
+  const long rowlen = split ? 3L * Cp : Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q) * 4;
+    const long r = i / q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) v = *(const float4*)(src + r * ld + c);
+    h4 hi;
+    hi[0] = (half_t)v.x; hi[1] = (half_t)v.y; hi[2] = (half_t)v.z; hi[3] = (half_t)v.w;
+    half_t* d = dst + r * rowlen + c;
+    *(h4*)d = hi;
+    if (split) {
+      h4 lo;
+      lo[0] = (half_t)(v.x - (float)hi[0]); lo[1] = (half_t)(v.y - (float)hi[1]);
+      lo[2] = (half_t)(v.z - (float)hi[2]); lo[3] = (half_t)(v.w - (float)hi[3]);
+      *(h4*)(d + Cp) = split == 1 ? lo : hi;
+      *(h4*)(d + 2L * Cp) = split == 1 ? hi : lo;
     }
   }
 }
@@ -984,7 +1066,13 @@ int bwd_tcast(const void* src, int src_f32, long ld, int R, int C, half_t* dst, 
   if (split && !src_f32) return mvd_fail("bwd_tcast: the split layout needs an fp32 source");
   if (rows16 && (Cp < C || Cp > 64 * cdiv(C, 64))) return mvd_fail("bwd_tcast: bad row-image width");
   dim3 grid(cdiv(Rp, 64), cdiv(C, 64));
-  if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split, rows16, Cp);
+  static const bool scalar_only = getenv("MVD_STAGE_SCALAR") != nullptr;  // A/B switch: the element-per-thread staging kernels
+  const bool vec = !scalar_only && !(C & 3) && !(ld & 3) && !(Rp & 63) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) &&
+                   (!rows16 || (!(Cp & 3) && !((uintptr_t)rows16 & 7)));
+  if (vec) {
+    if (src_f32) hipLaunchKernelGGL(tcast_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split, rows16, Cp);
+    else hipLaunchKernelGGL(tcast_vec_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp, 0, rows16, Cp);
+  } else if (src_f32) hipLaunchKernelGGL(tcast_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, R, C, dst, Rp, split, rows16, Cp);
   else hipLaunchKernelGGL(tcast_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, R, C, dst, Rp, 0, rows16, Cp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -999,7 +1087,11 @@ int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int 
   return 0;
 }
 int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* dst, hipStream_t s, int split) {
-  hipLaunchKernelGGL(cast_rows_kernel, dim3(gridn((size_t)rows * Cp)), dim3(256), 0, s, src, ld, rows, C, Cp, dst, split);
+  static const bool scalar_only = getenv("MVD_STAGE_SCALAR") != nullptr;
+  if (!scalar_only && !(C & 3) && !(Cp & 3) && !(ld & 3) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 7))
+    hipLaunchKernelGGL(cast_rows_vec_kernel, dim3(gridn((size_t)rows * (Cp >> 2))), dim3(256), 0, s, src, ld, rows, C, Cp, dst, split);
+  else
+    hipLaunchKernelGGL(cast_rows_kernel, dim3(gridn((size_t)rows * Cp)), dim3(256), 0, s, src, ld, rows, C, Cp, dst, split);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
