@@ -146,6 +146,44 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const T* __restrict__ src,
   }
 }
 
+// im2colT with 8- / 16-byte accesses (round 4): a thread gathers four consecutive channels of one output row (one set of index
+// divisions per four elements instead of per element) and stores eight consecutive rows of one (channel, tap) line at once.
+// Needs C % 4 == 0, ld % 4 == 0, Rp % 64 == 0 and aligned pointers; same values as im2colT_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void im2colT_vec_kernel(const T* __restrict__ src, long ld, int B, int H, int W, int C, int stride, int ups,
+                                                          int Ho, int Wo, half_t* __restrict__ dst, int Rp) {
+  __shared__ half_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+  const int R = B * Ho * Wo, IY = H << ups, IX = W << ups;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int rr = i >> 4, cc = (i & 15) * 4;
+    const int r = r0 + rr, c = c0 + cc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < C) {
+      const int xo = r % Wo, yo = (r / Wo) % Ho, b = r / (Wo * Ho);
+      const int y = yo * stride + ky, x = xo * stride + kx;
+      if (y >= 0 && y < IY && x >= 0 && x < IX) ld4(src + (((long)b * H + (y >> ups)) * W + (x >> ups)) * ld + c, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[rr][cc + e] = (half_t)v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int cc = i >> 3, g = i & 7;
+    const int c = c0 + cc;
+    if (c >= C) continue;
+    h8 hv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv[k] = tile[g * 8 + k][cc];
+    *(h8*)(dst + ((long)c * 9 + tap) * Rp + r0 + g * 8) = hv;
+  }
+}
+
 // fp32 rows (stride ld) -> dense fp16 rows of width Cp >= C (zero padded); split: rows of 3 Cp halfs, see tcast_kernel
 __global__ void cast_rows_kernel(const float* __restrict__ src, long ld, long rows, int C, int Cp, half_t* __restrict__ dst, int split) {
   const long total = rows * Cp;
@@ -210,6 +248,35 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const half_t* __restric
   for (int i = 0; i < 16; ++i) {
     const int ci = ci0 + ty + 4 * i, co = co0 + tx;
     if (ci < Cl && co < Np) wT[((long)t2 * Cl + ci) * Np + co] = tile[tx][ty + 4 * i];
+  }
+}
+
+// the same with 16-byte accesses on both sides (needs ldw % 8 == 0, Np % 8 == 0, Cl % 8 == 0, aligned pointers)
+__global__ __launch_bounds__(256) void pack_dgrad_vec_kernel(const half_t* __restrict__ w, int taps, int N, int ldw, int Cl, int Np,
+                                                             half_t* __restrict__ wT, int flip) {
+  __shared__ half_t tile[64][72];  // [co][ci]
+  const int t2 = blockIdx.z, t = flip ? taps - 1 - t2 : t2;
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int col = i >> 3, c8 = (i & 7) * 8;
+    const int co = co0 + col, ci = ci0 + c8;
+    h8 v = (h8)(half_t)0;
+    if (co < N && ci < Cl) v = *(const h8*)(w + ((long)t * N + co) * ldw + ci);
+    *(h8*)(&tile[col][c8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int cil = i >> 3, g = i & 7;
+    const int ci = ci0 + cil, co = co0 + g * 8;
+    if (ci >= Cl || co >= Np) continue;
+    h8 hv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv[k] = tile[g * 8 + k][cil];
+    *(h8*)(wT + ((long)t2 * Cl + ci) * Np + co) = hv;
   }
 }
 
@@ -1081,7 +1148,11 @@ int bwd_im2colT(const void* src, int src_f32, long ld, int B, int H, int W, int 
   const int Ho = ((H << ups) - 1) / stride + 1, Wo = ((W << ups) - 1) / stride + 1;
   if (Rp < B * Ho * Wo) return mvd_fail("bwd_im2colT: bad shape");
   dim3 grid(cdiv(Rp, 64), cdiv(C, 64), 9);
-  if (src_f32) hipLaunchKernelGGL(im2colT_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
+  static const bool scalar_only = getenv("MVD_STAGE_SCALAR") != nullptr;
+  if (!scalar_only && !(C & 3) && !(ld & 3) && !(Rp & 63) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
+    if (src_f32) hipLaunchKernelGGL(im2colT_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
+    else hipLaunchKernelGGL(im2colT_vec_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
+  } else if (src_f32) hipLaunchKernelGGL(im2colT_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
   else hipLaunchKernelGGL(im2colT_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, H, W, C, stride, ups, Ho, Wo, dst, Rp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -1096,7 +1167,11 @@ int bwd_cast_rows(const float* src, long ld, long rows, int C, int Cp, half_t* d
   return 0;
 }
 int bwd_pack_dgrad(const half_t* w, int taps, int N, int ldw, int Cl, int Np, half_t* wT, hipStream_t s, int flip) {
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(Np, 64), cdiv(Cl, 64), taps), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
+  static const bool scalar_only = getenv("MVD_STAGE_SCALAR") != nullptr;
+  if (!scalar_only && !(ldw & 7) && !(Np & 7) && !(Cl & 7) && !((uintptr_t)w & 15) && !((uintptr_t)wT & 15))
+    hipLaunchKernelGGL(pack_dgrad_vec_kernel, dim3(cdiv(Np, 64), cdiv(Cl, 64), taps), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
+  else
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(Np, 64), cdiv(Cl, 64), taps), dim3(256), 0, s, w, taps, N, ldw, Cl, Np, wT, flip);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

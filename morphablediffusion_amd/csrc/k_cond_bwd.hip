@@ -497,6 +497,51 @@ __global__ __launch_bounds__(256) void im2colT3d_kernel(const T* __restrict__ sr
   }
 }
 
+// with 8- / 16-byte accesses (see im2colT_vec_kernel, k_bwd.hip): four channels per gather, eight rows per store; same values
+template <typename T>
+__global__ __launch_bounds__(256) void im2colT3d_vec_kernel(const T* __restrict__ src, long ld, int B, int D, int H, int W, int C, int stride,
+                                                            int Do, int Ho, int Wo, half_t* __restrict__ dst, int Rp) {
+  __shared__ half_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int kz = tap / 9 - 1, ky = (tap / 3) % 3 - 1, kx = tap % 3 - 1;
+  const int R = B * Do * Ho * Wo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int rr = i >> 4, cc = (i & 15) * 4;
+    const int r = r0 + rr, c = c0 + cc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < C) {
+      const int xo = r % Wo, yo = (r / Wo) % Ho, zo = (r / (Wo * Ho)) % Do, b = r / (Wo * Ho * Do);
+      const int z = zo * stride + kz, y = yo * stride + ky, x = xo * stride + kx;
+      if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+        const T* p = src + ((((long)b * D + z) * H + y) * W + x) * ld + c;
+        if constexpr (sizeof(T) == 4) {
+          const float4 q = *(const float4*)p;
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+          const h4 q = *(const h4*)p;
+          v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[rr][cc + e] = (half_t)v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int cc = i >> 3, g = i & 7;
+    const int c = c0 + cc;
+    if (c >= C) continue;
+    h8 hv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv[k] = tile[g * 8 + k][cc];
+    *(h8*)(dst + ((long)c * 27 + tap) * Rp + r0 + g * 8) = hv;
+  }
+}
+
 // out[r][k] (+)= sum_n g[r][n] w[n][k]  (w fp16 [N][K], the LinW pack) for a handful of rows (FiLM / step-MLP adjoints).
 // One workgroup = 16 consecutive k x 16 lanes over n, combined through LDS in lane order.
 __global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* __restrict__ g, long ldg, int N, const half_t* __restrict__ w,
@@ -631,6 +676,13 @@ int cbwd_im2colT3d(const void* src, int src_f32, long ld, int B, int D, int H, i
   const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   if (Rp < B * Do * Ho * Wo) return mvd_fail("im2colT3d: bad shape");
   dim3 grid(cdiv(Rp, 64), cdiv(C, 64), 27);
+  static const bool scalar_only = getenv("MVD_STAGE_SCALAR") != nullptr;
+  if (!scalar_only && !(C & 3) && !(ld & 3) && !(Rp & 63) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
+    if (src_f32) hipLaunchKernelGGL(im2colT3d_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
+    else hipLaunchKernelGGL(im2colT3d_vec_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   if (src_f32) hipLaunchKernelGGL(im2colT3d_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
   else hipLaunchKernelGGL(im2colT3d_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)src, ld, B, D, H, W, C, stride, Do, Ho, Wo, dst, Rp);
   HIP_CHECK_RET(hipGetLastError());
