@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void bn_rows_relu_kernel(const float* __restri
 // above reads the column three times in dependent batches of eight strided loads (20 us per launch, 144 launches per training
 // step at 8 samples).  Same partial sums in the same order, same tree: bit-identical statistics and outputs (the masks drawn from
 // them do not move).
-constexpr int BN_MAXR = 24;
+// (two sizes: 24 rows per thread, and 48 -- a sparse point set DILATES under the strided conv, level 1 of a 4.6 k-voxel mesh has
+// 9.4 k sites)
+template <int BN_MAXR>
 __global__ __launch_bounds__(256) void bn_rows_relu_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                               float* __restrict__ stats_out, float* __restrict__ rmean,
@@ -564,8 +566,11 @@ int launch_bn_rows_relu(const float* x, float* y, int n, int C, const float* gam
                         hipStream_t s, float* rmean, float* rvar, float momentum) {
   if (n <= 0 || C <= 0) return 0;
   const char* loop_env = getenv("MVD_BN_LOOP");  // A/B + the bit-identity test: the looped form
-  if (n <= 256 * BN_MAXR && !(loop_env && loop_env[0] == '1'))
-    hipLaunchKernelGGL(bn_rows_relu_reg_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
+  const bool loop = loop_env && loop_env[0] == '1';
+  if (n <= 256 * 24 && !loop)
+    hipLaunchKernelGGL(bn_rows_relu_reg_kernel<24>, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
+  else if (n <= 256 * 48 && !loop)
+    hipLaunchKernelGGL(bn_rows_relu_reg_kernel<48>, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
   else
     hipLaunchKernelGGL(bn_rows_relu_kernel, dim3(C), dim3(256), 0, s, x, y, n, C, gamma, beta, eps, stats_out, rmean, rvar, momentum);
   HIP_CHECK_RET(hipGetLastError());
