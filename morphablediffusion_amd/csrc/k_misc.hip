@@ -118,6 +118,41 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld, int B,
   }
 }
 
+// The two layout conversions as 32 x 32 tiles through LDS: 128-byte runs on both sides (the element-per-thread forms above read
+// -- or write -- one float per cache line; the training step converts four source volumes and four gradient volumes of up to
+// 100 MB per call).  Taken for C >= 16; the 4- and 8-channel latents keep the simple kernels.  Same values.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ in, int C, int HW, float* __restrict__ out, int ldo,
+                                                                 int cpad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && p < HW) ? in[((long)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    if (p < HW && c < cpad) out[((long)b * HW + p) * ldo + c] = tile[tx][ty + 8 * i];
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_tiled_kernel(const float* __restrict__ in, int ld, int C, int HW, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (p < HW && c < C) ? in[((long)b * HW + p) * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    if (c < C && p < HW) out[((long)b * C + c) * HW + p] = tile[tx][ty + 8 * i];
+  }
+}
+
 // dst fp16 [taps][N][Cin]; src fp32 [N][Cin][taps] (conv / linear) or [Cin][N][taps] (ConvTranspose).
 // geglu: rows are re-ordered into alternating 32-row blocks (value | gate) so the GEMM epilogue can pair
 // fragment 0 with fragment 1 of a wave.
@@ -411,14 +446,20 @@ int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipS
 }
 
 int launch_nchw_to_nhwc(const float* in, int B, int C, int HW, float* out, int ldo, int cpad, hipStream_t s) {
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * HW * cpad)), dim3(256), 0, s, in, B, C, HW, out,
-                     ldo, cpad);
+  if (C >= 16 && HW >= 32 && B <= 65535 && cdiv(cpad, 32) <= 65535)
+    hipLaunchKernelGGL(nchw_to_nhwc_tiled_kernel, dim3(cdiv(HW, 32), cdiv(cpad, 32), B), dim3(256), 0, s, in, C, HW, out, ldo, cpad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * HW * cpad)), dim3(256), 0, s, in, B, C, HW, out,
+                       ldo, cpad);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 int launch_nhwc_to_nchw(const float* in, int ld, int B, int C, int HW, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * HW * C)), dim3(256), 0, s, in, ld, B, C, HW, out);
+  if (C >= 16 && HW >= 32 && B <= 65535 && cdiv(C, 32) <= 65535)
+    hipLaunchKernelGGL(nhwc_to_nchw_tiled_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, s, in, ld, C, HW, out);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * HW * C)), dim3(256), 0, s, in, ld, B, C, HW, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
