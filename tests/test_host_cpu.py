@@ -350,6 +350,25 @@ try:
     raise SystemExit("overlap not detected")
 except RuntimeError:
     pass
+# the model-level glue (training_step -> _start_grad_sync, sync_gradients, no_sync) on a stand-in with the engine's two members
+import types
+from morphablediffusion_amd.model import SyncMultiviewDiffusion as M
+class Eng:
+    def __init__(self, flat): self.flat_grads = flat
+    def grad_buckets(self): return buckets
+fake = types.SimpleNamespace(overlap_grad_sync=True, _grad_sync=None, _grad_comm=None, engine=Eng(local.clone()))
+M._start_grad_sync(fake)
+assert fake._grad_sync is not None
+assert M.sync_gradients(fake) is True and fake._grad_sync is None      # consumed: one averaging per backward pass
+assert torch.equal(fake.engine.flat_grads, ref)
+fake.engine.flat_grads.copy_(local)
+with M.no_sync(fake):                                                 # gradient accumulation: nothing is reduced
+    M._start_grad_sync(fake)
+    assert fake._grad_sync is None
+assert fake.overlap_grad_sync is True and torch.equal(fake.engine.flat_grads, local)
+fake.overlap_grad_sync = False                                        # the flat form
+M._start_grad_sync(fake)
+assert fake._grad_sync is None and M.sync_gradients(fake) is True and torch.equal(fake.engine.flat_grads, ref)
 print("BUCKET_OK", rank)
 dist.destroy_process_group()
 '''
