@@ -344,6 +344,17 @@ int mvd_op_group_norm_bwd(mvd_ctx* ctx, const float* x, const float* dy, int B, 
                           const float* beta, float eps, int act, float* dx, float* dgamma, float* dbeta, void* stream);
 int mvd_op_layer_norm_bwd(mvd_ctx* ctx, const float* x, const float* dy, int rows, int C, const float* gamma, float* dx,
                           float* dgamma, float* dbeta, void* stream);
+/* Row-chain kernel test / timing hook (csrc/k_rowchain.hip): the row-local tail of a SpatialTransformer block in ONE launch,
+ *   t2 = ao @ w_ao^T + b_ao + rowbias[sample] + xin   (flags & 1; otherwise t2 = xin)     ldm/modules/attention.py:196-200, 266-267
+ *   t3 = t2 + FF2(GEGLU(FF1(LayerNorm(t2))))                                              ldm/modules/attention.py:37-73, 268
+ *   out = t3 @ w_po^T + b_po + resid                  (flags & 2; otherwise out = fp16(t3)) ldm/modules/attention.py:333-336
+ * on fp32 operands in the reference's layouts (w1 [8C][C] value rows then gate rows, w2 [C][4C]); rows % 128 == 0, T (rows per
+ * sample) % 32 == 0, C in {64, 128, 256, 320}.  flags & 4 (without 2): the fp16 result is written as [hi | lo | hi] rows and
+ * returned as hi + lo.  iters > 0: the launch is repeated and *ms_out receives the mean milliseconds per launch. */
+int mvd_op_st_tail(mvd_ctx* ctx, int C, int rows, int T, const float* ao, const float* xin, const float* rowbias,
+                   const float* w_ao, const float* b_ao, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* w_po, const float* b_po, const float* resid, float* out,
+                   int flags, int iters, float* ms_out, void* stream);
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "engine.h"
+#include "rowchain.h"
 
 int engine_set_cameras(mvd_ctx* c, const float* K, const float* RT, int N, hipStream_t s);
 int engine_set_mesh(mvd_ctx* c, const float* vertices, const int32_t* coord, const int32_t* out_sh, const float* bounds,
@@ -27,6 +28,13 @@ const char* mvd_error_text() { return g_err.c_str(); }
 
 namespace {
 
+__global__ void split_rows_to_f32_kernel(const half_t* in, int rows, int C, float* out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * C; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / C, c = i % C;
+    const half_t hi = in[r * 3 * C + c], lo = in[r * 3 * C + C + c], h2 = in[r * 3 * C + 2 * C + c];
+    out[i] = (float)hi == (float)h2 ? (float)hi + (float)lo : __builtin_nanf("");
+  }
+}
 __global__ void f16_to_f32_kernel(const half_t* in, float* out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = (float)in[i];
@@ -1252,6 +1260,60 @@ int mvd_bench_group_norm(mvd_ctx* c, int B, int C, int HW, int groups, int flags
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *ms_out = ms / (float)iters;
+  return 0;
+}
+
+// The row-chain kernel (k_rowchain.hip) on fp32 operands in the reference's layouts: packs the weight stream, runs the kernel
+// once (iters > 0: `iters` more times between two events -> *ms_out = mean milliseconds) and returns the result in fp32.
+int mvd_op_st_tail(mvd_ctx* c, int C, int rows, int T, const float* ao, const float* xin, const float* rowbias, const float* w_ao,
+                   const float* b_ao, const float* ln_g, const float* ln_b, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const float* w_po, const float* b_po, const float* resid, float* out, int flags, int iters,
+                   float* ms_out, void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c) return mvd_fail("null context");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const int has_ao = flags & 1, has_po = (flags & 2) ? 1 : 0, split = (flags & 4) && !has_po;
+  if (!rowchain_takes(C, rows, T)) return mvd_fail("op_st_tail: shape not supported by the row-chain kernel");
+  const size_t n = (size_t)rows * C;
+  half_t* stream_w = ws_alloc<half_t>(c, rowchain_stream_halfs(C, has_ao, has_po));
+  float* tmp = ws_alloc<float>(c, (size_t)8 * C);
+  half_t* aoh = has_ao ? ws_alloc<half_t>(c, n) : nullptr;
+  half_t* oh = has_po ? nullptr : ws_alloc<half_t>(c, n * (split ? 3 : 1));
+  WS_CHECK(stream_w && tmp && (!has_ao || aoh) && (has_po || oh));
+  RcWeights w;
+  w.w_ao = w_ao; w.ln_g = ln_g; w.ln_b = ln_b; w.w1 = w1; w.b1 = b1; w.w2 = w2; w.b2 = b2; w.w_po = w_po;
+  RET_IF(rowchain_pack(w, C, has_ao, has_po, tmp, stream_w, s));
+  if (has_ao) RET_IF(launch_f32_to_f16(ao, aoh, n, s));
+  RowChain p;
+  memset(&p, 0, sizeof p);
+  p.stream = stream_w; p.rows = rows; p.T = T;
+  p.ao = aoh; p.ld_ao = C; p.xin = xin; p.ld_x = C; p.b_ao = b_ao; p.rowbias = rowbias; p.rb_ld = C;
+  p.b_po = b_po; p.resid = resid; p.ld_r = C;
+  p.out = has_po ? (void*)out : (void*)oh; p.ld_o = has_po ? C : (split ? 3 * C : C); p.out_split = split ? C : 0;
+  RET_IF(launch_rowchain(p, C, has_ao, has_po, s));
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    HIP_CHECK_RET(hipEventCreate(&e0));
+    HIP_CHECK_RET(hipEventCreate(&e1));
+    HIP_CHECK_RET(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) RET_IF(launch_rowchain(p, C, has_ao, has_po, s));
+    HIP_CHECK_RET(hipEventRecord(e1, s));
+    HIP_CHECK_RET(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (ms_out) *ms_out = ms / (float)iters;
+  }
+  if (!has_po) {
+    if (split) {  // [hi | lo | hi] rows -> hi + lo (NaN where the third block differs from the first)
+      hipLaunchKernelGGL(split_rows_to_f32_kernel, dim3(nblk(n)), dim3(256), 0, s, oh, rows, C, out);
+    } else {
+      hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(n)), dim3(256), 0, s, oh, out, n);
+    }
+  }
+  HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 

@@ -621,6 +621,23 @@ class Engine:
                                            _stream()))
         return out
 
+    def op_st_tail(self, xin, ln_g, ln_b, w1, b1, w2, b2, ao=None, w_ao=None, b_ao=None, rowbias=None, T=None, w_po=None, b_po=None,
+                   resid=None, split=False, iters=0):
+        """Row-chain kernel (csrc/k_rowchain.hip) through the C ABI: [to_out + t0] -> LayerNorm3 -> FF -> + t2 [-> proj_out + x_in].
+        Returns the fp32 result (and the mean milliseconds per launch when iters > 0)."""
+        dev = self.device
+        xin = _f32(xin, dev)
+        rows, Cc = xin.shape
+        keep = [_f32(t, dev) if t is not None else None for t in (ao, rowbias, w_ao, b_ao, ln_g, ln_b, w1, b1, w2, b2, w_po, b_po, resid)]
+        ao_, rb_, wao_, bao_, g_, b_, w1_, b1_, w2_, b2_, wpo_, bpo_, res_ = keep
+        flags = (1 if ao is not None else 0) | (2 if w_po is not None else 0) | (4 if split else 0)
+        out = torch.empty_like(xin)
+        ms = C.c_float(0)
+        L.check(self.lib.mvd_op_st_tail(self._ctx, Cc, rows, int(T or rows), L.ptr(ao_), L.ptr(xin), L.ptr(rb_), L.ptr(wao_), L.ptr(bao_),
+                                        L.ptr(g_), L.ptr(b_), L.ptr(w1_), L.ptr(b1_), L.ptr(w2_), L.ptr(b2_), L.ptr(wpo_), L.ptr(bpo_),
+                                        L.ptr(res_), L.ptr(out), flags, int(iters), C.byref(ms), _stream()))
+        return (out, ms.value) if iters > 0 else out
+
     def op_attention(self, q, k, v, heads):
         dev = self.device
         q, k, v = _f32(q, dev), _f32(k, dev), _f32(v, dev)

@@ -181,3 +181,58 @@ def test_attention_peaked_rows(eng):
     qh, kh, vh = [t.reshape(B, T, heads, d).permute(0, 2, 1, 3) for t in (q, k, v)]
     want = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
     close(eng.op_attention(q, k, v, heads), want, "attention peaked", rel=2e-3, mx=6e-3)
+
+
+# ---- row-chain kernel (k_rowchain.hip): [to_out + t0] -> LayerNorm3 -> FF1 -> GEGLU -> FF2 -> + t2 [-> proj_out + x_in] in one launch
+def _st_tail_case(C, rows, T, ao, po, seed=0):
+    g = torch.Generator().manual_seed(1000 * C + rows + 7 * seed)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    d = dict(xin=r(rows, C), ln_g=1.0 + 0.2 * r(C), ln_b=0.2 * r(C), w1=r(8 * C, C, sc=C ** -0.5), b1=0.3 * r(8 * C),
+             w2=r(C, 4 * C, sc=(4 * C) ** -0.5), b2=0.3 * r(C))
+    if ao:
+        d.update(ao=r(rows, C), w_ao=r(C, C, sc=C ** -0.5), b_ao=0.3 * r(C), rowbias=0.5 * r(rows // T, C), T=T)
+    if po:
+        d.update(w_po=r(C, C, sc=C ** -0.5), b_po=0.3 * r(C), resid=r(rows, C))
+    return d
+
+
+def _st_tail_ref(d):
+    t2 = d["xin"].double()
+    if "ao" in d:
+        T = d["T"]
+        a = d["ao"].half().double()  # the attention output is an fp16 tensor in the engine
+        t2 = t2 + a @ d["w_ao"].double().t() + d["b_ao"].double() + d["rowbias"].double().repeat_interleave(T, 0)
+    x = F.layer_norm(t2, (t2.shape[1],), d["ln_g"].double(), d["ln_b"].double(), 1e-5)
+    hmid = x @ d["w1"].double().t() + d["b1"].double()
+    v, gate = hmid.chunk(2, -1)
+    t3 = t2 + (v * F.gelu(gate)) @ d["w2"].double().t() + d["b2"].double()
+    if "w_po" in d:
+        return (t3 @ d["w_po"].double().t() + d["b_po"].double() + d["resid"].double()).float()
+    return t3.float()
+
+
+@pytest.mark.parametrize("C,rows,T,ao,po", [
+    (64, 256, 64, False, False), (64, 1024, 1024, True, True), (128, 512, 256, True, False), (128, 256, 32, False, True),
+    (256, 384, 64, True, True), (320, 1024, 1024, False, False), (320, 2048, 1024, True, True), (320, 4096, 1024, True, False),
+])
+def test_st_tail_rowchain(eng, C, rows, T, ao, po):
+    d = _st_tail_case(C, rows, T, ao, po)
+    got = eng.op_st_tail(**d)
+    close(got, _st_tail_ref(d), f"st_tail C={C} rows={rows} ao={ao} po={po}")
+
+
+def test_st_tail_rowchain_split_output(eng):
+    """fp16 result written as [hi | lo | hi] rows (the operand of an extended-precision proj_out): hi + lo carries ~22 bits."""
+    d = _st_tail_case(320, 1024, 1024, True, False, seed=3)
+    got = eng.op_st_tail(split=True, **d)
+    close(got, _st_tail_ref(d), "st_tail split", rel=6e-4, mx=3e-3)
+
+
+def test_st_tail_rowchain_identity_weights(eng):
+    """Transposition / permutation check: identity-like projections with asymmetric FF weights must reproduce the reference
+    (a swapped k permutation or row block shows as O(1) error, not as rounding)."""
+    C, rows = 128, 256
+    d = _st_tail_case(C, rows, 256, True, True, seed=5)
+    d["w_ao"] = torch.eye(C) + 0.01 * torch.arange(C * C, dtype=torch.float32).reshape(C, C).remainder(7.0) / 7.0
+    d["w_po"] = torch.eye(C).roll(3, 0)
+    close(eng.op_st_tail(**d), _st_tail_ref(d), "st_tail identity")
