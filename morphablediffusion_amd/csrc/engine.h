@@ -8,6 +8,7 @@
 
 #include "../../include/mvd.h"
 #include "common.h"
+#include "rowchain.h"
 
 struct RawTensor {
   float* d = nullptr;  // device fp32 copy in reference layout
@@ -61,6 +62,9 @@ struct STW {
   ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;  // qkv: to_q | to_k | to_v rows stacked
   int C = 0, heads = 8, a2_off = 0;
   std::string key;
+  // row-chain kernel (k_rowchain.hip): to_out | LayerNorm3-folded FF1 | FF2 | proj_out as one pre-packed fragment stream
+  // (null when the width is not one of its instantiated forms)
+  half_t* rc_stream = nullptr;
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;

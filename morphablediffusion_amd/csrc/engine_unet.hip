@@ -501,16 +501,24 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   WsScope ws_scope(c, WS_BLOCK);
   const int C = t.C, T = H * W, rows = f.Bv * T;
   const int wi = t.proj_in.xp ? 3 : 1, wo = t.proj_out.xp ? 3 : 1;  // extended precision: [hi | lo | hi] operands
+  // Row-chain form (k_rowchain.hip; inference at full batch): everything behind the attention -- to_out + attn2 + t0, LayerNorm3,
+  // FF1, GEGLU, FF2, the residual, proj_out + the block input -- is ONE launch with the rows resident in registers; the
+  // intermediates t2 / l3 / gg (and t3, unless an extended-precision proj_out wants its [hi | lo | hi] operand) do not exist.
+  // Below ~128 workgroups of 128 rows the layered GEMMs fill the chip better than one wave per 32 rows does.
+  static const bool no_rc = getenv("MVD_NO_ROWCHAIN") != nullptr;
+  static const int rc_min_rows = getenv("MVD_ROWCHAIN_MIN_ROWS") ? atoi(getenv("MVD_ROWCHAIN_MIN_ROWS")) : 16384;
+  const bool rc = !no_rc && !f.train && !sv && t.rc_stream && rows >= rc_min_rows && rowchain_takes(C, rows, T) && !(in.ld & 3) && !(out.ld & 3);
+  const bool rc_po = rc && !t.proj_out.xp;
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C * wi);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);
   half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
-  float* t2 = ws_alloc<float>(c, (size_t)rows * C);
-  half_t* gg = ws_alloc<half_t>(c, (size_t)rows * 4 * C);
-  half_t* t3 = ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
+  float* t2 = rc ? nullptr : ws_alloc<float>(c, (size_t)rows * C);
+  half_t* gg = rc ? nullptr : ws_alloc<half_t>(c, (size_t)rows * 4 * C);
+  half_t* t3 = rc_po ? nullptr : ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
   half_t* l3 = f.train ? ws_alloc<half_t>(c, (size_t)rows * C) : l1;  // the backward pass needs both LayerNorm outputs
-  WS_CHECK(n0 && t0 && l1 && qkv && ao && t2 && gg && t3 && l3);
+  WS_CHECK(n0 && t0 && l1 && qkv && ao && (rc || (t2 && gg)) && (rc_po || t3) && l3);
   if (in_carry && in_carry->sk > 1)
     RET_IF(run_group_norm(c, in_carry->slabs, C, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp,
                           in_carry->sk, in_carry->stride, in_carry->bias, in_carry->resid, in_carry->ldr, in.p, in.ld));
@@ -531,6 +539,34 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
     ProbeScope ps(c, f.s, "attn_kernel", 4.0 * f.Bv * (double)T * T * C, (double)rows * C * 8.0);
     RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));
   }
+  if (rc) {
+    RowChain rp;
+    memset(&rp, 0, sizeof rp);
+    rp.stream = t.rc_stream; rp.rows = rows; rp.T = T;
+    rp.ao = ao; rp.ld_ao = C; rp.xin = t0; rp.ld_x = C; rp.b_ao = t.attn_out.bias;
+    rp.rowbias = f.a2_all + t.a2_off; rp.rb_ld = c->a2_total;
+    if (rc_po) {
+      rp.b_po = t.proj_out.bias; rp.resid = in.p; rp.ld_r = in.ld; rp.out = out.p; rp.ld_o = out.ld;
+    } else {
+      rp.out = t3; rp.ld_o = C * wo; rp.out_split = t.proj_out.xp ? C : 0;
+    }
+    {
+      const double cc = (double)C * C, fl = 2.0 * rows * cc * (rc_po ? 14.0 : 13.0);
+      const double by = (double)rows * C * (2.0 + 4.0 + (rc_po ? 8.0 : 2.0 * wo)) + cc * 2.0 * (rc_po ? 14.0 : 13.0);
+      ProbeScope ps(c, f.s, "rowchain_kernel", fl, by);
+      RET_IF(launch_rowchain(rp, C, 1, rc_po ? 1 : 0, f.s));
+    }
+    if (rc_po) {
+      if (out_carry) {
+        out_carry->sk = 1;
+        out_carry->stride = (size_t)rows * C;
+        out_carry->bias = t.proj_out.bias;
+        out_carry->resid = in.p;
+        out_carry->ldr = in.ld;
+      }
+      return 0;
+    }
+  } else {
   // attn2 (single CLIP token -> per-sample constant, precomputed for all blocks in engine_unet) rides on the
   // attn1 output projection as a per-sample bias
   g = GemmArgs();
@@ -548,6 +584,7 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C * wo; g.resid = t2; g.ldr = C;
   g.out_split = t.proj_out.xp ? C : 0;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  }
   g = GemmArgs();
   g.a = t3; g.lda = C * wo; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
   int skp = 1;

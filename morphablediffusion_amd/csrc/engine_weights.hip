@@ -161,6 +161,27 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
+  if (rc_supported_c(C)) {  // the row-local tail of the block as one fragment stream (k_rowchain.hip); proj_out included: the
+                            // form without it reads the same stream and stops in front of that section
+    engine_build_rotate(c);
+    RawTensor *wao, *g3, *b3, *w1, *b1, *w2, *b2, *wpo;
+    RET_IF(get_raw(c, t + ".attn1.to_out.0.weight", &wao));
+    RET_IF(get_raw(c, t + ".norm3.weight", &g3));
+    RET_IF(get_raw(c, t + ".norm3.bias", &b3));
+    RET_IF(get_raw(c, t + ".ff.net.0.proj.weight", &w1));
+    RET_IF(get_raw(c, t + ".ff.net.0.proj.bias", &b1));
+    RET_IF(get_raw(c, t + ".ff.net.2.weight", &w2));
+    RET_IF(get_raw(c, t + ".ff.net.2.bias", &b2));
+    RET_IF(get_raw(c, p + ".proj_out.weight", &wpo));
+    if (wao->numel != (size_t)C * C || w1->numel != (size_t)8 * C * C || w2->numel != (size_t)4 * C * C || wpo->numel != (size_t)C * C)
+      return mvd_fail("build_st: transformer block weights do not have the row-chain kernel's shapes");
+    float* tmp = nullptr;
+    RET_IF(dmalloc(c, (void**)&tmp, (size_t)8 * C * sizeof(float)));
+    RET_IF(dmalloc(c, (void**)&s->rc_stream, rowchain_stream_halfs(C, 1, 1) * sizeof(half_t)));
+    RcWeights rw;
+    rw.w_ao = wao->d; rw.ln_g = g3->d; rw.ln_b = b3->d; rw.w1 = w1->d; rw.b1 = b1->d; rw.w2 = w2->d; rw.b2 = b2->d; rw.w_po = wpo->d;
+    RET_IF(rowchain_pack(rw, C, 1, 1, tmp, s->rc_stream, c->bs));
+  }
   return 0;
 }
 

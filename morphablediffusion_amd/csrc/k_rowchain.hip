@@ -32,6 +32,8 @@
 //     LayerNorm's gain is folded into FF1's columns.
 // HBM traffic per block at 32 x 32, C = 320: 42 MB in (t0 or t2) + 21 MB (attention output) + 42 MB residual + 42 MB out,
 // instead of 10 tensors of 21-168 MB.  Inference only (the training step keeps the layered path and its tape).
+#include <type_traits>
+
 #include "common.h"
 #include "igemm_epilogue.h"
 #include "rowchain.h"
@@ -39,6 +41,16 @@
 namespace {
 
 constexpr int RC_RING_BYTES = 128 * 1024;
+#ifndef RC_D
+#define RC_D 4
+#endif
+constexpr int RC_PF = RC_D;  // fragments read ahead of the MFMA that consumes them (register window)
+// bodies per iteration of the unit loop: whole ring cycles, alternating accumulator sets, and the register window keeps its phase
+__host__ __device__ constexpr int rc_ub(const RcLayout& L) {
+  int ub = L.UNR;
+  while ((ub * L.BODY_RAW) % RC_PF) ub += L.UNR;
+  return ub;
+}
 constexpr int RC_LDS_BYTES = RC_RING_BYTES + 4 * EPI_WAVE_BYTES;
 
 // position of the (k, h, e) operand slot inside a row of the source matrix (see the file comment)
@@ -49,7 +61,7 @@ __host__ __device__ constexpr int rc_loopq(const RcLayout& L, int r) { return (r
 // indices past the region continue into the next one (the prefetch window crosses region ends)
 __host__ __device__ constexpr int rc_qrel(const RcLayout& L, int R, int i) {
   if (R == 0) return i < L.PRO_REAL ? L.PRO_PAD + i : L.PRO + rc_loopq(L, i - L.PRO_REAL);
-  if (R == 1) return i < L.UNR * L.BODY_RAW ? rc_loopq(L, i) : 128 + (i - L.UNR * L.BODY_RAW);
+  if (R == 1) return i < rc_ub(L) * L.BODY_RAW ? rc_loopq(L, i) : rc_ub(L) * L.BODY + (i - rc_ub(L) * L.BODY_RAW);
   return i;
 }
 
@@ -59,9 +71,10 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   constexpr RcLayout L = rc_layout(C, AO, PO);
   constexpr int F = L.F, KC = L.KC, K1 = L.K1;
   static_assert(L.BODY == 32 || L.BODY == 64, "body must be one or two half-bodies");
-  static_assert(L.NU % L.UNR == 0 && L.UNR % 2 == 0, "whole loop iterations, alternating accumulator sets");
-  static_assert((L.UNR * L.BODY_RAW) % 4 == 0, "the prefetch window keeps its phase across loop iterations");
-  static_assert(L.BODY - L.BODY_RAW + 4 < 32 && L.TAIL_REAL >= 2, "the prefetch window reaches at most one half-body ahead");
+  constexpr int UB = rc_ub(L);
+  static_assert(L.NU % UB == 0 && UB % 2 == 0, "whole loop iterations, alternating accumulator sets");
+  static_assert((UB * L.BODY_RAW) % RC_PF == 0, "the prefetch window keeps its phase across loop iterations");
+  static_assert(L.BODY - L.BODY_RAW + RC_PF < 32 && L.TAIL_REAL >= 2 && L.BODY_RAW % 32 >= 8, "the prefetch window reaches at most one half-body ahead");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -72,12 +85,14 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
 
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.stream), (short)0, 0xFFFFFFFEu, 0x00020000);
   const unsigned voff = (unsigned)(wave * 8 * 1024 + lane * 16);
-  // half-body jg of the stream -> ring quarter s4: this wave's 8 of its 32 fragments
+  // half-body jg of the stream -> ring quarter s4: this wave's 8 of its 32 fragments, piece i (one 1 KiB DMA instruction)
+  auto dma_piece = [&](int jg, int s4, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + ((s4 * 32 + wave * 8 + i) << 10)), 16, voff + (i << 10), jg << 15, 0,
+                                             0);
+  };
   auto dma_hb = [&](int jg, int s4) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + ((s4 * 32 + wave * 8 + i) << 10)), 16, voff + (i << 10),
-                                               jg << 15, 0, 0);
+    for (int i = 0; i < 8; ++i) dma_piece(jg, s4, i);
   };
   constexpr int HB0 = L.PRO_PAD / 32;  // first half-body that holds a used fragment
   dma_hb(HB0, HB0 & 3);
@@ -122,24 +137,34 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   dma_hb(HB0 + 3, (HB0 + 3) & 3);
 
   auto rd = [&](int slot) -> h8 { return *(const h8*)(smem + (slot << 10) + lane * 16); };
-  h8 w[4];
+  h8 w[RC_PF];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) w[k] = rd(rc_qrel(L, 0, k) & 127);
+  for (int k = 0; k < RC_PF; ++k) w[k] = rd(rc_qrel(L, 0, k) & 127);
 
   int hb_base = 0;  // half-body index of the current region's base
-  // one MFMA: the i-th used fragment of region R times B fragment b, into c
+  // one MFMA: the i-th used fragment of region R times B fragment b, into c.  Ring protocol: entering half-body j the wave waits
+  // until at most its 8 newest DMA instructions are in flight (half-body j + 1 has landed, j + 2 may still fly) and meets the
+  // others; the first 8 steps of half-body j each issue one piece of half-body j + 3 into the quarter j - 1 just left.
   auto step = [&](int R, int i, const h8& b, f32x16& c) {
     const int q = rc_qrel(L, R, i);
     const bool bnd = i == 0 ? R != 0 : q / 32 != rc_qrel(L, R, i - 1) / 32;
-    if (bnd) {  // entering half-body q / 32: the one after it has landed once at most this wave's last 8 loads are in flight
+#ifndef RC_EXP_NOBAR
+    if (bnd) {
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      dma_hb(hb_base + q / 32 + 3, (q / 32 + 3) & 3);
     }
-    const int wi = (i + (R == 0 ? 0 : L.PRO_REAL)) & 3;
+#endif
+#ifdef RC_EXP_NODMA
+    if (R != 1)
+#endif
+    if ((q & 31) < 8 && !(R == 0 && q / 32 == HB0)) dma_piece(hb_base + q / 32 + 3, (q / 32 + 3) & 3, q & 31);
+    const int wi = (i + (R == 0 ? 0 : L.PRO_REAL)) % RC_PF;
     const h8 a = w[wi];
-    const int nreal = R == 0 ? L.PRO_REAL : (R == 1 ? L.UNR * L.BODY_RAW : L.TAIL_REAL);
-    if (R != 2 || i + 4 < nreal) w[wi] = rd(rc_qrel(L, R, i + 4) & 127);
+    const int nreal = R == 0 ? L.PRO_REAL : (R == 1 ? UB * L.BODY_RAW : L.TAIL_REAL);
+#ifdef RC_EXP_NOLDS
+    if (R != 1)
+#endif
+    if (R != 2 || i + RC_PF < nreal) w[wi] = rd(rc_qrel(L, R, i + RC_PF) & 127);
     c = MVD_MFMA_32x32x16(a, b, c, 0, 0, 0);
   };
 
@@ -181,50 +206,87 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   }
 
   f32x16 hvA, hgA, hvB, hgB;  // FF1 accumulators (value, gate) of two consecutive hidden units
+  h8 H0[2], H1[2];            // GEGLU products of two consecutive units as FF2 B fragments
   auto zero = [](f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
   };
-  auto gemm1 = [&](int R, int ibase, f32x16& hv, f32x16& hg) {
-    zero(hv);
-    zero(hg);
+  // GEGLU of one unit, cut into items that are issued a few at a time between the MFMAs of the neighbouring units (one wave per
+  // SIMD: the matrix pipe only stays busy if VALU work is fed in slices).  value * gelu(gate) with the exact-erf GELU
+  // (modules/attention.py:44) in the form  gelu(q) = max(q, 0) - |q| h(|q|),  h(a sqrt 2) = erfc(a) / 2 = (1 + a1 a + ... + a6 a^6)^-16 / 2
+  // (Abramowitz & Stegun 7.1.28, |error| <= 3e-7; igemm_epilogue.h): 16 scalar fp32 instructions per element, no compare / select.
+  // Items are stage-major (item k = stage k / 16 of element k % 16): neighbours are independent, dependent ones 16 items apart.
+  constexpr int NITEM = 16 * 16 + 8;
+  float ga[16], gp[16], go[16];
+  auto geglu_items = [&](int k0, int k1, const f32x16& hv, const f32x16& hg, h8 (&Ho)[2]) {
 #pragma unroll
-    for (int kk = 0; kk < K1; ++kk) {
-      step(R, ibase + 2 * kk, X[kk], hv);
-      step(R, ibase + 2 * kk + 1, X[kk], hg);
-    }
-  };
-  h8 H[2];
-  auto geglu = [&](const f32x16& hv, const f32x16& hg) {
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const f32x2 o = geglu_pair(f32x2{hv[r], hv[r + 1]}, f32x2{hg[r], hg[r + 1]});
-      H[r >> 3][r & 7] = (half_t)o.x;
-      H[r >> 3][(r & 7) + 1] = (half_t)o.y;
-    }
-  };
-  auto gemm2 = [&](int R, int ibase) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int f = 0; f < F; ++f) step(R, ibase + g * F + f, H[g], acc[f]);
-  };
-
-  gemm1(0, L.AO_N, hvA, hgA);  // FF1 of unit 0
-
-#pragma unroll 1
-  for (int it = 0; it < L.NU / L.UNR; ++it) {
-    hb_base = L.PRO / 32 + it * 4;
-#pragma unroll
-    for (int b = 0; b < L.UNR; ++b) {  // unit u = it * UNR + b: FF1 of unit u + 1 beside the GEGLU of unit u, then FF2 of unit u
-      if (b & 1) {
-        gemm1(1, b * L.BODY_RAW, hvA, hgA);
-        geglu(hvB, hgB);
-      } else {
-        gemm1(1, b * L.BODY_RAW, hvB, hgB);
-        geglu(hvA, hgA);
+    for (int k = k0; k < k1; ++k) {
+      if (k >= 256) {  // two results -> one packed fp16 pair of the B fragment
+        const int pr = k - 256;
+        Ho[pr >> 2][2 * (pr & 3)] = (half_t)go[2 * pr];
+        Ho[pr >> 2][2 * (pr & 3) + 1] = (half_t)go[2 * pr + 1];
+        continue;
       }
-      gemm2(1, b * L.BODY_RAW + L.G1);
+      const int st = k >> 4, e = k & 15;
+#ifdef RC_NO_GEGLU
+      if (st == 15) go[e] = hv[e] + hg[e];
+#else
+      switch (st) {
+        case 0: ga[e] = fabsf(hg[e]) * 0.70710678118654752f; break;
+        case 1: gp[e] = __builtin_fmaf(0.0000430638f, ga[e], 0.0002765672f); break;
+        case 2: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0001520143f); break;
+        case 3: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0092705272f); break;
+        case 4: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0422820123f); break;
+        case 5: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0705230784f); break;
+        case 6: gp[e] = __builtin_fmaf(gp[e], ga[e], 1.0f); break;
+        case 7: case 8: case 9: case 10: gp[e] = gp[e] * gp[e]; break;
+        case 11: gp[e] = __builtin_amdgcn_rcpf(gp[e]); break;
+        case 12: ga[e] = ga[e] * 0.70710678118654752f; break;  // |q| / 2
+        case 13: go[e] = fmaxf(hg[e], 0.f); break;
+        case 14: go[e] = __builtin_fmaf(-ga[e], gp[e], go[e]); break;
+        default: go[e] = hv[e] * go[e]; break;
+      }
+#endif
+    }
+  };
+  // FF1 of one unit (into nv, ng) [+ FF2 of the unit two back, from Hi] with the GEGLU of the unit between them (cv, cg -> Ho)
+  auto pipe = [&](int R, int ibase, auto NS, f32x16& nv, f32x16& ng, const f32x16& cv, const f32x16& cg, h8 (&Ho)[2], const h8 (&Hi)[2]) {
+    constexpr int nslot = decltype(NS)::value;
+    zero(nv);
+    zero(ng);
+#pragma unroll
+    for (int m = 0; m < nslot; ++m) {
+      // slot order: (value, gate, FF2) per k step -- three MFMAs apart on any one accumulator (two FF1 chains alone run the matrix
+      // pipe at about half rate: a 32 x 32 x 16 MFMA's result is not back within two issue intervals)
+      constexpr bool with_g2 = nslot > L.G1;
+      const int kk = with_g2 ? (m < 3 * KC ? m / 3 : KC) : m >> 1;
+      const int t = with_g2 ? (m < 3 * KC ? m % 3 : m - 3 * KC) : m & 1;
+      if (t == 2) step(R, ibase + m, Hi[kk / F], acc[kk % F]);
+      else step(R, ibase + m, X[kk], t ? ng : nv);
+      geglu_items(m * NITEM / nslot, (m + 1) * NITEM / nslot, cv, cg, Ho);
+#ifndef RC_NO_SCHEDBAR
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  };
+
+  // FF1 of unit 0, then FF1 of unit 1 beside the GEGLU of unit 0
+  zero(hvA);
+  zero(hgA);
+#pragma unroll
+  for (int m = 0; m < L.G1; ++m) step(0, L.AO_N + m, X[m >> 1], (m & 1) ? hgA : hvA);
+  pipe(0, L.AO_N + L.G1, std::integral_constant<int, L.G1>{}, hvB, hgB, hvA, hgA, H0, H1);
+
+#ifdef RC_EXP_NOLOOP
+  if (p.rows < 0)
+#endif
+#pragma unroll 1
+  for (int it = 0; it < L.NU / UB; ++it) {
+    hb_base = L.PRO / 32 + it * (UB * L.BODY / 32);
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {  // body j = it * UNR + b: FF1 of unit j + 2, GEGLU of unit j + 1, FF2 of unit j
+      if (b & 1) pipe(1, b * L.BODY_RAW, std::integral_constant<int, L.BODY_RAW>{}, hvB, hgB, hvA, hgA, H0, H1);
+      else pipe(1, b * L.BODY_RAW, std::integral_constant<int, L.BODY_RAW>{}, hvA, hgA, hvB, hgB, H1, H0);
     }
   }
 
@@ -340,18 +402,22 @@ __global__ void rowchain_pack_kernel(const RcWeights w, const RcLayout L, const 
         const int kk = r / F, f = r % F;
         for (int e = 0; e < 8; ++e) v[e] = w.w_ao[(long)(32 * f + r32) * C + 16 * kk + 8 * h + e];
       } else {
-        ff1(0, r - L.AO_N);
+        ff1((r - L.AO_N) / L.G1, (r - L.AO_N) % L.G1);
       }
     }
   } else if (q < L.PRO + L.LOOP) {
     const int u = (q - L.PRO) / L.BODY;
     int r = (q - L.PRO) % L.BODY;
-    if (r < L.G1) {
-      ff1(u + 1, r);
-    } else if (r < L.G1 + L.G2) {
-      r -= L.G1;
-      const int g = r / F, f = r % F;
-      for (int e = 0; e < 8; ++e) v[e] = w.w2[(long)(32 * f + r32) * (4 * C) + 32 * u + rc_perm(g, h, e)];
+    if (r < 3 * KC) {  // (value, gate, FF2) per k step
+      const int kk = r / 3, t = r % 3;
+      if (t < 2) {
+        ff1(u + 2, 2 * kk + t);
+      } else {
+        const int g = kk / F, f = kk % F;
+        for (int e = 0; e < 8; ++e) v[e] = w.w2[(long)(32 * f + r32) * (4 * C) + 32 * u + rc_perm(g, h, e)];
+      }
+    } else if (r < L.BODY_RAW) {
+      ff1(u + 2, 2 * KC + (r - 3 * KC));
     }
   } else if (q < L.NT) {
     int r = q - L.PRO - L.LOOP;
@@ -382,10 +448,23 @@ int launch_rc(const RowChain& p, hipStream_t s) {
   return 0;
 }
 
-template <int C>
-int launch_rc_c(const RowChain& p, int ao, int po, hipStream_t s) {
-  if (ao) return po ? launch_rc<C, true, true>(p, s) : launch_rc<C, true, false>(p, s);
-  return po ? launch_rc<C, false, true>(p, s) : launch_rc<C, false, false>(p, s);
+// instantiated forms: the engine uses (to_out, proj_out) = (1, 1) and, in front of an extended-precision proj_out, (1, 0);
+// (0, 0) is the feed-forward part alone (tests, tools/rowchain_bench.py)
+int launch_rc_any(const RowChain& p, int C, int ao, int po, hipStream_t s) {
+  const int key = C * 4 + (ao ? 2 : 0) + (po ? 1 : 0);
+  switch (key) {
+    case 64 * 4 + 3: return launch_rc<64, true, true>(p, s);
+    case 64 * 4 + 2: return launch_rc<64, true, false>(p, s);
+    case 64 * 4 + 0: return launch_rc<64, false, false>(p, s);
+    case 128 * 4 + 3: return launch_rc<128, true, true>(p, s);
+    case 128 * 4 + 2: return launch_rc<128, true, false>(p, s);
+    case 256 * 4 + 3: return launch_rc<256, true, true>(p, s);
+    case 256 * 4 + 2: return launch_rc<256, true, false>(p, s);
+    case 320 * 4 + 3: return launch_rc<320, true, true>(p, s);
+    case 320 * 4 + 2: return launch_rc<320, true, false>(p, s);
+    case 320 * 4 + 0: return launch_rc<320, false, false>(p, s);
+    default: return mvd_fail("rowchain: this (width, to_out, proj_out) form is not instantiated");
+  }
 }
 
 }  // namespace
@@ -409,10 +488,5 @@ int launch_rowchain(const RowChain& p, int C, int ao, int po, hipStream_t s) {
   if (po && p.out_split) return mvd_fail("rowchain: the split output belongs to the fp16 form");
   if ((p.ld_x & 3) || (p.ld_o & (po ? 3 : 7)) || (ao && (p.ld_ao & 7)) || (po && (p.ld_r & 3)) || (p.out_split & 7))
     return mvd_fail("rowchain: row strides must keep 16-byte alignment");
-  switch (C) {
-    case 64: return launch_rc_c<64>(p, ao, po, s);
-    case 128: return launch_rc_c<128>(p, ao, po, s);
-    case 256: return launch_rc_c<256>(p, ao, po, s);
-    default: return launch_rc_c<320>(p, ao, po, s);
-  }
+  return launch_rc_any(p, C, ao, po, s);
 }

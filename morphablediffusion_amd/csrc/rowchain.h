@@ -21,8 +21,9 @@ struct RcLayout {
 };
 
 // Stream (positions in fragments; the ring slot of position q is q % 128, a half-body = 32 consecutive positions):
-//   [0, PRO)              : PRO_PAD unused | to_out (AO_N = KC * F, order (k-step, row block)) | FF1 of unit 0 (G1)
-//   PRO + u * BODY, u < NU: FF1 of unit u + 1 (G1; zeros for u + 1 == NU) | FF2 of unit u (G2, order (half, row block)) | pad
+//   [0, PRO)              : PRO_PAD unused | to_out (AO_N = KC * F, order (k-step, row block)) | FF1 of unit 0 | FF1 of unit 1
+//   PRO + u * BODY, u < NU: FF1 of unit u + 2 (G1; zeros past the last unit) | FF2 of unit u (G2, order (half, row block)) | pad
+//                           (a three-stage pipeline: FF1 of unit u + 2 and FF2 of unit u run beside the GEGLU of unit u + 1)
 //   PRO + LOOP            : FF2 bias (F) | proj_out (KC * F) | pad to a half-body     -- TAIL
 //   + 96 positions of slack: the ring runs three half-bodies ahead without a bounds test
 constexpr RcLayout rc_layout(int C, bool ao, bool po) {
@@ -33,7 +34,7 @@ constexpr RcLayout rc_layout(int C, bool ao, bool po) {
   L.BODY = (L.BODY_RAW + 31) / 32 * 32;
   L.UNR = 128 / L.BODY;
   L.AO_N = ao ? L.KC * L.F : 0;
-  L.PRO_REAL = L.AO_N + L.G1;
+  L.PRO_REAL = L.AO_N + 2 * L.G1;
   L.PRO = (L.PRO_REAL + 127) / 128 * 128;
   L.PRO_PAD = L.PRO - L.PRO_REAL;
   L.LOOP = L.NU * L.BODY;

@@ -212,8 +212,9 @@ def _st_tail_ref(d):
 
 
 @pytest.mark.parametrize("C,rows,T,ao,po", [
-    (64, 256, 64, False, False), (64, 1024, 1024, True, True), (128, 512, 256, True, False), (128, 256, 32, False, True),
+    (64, 256, 64, False, False), (64, 1024, 1024, True, True), (128, 512, 256, True, False), (128, 256, 32, True, True),
     (256, 384, 64, True, True), (320, 1024, 1024, False, False), (320, 2048, 1024, True, True), (320, 4096, 1024, True, False),
+    (64, 128, 128, True, True),
 ])
 def test_st_tail_rowchain(eng, C, rows, T, ao, po):
     d = _st_tail_case(C, rows, T, ao, po)
