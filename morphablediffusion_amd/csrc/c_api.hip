@@ -859,12 +859,19 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
   GemmArgs g;
   g.a = xn; g.a_f32 = 1; g.lda = cpad; g.w = &cw; g.out = on; g.ldc = Cout; g.resid = rn; g.ldr = Cout;
   g.use_bias = bias != nullptr; g.force_splitk = force_splitk;
-  if (cpad % 64 == 0) {  // exercise the fp16-source paths (incl. the LDS-halo 3x3 kernel) the UNet uses
+  if (cpad % 64 == 0) {  // exercise the fp16-source paths (incl. the LDS-halo 3x3 kernels) the UNet uses
     half_t* xh = ws_alloc<half_t>(c, (size_t)B * H * W * cpad);
     WS_CHECK(xh);
     RET_IF(launch_f32_to_f16(xn, xh, (size_t)B * H * W * cpad, s));
     g.a = xh;
     g.a_f32 = 0;
+    const int bnx = Cout % 160 == 0 ? 160 : (Cout % 128 == 0 ? 128 : 0);
+    if (taps == 9 && bnx && !getenv("MVD_NO_CONV3X")) {  // ... and the conv3x form of the weights (k_conv3x.hip), as build_conv3x_streams does
+      cw.wx = ws_alloc<half_t>(c, conv3x_stream_halfs(Cout, cpad, bnx));
+      WS_CHECK(cw.wx);
+      RET_IF(conv3x_pack(wp, Cout, cpad, bnx, cw.wx, s));
+      cw.wx_bn = bnx;
+    }
   }
   if (upsample && taps == 9 && stride == 1 && cpad == Cin && B * H * W >= 2048) {
     // the UNet's path for large upsample convs: four parity-folded 2x2 convs (fp32 source, as in the decoder)
@@ -1071,6 +1078,13 @@ int mvd_bench_conv(mvd_ctx* c, int B, int C, int H, int W, int Cout, int iters, 
   hipLaunchKernelGGL(fill_pattern_f16_kernel, dim3(nblk(nw)), dim3(256), 0, s, w, nw, 91u);
   ConvW cw;
   cw.w = w; cw.N = Cout; cw.Cin = C; cw.taps = 9;
+  const int bnx = Cout % 160 == 0 ? 160 : (Cout % 128 == 0 ? 128 : 0);
+  if (C % 64 == 0 && bnx && !getenv("MVD_NO_CONV3X")) {
+    cw.wx = ws_alloc<half_t>(c, conv3x_stream_halfs(Cout, C, bnx));
+    WS_CHECK(cw.wx);
+    RET_IF(conv3x_pack(w, Cout, C, bnx, cw.wx, s));
+    cw.wx_bn = bnx;
+  }
   GemmArgs g;
   g.a = a; g.lda = C; g.w = &cw; g.out = o; g.ldc = Cout; g.use_bias = false;
   RET_IF(run_conv2d(c, g, B, H, W, 1, 0, s));  // warm-up

@@ -88,6 +88,8 @@ struct IGemm {
   int par_ntaps[8];
   int par_tap[8][8];
   int par_oz[8], par_oy[8], par_ox[8];
+  const half_t* wx;     // the same weights as a conv3x fragment stream (k_conv3x.hip) packed for column tiles of wx_bn, or null
+  int wx_bn;
   int bn;               // column-tile width (64 / 128 / 160); 0 = pick from N
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1
@@ -123,6 +125,10 @@ bool conv3_halo_eligible(const IGemm& g);
 int conv3_halo_tiles(const IGemm& g, int bn);
 int launch_conv3_halo(const IGemm& g, hipStream_t s);
 int igemm_pick_splitk(int M, int N, int ksteps, int bn);
+bool conv3x_eligible(const IGemm& g, int bn);
+size_t conv3x_stream_halfs(int N, int Cin, int bn);
+int conv3x_pack(const half_t* w, int N, int Cin, int bn, half_t* stream, hipStream_t s);
+int launch_conv3x(const IGemm& g, const half_t* stream, int bn, hipStream_t s);
 bool gemm_dma_eligible(const IGemm& g);
 void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, int* splitk_out);
 int launch_target_encoder(const float* x, const float* pre, int n_views, const half_t* const* w, const float* const* bias,

@@ -27,6 +27,8 @@ struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
   int xp = 0;
   int cin_l = 0;  // logical input width when xp (Cin / 3)
   half_t* w = nullptr;
+  half_t* wx = nullptr;    // 3x3 ResBlock convs at 16-divisible resolutions: the weights as a conv3x fragment stream (k_conv3x.hip)
+  int wx_bn = 0;           // ... packed for column tiles of this width
   half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
   float* bias = nullptr;
   int N = 0, Cin = 0, taps = 1;

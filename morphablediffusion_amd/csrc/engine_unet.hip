@@ -31,6 +31,8 @@ void igemm_fill(IGemm& g, const GemmArgs& ga) {
   g.Cin = ga.w->Cin;
   g.cin_alg = ga.w->xp ? ga.w->cin_l : ga.w->Cin;
   g.w = ga.w->w;
+  g.wx = ga.w->wx;
+  g.wx_bn = ga.w->wx_bn;
   g.N = ga.w->N;
   g.out = ga.out;
   g.out_f32 = ga.out_f32;
@@ -58,6 +60,56 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
   //  a half rounds, A read three times -- and 37 us as 2 x 160; MVD_IGEMM_F32_BN128=1 restores the old choice)
   static const bool f32_bn128 = getenv("MVD_IGEMM_F32_BN128") != nullptr;
   if (g.a_f32 && g.bn == 160 && f32_bn128) g.bn = 128;
+  static const bool no_cx = getenv("MVD_NO_CONV3X") != nullptr;
+  if (!no_cx && c->use_halo && g.wx && conv3x_eligible(g, g.wx_bn)) {
+    // conv3x (k_conv3x.hip): one workgroup per CU and 16 x 16 pixel tile x wx_bn columns; split over 64-channel chunks when the
+    // tiles do not fill the chip (microseconds, as for the halo kernel below)
+    const int ncc = g.Cin / 64, tiles = g.B * (g.Y / 16) * (g.X / 16) * (g.N / g.wx_bn);
+    double best = 1e30;
+    int sk = 1;
+    for (int s2 = 1; s2 <= 8 && s2 <= ncc; ++s2) {
+      const int rounds = cdiv(tiles * s2, 256), steps = cdiv(ncc, s2) * 9;
+      double t = rounds * (steps * (g.wx_bn == 160 ? 0.75 : 0.62) + 8.0);
+      if (s2 > 1) t += 3.0 + (s2 + 1) * (double)M * g.N * 4.0 / 3.5e6;
+      if (t < best) {
+        best = t;
+        sk = s2;
+      }
+    }
+    if (force_splitk > 0) sk = force_splitk < ncc ? force_splitk : ncc;
+    if (sk > 1) sk = cdiv(ncc, cdiv(ncc, sk));
+    WsScope ws_scope(c, WS_TEMP);
+    g.splitk = sk;
+    g.partial = nullptr;
+    g.bn = g.wx_bn;
+    bool deferred = false;
+    if (sk > 1) {
+      static const int defer_max = getenv("MVD_DEFER_MAX") ? atoi(getenv("MVD_DEFER_MAX")) : 16;
+      if (defer && defer->slabs && defer->sk_used && sk <= defer_max && (size_t)sk * M * g.N <= defer->slabs_cap &&
+          (!g.resid || (defer->defer_epilogue && g.resid_f32))) {
+        g.partial = defer->slabs;
+        deferred = true;
+      } else {
+        g.partial = ws_alloc<float>(c, (size_t)sk * M * g.N);
+        if (!g.partial) g.splitk = 1;
+      }
+    }
+    if (defer && defer->sk_used) *defer->sk_used = deferred ? sk : 1;
+    const double kalg = (double)(g.cin_alg ? g.cin_alg : g.Cin);
+    const double flops = 2.0 * M * g.N * kalg * 9.0;
+    double bytes = (double)M * kalg * 2 + 9.0 * g.N * kalg * 2 + (g.splitk > 1 ? 0.0 : (double)M * g.N * 4);
+    if (g.resid && g.splitk <= 1) bytes += (double)M * g.N * 4;
+    int r;
+    {
+      ProbeScope ps(c, s, g.wx_bn == 160 ? "conv3x_kernel<5>" : "conv3x_kernel<4>", flops, bytes);
+      r = launch_conv3x(g, g.wx, g.wx_bn, s);
+    }
+    if (!r && g.splitk > 1 && !deferred) {
+      ProbeScope ps(c, s, "splitk_reduce_kernel", 0.0, (double)M * g.N * 4.0 * (g.splitk + 1));
+      r = launch_splitk_reduce(g, s);
+    }
+    return r;
+  }
   const bool halo = c->use_halo && conv3_halo_eligible(g);
   static const bool use_dense = getenv("MVD_NO_GEMM_DMA") == nullptr;
   static const int dense_min_m = getenv("MVD_DENSE_MIN_M") ? atoi(getenv("MVD_DENSE_MIN_M")) : 64;
@@ -458,10 +510,15 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
     RET_IF(run_group_norm(c, h1, r.cout, f.Bv, H * W, r.n2, 32, 1e-5f, ACT_SILU, nullptr, a2, r.cout * w2, f.s, 0, r.c2.xp));
   const float* resid = in.p;
   int ldr = in.ld;
+  bool skip_outlives_scope = true;  // no skip conv: the residual is the block input, owned by the caller
   if (r.has_skip) {
     // (a deferred conv2 hands the residual to the NEXT block's GroupNorm: the skip conv's result then lives in the carry)
-    float* sk = (out_carry && out_carry->aux && out_carry->aux_cap >= (size_t)rows * r.cout) ? out_carry->aux
-                                                                                              : ws_alloc<float>(c, (size_t)rows * r.cout);
+    // A deferred conv2 hands `resid` to the NEXT block's GroupNorm, i.e. beyond this function's workspace scope: the skip conv's
+    // result may then only live in the carry's own storage.  Without that storage (carry_storage could not get the second
+    // buffer) conv2 must not defer.
+    const bool sk_in_carry = out_carry && out_carry->aux && out_carry->aux_cap >= (size_t)rows * r.cout;
+    skip_outlives_scope = sk_in_carry;
+    float* sk = sk_in_carry ? out_carry->aux : ws_alloc<float>(c, (size_t)rows * r.cout);
     WS_CHECK(sk);
     GemmArgs gs;
     gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
@@ -478,7 +535,7 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   GemmArgs g2;
   g2.a = a2; g2.lda = r.cout * w2; g2.w = &r.c2; g2.out = out.p; g2.ldc = out.ld; g2.resid = resid; g2.ldr = ldr;
   int sk2 = 1;
-  if (out_carry && out_carry->slabs) {
+  if (out_carry && out_carry->slabs && skip_outlives_scope) {
     g2.slabs = out_carry->slabs; g2.slabs_cap = out_carry->cap; g2.sk_used = &sk2; g2.defer_epilogue = true;
   }
   RET_IF(run_conv2d(c, g2, f.Bv, H, W, 1, 0, f.s));

@@ -1,6 +1,7 @@
 // Weight store: turns the reference's state_dict (uploaded key by key, fp32, reference layouts) into the
 // packed / folded device layouts the kernels consume, and builds the UNet block plan from the config
 // exactly as the reference ctor does (openaimodel.py:535-720, attention.py:87-115).
+#include <algorithm>
 #include <math.h>
 #include <string.h>
 
@@ -579,6 +580,32 @@ int xp_ops(mvd_ctx* c, const std::vector<UOp>& ops, bool convs3) {
   return 0;
 }
 
+// The 3x3 ResBlock convolutions that run at resolutions divisible by 16 also get their weights as a conv3x fragment stream
+// (k_conv3x.hip); the level of a convolution is not recorded in ResW, its width is: levels 0 .. l16 have at most
+// model_channels * channel_mult[l16] output channels, where l16 is the last level whose resolution is a multiple of 16.
+int build_conv3x_streams(mvd_ctx* c) {
+  static const bool off = getenv("MVD_NO_CONV3X") != nullptr;
+  if (off || !c->has_unet) return 0;
+  int l16 = -1;
+  for (int l = 0; l < 4 && ((c->u.image_size >> l) % 16) == 0 && (c->u.image_size >> l) >= 16; ++l) l16 = l;
+  if (l16 < 0) return 0;
+  int nmax = 0;
+  for (int l = 0; l <= l16; ++l) nmax = std::max(nmax, c->u.model_channels * c->u.channel_mult[l]);
+  for (ResW& r : c->res) {
+    ConvW* cs[2] = {&r.c1, &r.c2};
+    for (ConvW* w : cs) {
+      if (w->taps != 9 || w->Cin % 64 || w->N > nmax) continue;
+      const int bn = w->N % 160 == 0 ? 160 : (w->N % 128 == 0 ? 128 : 0);
+      if (!bn) continue;
+      engine_build_rotate(c);
+      RET_IF(dmalloc(c, (void**)&w->wx, conv3x_stream_halfs(w->N, w->Cin, bn) * sizeof(half_t)));
+      RET_IF(conv3x_pack(w->w, w->N, w->Cin, bn, w->wx, c->bs));
+      w->wx_bn = bn;
+    }
+  }
+  return engine_build_join(c);
+}
+
 int apply_xp_policy(mvd_ctx* c) {
   const int lvl = getenv("MVD_XP") ? atoi(getenv("MVD_XP")) : c->precision_level;
   if (lvl <= 0 || !c->has_unet) return 0;
@@ -848,7 +875,8 @@ int build_hot_sections(mvd_ctx* c) {
   if (c->has_unet) {
     RET_IF(build_unet_section(c));
     RET_IF(apply_xp_policy(c));
-    RET_IF(engine_build_join(c));  // the adjoint packs read the forward packs
+    RET_IF(engine_build_join(c));  // the adjoint packs and the conv3x streams read the forward packs
+    RET_IF(build_conv3x_streams(c));
     if (c->train_mode) RET_IF(engine_build_dgrad(c));
   }
   if (c->has_step) RET_IF(build_step_section(c));

@@ -556,6 +556,10 @@ class SyncMultiviewDiffusion(nn.Module):
         joins the stream and applies the 1 / world_size.  Otherwise ONE all-reduce on the flat gradient arena.  No-op without an
         initialised process group."""
         sync, self._grad_sync = self._grad_sync, None  # one averaging per backward pass, as with the flat all-reduce
+        if self.overlap_grad_sync is None:
+            # inside no_sync(): DistributedDataParallel suppresses EVERY reduction there -- a flat all-reduce here would average
+            # (and scale by 1 / world) a half-accumulated arena, and the earlier micro-batches again at the final averaging
+            return False
         if sync is not None:
             return sync.finish()
         return sync_flat_gradients(self.engine.flat_grads)
@@ -737,9 +741,14 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.steps_skipped = 0
         self.growth_interval = 2000  # torch.cuda.amp.GradScaler's defaults: x2 after 2000 clean steps, x0.5 on overflow
         self._clean = 0
-        # loss_scale == 1 (the bfloat16 build: fp32 exponent range) means NO loss scaling: no overflow check, no read-back of
-        # the "skipped" flag (a stream synchronisation per step), no scale growth -- torch.optim.AdamW's own behaviour
-        self.dynamic_scale = float(model.loss_scale) != 1.0
+
+    @property
+    def dynamic_scale(self):
+        """loss_scale == 1 (the bfloat16 build: fp32 exponent range) means NO loss scaling: no overflow check, no read-back of the
+        "skipped" flag (a stream synchronisation per step), no scale growth -- torch.optim.AdamW's own behaviour.  Derived from
+        the model's CURRENT scale at every step: load_state_dict restores the scale, and a resumed run must check (or not) as
+        the run that wrote the checkpoint did."""
+        return float(self.model.loss_scale) != 1.0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -780,11 +789,37 @@ class ArenaAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         arena = state_dict.get("arena")
-        super().load_state_dict({k: v for k, v in state_dict.items() if k != "arena"})
-        if arena is None:
-            raise KeyError("ArenaAdamW.load_state_dict: the checkpoint has no 'arena' entry (moments, step, loss scale)")
+        rest = {k: v for k, v in state_dict.items() if k != "arena"}
         eng = self.model.engine
         eng.ensure_moments()
+        if arena is None:
+            # A checkpoint written by torch.optim.AdamW itself (the reference's optimiser, or this class before it carried the
+            # arenas): per-parameter exp_avg / exp_avg_sq in ``state``.  They are adopted when the saved parameters line up with
+            # this optimiser's (same count and sizes, group by group); otherwise the moments restart from zero, loudly.
+            import warnings
+            state = rest.get("state", {})
+            mine = [p_ for g_ in self.param_groups for p_ in g_["params"]]
+            saved = [i for g_ in rest.get("param_groups", []) for i in g_["params"]]
+            ok = len(state) > 0 and len(saved) == len(mine) and all(
+                i in state and state[i]["exp_avg"].numel() == p_.numel() for i, p_ in zip(saved, mine))
+            super().load_state_dict({"state": {}, "param_groups": rest["param_groups"]} if "param_groups" in rest else rest)
+            eng.flat_m.zero_()
+            eng.flat_v.zero_()
+            self.steps_done = self.steps_skipped = self._clean = 0
+            if ok:
+                base = eng.flat_params.data_ptr()
+                for i, p_ in zip(saved, mine):
+                    off = (p_.data_ptr() - base) // 4
+                    eng.flat_m[off:off + p_.numel()].copy_(state[i]["exp_avg"].reshape(-1).to(eng.flat_m.device))
+                    eng.flat_v[off:off + p_.numel()].copy_(state[i]["exp_avg_sq"].reshape(-1).to(eng.flat_v.device))
+                self.steps_done = int(max(float(state[i]["step"]) for i in saved))
+                warnings.warn("ArenaAdamW: adopted the per-parameter moments of a torch.optim.AdamW checkpoint "
+                              f"(step {self.steps_done}); the loss scale keeps its current value")
+            else:
+                warnings.warn("ArenaAdamW: the checkpoint carries no 'arena' entry and its per-parameter state does not line up "
+                              "with this model's parameters: Adam moments and the bias-correction step restart from zero")
+            return
+        super().load_state_dict(rest)
         if int(arena["numel"]) != eng.flat_params.numel():
             raise ValueError(f"ArenaAdamW: checkpoint arena has {arena['numel']} elements, the engine {eng.flat_params.numel()}")
         eng.flat_m.copy_(arena["exp_avg"].to(eng.flat_m.device))  # in place: the library holds these pointers
@@ -792,7 +827,7 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.steps_done = int(arena["step"])
         self.steps_skipped = int(arena.get("steps_skipped", 0))
         self._clean = int(arena.get("clean_steps", 0))
-        self.model.loss_scale = float(arena["loss_scale"])
+        self.model.loss_scale = float(arena["loss_scale"])  # dynamic_scale follows it (property)
 
 
 class LambdaLinearScheduler:
@@ -936,25 +971,20 @@ class SyncDDIMSampler:
             host_steps = [int(v) for v in time_steps.tolist()]
         from .engine import MAX_SAMPLE_SLOTS
         if B > 1 and self.sample_batching == "batched" and B <= MAX_SAMPLE_SLOTS:
-            # All samples share each UNet pass (batch 2 * B * views with guidance), as the reference's own batching does
-            # (eval/generate_all_facescape.py:106-108,128-129); every sample's volume is built first, into its slot.
-            for bi in range(B):
-                m.spatial_volume._set_sample(batch, bi)
-                self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N,
-                                   tag=f".{bi}" if bi else "")
-            slots = [bi % MAX_SAMPLE_SLOTS for bi in range(B)]
-            for ni in range(0, NL, batch_view_num):
-                sl = slice(ni, min(NL, ni + batch_view_num))
-                idx = local_idx[sl]
-                r = eng.denoise_views_batch(
-                    slots, x_target_noisy[:, sl], x_input, clip_embed.reshape(B, -1), host_steps, t_embed,
-                    v_embed[:, lo + sl.start:lo + sl.stop], idx, float(unconditional_scale),
-                    None if is_step0 else noise[:, sl], coef, want_eps=return_eps)
-                if return_eps:
-                    out[:, sl], eps_out[:, sl] = r
-                else:
-                    out[:, sl] = r
-            return (out, eps_out) if return_eps else out
+            try:
+                return self._denoise_apply_batched(x_target_noisy, x_input, clip_embed, host_steps, t_embed, v_embed, local_idx, lo, NL,
+                                                   rank, world, N, unconditional_scale, batch_view_num, is_step0, batch, noise, coef,
+                                                   out, eps_out, return_eps)
+            except Exception as e:  # MvdError from the library
+                if "workspace" not in str(e):
+                    raise
+                # One UNet pass of 2 * B * views plus B slot volumes needs more workspace than the per-sample loop an eval batch
+                # may have been sized for: fall back to that loop (each sample then equals its single-sample run) and stay there
+                import warnings
+                warnings.warn(f"batched sampling of {B} samples does not fit the engine's workspace ({e}); "
+                              "falling back to the per-sample loop (MVD_SAMPLE_BATCHING=loop)")
+                self.sample_batching = "loop"
+                m.spatial_volume.invalidate()
         for bi in range(B):
             m.spatial_volume._set_sample(batch, bi)
             self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N)
@@ -969,6 +999,31 @@ class SyncDDIMSampler:
                     out[bi, sl], eps_out[bi, sl] = r
                 else:
                     out[bi, sl] = r
+        return (out, eps_out) if return_eps else out
+
+    def _denoise_apply_batched(self, x_target_noisy, x_input, clip_embed, host_steps, t_embed, v_embed, local_idx, lo, NL, rank, world,
+                               N, unconditional_scale, batch_view_num, is_step0, batch, noise, coef, out, eps_out, return_eps):
+        from .engine import MAX_SAMPLE_SLOTS
+        m, eng = self.model, self.model.engine
+        B = x_target_noisy.shape[0]
+        # All samples share each UNet pass (batch 2 * B * views with guidance), as the reference's own batching does
+        # (eval/generate_all_facescape.py:106-108,128-129); every sample's volume is built first, into its slot.
+        for bi in range(B):
+            m.spatial_volume._set_sample(batch, bi)
+            self._build_volume(x_target_noisy[bi], t_embed[bi], v_embed[bi, lo:lo + NL], local_idx, rank, world, N,
+                               tag=f".{bi}" if bi else "")
+        slots = [bi % MAX_SAMPLE_SLOTS for bi in range(B)]
+        for ni in range(0, NL, batch_view_num):
+            sl = slice(ni, min(NL, ni + batch_view_num))
+            idx = local_idx[sl]
+            r = eng.denoise_views_batch(
+                slots, x_target_noisy[:, sl], x_input, clip_embed.reshape(B, -1), host_steps, t_embed,
+                v_embed[:, lo + sl.start:lo + sl.stop], idx, float(unconditional_scale),
+                None if is_step0 else noise[:, sl], coef, want_eps=return_eps)
+            if return_eps:
+                out[:, sl], eps_out[:, sl] = r
+            else:
+                out[:, sl] = r
         return (out, eps_out) if return_eps else out
 
     def _buf(self, name, shape, device):

@@ -237,3 +237,30 @@ def test_st_tail_rowchain_identity_weights(eng):
     d["w_ao"] = torch.eye(C) + 0.01 * torch.arange(C * C, dtype=torch.float32).reshape(C, C).remainder(7.0) / 7.0
     d["w_po"] = torch.eye(C).roll(3, 0)
     close(eng.op_st_tail(**d), _st_tail_ref(d), "st_tail identity")
+
+
+# ---- conv3x (k_conv3x.hip): 3x3 stride-1 convolutions at 16-divisible resolutions, weights as a pre-packed fragment stream
+@pytest.mark.parametrize("B,Cin,H,W,Cout,res,sk", [
+    (1, 64, 16, 16, 160, False, 0), (2, 128, 32, 32, 320, True, 0), (3, 192, 16, 32, 128, True, 0), (2, 320, 16, 16, 640, True, 2),
+    (1, 960, 32, 32, 320, False, 0), (2, 64, 48, 16, 256, True, 0), (1, 256, 16, 16, 160, False, 4),
+])
+def test_conv3x(eng, B, Cin, H, W, Cout, res, sk):
+    x = rnd(B, Cin, H, W)
+    w = rnd(Cout, Cin, 3, 3, seed=3, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=4)
+    want = F.conv2d(x, w, b, padding=1)
+    r = rnd(*want.shape, seed=5) if res else None
+    if r is not None:
+        want = want + r
+    close(eng.op_conv(x, w, b, resid=r, force_splitk=sk), want, f"conv3x B={B} {Cin}->{Cout} {H}x{W} res={res} sk={sk}")
+
+
+def test_conv3x_impulse(eng):
+    """A one-hot input pixel / channel reproduces the (flipped) kernel around it: catches a swapped tap, a transposed fragment or a
+    mis-placed halo row exactly (products are exact in fp16 for these weights)."""
+    Cin, Cout, H = 64, 160, 16
+    w = (torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3) % 127 - 63) / 64.0
+    x = torch.zeros(1, Cin, H, H)
+    x[0, 5, 7, 9] = 1.0
+    x[0, 63, 0, 15] = 2.0
+    close(eng.op_conv(x, w), F.conv2d(x, w, padding=1), "conv3x impulse", rel=1e-6, mx=1e-6)

@@ -24,9 +24,9 @@ VARIANTS = {
     "k_step_plan": {"MVD_OLD_PLAN": "1"},
     "layered_encoder_own_reduce": {"MVD_NO_FUSED_ENC": "1", "MVD_NO_DEFER_REDUCE": "1"},
     "scalar_layernorm_f32_bn128": {"MVD_LN_SCALAR": "1", "MVD_IGEMM_F32_BN128": "1"},
-    # the row-chain kernel (transformer tail in one launch) at a batch where the default is the layered GEMMs, and the reverse
-    "rowchain_at_every_batch": {"MVD_ROWCHAIN_MIN_ROWS": "0"},
-    "no_rowchain": {"MVD_NO_ROWCHAIN": "1"},
+    # the row-chain kernel (k_rowchain.hip: transformer tail in one launch) at a batch where the default is the layered GEMMs,
+    # together with the halo kernel of rounds 1-4 in place of conv3x (k_conv3x.hip) for the 3x3 convolutions
+    "rowchain_at_every_batch_halo_conv": {"MVD_ROWCHAIN_MIN_ROWS": "0", "MVD_NO_CONV3X": "1"},
 }
 
 

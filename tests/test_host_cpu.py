@@ -166,8 +166,11 @@ class FakeModel:
     def get_viewpoint_embedding(self, batch): return torch.zeros(1, self.view_num, 4)
     def embed_time(self, t): return torch.zeros(t.shape[0], 256)
 
+WORLD = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+NV = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+
 def run(shard, exchange="all_gather"):
-    N = 8
+    N = NV
     m = FakeModel(N)
     s = SyncDDIMSampler(m, 50, shard_views=shard, exchange=exchange)
     g = torch.Generator().manual_seed(7)
@@ -175,16 +178,17 @@ def run(shard, exchange="all_gather"):
                     batch_view_num=2, batch=synthetic.make_batch(N, "perspective", 50), generator=g)
     return x
 
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=WORLD)
 sharded = run(True)
 single = run(False)
-assert sharded.shape == single.shape == (1, 8, 4, 32, 32)
+assert sharded.shape == single.shape == (1, NV, 4, 32, 32)
 assert torch.equal(sharded, single)  # all-gather + fixed view-order sum: bit-identical to the single-rank trajectory
 legacy = run(True, "all_reduce")
 err = ((legacy - run(False, "all_reduce")).abs().max() / single.abs().max()).item()  # fp32 summation order differs
 assert err < 1e-5, err
-lo, hi = SyncDDIMSampler(FakeModel(8), 50, shard_views=True).view_range(8)
-assert (lo, hi) == ((0, 4) if dist.get_rank() == 0 else (4, 8))
+lo, hi = SyncDDIMSampler(FakeModel(NV), 50, shard_views=True).view_range(NV)
+per = NV // WORLD
+assert (lo, hi) == (dist.get_rank() * per, (dist.get_rank() + 1) * per)  # contiguous slices: rank g owns views [g N/G, (g+1) N/G)
 print("RANK_OK", dist.get_rank(), err)
 dist.destroy_process_group()
 '''
@@ -198,6 +202,21 @@ def test_view_sharded_sampler_two_ranks_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-2000:]
+
+
+@pytest.mark.parametrize("views", [16, 32])
+def test_view_sharded_sampler_eight_ranks_gloo(tmp_path, views):
+    """The partitions BASELINE.json names, instantiated: 8 ranks x 2 views (configs[2], N = 16) and 8 ranks x 4 views (configs[4],
+    N = 32) -- view_range, the full-size noise draw sliced per rank, the placement of each rank's slice in the all-gather, the
+    fixed view-order sum and the final gather must reproduce the single-rank 50-step trajectory BIT FOR BIT (engine stand-in
+    with view-order-sensitive arithmetic)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER % {"root": ROOT, "port": 29751 + views})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "8", str(views)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")) for r in range(8)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-2000:]
 
@@ -326,7 +345,8 @@ import torch, torch.distributed as dist
 from morphablediffusion_amd.model import BucketedGradSync, sync_flat_gradients
 
 rank = int(sys.argv[1])
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+WORLD = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=WORLD)
 g = torch.Generator().manual_seed(100 + rank)
 local = torch.randn(4096, generator=g)
 # buckets in completion order, ranges out of address order, a late bucket made of scattered pieces; [3000, 4096) is in no
@@ -339,12 +359,24 @@ sync.start()
 assert waited == [0, 1, 2]
 assert sync.uncovered() == [(3000, 1096)]
 # after start(): bucket ranges hold the SUM over ranks, the rest is still local
-other = torch.randn(4096, generator=torch.Generator().manual_seed(100 + (1 - rank)))
-assert torch.equal(flat[0:3000], (local + other)[0:3000]) and torch.equal(flat[3000:], local[3000:])
+everyone = [torch.randn(4096, generator=torch.Generator().manual_seed(100 + r)) for r in range(WORLD)]
+total = torch.stack(everyone).sum(0)
+if WORLD == 2:   # two addends: the sum is order-independent, so the collective's result is known bit for bit
+    assert torch.equal(flat[0:3000], total[0:3000])
+assert torch.allclose(flat[0:3000], total[0:3000], rtol=0, atol=1e-5) and torch.equal(flat[3000:], local[3000:])
 assert sync.finish() is True and sync.finish() is True       # idempotent
 ref = local.clone()
 sync_flat_gradients(ref)
-assert torch.equal(flat, ref)                                # element for element the flat all-reduce's result
+def same(a, b):
+    # two ranks: a two-term sum has one order -> element for element the flat all-reduce's result.  More ranks: a ring / tree
+    # all-reduce sums a CHUNK's terms in an order that depends on where the chunk lies in its message (gloo and RCCL alike), so
+    # bucket-sized and arena-sized messages agree to fp32 rounding only
+    return torch.equal(a, b) if WORLD == 2 else torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+assert same(flat, ref)
+assert torch.allclose(flat, total / WORLD, rtol=1e-6, atol=1e-6)   # the mean over ranks: 1 / world applied exactly once
+gathered = [torch.empty_like(flat) for _ in range(WORLD)]
+dist.all_gather(gathered, flat)
+assert all(torch.equal(gathered[0], t) for t in gathered)          # every rank ends with the same gradients, bit for bit
 try:
     BucketedGradSync(flat, [[(0, 100)], [(50, 100)]]).uncovered()
     raise SystemExit("overlap not detected")
@@ -360,15 +392,18 @@ fake = types.SimpleNamespace(overlap_grad_sync=True, _grad_sync=None, _grad_comm
 M._start_grad_sync(fake)
 assert fake._grad_sync is not None
 assert M.sync_gradients(fake) is True and fake._grad_sync is None      # consumed: one averaging per backward pass
-assert torch.equal(fake.engine.flat_grads, ref)
+assert same(fake.engine.flat_grads, ref)
 fake.engine.flat_grads.copy_(local)
 with M.no_sync(fake):                                                 # gradient accumulation: nothing is reduced
     M._start_grad_sync(fake)
     assert fake._grad_sync is None
+    # ... and a sync_gradients() call inside the context (a loop that calls it after every micro-batch) is a no-op too,
+    # as under DistributedDataParallel.no_sync(): no collective, no 1 / world scaling of the half-accumulated arena
+    assert M.sync_gradients(fake) is False and torch.equal(fake.engine.flat_grads, local)
 assert fake.overlap_grad_sync is True and torch.equal(fake.engine.flat_grads, local)
 fake.overlap_grad_sync = False                                        # the flat form
 M._start_grad_sync(fake)
-assert fake._grad_sync is None and M.sync_gradients(fake) is True and torch.equal(fake.engine.flat_grads, ref)
+assert fake._grad_sync is None and M.sync_gradients(fake) is True and same(fake.engine.flat_grads, ref)
 print("BUCKET_OK", rank)
 dist.destroy_process_group()
 '''
@@ -382,6 +417,18 @@ def test_bucketed_gradient_allreduce_equals_flat_two_ranks_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"BUCKET_OK {r}" in o, o[-2000:]
+
+
+def test_bucketed_gradient_allreduce_equals_flat_eight_ranks_gloo(tmp_path):
+    """The same reducer at the world size of BASELINE configs[3] (8 ranks): bucketed == flat element for element on every rank, the
+    uncovered tail reduced by finish(), no_sync() suppresses every collective, 1 / 8 applied once."""
+    script = tmp_path / "bworker8.py"
+    script.write_text(BUCKET_WORKER % {"root": ROOT, "port": 29747})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")) for r in range(8)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"BUCKET_OK {r}" in o, o[-2000:]
 
