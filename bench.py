@@ -37,6 +37,9 @@ def pmc_traffic(family, config):
             d = json.load(f)
         if d.get("config") != config:
             return None
+        from morphablediffusion_amd.lib import csrc_sha16
+        if d.get("csrc_sha16") != csrc_sha16():  # counters of another build: not this run's traffic
+            return None
         return d["bytes_per_launch"].get(family)
     except (OSError, ValueError, KeyError):
         return None
@@ -535,7 +538,8 @@ def main():
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this build (FETCH x 2 per the gfx950 correction); null when
                 # no summary for this workload is present -- the number is never hard-coded here
                 "traffic": pmc_traffic(dominant, args.config) if (world == 1 and not args.simulate_gpus) else None,
-                "traffic_unit": "bytes per launch, family average, from " + PMC_TRAFFIC_FILE,
+                "traffic_unit": "bytes per launch, family average, from " + PMC_TRAFFIC_FILE +
+                                " (null unless that file's csrc_sha16 stamp equals this tree's library sources)",
                 "kernel": dominant,
                 "how": f"HIP events on the launch stream around a deterministic 1-in-{args.probe_stride} sample of this "
                        f"family's launches INSIDE the timed region ({dom['launches_bracketed']} of {dom['launches']} launches, "

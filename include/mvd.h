@@ -164,6 +164,20 @@ int mvd_fuse_vertex_features(mvd_ctx* ctx, const float* vf_all, int n_views, flo
 int mvd_stage_target_encoder(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local,
                              float* feats, void* stream);
 int mvd_stage_sparse_dense(mvd_ctx* ctx, const float* fused, int train_mode, float* dense_out, int32_t* shape_out, void* stream);
+/* The view-sharded step's ONE collective behind the C ABI (replaces nothing in the reference, whose sampler
+ * is single-GPU: ldm/models/diffusion/morphable_diffusion.py:701-739).  Rank g owns views [g N/G, (g+1) N/G); every step each
+ * rank computes the per-view vertex features of its views (mvd_vertex_view_features) and ALL-GATHERS them, so that every rank
+ * sums the N views in index order (mvd_fuse_vertex_features): bit-identical to the single-GPU step.
+ *   mvd_comm_unique_id : one rank creates the RCCL id (128 bytes) and hands it to the others over any side channel
+ *   mvd_comm_init      : collective; creates the communicator this context owns (librccl.so is opened on first use)
+ *   mvd_exchange_view_features : ncclAllGather of [n_local][Nv][16] fp32 from `local` into `all` ([N][Nv][16], rank r's slice
+ *                        at views [r n_local, (r+1) n_local)) on `stream` -- no Python and no torch.distributed on the step path
+ *   mvd_comm_destroy   : also done by mvd_destroy */
+typedef struct { char internal[128]; } mvd_rccl_id;
+int mvd_comm_unique_id(mvd_rccl_id* id_out);
+int mvd_comm_init(mvd_ctx* ctx, const mvd_rccl_id* id, int rank, int world);
+int mvd_comm_destroy(mvd_ctx* ctx);
+int mvd_exchange_view_features(mvd_ctx* ctx, const float* local, float* all, int n_local, void* stream);
 /* Cross-stream hand-over of the volume.  The exchange + mvd_fuse_vertex_features + mvd_volume_from_fused may run on a
  * communication stream of the caller while `stream` of mvd_denoise_views already executes the UNet's input blocks (which
  * need none of it): record a hipEvent_t after mvd_volume_from_fused on that stream and register it here; every later reader

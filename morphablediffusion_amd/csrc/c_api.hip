@@ -1,5 +1,6 @@
 // extern "C" surface of libmvd_hip.so (declared in include/mvd.h).
 #include <array>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -137,6 +138,7 @@ void mvd_destroy(mvd_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
+  mvd_comm_destroy(c);
   for (auto& kv : c->raw)
     if (!c->param_index.count(kv.first)) hipFree(kv.second.d);  // master parameters live in the arena
   float* arenas[4] = {c->arena_p, c->arena_g, c->arena_m, c->arena_v};
@@ -834,6 +836,95 @@ int mvd_denoise_views(mvd_ctx* c, const float* x_noisy, const float* x_input, co
                       float sigma, float* eps_out, float* x_prev, void* stream) {
   return mvd_denoise_views_batch(c, 1, nullptr, x_noisy, x_input, clip, &timestep, t_embed, v_embed, view_idx, TN, cfg_scale, noise,
                                  sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma, eps_out, x_prev, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------ view exchange over RCCL
+// the sharded step's ONE collective -- the all-gather of the per-view vertex features -- behind the C
+// ABI, on a stream of the caller, with a communicator the library owns.  librccl.so is opened on first use (dlopen: the
+// library itself has no link-time dependency on it, single-GPU users never load it).  The unique id travels over whatever
+// side channel the host has (the Python mirror broadcasts it with torch.distributed).
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  int (*get_unique_id)(void*) = nullptr;
+  int (*comm_init_rank)(void**, int, mvd_rccl_id, int) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*get_error_string)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.h) break;
+    }
+    if (api.h) {
+      api.get_unique_id = (int (*)(void*))dlsym(api.h, "ncclGetUniqueId");
+      api.comm_init_rank = (int (*)(void**, int, mvd_rccl_id, int))dlsym(api.h, "ncclCommInitRank");
+      api.comm_destroy = (int (*)(void*))dlsym(api.h, "ncclCommDestroy");
+      api.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.h, "ncclAllGather");
+      api.get_error_string = (const char* (*)(int))dlsym(api.h, "ncclGetErrorString");
+      if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) api.h = nullptr;
+    }
+  }
+  return api.h ? &api : nullptr;
+}
+int rccl_fail(RcclApi* a, const char* what, int rc) {
+  static thread_local std::string msg;
+  msg = std::string(what) + ": " + (a && a->get_error_string ? a->get_error_string(rc) : "RCCL error");
+  return mvd_fail(msg.c_str());
+}
+}  // namespace
+
+int mvd_comm_unique_id(mvd_rccl_id* id_out) {
+  RcclApi* a = rccl_api();
+  if (!a) return mvd_fail("mvd_comm_unique_id: librccl.so could not be opened");
+  const int rc = a->get_unique_id(id_out);
+  return rc ? rccl_fail(a, "ncclGetUniqueId", rc) : 0;
+}
+
+int mvd_comm_init(mvd_ctx* c, const mvd_rccl_id* id, int rank, int world) {
+  if (!c || !id || world < 1 || rank < 0 || rank >= world) return mvd_fail("mvd_comm_init: bad arguments");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  RcclApi* a = rccl_api();
+  if (!a) return mvd_fail("mvd_comm_init: librccl.so could not be opened");
+  if (c->comm) {
+    a->comm_destroy(c->comm);
+    c->comm = nullptr;
+  }
+  const int rc = a->comm_init_rank(&c->comm, world, *id, rank);
+  if (rc) {
+    c->comm = nullptr;
+    return rccl_fail(a, "ncclCommInitRank", rc);
+  }
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return 0;
+}
+
+int mvd_comm_destroy(mvd_ctx* c) {
+  if (!c || !c->comm) return 0;
+  RcclApi* a = rccl_api();
+  if (a) a->comm_destroy(c->comm);
+  c->comm = nullptr;
+  c->comm_world = 1;
+  c->comm_rank = 0;
+  return 0;
+}
+
+int mvd_exchange_view_features(mvd_ctx* c, const float* local, float* all, int n_local, void* stream) {
+  if (!c || !c->comm) return mvd_fail("mvd_exchange_view_features: no communicator (mvd_comm_init)");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!local || !all || n_local <= 0 || c->mesh.Nv <= 0) return mvd_fail("mvd_exchange_view_features: bad arguments / no mesh is set");
+  RcclApi* a = rccl_api();
+  const size_t count = (size_t)n_local * c->mesh.Nv * 16;  // fp32 elements this rank contributes: [n_local][Nv][16]
+  const int rc = a->all_gather(local, all, count, /* ncclFloat32 */ 7, c->comm, S(stream));
+  return rc ? rccl_fail(a, "ncclAllGather", rc) : 0;
 }
 
 // ------------------------------------------------------------------------------------------ test hooks

@@ -208,6 +208,9 @@ struct mvd_ctx {
   mvd_unet_config u;
   mvd_volume_config v;
   int device = 0;
+  // RCCL communicator of the view-sharded step's one exchange (mvd_comm_init; librccl.so is opened on demand, c_api.hip)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
   bool vae_exact = false;   // first-stage encoder / decoder with every conv and the attention in extended precision (mvd_set_vae_precision)

@@ -591,8 +591,16 @@ int build_conv3x_streams(mvd_ctx* c) {
   if (l16 < 0) return 0;
   int nmax = 0;
   for (int l = 0; l <= l16; ++l) nmax = std::max(nmax, c->u.model_channels * c->u.channel_mult[l]);
+  std::vector<ConvW*> cs;
   for (ResW& r : c->res) {
-    ConvW* cs[2] = {&r.c1, &r.c2};
+    cs.push_back(&r.c1);
+    cs.push_back(&r.c2);
+  }
+  for (CondW& d : c->conds) {  // the DepthTransformers' 3x3 output convolutions (attention.py:66-73)
+    cs.push_back(&d.conv1);
+    cs.push_back(&d.conv2);
+  }
+  {
     for (ConvW* w : cs) {
       if (w->taps != 9 || w->Cin % 64 || w->N > nmax) continue;
       const int bn = w->N % 160 == 0 ? 160 : (w->N % 128 == 0 ? 128 : 0);

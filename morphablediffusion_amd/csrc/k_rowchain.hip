@@ -216,35 +216,46 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   // (modules/attention.py:44) in the form  gelu(q) = max(q, 0) - |q| h(|q|),  h(a sqrt 2) = erfc(a) / 2 = (1 + a1 a + ... + a6 a^6)^-16 / 2
   // (Abramowitz & Stegun 7.1.28, |error| <= 3e-7; igemm_epilogue.h): 16 scalar fp32 instructions per element, no compare / select.
   // Items are stage-major (item k = stage k / 16 of element k % 16): neighbours are independent, dependent ones 16 items apart.
-  constexpr int NITEM = 16 * 16 + 8;
-  float ga[16], gp[16], go[16];
+  // One wave per SIMD issues everything itself: per MFMA (32 cycles) there are ~8 issue slots of 4 cycles, a transcendental takes
+  // four of them.  Scalar fp32 the GEGLU costs 76 cycles per element (rcp form: 15 + 1 transcendental; the exp2 / log2 form trades
+  // five plain instructions for one more transcendental: the same 76) -- 1216 of a unit's 1984 MFMA cycles, with the MFMA and
+  // LDS issue on top the port is full.  PACKED fp32 (v_pk_*_f32: two elements per 4-cycle slot, |x| as max(x, -x) since the
+  // packed forms have no abs modifier) brings it to 48 cycles per element.  Items are stage-major over the 8 element pairs, so
+  // dependent packed instructions are 8 items apart (no wait states), and a few of them go out with every MFMA.
+  constexpr int NST = 18;
+  constexpr int NITEM = NST * 8;
+  f32x2 ga[8], gp[8], go[8];
   auto geglu_items = [&](int k0, int k1, const f32x16& hv, const f32x16& hg, h8 (&Ho)[2]) {
 #pragma unroll
     for (int k = k0; k < k1; ++k) {
-      if (k >= 256) {  // two results -> one packed fp16 pair of the B fragment
-        const int pr = k - 256;
-        Ho[pr >> 2][2 * (pr & 3)] = (half_t)go[2 * pr];
-        Ho[pr >> 2][2 * (pr & 3) + 1] = (half_t)go[2 * pr + 1];
-        continue;
-      }
-      const int st = k >> 4, e = k & 15;
+      const int st = k >> 3, e = k & 7;
+      const f32x2 q = f32x2{hg[2 * e], hg[2 * e + 1]};
 #ifdef RC_NO_GEGLU
-      if (st == 15) go[e] = hv[e] + hg[e];
+      if (st == NST - 2) go[e] = f32x2{hv[2 * e], hv[2 * e + 1]} + q;
+      if (st == NST - 1) {
+        Ho[e >> 2][2 * (e & 3)] = (half_t)go[e].x;
+        Ho[e >> 2][2 * (e & 3) + 1] = (half_t)go[e].y;
+      }
 #else
       switch (st) {
-        case 0: ga[e] = fabsf(hg[e]) * 0.70710678118654752f; break;
-        case 1: gp[e] = __builtin_fmaf(0.0000430638f, ga[e], 0.0002765672f); break;
-        case 2: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0001520143f); break;
-        case 3: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0092705272f); break;
-        case 4: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0422820123f); break;
-        case 5: gp[e] = __builtin_fmaf(gp[e], ga[e], 0.0705230784f); break;
-        case 6: gp[e] = __builtin_fmaf(gp[e], ga[e], 1.0f); break;
-        case 7: case 8: case 9: case 10: gp[e] = gp[e] * gp[e]; break;
-        case 11: gp[e] = __builtin_amdgcn_rcpf(gp[e]); break;
-        case 12: ga[e] = ga[e] * 0.70710678118654752f; break;  // |q| / 2
-        case 13: go[e] = fmaxf(hg[e], 0.f); break;
-        case 14: go[e] = __builtin_fmaf(-ga[e], gp[e], go[e]); break;
-        default: go[e] = hv[e] * go[e]; break;
+        case 0: ga[e] = q * 0.70710678118654752f; break;
+        case 1: ga[e] = __builtin_elementwise_max(ga[e], -ga[e]); break;  // |q| / sqrt 2
+        case 2: gp[e] = ga[e] * 0.0000430638f + 0.0002765672f; break;
+        case 3: gp[e] = gp[e] * ga[e] + 0.0001520143f; break;
+        case 4: gp[e] = gp[e] * ga[e] + 0.0092705272f; break;
+        case 5: gp[e] = gp[e] * ga[e] + 0.0422820123f; break;
+        case 6: gp[e] = gp[e] * ga[e] + 0.0705230784f; break;
+        case 7: gp[e] = gp[e] * ga[e] + 1.0f; break;
+        case 8: case 9: case 10: case 11: gp[e] = gp[e] * gp[e]; break;
+        case 12: gp[e] = f32x2{__builtin_amdgcn_rcpf(gp[e].x), __builtin_amdgcn_rcpf(gp[e].y)}; break;  // 2 h
+        case 13: ga[e] = ga[e] * 0.70710678118654752f; break;                                            // |q| / 2
+        case 14: go[e] = __builtin_elementwise_max(q, f32x2{0.f, 0.f}); break;
+        case 15: go[e] = go[e] - ga[e] * gp[e]; break;  // gelu(q) = max(q, 0) - |q| h
+        case 16: go[e] = f32x2{hv[2 * e], hv[2 * e + 1]} * go[e]; break;
+        default:
+          Ho[e >> 2][2 * (e & 3)] = (half_t)go[e].x;
+          Ho[e >> 2][2 * (e & 3) + 1] = (half_t)go[e].y;
+          break;
       }
 #endif
     }

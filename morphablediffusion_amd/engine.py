@@ -296,6 +296,34 @@ class Engine:
         L.check(self.lib.mvd_fuse_vertex_features(self._ctx, L.ptr(vf), vf.shape[0], L.ptr(out), _stream()))
         return out
 
+    # ---- the sharded step's exchange behind the C ABI (RCCL communicator owned by the library) ----------------------------
+    def comm_init(self, rank=None, world=None):
+        """Creates the library's RCCL communicator over the ranks of the default torch.distributed group (the 128-byte unique id
+        is created on rank 0 and broadcast through that group -- any backend); world 1 needs no process group."""
+        import torch.distributed as dist
+        if world is None:
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            rank = dist.get_rank() if world > 1 else 0
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            L.check(self.lib.mvd_comm_unique_id(C.byref(ident)))
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        L.check(self.lib.mvd_comm_init(self._ctx, C.byref(ident), int(rank), int(world)))
+        self.comm_world = world
+
+    def comm_destroy(self):
+        L.check(self.lib.mvd_comm_destroy(self._ctx))
+        self.comm_world = 0
+
+    def exchange_view_features(self, vf_local, vf_all):
+        """ncclAllGather of this rank's [n_local,Nv,16] into vf_all [N,Nv,16] on the current stream (mvd_exchange_view_features)."""
+        assert vf_local.is_contiguous() and vf_all.is_contiguous() and vf_local.dtype == vf_all.dtype == torch.float32
+        L.check(self.lib.mvd_exchange_view_features(self._ctx, L.ptr(vf_local), L.ptr(vf_all), vf_local.shape[0], _stream()))
+        return vf_all
+
     def stage_target_encoder(self, x_noisy, t_embed, v_embed):
         """NoisyTargetViewEncoder alone (network.py:181-207): x_noisy [n,4,s,s], t_embed [time_dim], v_embed [n,view_dim] ->
         [n,16,s,s].  Parity probe."""

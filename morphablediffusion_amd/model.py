@@ -929,6 +929,14 @@ class SyncDDIMSampler:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def use_library_exchange(self):
+        """Moves the per-step all-gather behind the C ABI: the library creates its own RCCL communicator over the ranks of the
+        default process group (Engine.comm_init) and `mvd_exchange_view_features` enqueues the ncclAllGather on the
+        communication stream.  Collective: every rank calls it once, after init_process_group."""
+        rank, world = self._world()
+        if world > 1 and not self.simulate_world:
+            self.model.engine.comm_init(rank, world)
+
     def view_range(self, N):
         rank, world = self._world()
         if N % world:
@@ -1062,7 +1070,11 @@ class SyncDDIMSampler:
             fused_buf = self._buf("fused" + tag, (Nv, 16), dev) if dev.type == "cuda" else None
 
             def tail():
-                if real:
+                if real and getattr(eng, "comm_world", 0) == world:
+                    # the library's own communicator (mvd_comm_init): ncclAllGather enqueued by the C ABI on this stream, no
+                    # torch.distributed on the step path (SyncDDIMSampler.use_library_exchange)
+                    eng.exchange_view_features(vf_loc, vf_all)
+                elif real:
                     dist.all_gather_into_tensor(vf_all, vf_loc)  # RCCL over xGMI; rank r's slice lands at views [r*NL, ...)
                 elif world > 1:  # --simulate-gpus: stand in for the other ranks' slices
                     for r in range(1, world):

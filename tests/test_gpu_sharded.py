@@ -155,3 +155,32 @@ def test_two_rank_training_step_bucketed_sync_equals_flat():
     assert torch.equal(parts[0]["bucketed"], parts[1]["bucketed"])  # every rank holds the same averaged gradients
     print(f"[property] 2-rank training step: {parts[0]['n_buckets']} gradient buckets, bucketed == flat on the UNet range, "
           f"conditioner range within {aux:.1e}")
+
+
+def test_library_owned_rccl_exchange_one_rank():
+    """The step's collective behind the C ABI (mvd_comm_unique_id / mvd_comm_init / mvd_exchange_view_features): the library opens
+    librccl.so itself, owns the communicator and enqueues the ncclAllGather on the caller's stream.  One GPU per rank is all a
+    test box offers, so this is the world-1 instance (the gather of one rank's slice is that slice, on a side stream, ordered
+    by stream semantics); rank > 1 placement is the same call and is covered on the CPU by the 8-rank gloo tests of
+    tests/test_host_cpu.py with torch.distributed in the role of the exchange."""
+    from morphablediffusion_amd import lib as L
+    m = _model()
+    try:
+        eng = m.engine
+        batch, x_T, x_in, clip, noise = _inputs()
+        m.spatial_volume._set_sample({k: v.cuda() for k, v in batch.items()}, 0)  # the mesh defines Nv
+        eng.comm_init(rank=0, world=1)
+        Nv = eng.num_vertices
+        loc = torch.randn(N_VIEWS, Nv, 16, device="cuda")
+        out = torch.zeros_like(loc)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.exchange_view_features(loc, out)
+        side.synchronize()
+        assert torch.equal(out, loc)
+        with pytest.raises(L.MvdError):
+            eng.comm_destroy()
+            eng.exchange_view_features(loc, out)  # no communicator any more: loud
+    finally:
+        m.engine.close()

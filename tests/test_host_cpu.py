@@ -519,9 +519,15 @@ def test_bench_reads_roofline_traffic_from_the_pmc_summary(tmp_path, monkeypatch
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     f = tmp_path / "pmc.json"
-    f.write_text(json.dumps({"config": "headline", "bytes_per_launch": {"gemm_dma_kernel<128,0>": 1.25e8}}))
+    from morphablediffusion_amd.lib import csrc_sha16
+    f.write_text(json.dumps({"config": "headline", "csrc_sha16": csrc_sha16(), "bytes_per_launch": {"gemm_dma_kernel<128,0>": 1.25e8}}))
     monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
     assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "headline") == 1.25e8
+    stale = tmp_path / "stale.json"  # counters of another build of the library: refused
+    stale.write_text(json.dumps({"config": "headline", "csrc_sha16": "0" * 16, "bytes_per_launch": {"gemm_dma_kernel<128,0>": 1.25e8}}))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(stale))
+    assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "headline") is None
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
     assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "n8") is None      # a summary of another workload
     assert bench.pmc_traffic("attn_kernel", "headline") is None           # family not in the summary
     monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(tmp_path / "missing.json"))

@@ -7,7 +7,7 @@ import collections, csv, json, re, sys
 
 steps = float(sys.argv[4]) if len(sys.argv) > 4 else 5.0
 json_out = sys.argv[5] if len(sys.argv) > 5 else None  # {family: HBM-side bytes per launch}: what bench.py reports as roofline.traffic
-PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel)<[^>]*>|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv|target_encoder"
+PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel|conv3x_kernel)<[^>]*>|rowchain_kernel|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv|target_encoder"
 
 
 def fam_of(name):
@@ -22,6 +22,9 @@ def fam_of(name):
     m3 = re.match(r"(conv3_dma_kernel)<([^>]*)>", k)
     if m3:
         k = "conv3_dma_kernel<" + ",".join(x.strip() for x in m3.group(2).split(",")) + ">"
+    m5 = re.match(r"conv3x_kernel<([^>]*)>", k)
+    if m5:
+        k = "conv3x_kernel<" + m5.group(1).strip() + ">"
     m4 = re.match(r"igemm_kernel<([^>]*)>", k)
     if m4:
         a = [x.strip() for x in m4.group(1).split(",")]
@@ -56,6 +59,10 @@ if json_out:
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                      "--no-extras; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, family average",
            "config": line["config"].get("name"), "bytes_per_launch": {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from morphablediffusion_amd.lib import csrc_sha16
+    out["csrc_sha16"] = csrc_sha16()  # bench.py refuses the file when the library sources have changed since
     for k in fe:
         n = len(nf[k])
         if n:
