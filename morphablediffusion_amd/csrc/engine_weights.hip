@@ -162,7 +162,8 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
-  if (rc_supported_c(C)) {  // the row-local tail of the block as one fragment stream (k_rowchain.hip); proj_out included: the
+  if (rc_supported_c(C) && !c->train_mode) {  // (inference contexts: a training context re-packs every step and never takes this path)
+    // the row-local tail of the block as one fragment stream (k_rowchain.hip); proj_out included: the
                             // form without it reads the same stream and stops in front of that section
     engine_build_rotate(c);
     RawTensor *wao, *g3, *b3, *w1, *b1, *w2, *b2, *wpo;

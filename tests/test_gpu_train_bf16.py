@@ -52,3 +52,22 @@ def test_training_step_bf16_vs_reference_and_fp16_control():
     assert f["loss_rel_err"] <= 1e-3 and f["pred_rel_l2"] <= 2e-3 and f["grad_trunk_worst"] <= 1e-2
     # both dtypes descend alike on the same batch (same optimiser, fp32 masters)
     assert abs(b["losses"][-1] - f["losses"][-1]) <= 0.1 * f["losses"][0]
+
+
+def test_full_width_training_gradients_bf16_vs_reference_golden():
+    """The full-width step (916.9 M parameters, B = 2) in bfloat16 against tests/golden/train_full.npz -- the reference's own
+    training_step + loss.backward() -- in a process of its own (tools/train_full_check.py).  Bounds = 8 x the fp16 ones of
+    tests/test_gpu_train.py::test_training_step_full_width_gradients_vs_reference (8- against 11-bit significands): trunk tensors
+    8e-2, DepthTransformer tensors 0.3, loss 4e-3."""
+    if not os.path.exists(os.path.join(ROOT, "morphablediffusion_amd", "libmvd_hip_bf16.so")):
+        pytest.fail("libmvd_hip_bf16.so is missing")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_full_check.py")], cwd=ROOT, env=dict(os.environ, MVD_DTYPE="bf16"),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(f"[parity] full-width training step in bf16: loss rel {d['loss_rel_err']:.2e}, trunk gradients worst {d['grad_trunk_worst']:.2e} "
+          f"({d['worst_trunk']}) median {d['grad_trunk_median']:.2e}, DepthTransformer worst {d['grad_dt_worst']:.2e} ({d['worst_dt']}) "
+          f"median {d['grad_dt_median']:.2e}")
+    assert d["dtype"] == "bf16" and d["n_cond"] == 6 and d["n_rest"] == 20
+    assert d["loss_rel_err"] <= 4e-3
+    assert d["grad_trunk_worst"] <= 8e-2 and d["grad_dt_worst"] <= 0.3
