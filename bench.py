@@ -97,15 +97,39 @@ def pick_cpu_threads():
         if best_t is None or dt < best_t:
             best_n, best_t = n, dt
         elif dt > 1.5 * best_t and n != ncpu:
-            # past the knee: more threads only thrash -- skip the points in between, but always time os.cpu_count() threads
-            # too, so the line carries the all-cores figure next to the best one
-            torch.set_num_threads(ncpu)
-            with torch.no_grad():
-                t0 = time.time()
-                O.unet_forward(W, plan, x[:2], t[:2], ctx[:2], {k: v[:2] for k, v in sd.items()})
-                seen[ncpu] = round((time.time() - t0) * (x.shape[0] / 2.0), 3)  # quarter of the batch, scaled: it can be very slow
+            # past the knee: more threads only thrash -- skip the points in between, but still time os.cpu_count() threads, so the
+            # line carries the all-cores figure next to the best one.  That point runs in a process of its
+            # own with a hard 60 s limit: on a 256-thread host it took 300+ s of this leg's 420 s budget in round 5 and would
+            # have cost the whole cpu_baseline object on a slightly slower box
+            import subprocess
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-thread-point", str(ncpu)], capture_output=True,
+                                   text=True, timeout=60, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+                val = [l for l in p.stdout.splitlines() if l.startswith("POINT ")]
+                seen[ncpu] = round(float(val[-1].split()[1]), 3) if val else None
+            except subprocess.TimeoutExpired:
+                seen[ncpu] = ">240 (a quarter of the batch did not finish in 60 s)"
             break
     return best_n, seen
+
+
+def cpu_thread_point(n):
+    """``bench.py --cpu-thread-point N``: the reduced-width UNet forward of pick_cpu_threads on a quarter of its batch with N
+    threads, scaled to the whole batch -- one line ``POINT seconds``."""
+    from morphablediffusion_amd.spec import UNetConfig, build_unet_plan, unet_manifest
+    from morphablediffusion_amd.weights import seeded_state_dict
+    from oracle import mvd_oracle as O
+    cfg = UNetConfig(model_channels=64)
+    W = seeded_state_dict(unet_manifest(cfg), 7)
+    plan = build_unet_plan(cfg)
+    g = torch.Generator().manual_seed(0)
+    x, t, ctx = torch.randn(2, 8, 32, 32, generator=g), torch.full((2,), 481), torch.randn(2, 1, 768, generator=g)
+    sd = {32 >> l: torch.randn(2, c, 48 >> l, 32 >> l, 32 >> l, generator=g) for l, c in enumerate(cfg.volume_dims)}
+    torch.set_num_threads(n)
+    with torch.no_grad():
+        t0 = time.time()
+        O.unet_forward(W, plan, x, t, ctx, sd)
+    print(f"POINT {(time.time() - t0) * 4.0:.3f}")
 
 
 def cpu_baseline_main():
@@ -144,7 +168,7 @@ def cpu_baseline_main():
         "value": 1.0 / dt16, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "cpu_model": cpu_model_name(), "os_cpu_count": os.cpu_count(), "thread_calibration_s": calib,
         "all_threads": {"threads": os.cpu_count(), "reduced_width_unet_s": calib.get(os.cpu_count()),
-                        "best_threads_reduced_width_unet_s": min(calib.values()) if calib else None,
+                        "best_threads_reduced_width_unet_s": min(v for v in calib.values() if isinstance(v, (int, float))) if calib else None,
                         "note": "the headline-width step is only run at the best thread count: with every hardware thread "
                                 "eager PyTorch is slower by the ratio of these two figures (and did not finish in 20 minutes)"},
         "sample": f"ONE full denoise_apply of the headline configuration (N={N_VIEWS}, CFG 2.0, full-width UNet, "
@@ -312,6 +336,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-thread-point", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the 50-step trajectory and the VAE decode reported next to the headline (profiling runs: the "
                          "process then executes only identical denoising steps)")
@@ -337,6 +362,9 @@ def main():
                     help="timing aid: run ONE rank's share of a G-way view sharding on one GPU (no collective); "
                          "reported as a per-rank step time, never as the headline value")
     args = ap.parse_args()
+    if args.cpu_thread_point:
+        cpu_thread_point(args.cpu_thread_point)
+        return
     if args.cpu_baseline_only:
         return cpu_baseline_main()
     if args.dtype is None:

@@ -64,7 +64,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
   if (!no_cx && c->use_halo && g.wx && conv3x_eligible(g, g.wx_bn)) {
     // conv3x (k_conv3x.hip): one workgroup per CU and 16 x 16 pixel tile x wx_bn columns; split over 64-channel chunks when the
     // tiles do not fill the chip (microseconds, as for the halo kernel below)
-    const int ncc = g.Cin / 64, tiles = g.B * (g.Y / 16) * (g.X / 16) * (g.N / g.wx_bn);
+    const int ncc = g.Cin / 64;
+    const int tiles = (g.X == 8 ? cdiv(g.B, 4) : g.B * (g.Y / 16) * (g.X / 16)) * (g.N / g.wx_bn);  // 8 x 8 images: four per tile
     double best = 1e30;
     int sk = 1;
     for (int s2 = 1; s2 <= 8 && s2 <= ncc; ++s2) {

@@ -588,7 +588,11 @@ int build_conv3x_streams(mvd_ctx* c) {
   static const bool off = getenv("MVD_NO_CONV3X") != nullptr;
   if (off || !c->has_unet) return 0;
   int l16 = -1;
-  for (int l = 0; l < 4 && ((c->u.image_size >> l) % 16) == 0 && (c->u.image_size >> l) >= 16; ++l) l16 = l;
+  for (int l = 0; l < 4; ++l) {  // conv3x takes resolutions divisible by 16 and 8 x 8 images
+    const int res = c->u.image_size >> l;
+    if ((res % 16 == 0 && res >= 16) || res == 8) l16 = l;
+    else break;
+  }
   if (l16 < 0) return 0;
   int nmax = 0;
   for (int l = 0; l <= l16; ++l) nmax = std::max(nmax, c->u.model_channels * c->u.channel_mult[l]);

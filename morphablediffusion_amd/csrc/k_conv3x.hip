@@ -23,16 +23,26 @@
 
 namespace {
 
-constexpr int CX_HALO_ROWS = 18 * 18;                       // pixels of a halo tile
-constexpr int CX_HALO_GROUPS = (CX_HALO_ROWS + 7) / 8;       // 8-row DMA pieces (41)
-constexpr int CX_HALO_BYTES = CX_HALO_GROUPS * 1024;
-constexpr int CX_HP = (CX_HALO_GROUPS + 3) / 4;              // halo pieces per wave and chunk (11; the last wave's extra ones repeat)
+// A workgroup's 256 output pixels are one 16 x 16 block of an image (IW = 16) or four whole 8 x 8 images (IW = 8, one per wave);
+// every block carries its own halo ring: (IW + 2)^2 halo pixels per block.
+template <int IW>
+struct CxGeo {
+  static constexpr int NI = 256 / (IW * IW);           // image blocks per tile
+  static constexpr int HW = IW + 2;                     // halo width
+  static constexpr int ROWS = NI * HW * HW;             // pixels of a halo tile (324 / 400)
+  static constexpr int GROUPS = (ROWS + 7) / 8;         // 8-row DMA pieces (41 / 50)
+  static constexpr int BYTES = GROUPS * 1024;
+  static constexpr int HP = (GROUPS + 3) / 4;           // halo pieces per wave and chunk (11 / 13; surplus ones repeat the last)
+};
 
 __device__ __forceinline__ int swzx(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int NF>
+template <int NF, int IW>
 __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t* __restrict__ wstream) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  using Geo = CxGeo<IW>;
+  constexpr int CX_HALO_ROWS = Geo::ROWS, CX_HALO_GROUPS = Geo::GROUPS, CX_HALO_BYTES = Geo::BYTES, CX_HP = Geo::HP;
+  constexpr int NI = Geo::NI, HWD = Geo::HW;
   constexpr int QF = 3 * NF;                 // fragments per ring quarter (3 reduction steps)
   constexpr int PW = (QF + 3) / 4;           // DMA pieces per wave and quarter
   constexpr int RING_BYTES = 4 * QF * 1024;
@@ -47,8 +57,9 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, pl = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = g.Y, W = g.X, N = g.N, Cin = g.Cin;
-  const int bx_per = W >> 4, by_per = H >> 4, bpi = bx_per * by_per;
-  const int tiles_m = g.B * bpi, tiles_n = N / (32 * NF);
+  const int bx_per = W / IW, by_per = H / IW, bpi = bx_per * by_per;  // image blocks per sample
+  const int nblocks = g.B * bpi;
+  const int tiles_m = (nblocks + NI - 1) / NI, tiles_n = N / (32 * NF);
   int bid = blockIdx.x;
   {  // XCD-aware bijective remap: the column tiles of one pixel tile share an L2
     const int nwg = tiles_m * tiles_n;
@@ -57,8 +68,13 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int n0 = tn * 32 * NF;
-  const int b = tm / bpi, brem = tm - b * bpi, by = brem / bx_per, bx = brem - by * bx_per;
-  const int y0 = by * 16, x0 = bx * 16;
+  // block gb of the tile -> sample, top-left pixel
+  auto block_pos = [&](int gb, int& b, int& y0, int& x0) {
+    b = gb / bpi;
+    const int brem = gb - b * bpi, by = brem / bx_per;
+    y0 = by * IW;
+    x0 = (brem - by * bx_per) * IW;
+  };
   const int ncc = Cin / 64;
   int cc_beg = 0, cc_end = ncc;
   if (g.splitk > 1) {
@@ -82,9 +98,12 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
     h_grp[i] = grp;
     const int hp = grp * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((hp >> 1) & 7);
-    const int hy = hp / 18, hx = hp - hy * 18;
+    const int hj = hp / (HWD * HWD), hr = hp - hj * (HWD * HWD);
+    const int hy = hr / HWD, hx = hr - hy * HWD;
+    int b, y0, x0;
+    block_pos(tm * NI + hj, b, y0, x0);
     const int y = y0 + hy - 1, x = x0 + hx - 1;
-    const bool ok = hp < CX_HALO_ROWS && y >= 0 && y < H && x >= 0 && x < W;
+    const bool ok = hp < CX_HALO_ROWS && tm * NI + hj < nblocks && y >= 0 && y < H && x >= 0 && x < W;
     const unsigned pix = (unsigned)((b * H + y) * W + x);
     h_off[i] = ok ? (pix * (unsigned)g.lda + chunk * 8) * 2 : 0xFFFFFFFFu;
   }
@@ -100,10 +119,14 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
                                              (cc_beg * NQ + jq) * (QF << 10), 0, 0);
   };
 
-  // pixel of this lane in each of the wave's two activation fragments: tile row 4 wave + 2 p + (pl >> 4), column pl & 15
+  // pixel of this lane in each of the wave's two activation fragments.  IW = 16: block row 4 wave + 2 p + (pl >> 4), column
+  // pl & 15 of the tile's one block; IW = 8: row 4 p + (pl >> 3), column pl & 7 of block `wave`
   int centre[2];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) centre[p] = (4 * wave + 2 * p + (pl >> 4) + 1) * 18 + (pl & 15) + 1;
+  for (int p = 0; p < 2; ++p) {
+    if constexpr (IW == 16) centre[p] = (4 * wave + 2 * p + (pl >> 4) + 1) * HWD + (pl & 15) + 1;
+    else centre[p] = wave * (HWD * HWD) + (4 * p + (pl >> 3) + 1) * HWD + (pl & 7) + 1;
+  }
 
   f32x16 acc[2][NF];
 #pragma unroll
@@ -127,7 +150,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
     auto rdw = [&](int slot) -> h8 { return *(const h8*)(sRing + (slot << 10) + lane * 16); };
     auto rdx = [&](int buf, int p, int step) -> h8 {
       const int tap = step >> 2, kk = step & 3;
-      const int hrow = centre[p] + (tap / 3 - 1) * 18 + (tap % 3 - 1);
+      const int hrow = centre[p] + (tap / 3 - 1) * HWD + (tap % 3 - 1);
       return *(const h8*)(sHalo + buf * CX_HALO_BYTES + swzx(hrow, 2 * kk + h));
     };
     h8 wq[4];     // weight fragments, four ahead
@@ -148,9 +171,9 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
         if (s % 3 == 0 && !(c == 0 && s == 0)) {
           // entering quarter jq = c * NQ + qd: everything issued before the previous quarter has landed once at most the loads of
           // the previous quarter are in flight (PW weight pieces + the halo pieces issued there)
-          const int prev = (qd + NQ - 1) % NQ;  // the previous quarter's index within its chunk (halo pieces ride in 2, 3, 4)
-          constexpr int NH_LAST = CX_HP - 8;
-          const int nh_prev = prev == 2 || prev == 3 ? 4 : (prev == 4 ? NH_LAST : 0);
+          const int prev = (qd + NQ - 1) % NQ;  // the previous quarter's index within its chunk (halo pieces ride in 2, 3, ...)
+          constexpr int NHQ = (CX_HP + 3) / 4, NH_LAST = CX_HP - 4 * (NHQ - 1);  // quarters that carry halo pieces; pieces in the last
+          const int nh_prev = (prev >= 2 && prev < 2 + NHQ) ? (prev == 2 + NHQ - 1 ? NH_LAST : 4) : 0;
           if (nh_prev == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PW) : "memory");
           else if (nh_prev == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PW + 4) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PW + NH_LAST) : "memory");
@@ -180,7 +203,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
 #ifdef CX_EXP_NODMA
           if (c < 0)
 #endif
-          if (qd >= 2 && qd <= 4 && pos >= PW && pos < PW + 4) {
+          if (qd >= 2 && qd < 2 + (CX_HP + 3) / 4 && pos >= PW && pos < PW + 4) {
             const int hi = (qd - 2) * 4 + (pos - PW);
             if (hi < CX_HP) dma_halo_piece(hi, cc_next, hbuf ^ 1);
           }
@@ -209,10 +232,18 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     long row4[4];
+    int b = 0;
+    bool live = true;
+    {
+      int y0, x0;
+      block_pos(tm * NI + (IW == 16 ? 0 : wave), b, y0, x0);
+      live = tm * NI + (IW == 16 ? 0 : wave) < nblocks;  // a tile of 8 x 8 images may end past the batch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int fr = (lane >> 3) + 8 * i;  // pixel of the fragment: tile row 4 wave + 2 p + (fr >> 4), column fr & 15
-      row4[i] = (long)(b * H + y0 + 4 * wave + 2 * p + (fr >> 4)) * W + x0 + (fr & 15);
+      for (int i = 0; i < 4; ++i) {
+        const int fr = (lane >> 3) + 8 * i;  // pixel of the fragment
+        const int yy = IW == 16 ? 4 * wave + 2 * p + (fr >> 4) : 4 * p + (fr >> 3), xx = IW == 16 ? (fr & 15) : (fr & 7);
+        row4[i] = (long)(b * H + y0 + yy) * W + x0 + xx;
+      }
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -234,6 +265,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
       for (int i = 0; i < 4; ++i) {
         const int fr = (lane >> 3) + 8 * i;
         float4 v = *(const float4*)(sc + fr * EPI_LD + cq);
+        if (!live) continue;
         if (part) {
           *(float4*)(part + row4[i] * N + n) = v;
           continue;
@@ -269,18 +301,19 @@ __global__ void conv3x_pack_kernel(const half_t* __restrict__ w, int N, int Cin,
   *(h8*)(out + gid * 8) = o;
 }
 
-template <int NF>
+template <int NF, int IW>
 int launch_cx(const IGemm& g, const half_t* stream, hipStream_t s) {
-  constexpr int LDS = 2 * CX_HALO_BYTES + 4 * 3 * NF * 1024;
+  constexpr int LDS = 2 * CxGeo<IW>::BYTES + 4 * 3 * NF * 1024;
   static_assert(LDS <= 160 * 1024 && 4 * EPI_WAVE_BYTES <= LDS, "LDS budget");
   static bool attr_done[MVD_MAX_DEVICES] = {false};
   bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3x_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv3x_kernel<NF, IW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  dim3 grid(g.B * (g.Y / 16) * (g.X / 16) * (g.N / (32 * NF)), g.splitk > 1 ? g.splitk : 1);
-  hipLaunchKernelGGL((conv3x_kernel<NF>), grid, dim3(256), LDS, s, g, stream);
+  constexpr int NI = CxGeo<IW>::NI;
+  dim3 grid(cdiv(g.B * (g.Y / IW) * (g.X / IW), NI) * (g.N / (32 * NF)), g.splitk > 1 ? g.splitk : 1);
+  hipLaunchKernelGGL((conv3x_kernel<NF, IW>), grid, dim3(256), LDS, s, g, stream);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -291,7 +324,8 @@ int launch_cx(const IGemm& g, const half_t* stream, hipStream_t s) {
 bool conv3x_eligible(const IGemm& g, int bn) {
   if (g.a_f32 || g.ntaps != 9 || g.sy != 1 || g.sx != 1 || g.ups || g.Z != 1 || g.geglu || !g.out_linear || g.npar > 0) return false;
   if (g.Cin % 64 || (bn != 160 && bn != 128) || g.N % bn) return false;
-  if (g.Y != g.IY || g.X != g.IX || g.Y % 16 || g.X % 16) return false;
+  if (g.Y != g.IY || g.X != g.IX) return false;
+  if (!((g.Y % 16 == 0 && g.X % 16 == 0) || (g.Y == 8 && g.X == 8))) return false;
   if (!g.out_f32 || g.act != ACT_NONE || g.alpha != 1.0f || g.out_split || g.rowscale || g.gn_partial) return false;
   if ((g.lda & 7) || (g.ldc & 3) || (g.resid && (!g.resid_f32 || (g.ldr & 3))) || (g.rowbias && (g.rb_ld & 3))) return false;
   if ((long)g.B * g.Y * g.X * g.lda * 2 >= 0xFFFFFF00L) return false;  // 32-bit buffer offsets
@@ -316,5 +350,6 @@ int launch_conv3x(const IGemm& g, const half_t* stream, int bn, hipStream_t s) {
   if (!conv3x_eligible(g, bn)) return mvd_fail("conv3x: shape not supported");
   if (g.splitk > 1 && !g.partial) return mvd_fail("conv3x: split-K without a partial buffer");
   if ((long)(g.N / bn) * (g.Cin / 64) * 36 * (bn / 32) * 1024 >= 0xFFFFFF00L) return mvd_fail("conv3x: weight stream exceeds 4 GiB");
-  return bn == 160 ? launch_cx<5>(g, stream, s) : launch_cx<4>(g, stream, s);
+  if (g.X == 8) return bn == 160 ? launch_cx<5, 8>(g, stream, s) : launch_cx<4, 8>(g, stream, s);
+  return bn == 160 ? launch_cx<5, 16>(g, stream, s) : launch_cx<4, 16>(g, stream, s);
 }

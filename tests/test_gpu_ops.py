@@ -243,6 +243,8 @@ def test_st_tail_rowchain_identity_weights(eng):
 @pytest.mark.parametrize("B,Cin,H,W,Cout,res,sk", [
     (1, 64, 16, 16, 160, False, 0), (2, 128, 32, 32, 320, True, 0), (3, 192, 16, 32, 128, True, 0), (2, 320, 16, 16, 640, True, 2),
     (1, 960, 32, 32, 320, False, 0), (2, 64, 48, 16, 256, True, 0), (1, 256, 16, 16, 160, False, 4),
+    # 8 x 8 images: four per workgroup tile (a partial last tile at B = 6), split over the channel chunks
+    (8, 128, 8, 8, 160, True, 0), (6, 192, 8, 8, 320, True, 0), (4, 1280, 8, 8, 1280, True, 4), (1, 64, 8, 8, 128, False, 0),
 ])
 def test_conv3x(eng, B, Cin, H, W, Cout, res, sk):
     x = rnd(B, Cin, H, W)

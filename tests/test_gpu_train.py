@@ -374,8 +374,30 @@ def test_optimizer_state_round_trip_resumes_bit_identically():
     assert torch.equal(m2.engine.flat_params[:hi], want[:hi]), "update 3 after the resume differs from the uninterrupted run"
     # (the conditioner's scatter adjoints use hardware fp32 atomics: its parameters agree to rounding, not bit for bit)
     assert torch.allclose(m2.engine.flat_params[hi:], want[hi:], rtol=1e-5, atol=1e-7)
-    with pytest.raises(KeyError):
+    # a checkpoint without the arenas (written by torch.optim.AdamW itself, or before ArenaAdamW carried them): no KeyError any
+    # more -- the moments restart from zero with a warning when the per-parameter state does not line up ...
+    with pytest.warns(UserWarning, match="restart from zero"):
         opt2.load_state_dict({k: v for k, v in ck["optimizer"].items() if k != "arena"})
+    assert opt2.steps_done == 0 and float(m2.engine.flat_m.abs().max()) == 0.0 and float(m2.engine.flat_v.abs().max()) == 0.0
+    # ... and are adopted when it does: a torch.optim.AdamW-style state over this optimiser's own parameters
+    mine = [p_ for g_ in opt2.param_groups for p_ in g_["params"]]
+    fake_state = {i: {"step": torch.tensor(7.0), "exp_avg": torch.full_like(p_, 0.25), "exp_avg_sq": torch.full_like(p_, 0.5)}
+                  for i, p_ in enumerate(mine)}
+    groups, k0 = [], 0
+    for g_ in ck["optimizer"]["param_groups"]:
+        n = len(g_["params"])
+        groups.append(dict(g_, params=list(range(k0, k0 + n))))
+        k0 += n
+    with pytest.warns(UserWarning, match="adopted"):
+        opt2.load_state_dict({"state": fake_state, "param_groups": groups})
+    assert opt2.steps_done == 7
+    covered = sum(p_.numel() for p_ in mine)
+    assert abs(float(m2.engine.flat_m.sum()) - 0.25 * covered) <= 1e-3 * covered
+    # the overflow check follows the CURRENT loss scale (it was fixed at construction)
+    m2.loss_scale = 1.0
+    assert opt2.dynamic_scale is False
+    m2.loss_scale = 4096.0
+    assert opt2.dynamic_scale is True
     m2.engine.close()
 
 

@@ -57,8 +57,10 @@ def test_training_step_bf16_vs_reference_and_fp16_control():
 def test_full_width_training_gradients_bf16_vs_reference_golden():
     """The full-width step (916.9 M parameters, B = 2) in bfloat16 against tests/golden/train_full.npz -- the reference's own
     training_step + loss.backward() -- in a process of its own (tools/train_full_check.py).  Bounds = 8 x the fp16 ones of
-    tests/test_gpu_train.py::test_training_step_full_width_gradients_vs_reference (8- against 11-bit significands): trunk tensors
-    8e-2, DepthTransformer tensors 0.3, loss 4e-3."""
+    tests/test_gpu_train.py::test_training_step_full_width_gradients_vs_reference would allow 8e-2 / 0.4 (8- against 11-bit
+    significands); asserted is what the full-width step measures with headroom -- trunk tensors 4e-2 (measured worst 2.4e-2,
+    median 9.8e-3), DepthTransformer tensors 8e-2 (measured worst 4.9e-2, median 3.1e-2), loss 1e-3 (5.3e-5): at full width the
+    wider reductions average the operand rounding further than at the reduced width of the test above."""
     if not os.path.exists(os.path.join(ROOT, "morphablediffusion_amd", "libmvd_hip_bf16.so")):
         pytest.fail("libmvd_hip_bf16.so is missing")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_full_check.py")], cwd=ROOT, env=dict(os.environ, MVD_DTYPE="bf16"),
@@ -69,5 +71,5 @@ def test_full_width_training_gradients_bf16_vs_reference_golden():
           f"({d['worst_trunk']}) median {d['grad_trunk_median']:.2e}, DepthTransformer worst {d['grad_dt_worst']:.2e} ({d['worst_dt']}) "
           f"median {d['grad_dt_median']:.2e}")
     assert d["dtype"] == "bf16" and d["n_cond"] == 6 and d["n_rest"] == 20
-    assert d["loss_rel_err"] <= 4e-3
-    assert d["grad_trunk_worst"] <= 8e-2 and d["grad_dt_worst"] <= 0.3
+    assert d["loss_rel_err"] <= 1e-3
+    assert d["grad_trunk_worst"] <= 4e-2 and d["grad_dt_worst"] <= 8e-2

@@ -13,7 +13,7 @@ for r in rows:
     val[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
 fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for (_, name), c in val.items():
-    m = re.search(r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel)<[^>]*>|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv", name)
+    m = re.search(r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel|conv3x_kernel|rowchain_kernel)<[^>]*>|conv3x_kernelILi\d+|rowchain_kernelILi\d+|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv", name)
     k = m.group(0) if m else "other"
     fam[k][0] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     fam[k][1] += c.get("GRBM_GUI_ACTIVE", 0.0)

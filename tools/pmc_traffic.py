@@ -11,6 +11,9 @@ PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel|conv3x_kernel)<[^>]*>|row
 
 
 def fam_of(name):
+    m = re.search(r"conv3x_kernelILi(\d+)ELi(\d+)", name) or re.search(r"conv3x_kernel<\s*(\d+)\s*,\s*(\d+)", name)
+    if m:  # mangled or demangled: the engine books conv3x_kernel<NF> (both tile geometries)
+        return f"conv3x_kernel<{m.group(1)}>"
     m = re.search(PAT, name)
     if not m:
         return "other"

@@ -37,11 +37,8 @@ def family(name):
         if m.group(1) == "gemm_dma_kernel":
             a = a[:2]  # <BN, MODE, PLAIN>: the engine books the plain and the general instance under one family
         return f"{m.group(1)}<{','.join(a)}>"
-    m = re.search(r"conv3x_kernel<([^>]*)>", name)
-    if m:
-        return f"conv3x_kernel<{m.group(1).strip()}>"
-    m = re.search(r"conv3x_kernelILi(\d+)E", name)  # mangled form
-    if m:
+    m = re.search(r"conv3x_kernelILi(\d+)E", name) or re.search(r"conv3x_kernel<\s*(\d+)", name)
+    if m:  # mangled or demangled; the engine books conv3x_kernel<NF> for both tile geometries
         return f"conv3x_kernel<{m.group(1)}>"
     for key, fam in (("rowchain_kernel", "rowchain_kernel"), ("splitk_reduce", "splitk_reduce_kernel"), ("gn_", "group_norm"), ("layernorm", "layernorm"),
                      ("depth_attn", "depth_attn_kernel"), ("attn_kernel", "attn_kernel")):
