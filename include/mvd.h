@@ -369,6 +369,13 @@ int mvd_op_st_tail(mvd_ctx* ctx, int C, int rows, int T, const float* ao, const 
                    const float* w_ao, const float* b_ao, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w_po, const float* b_po, const float* resid, float* out,
                    int flags, int iters, float* ms_out, void* stream);
+/* Row-head kernel test / timing hook (csrc/k_rowchain.hip: rowhead_kernel), the row-local front of a SpatialTransformer block in ONE
+ * launch, C = 320:  t0 = n0 @ w_pi^T + b_pi (fp32 out; n0 = the GroupNorm output, rounded to fp16 as in the engine);
+ * qkv = LayerNorm(t0; ln_g, ln_b) @ [w_q; w_k; w_v]^T (fp16 in the engine, returned as fp32 [rows][3C]).
+ * ldm/modules/attention.py:325-332, 266, 186-190.  rows % 128 == 0. */
+int mvd_op_st_head(mvd_ctx* ctx, int rows, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g,
+                   const float* ln_b, const float* w_q, const float* w_k, const float* w_v, float* t0_out, float* qkv_out,
+                   int iters, float* ms_out, void* stream);
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and
  * returns the mean kernel time in ms measured with HIP events on that stream */
 int mvd_bench_conv(mvd_ctx* ctx, int B, int C, int H, int W, int Cout, int iters, float* ms_out, void* stream);

@@ -1422,4 +1422,45 @@ int mvd_op_st_tail(mvd_ctx* c, int C, int rows, int T, const float* ao, const fl
   return 0;
 }
 
+// The row-head kernel (k_rowchain.hip: proj_in -> t0, LayerNorm1, q | k | v) on fp32 operands in the reference's layouts, C = 320.
+int mvd_op_st_head(mvd_ctx* c, int rows, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g, const float* ln_b,
+                   const float* w_q, const float* w_k, const float* w_v, float* t0_out, float* qkv_out, int iters, float* ms_out,
+                   void* stream) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c) return mvd_fail("null context");
+  hipStream_t s = S(stream);
+  WsScope ws_scope(c);
+  const int C = RH_C;
+  const size_t n = (size_t)rows * C;
+  half_t* stream_w = ws_alloc<half_t>(c, rowhead_stream_halfs());
+  float* tmp = ws_alloc<float>(c, (size_t)3 * C);
+  half_t* n0h = ws_alloc<half_t>(c, n);
+  half_t* qkvh = ws_alloc<half_t>(c, 3 * n);
+  WS_CHECK(stream_w && tmp && n0h && qkvh);
+  RhWeights w;
+  w.w_pi = w_pi; w.ln_g = ln_g; w.ln_b = ln_b; w.w_q = w_q; w.w_k = w_k; w.w_v = w_v;
+  RET_IF(rowhead_pack(w, tmp, stream_w, s));
+  RET_IF(launch_f32_to_f16(n0, n0h, n, s));
+  RowHead p;
+  p.stream = stream_w; p.rows = rows; p.n0 = n0h; p.ld_n0 = C; p.b_pi = b_pi; p.t0 = t0_out; p.ld_t0 = C; p.qkv = qkvh; p.ld_qkv = 3 * C;
+  RET_IF(launch_rowhead(p, s));
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    HIP_CHECK_RET(hipEventCreate(&e0));
+    HIP_CHECK_RET(hipEventCreate(&e1));
+    HIP_CHECK_RET(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) RET_IF(launch_rowhead(p, s));
+    HIP_CHECK_RET(hipEventRecord(e1, s));
+    HIP_CHECK_RET(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (ms_out) *ms_out = ms / (float)iters;
+  }
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(3 * n)), dim3(256), 0, s, qkvh, qkv_out, 3 * n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -67,6 +67,7 @@ struct STW {
   // row-chain kernel (k_rowchain.hip): to_out | LayerNorm3-folded FF1 | FF2 | proj_out as one pre-packed fragment stream
   // (null when the width is not one of its instantiated forms)
   half_t* rc_stream = nullptr;
+  half_t* rh_stream = nullptr;  // ... and proj_in | LayerNorm1-folded q|k|v for the row-head kernel (C = 320)
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;

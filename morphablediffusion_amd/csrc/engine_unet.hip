@@ -583,6 +583,16 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   else
     RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
+  static const bool no_rh = getenv("MVD_NO_ROWHEAD") != nullptr;
+  if (rc && !no_rh && t.rh_stream && !t.proj_in.xp) {
+    // row-head kernel: proj_in -> t0, LayerNorm1 and the q | k | v projection in one launch (k_rowchain.hip)
+    RowHead hp;
+    hp.stream = t.rh_stream; hp.rows = rows; hp.n0 = n0; hp.ld_n0 = C; hp.b_pi = t.proj_in.bias; hp.t0 = t0; hp.ld_t0 = C;
+    hp.qkv = qkv; hp.ld_qkv = 3 * C;
+    const double cc = (double)C * C;
+    ProbeScope ps(c, f.s, "rowhead_kernel", 2.0 * rows * cc * 4.0, (double)rows * C * (2.0 + 4.0 + 6.0) + cc * 2.0 * 4.0);
+    RET_IF(launch_rowhead(hp, f.s));
+  } else {
   g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
@@ -593,6 +603,7 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   g = GemmArgs();
   g.a = l1; g.lda = C; g.w = &t.qkv; g.out = qkv; g.out_f32 = 0; g.ldc = 3 * C; g.use_bias = false;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  }
   {
     ProbeScope ps(c, f.s, "attn_kernel", 4.0 * f.Bv * (double)T * T * C, (double)rows * C * 8.0);
     RET_IF(launch_attention(qkv, 3 * C, qkv + 2 * C, 3 * C, ao, C, f.Bv, T, t.heads, C / t.heads, f.s));

@@ -183,6 +183,17 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
     RcWeights rw;
     rw.w_ao = wao->d; rw.ln_g = g3->d; rw.ln_b = b3->d; rw.w1 = w1->d; rw.b1 = b1->d; rw.w2 = w2->d; rw.b2 = b2->d; rw.w_po = wpo->d;
     RET_IF(rowchain_pack(rw, C, 1, 1, tmp, s->rc_stream, c->bs));
+    if (C == RH_C) {  // the front of the block (proj_in, LayerNorm1, q | k | v) for the row-head kernel
+      RawTensor *wpi, *g1, *b1n;
+      RET_IF(get_raw(c, p + ".proj_in.weight", &wpi));
+      RET_IF(get_raw(c, t + ".norm1.weight", &g1));
+      RET_IF(get_raw(c, t + ".norm1.bias", &b1n));
+      if (wpi->numel != (size_t)C * C || q->numel != (size_t)C * C) return mvd_fail("build_st: unexpected proj_in / to_q shape");
+      RET_IF(dmalloc(c, (void**)&s->rh_stream, rowhead_stream_halfs() * sizeof(half_t)));
+      RhWeights hw;
+      hw.w_pi = wpi->d; hw.ln_g = g1->d; hw.ln_b = b1n->d; hw.w_q = q->d; hw.w_k = k->d; hw.w_v = v->d;
+      RET_IF(rowhead_pack(hw, tmp, s->rh_stream, c->bs));
+    }
   }
   return 0;
 }

@@ -446,6 +446,227 @@ __global__ void rowchain_pack_kernel(const RcWeights w, const RcLayout L, const 
   *(h8*)(out + gid * 8) = o;
 }
 
+
+// ---------------------------------------------------------------------------------------------------- row head
+// proj_in -> t0, LayerNorm1, q | k | v in one launch (rowchain.h).  Same ring, same transposed products; the q|k|v product
+// runs in groups of three 32-feature row blocks whose results are converted, transposed through a wave-private scratch and stored
+// while the next group multiplies (the stores are issued right behind a half-body boundary: the boundary's vmcnt(8) also
+// waits for stores, so they get a whole half-body to be acknowledged).
+constexpr int RH_SCR_LD = 104;                           // halfs per scratch row (96 + pad: 208 bytes, 16-byte aligned)
+constexpr int RH_SCR_WAVE = 32 * RH_SCR_LD * 2;          // 6656 bytes per wave (>= EPI_WAVE_BYTES: the t0 store uses it too)
+constexpr int RH_LDS_BYTES = RC_RING_BYTES + 4 * RH_SCR_WAVE;
+static_assert(RH_SCR_WAVE >= EPI_WAVE_BYTES, "scratch");
+
+__global__ __launch_bounds__(256) void rowhead_kernel(const RowHead p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = RH_C, F = RH_F, KC = RH_KC, K1 = RH_K1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, pl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  const long pix = m0 + pl;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.stream), (short)0, 0xFFFFFFFEu, 0x00020000);
+  const unsigned voff = (unsigned)(wave * 8 * 1024 + lane * 16);
+  auto dma_piece = [&](int jg, int s4, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(smem + ((s4 * 32 + wave * 8 + i) << 10)), 16, voff + (i << 10), jg << 15, 0,
+                                             0);
+  };
+  constexpr int HB0 = RH_PAD / 32;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(HB0 + j, (HB0 + j) & 3, i);
+
+  f32x16 acc[F];
+  h8 X[K1];
+  {
+    const half_t* ar = p.n0 + pix * p.ld_n0 + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) X[kk] = *(const h8*)(ar + 16 * kk);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b = *(const float4*)(p.b_pi + 4 * h + 32 * f + 8 * j);
+        acc[f][4 * j] = b.x; acc[f][4 * j + 1] = b.y; acc[f][4 * j + 2] = b.z; acc[f][4 * j + 3] = b.w;
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(HB0 + 3, (HB0 + 3) & 3, i);
+
+  auto rd = [&](int slot) -> h8 { return *(const h8*)(smem + (slot << 10) + lane * 16); };
+  // stream position of the i-th used fragment of region R (0: proj_in, 1: one loop iteration = two groups)
+  auto qrel = [](int R, int i) { return R == 0 ? (i < RH_PI ? RH_PAD + i : RH_PRO + (i - RH_PI)) : i; };
+  h8 w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = rd(qrel(0, k) & 127);
+  int hb_base = 0;
+  // as rowchain_kernel's step; used = false: the position exists in the stream (the 64th of a group) but carries no MFMA
+  auto step = [&](int R, int i, const h8& b, f32x16& c, bool used) {
+    const int q = qrel(R, i);
+    const bool bnd = i == 0 ? R != 0 : q / 32 != qrel(R, i - 1) / 32;
+    if (bnd) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if ((q & 31) < 8 && !(R == 0 && q / 32 == HB0)) dma_piece(hb_base + q / 32 + 3, (q / 32 + 3) & 3, q & 31);
+    const int wi = (i + (R == 0 ? 0 : RH_PI)) & 3;
+    const h8 a = w[wi];
+    w[wi] = rd(qrel(R, i + 4) & 127);
+    if (used) c = MVD_MFMA_32x32x16(a, b, c, 0, 0, 0);
+  };
+
+  // ---- proj_in: t0^T = W n0^T + b
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+    for (int f = 0; f < F; ++f) step(0, kk * F + f, X[kk], acc[f], true);
+
+  // ---- t0 -> memory (the residual of the block's second half): 32 x 32 blocks through the scratch, 128-byte row segments
+  float* sc = (float*)(smem + RC_RING_BYTES + wave * RH_SCR_WAVE);
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(float4*)(sc + pl * EPI_LD + 8 * j + 4 * h) = make_float4(acc[f][4 * j], acc[f][4 * j + 1], acc[f][4 * j + 2], acc[f][4 * j + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int cq = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int fr = (lane >> 3) + 8 * i;
+      *(float4*)(p.t0 + (long)(m0 + fr) * p.ld_t0 + 32 * f + cq) = *(const float4*)(sc + fr * EPI_LD + cq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- LayerNorm1 (gain and shift live in the packed q|k|v weights)
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[f][r];
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / (float)C);
+    float v = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc[f][r] - mean;
+        v += d * d;
+      }
+    v += __shfl_xor(v, 32);
+    const float rstd = rsqrtf(v * (1.0f / (float)C) + 1e-5f);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) X[2 * f + g][e] = (half_t)((acc[f][8 * g + e] - mean) * rstd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) X[KC][e] = (half_t)((h == 0 && e < 2) ? 1.0f : 0.0f);
+  }
+
+  // ---- q | k | v in ten groups of three row blocks; the result of group g leaves while group g + 1 multiplies
+  half_t* hs = (half_t*)(smem + RC_RING_BYTES + wave * RH_SCR_WAVE);  // [32 rows][RH_SCR_LD]
+  f32x16 rA[3], rB[3];
+  auto zero = [](f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  };
+  // store work of one finished group, in items: 0..11 convert + scratch write of (row block j = k / 4, register quad k % 4), 12..17
+  // one 16-byte piece each from the scratch to memory
+  auto store_items = [&](int k0, int k1, const f32x16 (&r)[3], int g) {
+#pragma unroll
+    for (int k = k0; k < k1; ++k) {
+      if (k < 12) {
+        const int j = k >> 2, qd = k & 3;
+        h4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (half_t)r[j][4 * qd + e];
+        *(h4*)(hs + pl * RH_SCR_LD + 32 * j + 8 * qd + 4 * h) = v;
+      } else if (k < 18) {
+        const int id = lane + 64 * (k - 12), row = id / 12, col = id - row * 12;
+        *(h8*)(p.qkv + (long)(m0 + row) * p.ld_qkv + 96 * g + 8 * col) = *(const h8*)(hs + row * RH_SCR_LD + 8 * col);
+      }
+    }
+  };
+  auto group = [&](int ibase, f32x16 (&cur)[3], const f32x16 (&prev)[3], int gprev, bool has_prev) {
+    zero(cur[0]);
+    zero(cur[1]);
+    zero(cur[2]);
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      if (m < 63) step(1, ibase + m, X[m / 3], cur[m % 3], true);
+      else step(1, ibase + m, X[0], cur[0], false);
+      // the previous group's 18 store items: conversions and scratch writes over the first slots, the memory stores right
+      // behind the next half-body boundary (slot 32 of a group) so that they are acknowledged before the one after it
+      if (has_prev) {
+        if (m < 12) store_items(m, m + 1, prev, gprev);
+        if (m >= 33 && m < 39) store_items(12 + (m - 33), 12 + (m - 33) + 1, prev, gprev);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int it = 0; it < RH_NG / 2; ++it) {
+    hb_base = RH_PRO / 32 + it * 4;
+    group(0, rA, rB, 2 * it - 1, it > 0);
+    group(64, rB, rA, 2 * it, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_items(0, 18, rB, RH_NG - 1);
+#endif
+}
+
+__global__ void rowhead_bias_fold_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                         const float* __restrict__ ln_b, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= 3 * RH_C) return;
+  const float* w = (r < RH_C ? wq : (r < 2 * RH_C ? wk : wv)) + (long)(r % RH_C) * RH_C;
+  double s = 0.0;
+  for (int c = 0; c < RH_C; ++c) s += (double)w[c] * (double)ln_b[c];
+  out[r] = (float)s;
+}
+
+__global__ void rowhead_pack_kernel(const RhWeights w, const float* __restrict__ bf, half_t* __restrict__ out) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)RH_NT_ALLOC * 64) return;
+  const int q = (int)(gid >> 6), l = (int)(gid & 63), h = l >> 5, r32 = l & 31;
+  constexpr int C = RH_C, F = RH_F, KC = RH_KC;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (q >= RH_PAD && q < RH_PRO) {  // proj_in, natural k order
+    const int r = q - RH_PAD, kk = r / F, f = r % F;
+    for (int e = 0; e < 8; ++e) v[e] = w.w_pi[(long)(32 * f + r32) * C + 16 * kk + 8 * h + e];
+  } else if (q >= RH_PRO && q < RH_NT) {
+    const int g = (q - RH_PRO) / RH_BODY, r = (q - RH_PRO) % RH_BODY;
+    if (r < 63) {
+      const int kk = r / 3, j = r % 3;
+      const int row = 32 * (3 * g + j) + r32;  // row of the stacked q | k | v matrix
+      const float* src = (row < C ? w.w_q : (row < 2 * C ? w.w_k : w.w_v)) + (long)(row % C) * C;
+      if (kk < KC) {
+        for (int e = 0; e < 8; ++e) {
+          const int c = rc_perm(kk, h, e);
+          v[e] = src[c] * w.ln_g[c];
+        }
+      } else if (h == 0) {
+        const float b = bf[row];
+        const half_t hi = (half_t)b;
+        v[0] = (float)hi;
+        v[1] = b - (float)hi;
+      }
+    }
+  }
+  h8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+  *(h8*)(out + gid * 8) = o;
+}
+
 template <int C, bool AO, bool PO>
 int launch_rc(const RowChain& p, hipStream_t s) {
   static bool attr_done[MVD_MAX_DEVICES] = {false};
@@ -479,6 +700,29 @@ int launch_rc_any(const RowChain& p, int C, int ao, int po, hipStream_t s) {
 }
 
 }  // namespace
+
+size_t rowhead_stream_halfs() { return (size_t)RH_NT_ALLOC * 512; }
+
+int rowhead_pack(const RhWeights& w, float* tmp, half_t* stream, hipStream_t s) {
+  hipLaunchKernelGGL(rowhead_bias_fold_kernel, dim3(cdiv(3 * RH_C, 128)), dim3(128), 0, s, w.w_q, w.w_k, w.w_v, w.ln_b, tmp);
+  const long n = (long)RH_NT_ALLOC * 64;
+  hipLaunchKernelGGL(rowhead_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, tmp, stream);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_rowhead(const RowHead& p, hipStream_t s) {
+  if (p.rows <= 0 || p.rows % 128 || (p.ld_n0 & 7) || (p.ld_t0 & 3) || (p.ld_qkv & 7)) return mvd_fail("rowhead: rows % 128 and 16-byte aligned row strides");
+  static bool attr_done[MVD_MAX_DEVICES] = {false};
+  bool& attr_set = attr_done[mvd_current_device()];
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)rowhead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RH_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rowhead_kernel, dim3(p.rows / 128), dim3(256), RH_LDS_BYTES, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 bool rowchain_takes(int C, int rows, int T) { return rc_supported_c(C) && rows > 0 && rows % 128 == 0 && T % 32 == 0; }
 

@@ -77,6 +77,37 @@ struct RowChain {
   int out_split;        // !po: 0, or C -> [hi | lo | hi] rows of 3C halfs (extended-precision consumer, IGemm::out_split)
 };
 
+// ---- "row head" (k_rowchain.hip: rowhead_kernel): the row-local FRONT of the block, behind the GroupNorm and in front of the attention,
+//   t0 = proj_in(n0) + b   ->   LayerNorm1   ->   q | k | v = to_q / to_k / to_v (no bias)        modules/attention.py:325-332, 266, 186-190
+// Stream (C = 320 only): 56 unused | proj_in (20 k steps x 10 row blocks, natural k: its B operand is the fp16 GroupNorm output read
+// from memory) | 10 groups of 64: (21 k steps x 3 row blocks of the stacked, LayerNorm-folded q|k|v matrix, the 21st step carrying
+// W beta as fp16 hi + lo) + one unused position | 96 of slack
+constexpr int RH_C = 320, RH_F = 10, RH_KC = 20, RH_K1 = 21, RH_PRO = 256, RH_PI = 200, RH_PAD = RH_PRO - RH_PI, RH_NG = 10, RH_BODY = 64,
+              RH_NT = RH_PRO + RH_NG * RH_BODY, RH_NT_ALLOC = RH_NT + 96;
+struct RhWeights {
+  const float* w_pi;   // [C][C]   proj_in.weight (1x1 conv)
+  const float* ln_g;   // [C]      norm1.weight
+  const float* ln_b;   // [C]      norm1.bias
+  const float* w_q;    // [C][C]   attn1.to_q.weight
+  const float* w_k;    // [C][C]
+  const float* w_v;    // [C][C]
+};
+struct RowHead {
+  const half_t* stream;
+  int rows;
+  const half_t* n0;     // GroupNorm output fp16 [rows][ld_n0]
+  int ld_n0;
+  const float* b_pi;    // proj_in bias [C]
+  float* t0;            // fp32 [rows][ld_t0]: the residual the to_out projection adds later
+  int ld_t0;
+  half_t* qkv;          // fp16 [rows][ld_qkv], columns q | k | v
+  int ld_qkv;
+};
+size_t rowhead_stream_halfs();
+// tmp: 3C floats of scratch (the folded q|k|v bias)
+int rowhead_pack(const RhWeights& w, float* tmp, half_t* stream, hipStream_t s);
+int launch_rowhead(const RowHead& p, hipStream_t s);
+
 bool rowchain_takes(int C, int rows, int T);
 size_t rowchain_stream_halfs(int C, int ao, int po);
 // tmp: 8C floats of scratch (the folded FF1 bias)

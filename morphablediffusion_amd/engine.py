@@ -666,6 +666,19 @@ class Engine:
                                         L.ptr(res_), L.ptr(out), flags, int(iters), C.byref(ms), _stream()))
         return (out, ms.value) if iters > 0 else out
 
+    def op_st_head(self, n0, w_pi, b_pi, ln_g, ln_b, w_q, w_k, w_v, iters=0):
+        """Row-head kernel (csrc/k_rowchain.hip) through the C ABI: proj_in -> t0, LayerNorm1, q | k | v.  Returns (t0, qkv[, ms])."""
+        dev = self.device
+        n0 = _f32(n0, dev)
+        rows, Cc = n0.shape
+        keep = [_f32(t, dev) for t in (w_pi, b_pi, ln_g, ln_b, w_q, w_k, w_v)]
+        t0 = torch.empty(rows, Cc, device=dev)
+        qkv = torch.empty(rows, 3 * Cc, device=dev)
+        ms = C.c_float(0)
+        L.check(self.lib.mvd_op_st_head(self._ctx, rows, L.ptr(n0), *[L.ptr(t) for t in keep], L.ptr(t0), L.ptr(qkv), int(iters),
+                                        C.byref(ms), _stream()))
+        return (t0, qkv, ms.value) if iters > 0 else (t0, qkv)
+
     def op_attention(self, q, k, v, heads):
         dev = self.device
         q, k, v = _f32(q, dev), _f32(k, dev), _f32(v, dev)

@@ -266,3 +266,36 @@ def test_conv3x_impulse(eng):
     x[0, 5, 7, 9] = 1.0
     x[0, 63, 0, 15] = 2.0
     close(eng.op_conv(x, w), F.conv2d(x, w, padding=1), "conv3x impulse", rel=1e-6, mx=1e-6)
+
+
+# ---- row-head kernel (k_rowchain.hip): proj_in -> t0, LayerNorm1, q | k | v in one launch
+@pytest.mark.parametrize("rows", [128, 1024, 4096])
+def test_st_head_rowhead(eng, rows):
+    C = 320
+    g = torch.Generator().manual_seed(77 + rows)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    n0, w_pi, b_pi = r(rows, C), r(C, C, sc=C ** -0.5), 0.3 * r(C)
+    ln_g, ln_b = 1.0 + 0.2 * r(C), 0.2 * r(C)
+    wq, wk, wv = (r(C, C, sc=C ** -0.5) for _ in range(3))
+    t0, qkv = eng.op_st_head(n0, w_pi, b_pi, ln_g, ln_b, wq, wk, wv)
+    t0_ref = n0.half().double() @ w_pi.double().t() + b_pi.double()
+    l1 = F.layer_norm(t0_ref, (C,), ln_g.double(), ln_b.double(), 1e-5)
+    qkv_ref = l1 @ torch.cat([wq, wk, wv]).double().t()
+    close(t0, t0_ref.float(), f"st_head t0 rows={rows}")
+    close(qkv, qkv_ref.float(), f"st_head qkv rows={rows}")
+
+
+def test_st_head_rowhead_asymmetric(eng):
+    """A permutation as proj_in and distinct q / k / v row patterns: a swapped row block or k permutation shows as O(1) error."""
+    C, rows = 320, 256
+    n0 = (torch.arange(rows * C, dtype=torch.float32).reshape(rows, C) % 97 - 48) / 32.0
+    w_pi = torch.eye(C).roll(5, 0)
+    wq = torch.eye(C).roll(1, 1) * 0.5
+    wk = torch.diag(torch.linspace(0.5, 1.5, C))
+    wv = torch.eye(C).flip(0)
+    ln_g, ln_b = torch.linspace(0.8, 1.2, C), torch.linspace(-0.1, 0.1, C)
+    t0, qkv = eng.op_st_head(n0, w_pi, torch.zeros(C), ln_g, ln_b, wq, wk, wv)
+    t0_ref = n0.double() @ w_pi.double().t()
+    l1 = F.layer_norm(t0_ref, (C,), ln_g.double(), ln_b.double(), 1e-5)
+    close(t0, t0_ref.float(), "st_head asym t0", rel=1e-6, mx=1e-6)
+    close(qkv, (l1 @ torch.cat([wq, wk, wv]).double().t()).float(), "st_head asym qkv")

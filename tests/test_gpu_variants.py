@@ -26,6 +26,7 @@ VARIANTS = {
     "scalar_layernorm_f32_bn128": {"MVD_LN_SCALAR": "1", "MVD_IGEMM_F32_BN128": "1"},
     # the row-chain kernel (k_rowchain.hip: transformer tail in one launch) at a batch where the default is the layered GEMMs,
     # together with the halo kernel of rounds 1-4 in place of conv3x (k_conv3x.hip) for the 3x3 convolutions
+    # (the row-head kernel -- proj_in, LayerNorm1, q|k|v in one launch -- rides on the same switch)
     "rowchain_at_every_batch_halo_conv": {"MVD_ROWCHAIN_MIN_ROWS": "0", "MVD_NO_CONV3X": "1"},
 }
 

@@ -7,7 +7,7 @@ import collections, csv, json, re, sys
 
 steps = float(sys.argv[4]) if len(sys.argv) > 4 else 5.0
 json_out = sys.argv[5] if len(sys.argv) > 5 else None  # {family: HBM-side bytes per launch}: what bench.py reports as roofline.traffic
-PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel|conv3x_kernel)<[^>]*>|rowchain_kernel|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv|target_encoder"
+PAT = r"(gemm_dma_kernel|conv3_dma_kernel|igemm_kernel|conv3x_kernel)<[^>]*>|rowhead_kernel|rowchain_kernel|attn_kernel|depth_attn|gn_|layernorm|splitk_reduce|sparse_conv|target_encoder"
 
 
 def fam_of(name):

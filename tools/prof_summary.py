@@ -40,7 +40,7 @@ def family(name):
     m = re.search(r"conv3x_kernelILi(\d+)E", name) or re.search(r"conv3x_kernel<\s*(\d+)", name)
     if m:  # mangled or demangled; the engine books conv3x_kernel<NF> for both tile geometries
         return f"conv3x_kernel<{m.group(1)}>"
-    for key, fam in (("rowchain_kernel", "rowchain_kernel"), ("splitk_reduce", "splitk_reduce_kernel"), ("gn_", "group_norm"), ("layernorm", "layernorm"),
+    for key, fam in (("rowhead_kernel", "rowhead_kernel"), ("rowchain_kernel", "rowchain_kernel"), ("splitk_reduce", "splitk_reduce_kernel"), ("gn_", "group_norm"), ("layernorm", "layernorm"),
                      ("depth_attn", "depth_attn_kernel"), ("attn_kernel", "attn_kernel")):
         if key in name:
             return fam
