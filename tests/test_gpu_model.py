@@ -125,6 +125,21 @@ def test_unet_blocks_small_vs_golden():
         e.unet_block("input_blocks.1.0", h64)  # a ResBlock without its timesteps
 
 
+def test_unet_blocks_small_vs_golden_through_the_rowchain_kernel():
+    """The same block fixtures with the row-chain kernel forced at every batch (MVD_ROWCHAIN_MIN_ROWS=0, read once per process,
+    hence the subprocess): the transformer blocks st32 / st16 / st8 then take rowchain_kernel<64 | 128 | 256, 1, 1> -- the
+    reference's own block outputs pin the kernel's LayerNorm folding, k permutation and residual plumbing at three widths."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-k", "test_unet_blocks_small_vs_golden and not rowchain"],
+                       cwd=root, env=dict(os.environ, MVD_ROWCHAIN_MIN_ROWS="0"), capture_output=True, text=True, timeout=900)
+    for line in r.stdout.splitlines():
+        if "st32" in line or "st16" in line or "st8" in line:
+            print("[rowchain forced]", line)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:]
+
+
 def test_unet_full_vs_golden():
     from morphablediffusion_amd.model import DepthWiseAttention
     cfg = gi.FULL_UNET
