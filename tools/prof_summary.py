@@ -47,7 +47,7 @@ def family(name):
     return None
 
 
-skip = ("pack_weight", "fold_", "copyBuffer", "permute_geglu", "relu_beta", "f32_to_f16_kernel", "fill_pattern", "at::native",
+skip = ("conv3x_pack", "rowchain_pack", "rowhead_pack", "bias_fold", "pack_weight", "fold_", "copyBuffer", "permute_geglu", "relu_beta", "f32_to_f16_kernel", "fill_pattern", "at::native",
         "pack_upconv", "fillBuffer")
 fam_t, fam_n, other, tot, calls = {}, {}, [], 0.0, 0
 for name, n, t in rows_from(path):
