@@ -364,7 +364,7 @@ int mvd_op_layer_norm_bwd(mvd_ctx* ctx, const float* x, const float* dy, int row
  *   out = t3 @ w_po^T + b_po + resid                  (flags & 2; otherwise out = fp16(t3)) ldm/modules/attention.py:333-336
  * on fp32 operands in the reference's layouts (w1 [8C][C] value rows then gate rows, w2 [C][4C]); rows % 128 == 0, T (rows per
  * sample) % 32 == 0, C in {64, 128, 256, 320}.  flags & 4 (without 2): the fp16 result is written as [hi | lo | hi] rows and
- * returned as hi + lo.  iters > 0: the launch is repeated and *ms_out receives the mean milliseconds per launch. */
+ * returned as hi + lo; flags & 8 (with 2): proj_out in extended precision.  iters > 0: the launch is repeated and *ms_out receives the mean milliseconds per launch. */
 int mvd_op_st_tail(mvd_ctx* ctx, int C, int rows, int T, const float* ao, const float* xin, const float* rowbias,
                    const float* w_ao, const float* b_ao, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w_po, const float* b_po, const float* resid, float* out,
@@ -372,8 +372,9 @@ int mvd_op_st_tail(mvd_ctx* ctx, int C, int rows, int T, const float* ao, const 
 /* Row-head kernel test / timing hook (csrc/k_rowchain.hip: rowhead_kernel), the row-local front of a SpatialTransformer block in ONE
  * launch, C = 320:  t0 = n0 @ w_pi^T + b_pi (fp32 out; n0 = the GroupNorm output, rounded to fp16 as in the engine);
  * qkv = LayerNorm(t0; ln_g, ln_b) @ [w_q; w_k; w_v]^T (fp16 in the engine, returned as fp32 [rows][3C]).
- * ldm/modules/attention.py:325-332, 266, 186-190.  rows % 128 == 0. */
-int mvd_op_st_head(mvd_ctx* ctx, int rows, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g,
+ * ldm/modules/attention.py:325-332, 266, 186-190.  rows % 128 == 0.  xp != 0: proj_in in extended precision (fp16 hi + lo parts of
+ * both operands, three products) -- n0 is then NOT rounded to fp16 first. */
+int mvd_op_st_head(mvd_ctx* ctx, int rows, int xp, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g,
                    const float* ln_b, const float* w_q, const float* w_k, const float* w_v, float* t0_out, float* qkv_out,
                    int iters, float* ms_out, void* stream);
 /* time of the dominant kernel, for bench.py: runs the 3x3 conv implicit GEMM `iters` times on stream and

@@ -1378,7 +1378,7 @@ int mvd_op_st_tail(mvd_ctx* c, int C, int rows, int T, const float* ao, const fl
   if (!c) return mvd_fail("null context");
   hipStream_t s = S(stream);
   WsScope ws_scope(c);
-  const int has_ao = flags & 1, has_po = (flags & 2) ? 1 : 0, split = (flags & 4) && !has_po;
+  const int has_ao = flags & 1, has_po = (flags & 2) ? ((flags & 8) ? 2 : 1) : 0, split = (flags & 4) && !has_po;
   if (!rowchain_takes(C, rows, T)) return mvd_fail("op_st_tail: shape not supported by the row-chain kernel");
   const size_t n = (size_t)rows * C;
   half_t* stream_w = ws_alloc<half_t>(c, rowchain_stream_halfs(C, has_ao, has_po));
@@ -1423,7 +1423,7 @@ int mvd_op_st_tail(mvd_ctx* c, int C, int rows, int T, const float* ao, const fl
 }
 
 // The row-head kernel (k_rowchain.hip: proj_in -> t0, LayerNorm1, q | k | v) on fp32 operands in the reference's layouts, C = 320.
-int mvd_op_st_head(mvd_ctx* c, int rows, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g, const float* ln_b,
+int mvd_op_st_head(mvd_ctx* c, int rows, int xp, const float* n0, const float* w_pi, const float* b_pi, const float* ln_g, const float* ln_b,
                    const float* w_q, const float* w_k, const float* w_v, float* t0_out, float* qkv_out, int iters, float* ms_out,
                    void* stream) {
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
@@ -1432,24 +1432,25 @@ int mvd_op_st_head(mvd_ctx* c, int rows, const float* n0, const float* w_pi, con
   WsScope ws_scope(c);
   const int C = RH_C;
   const size_t n = (size_t)rows * C;
-  half_t* stream_w = ws_alloc<half_t>(c, rowhead_stream_halfs());
+  half_t* stream_w = ws_alloc<half_t>(c, rowhead_stream_halfs(xp));
   float* tmp = ws_alloc<float>(c, (size_t)3 * C);
-  half_t* n0h = ws_alloc<half_t>(c, n);
+  half_t* n0h = ws_alloc<half_t>(c, n * (xp ? 3 : 1));
   half_t* qkvh = ws_alloc<half_t>(c, 3 * n);
   WS_CHECK(stream_w && tmp && n0h && qkvh);
   RhWeights w;
   w.w_pi = w_pi; w.ln_g = ln_g; w.ln_b = ln_b; w.w_q = w_q; w.w_k = w_k; w.w_v = w_v;
-  RET_IF(rowhead_pack(w, tmp, stream_w, s));
-  RET_IF(launch_f32_to_f16(n0, n0h, n, s));
+  RET_IF(rowhead_pack(w, xp, tmp, stream_w, s));
+  if (xp) RET_IF(launch_rows_f32_to_f16_split(n0, C, rows, C, n0h, s));  // [hi | lo | hi] rows, as the GroupNorm's split mode writes
+  else RET_IF(launch_f32_to_f16(n0, n0h, n, s));
   RowHead p;
-  p.stream = stream_w; p.rows = rows; p.n0 = n0h; p.ld_n0 = C; p.b_pi = b_pi; p.t0 = t0_out; p.ld_t0 = C; p.qkv = qkvh; p.ld_qkv = 3 * C;
-  RET_IF(launch_rowhead(p, s));
+  p.stream = stream_w; p.rows = rows; p.n0 = n0h; p.ld_n0 = xp ? 3 * C : C; p.b_pi = b_pi; p.t0 = t0_out; p.ld_t0 = C; p.qkv = qkvh; p.ld_qkv = 3 * C;
+  RET_IF(launch_rowhead(p, xp, s));
   if (iters > 0) {
     hipEvent_t e0, e1;
     HIP_CHECK_RET(hipEventCreate(&e0));
     HIP_CHECK_RET(hipEventCreate(&e1));
     HIP_CHECK_RET(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) RET_IF(launch_rowhead(p, s));
+    for (int i = 0; i < iters; ++i) RET_IF(launch_rowhead(p, xp, s));
     HIP_CHECK_RET(hipEventRecord(e1, s));
     HIP_CHECK_RET(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -68,6 +68,7 @@ struct STW {
   // (null when the width is not one of its instantiated forms)
   half_t* rc_stream = nullptr;
   half_t* rh_stream = nullptr;  // ... and proj_in | LayerNorm1-folded q|k|v for the row-head kernel (C = 320)
+  int rc_po = 1, rh_xp = 0;     // forms the streams were packed for: proj_out plain (1) / extended precision (2); proj_in likewise
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;

@@ -566,7 +566,8 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   static const bool no_rc = getenv("MVD_NO_ROWCHAIN") != nullptr;
   static const int rc_min_rows = getenv("MVD_ROWCHAIN_MIN_ROWS") ? atoi(getenv("MVD_ROWCHAIN_MIN_ROWS")) : 16384;
   const bool rc = !no_rc && !f.train && !sv && t.rc_stream && rows >= rc_min_rows && rowchain_takes(C, rows, T) && !(in.ld & 3) && !(out.ld & 3);
-  const bool rc_po = rc && !t.proj_out.xp;
+  static const bool no_xpf = getenv("MVD_NO_XP_FUSE") != nullptr;  // A/B: extended-precision proj_in / proj_out as separate GEMMs
+  const bool rc_po = rc && t.rc_po == (t.proj_out.xp ? 2 : 1) && !(no_xpf && t.proj_out.xp);  // the stream was packed for this precision form of proj_out
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C * wi);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);
@@ -584,14 +585,14 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
     RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
   static const bool no_rh = getenv("MVD_NO_ROWHEAD") != nullptr;
-  if (rc && !no_rh && t.rh_stream && !t.proj_in.xp) {
+  if (rc && !no_rh && t.rh_stream && t.rh_xp == (t.proj_in.xp ? 1 : 0) && !(no_xpf && t.proj_in.xp)) {
     // row-head kernel: proj_in -> t0, LayerNorm1 and the q | k | v projection in one launch (k_rowchain.hip)
     RowHead hp;
-    hp.stream = t.rh_stream; hp.rows = rows; hp.n0 = n0; hp.ld_n0 = C; hp.b_pi = t.proj_in.bias; hp.t0 = t0; hp.ld_t0 = C;
+    hp.stream = t.rh_stream; hp.rows = rows; hp.n0 = n0; hp.ld_n0 = C * wi; hp.b_pi = t.proj_in.bias; hp.t0 = t0; hp.ld_t0 = C;
     hp.qkv = qkv; hp.ld_qkv = 3 * C;
     const double cc = (double)C * C;
     ProbeScope ps(c, f.s, "rowhead_kernel", 2.0 * rows * cc * 4.0, (double)rows * C * (2.0 + 4.0 + 6.0) + cc * 2.0 * 4.0);
-    RET_IF(launch_rowhead(hp, f.s));
+    RET_IF(launch_rowhead(hp, t.rh_xp, f.s));
   } else {
   g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
@@ -623,7 +624,7 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
       const double cc = (double)C * C, fl = 2.0 * rows * cc * (rc_po ? 14.0 : 13.0);
       const double by = (double)rows * C * (2.0 + 4.0 + (rc_po ? 8.0 : 2.0 * wo)) + cc * 2.0 * (rc_po ? 14.0 : 13.0);
       ProbeScope ps(c, f.s, "rowchain_kernel", fl, by);
-      RET_IF(launch_rowchain(rp, C, 1, rc_po ? 1 : 0, f.s));
+      RET_IF(launch_rowchain(rp, C, 1, rc_po ? t.rc_po : 0, f.s));
     }
     if (rc_po) {
       if (out_carry) {

@@ -162,39 +162,6 @@ int build_st(mvd_ctx* c, const std::string& p, int C, STW* s) {
   RET_IF(pack_conv(c, t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", false, false, &s->attn_out));
   RET_IF(pack_conv(c, t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", false, true, &s->ff1));
   RET_IF(pack_conv(c, t + ".ff.net.2.weight", t + ".ff.net.2.bias", false, false, &s->ff2));
-  if (rc_supported_c(C) && !c->train_mode) {  // (inference contexts: a training context re-packs every step and never takes this path)
-    // the row-local tail of the block as one fragment stream (k_rowchain.hip); proj_out included: the
-                            // form without it reads the same stream and stops in front of that section
-    engine_build_rotate(c);
-    RawTensor *wao, *g3, *b3, *w1, *b1, *w2, *b2, *wpo;
-    RET_IF(get_raw(c, t + ".attn1.to_out.0.weight", &wao));
-    RET_IF(get_raw(c, t + ".norm3.weight", &g3));
-    RET_IF(get_raw(c, t + ".norm3.bias", &b3));
-    RET_IF(get_raw(c, t + ".ff.net.0.proj.weight", &w1));
-    RET_IF(get_raw(c, t + ".ff.net.0.proj.bias", &b1));
-    RET_IF(get_raw(c, t + ".ff.net.2.weight", &w2));
-    RET_IF(get_raw(c, t + ".ff.net.2.bias", &b2));
-    RET_IF(get_raw(c, p + ".proj_out.weight", &wpo));
-    if (wao->numel != (size_t)C * C || w1->numel != (size_t)8 * C * C || w2->numel != (size_t)4 * C * C || wpo->numel != (size_t)C * C)
-      return mvd_fail("build_st: transformer block weights do not have the row-chain kernel's shapes");
-    float* tmp = nullptr;
-    RET_IF(dmalloc(c, (void**)&tmp, (size_t)8 * C * sizeof(float)));
-    RET_IF(dmalloc(c, (void**)&s->rc_stream, rowchain_stream_halfs(C, 1, 1) * sizeof(half_t)));
-    RcWeights rw;
-    rw.w_ao = wao->d; rw.ln_g = g3->d; rw.ln_b = b3->d; rw.w1 = w1->d; rw.b1 = b1->d; rw.w2 = w2->d; rw.b2 = b2->d; rw.w_po = wpo->d;
-    RET_IF(rowchain_pack(rw, C, 1, 1, tmp, s->rc_stream, c->bs));
-    if (C == RH_C) {  // the front of the block (proj_in, LayerNorm1, q | k | v) for the row-head kernel
-      RawTensor *wpi, *g1, *b1n;
-      RET_IF(get_raw(c, p + ".proj_in.weight", &wpi));
-      RET_IF(get_raw(c, t + ".norm1.weight", &g1));
-      RET_IF(get_raw(c, t + ".norm1.bias", &b1n));
-      if (wpi->numel != (size_t)C * C || q->numel != (size_t)C * C) return mvd_fail("build_st: unexpected proj_in / to_q shape");
-      RET_IF(dmalloc(c, (void**)&s->rh_stream, rowhead_stream_halfs() * sizeof(half_t)));
-      RhWeights hw;
-      hw.w_pi = wpi->d; hw.ln_g = g1->d; hw.ln_b = b1n->d; hw.w_q = q->d; hw.w_k = k->d; hw.w_v = v->d;
-      RET_IF(rowhead_pack(hw, tmp, s->rh_stream, c->bs));
-    }
-  }
   return 0;
 }
 
@@ -630,6 +597,55 @@ int build_conv3x_streams(mvd_ctx* c) {
   return engine_build_join(c);
 }
 
+// The row-local halves of the transformer blocks as fragment streams (k_rowchain.hip): to_out | LayerNorm3-folded FF1 | FF2 |
+// proj_out for the row-chain kernel, proj_in | LayerNorm1-folded q|k|v for the row head (C = 320).  Packed AFTER the
+// extended-precision policy: a block whose proj_in / proj_out run in extended precision gets the (hi, lo) forms of those sections.
+// Inference contexts only (a training context re-packs every step and never takes these paths).
+int build_rowchain_streams(mvd_ctx* c) {
+  if (!c->has_unet || c->train_mode) return 0;
+  for (STW& st : c->st) {
+    const int C = st.C;
+    if (!rc_supported_c(C)) continue;
+    const std::string& p = st.key;
+    const std::string t = p + ".transformer_blocks.0";
+    engine_build_rotate(c);
+    RawTensor *wao, *g3, *b3, *w1, *b1, *w2, *b2, *wpo;
+    RET_IF(get_raw(c, t + ".attn1.to_out.0.weight", &wao));
+    RET_IF(get_raw(c, t + ".norm3.weight", &g3));
+    RET_IF(get_raw(c, t + ".norm3.bias", &b3));
+    RET_IF(get_raw(c, t + ".ff.net.0.proj.weight", &w1));
+    RET_IF(get_raw(c, t + ".ff.net.0.proj.bias", &b1));
+    RET_IF(get_raw(c, t + ".ff.net.2.weight", &w2));
+    RET_IF(get_raw(c, t + ".ff.net.2.bias", &b2));
+    RET_IF(get_raw(c, p + ".proj_out.weight", &wpo));
+    if (wao->numel != (size_t)C * C || w1->numel != (size_t)8 * C * C || w2->numel != (size_t)4 * C * C || wpo->numel != (size_t)C * C)
+      return mvd_fail("build_rowchain_streams: transformer block weights do not have the row-chain kernel's shapes");
+    st.rc_po = st.proj_out.xp ? 2 : 1;
+    float* tmp = nullptr;
+    RET_IF(dmalloc(c, (void**)&tmp, (size_t)8 * C * sizeof(float)));
+    RET_IF(dmalloc(c, (void**)&st.rc_stream, rowchain_stream_halfs(C, 1, st.rc_po) * sizeof(half_t)));
+    RcWeights rw;
+    rw.w_ao = wao->d; rw.ln_g = g3->d; rw.ln_b = b3->d; rw.w1 = w1->d; rw.b1 = b1->d; rw.w2 = w2->d; rw.b2 = b2->d; rw.w_po = wpo->d;
+    RET_IF(rowchain_pack(rw, C, 1, st.rc_po, tmp, st.rc_stream, c->bs));
+    if (C == RH_C) {
+      RawTensor *wpi, *g1, *b1n, *q, *k, *v;
+      RET_IF(get_raw(c, p + ".proj_in.weight", &wpi));
+      RET_IF(get_raw(c, t + ".norm1.weight", &g1));
+      RET_IF(get_raw(c, t + ".norm1.bias", &b1n));
+      RET_IF(get_raw(c, t + ".attn1.to_q.weight", &q));
+      RET_IF(get_raw(c, t + ".attn1.to_k.weight", &k));
+      RET_IF(get_raw(c, t + ".attn1.to_v.weight", &v));
+      if (wpi->numel != (size_t)C * C || q->numel != (size_t)C * C) return mvd_fail("build_rowchain_streams: unexpected proj_in / to_q shape");
+      st.rh_xp = st.proj_in.xp ? 1 : 0;
+      RET_IF(dmalloc(c, (void**)&st.rh_stream, rowhead_stream_halfs(st.rh_xp) * sizeof(half_t)));
+      RhWeights hw;
+      hw.w_pi = wpi->d; hw.ln_g = g1->d; hw.ln_b = b1n->d; hw.w_q = q->d; hw.w_k = k->d; hw.w_v = v->d;
+      RET_IF(rowhead_pack(hw, st.rh_xp, tmp, st.rh_stream, c->bs));
+    }
+  }
+  return engine_build_join(c);
+}
+
 int apply_xp_policy(mvd_ctx* c) {
   const int lvl = getenv("MVD_XP") ? atoi(getenv("MVD_XP")) : c->precision_level;
   if (lvl <= 0 || !c->has_unet) return 0;
@@ -901,6 +917,7 @@ int build_hot_sections(mvd_ctx* c) {
     RET_IF(apply_xp_policy(c));
     RET_IF(engine_build_join(c));  // the adjoint packs and the conv3x streams read the forward packs
     RET_IF(build_conv3x_streams(c));
+    RET_IF(build_rowchain_streams(c));
     if (c->train_mode) RET_IF(engine_build_dgrad(c));
   }
   if (c->has_step) RET_IF(build_step_section(c));

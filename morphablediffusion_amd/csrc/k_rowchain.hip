@@ -65,7 +65,7 @@ __host__ __device__ constexpr int rc_qrel(const RcLayout& L, int R, int i) {
   return i;
 }
 
-template <int C, bool AO, bool PO>
+template <int C, bool AO, int PO>
 __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr RcLayout L = rc_layout(C, AO, PO);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   // one MFMA: the i-th used fragment of region R times B fragment b, into c.  Ring protocol: entering half-body j the wave waits
   // until at most its 8 newest DMA instructions are in flight (half-body j + 1 has landed, j + 2 may still fly) and meets the
   // others; the first 8 steps of half-body j each issue one piece of half-body j + 3 into the quarter j - 1 just left.
-  auto step = [&](int R, int i, const h8& b, f32x16& c) {
+  auto step = [&](int R, int i, const h8& b, f32x16& c, const h8* b2 = nullptr) {
     const int q = rc_qrel(L, R, i);
     const bool bnd = i == 0 ? R != 0 : q / 32 != rc_qrel(L, R, i - 1) / 32;
 #ifndef RC_EXP_NOBAR
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
 #endif
     if (R != 2 || i + RC_PF < nreal) w[wi] = rd(rc_qrel(L, R, i + RC_PF) & 127);
     c = MVD_MFMA_32x32x16(a, b, c, 0, 0, 0);
+    if (b2) c = MVD_MFMA_32x32x16(a, *b2, c, 0, 0, 0);  // the same weight fragment against a second activation fragment
   };
 
   // ---- to_out projection onto t0 + biases -> t2 (order (k step, row block): consecutive MFMAs hit different accumulators)
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
   hb_base = (L.PRO + L.LOOP) / 32;
 #pragma unroll
   for (int f = 0; f < F; ++f) step(2, f, X[KC], acc[f]);
-  if constexpr (PO) {
+  if constexpr (PO == 1) {
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -319,6 +320,30 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
 #pragma unroll
       for (int f = 0; f < F; ++f) step(2, F + kk * F + f, X[kk], acc[f]);
   }
+  if constexpr (PO == 2) {
+    // extended precision (ConvW::xp: a_hi w_hi + a_lo w_hi + a_hi w_lo): t3 splits into fp16 hi + lo in registers, every weight
+    // position holds a hi and a lo fragment; the hi fragment multiplies both activation parts
+    h8 XL[KC];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const half_t hi = (half_t)acc[f][8 * g + e];
+          X[2 * f + g][e] = hi;
+          XL[2 * f + g][e] = (half_t)(acc[f][8 * g + e] - (float)hi);
+        }
+#pragma unroll
+    for (int f = 0; f < F; ++f) zero(acc[f]);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        step(2, F + 2 * (kk * F + f), X[kk], acc[f], &XL[kk]);
+        step(2, F + 2 * (kk * F + f) + 1, X[kk], acc[f]);
+      }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's run-ahead loads (into the slack of the stream)
 
   // ---- store: each 32 x 32 block through a wave-private LDS scratch -> full 128-byte row segments
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
     for (int j = 0; j < 4; ++j)
       *(float4*)(sc + pl * EPI_LD + 8 * j + 4 * h) = make_float4(acc[f][4 * j], acc[f][4 * j + 1], acc[f][4 * j + 2], acc[f][4 * j + 3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (PO) {
+    if constexpr (PO != 0) {
       const int cq = (lane & 7) * 4, n = 32 * f + cq;
       const float4 bp = *(const float4*)(p.b_po + n);
 #pragma unroll
@@ -434,10 +459,17 @@ __global__ void rowchain_pack_kernel(const RcWeights w, const RcLayout L, const 
     int r = q - L.PRO - L.LOOP;
     if (r < F) {
       bias_pair(w.b2[32 * r + r32]);
-    } else if (L.po && r < F + KC * F) {
+    } else if (L.po == 1 && r < F + KC * F) {
       r -= F;
       const int kk = r / F, f = r % F;
       for (int e = 0; e < 8; ++e) v[e] = w.w_po[(long)(32 * f + r32) * C + rc_perm(kk, h, e)];
+    } else if (L.po == 2 && r < F + 2 * KC * F) {  // (hi, lo) per (k step, row block)
+      r -= F;
+      const int lo = r & 1, kk = (r >> 1) / F, f = (r >> 1) % F;
+      for (int e = 0; e < 8; ++e) {
+        const float x = w.w_po[(long)(32 * f + r32) * C + rc_perm(kk, h, e)];
+        v[e] = lo ? x - (float)(half_t)x : x;
+      }
     }
   }
   h8 o;
@@ -457,9 +489,11 @@ constexpr int RH_SCR_WAVE = 32 * RH_SCR_LD * 2;          // 6656 bytes per wave 
 constexpr int RH_LDS_BYTES = RC_RING_BYTES + 4 * RH_SCR_WAVE;
 static_assert(RH_SCR_WAVE >= EPI_WAVE_BYTES, "scratch");
 
+template <bool XP>
 __global__ __launch_bounds__(256) void rowhead_kernel(const RowHead p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = RH_C, F = RH_F, KC = RH_KC, K1 = RH_K1;
+  constexpr int RH_PI = rh_pi(XP), RH_PRO = rh_pro(XP), RH_PAD = rh_pad(XP);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, pl = lane & 31;
@@ -480,10 +514,15 @@ __global__ __launch_bounds__(256) void rowhead_kernel(const RowHead p) {
 
   f32x16 acc[F];
   h8 X[K1];
+  [[maybe_unused]] h8 XL[XP ? KC : 1];
   {
     const half_t* ar = p.n0 + pix * p.ld_n0 + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) X[kk] = *(const h8*)(ar + 16 * kk);
+    if constexpr (XP) {  // [hi | lo | hi] rows: the lo part
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) XL[kk] = *(const h8*)(ar + C + 16 * kk);
+    }
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -499,13 +538,16 @@ __global__ __launch_bounds__(256) void rowhead_kernel(const RowHead p) {
 
   auto rd = [&](int slot) -> h8 { return *(const h8*)(smem + (slot << 10) + lane * 16); };
   // stream position of the i-th used fragment of region R (0: proj_in, 1: one loop iteration = two groups)
-  auto qrel = [](int R, int i) { return R == 0 ? (i < RH_PI ? RH_PAD + i : RH_PRO + (i - RH_PI)) : i; };
+  auto qrel = [](int R, int i) {
+    constexpr int PI = rh_pi(XP), PAD = rh_pad(XP), PRO = rh_pro(XP);
+    return R == 0 ? (i < PI ? PAD + i : PRO + (i - PI)) : i;
+  };
   h8 w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = rd(qrel(0, k) & 127);
   int hb_base = 0;
   // as rowchain_kernel's step; used = false: the position exists in the stream (the 64th of a group) but carries no MFMA
-  auto step = [&](int R, int i, const h8& b, f32x16& c, bool used) {
+  auto step = [&](int R, int i, const h8& b, f32x16& c, bool used, const h8* b2 = nullptr) {
     const int q = qrel(R, i);
     const bool bnd = i == 0 ? R != 0 : q / 32 != qrel(R, i - 1) / 32;
     if (bnd) {
@@ -517,13 +559,21 @@ __global__ __launch_bounds__(256) void rowhead_kernel(const RowHead p) {
     const h8 a = w[wi];
     w[wi] = rd(qrel(R, i + 4) & 127);
     if (used) c = MVD_MFMA_32x32x16(a, b, c, 0, 0, 0);
+    if (b2) c = MVD_MFMA_32x32x16(a, *b2, c, 0, 0, 0);
   };
 
-  // ---- proj_in: t0^T = W n0^T + b
+  // ---- proj_in: t0^T = W n0^T + b (extended precision: w_hi (n_hi + n_lo) + w_lo n_hi)
 #pragma unroll
   for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-    for (int f = 0; f < F; ++f) step(0, kk * F + f, X[kk], acc[f], true);
+    for (int f = 0; f < F; ++f) {
+      if constexpr (XP) {
+        step(0, 2 * (kk * F + f), X[kk], acc[f], true, &XL[kk]);
+        step(0, 2 * (kk * F + f) + 1, X[kk], acc[f], true);
+      } else {
+        step(0, kk * F + f, X[kk], acc[f], true);
+      }
+    }
 
   // ---- t0 -> memory (the residual of the block's second half): 32 x 32 blocks through the scratch, 128-byte row segments
   float* sc = (float*)(smem + RC_RING_BYTES + wave * RH_SCR_WAVE);
@@ -633,15 +683,19 @@ __global__ void rowhead_bias_fold_kernel(const float* __restrict__ wq, const flo
   out[r] = (float)s;
 }
 
-__global__ void rowhead_pack_kernel(const RhWeights w, const float* __restrict__ bf, half_t* __restrict__ out) {
+__global__ void rowhead_pack_kernel(const RhWeights w, const int xp, const float* __restrict__ bf, half_t* __restrict__ out) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)RH_NT_ALLOC * 64) return;
+  const int RH_PAD = rh_pad(xp), RH_PRO = rh_pro(xp), RH_NT = rh_nt(xp);
+  if (gid >= (long)rh_nt_alloc(xp) * 64) return;
   const int q = (int)(gid >> 6), l = (int)(gid & 63), h = l >> 5, r32 = l & 31;
   constexpr int C = RH_C, F = RH_F, KC = RH_KC;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (q >= RH_PAD && q < RH_PRO) {  // proj_in, natural k order
-    const int r = q - RH_PAD, kk = r / F, f = r % F;
-    for (int e = 0; e < 8; ++e) v[e] = w.w_pi[(long)(32 * f + r32) * C + 16 * kk + 8 * h + e];
+  if (q >= RH_PAD && q < RH_PRO) {  // proj_in, natural k order; extended precision: (hi, lo) per (k step, row block)
+    const int r0 = q - RH_PAD, lo = xp ? (r0 & 1) : 0, r = xp ? (r0 >> 1) : r0, kk = r / F, f = r % F;
+    for (int e = 0; e < 8; ++e) {
+      const float x = w.w_pi[(long)(32 * f + r32) * C + 16 * kk + 8 * h + e];
+      v[e] = lo ? x - (float)(half_t)x : x;
+    }
   } else if (q >= RH_PRO && q < RH_NT) {
     const int g = (q - RH_PRO) / RH_BODY, r = (q - RH_PRO) % RH_BODY;
     if (r < 63) {
@@ -667,7 +721,7 @@ __global__ void rowhead_pack_kernel(const RhWeights w, const float* __restrict__
   *(h8*)(out + gid * 8) = o;
 }
 
-template <int C, bool AO, bool PO>
+template <int C, bool AO, int PO>
 int launch_rc(const RowChain& p, hipStream_t s) {
   static bool attr_done[MVD_MAX_DEVICES] = {false};
   bool& attr_set = attr_done[mvd_current_device()];
@@ -680,57 +734,65 @@ int launch_rc(const RowChain& p, hipStream_t s) {
   return 0;
 }
 
-// instantiated forms: the engine uses (to_out, proj_out) = (1, 1) and, in front of an extended-precision proj_out, (1, 0);
+// instantiated forms: the engine uses (to_out, proj_out) = (1, 1) and (1, 2) (extended-precision proj_out); (1, 0) writes x + ff(x);
 // (0, 0) is the feed-forward part alone (tests, tools/rowchain_bench.py)
 int launch_rc_any(const RowChain& p, int C, int ao, int po, hipStream_t s) {
-  const int key = C * 4 + (ao ? 2 : 0) + (po ? 1 : 0);
+  const int key = C * 8 + (ao ? 4 : 0) + po;
   switch (key) {
-    case 64 * 4 + 3: return launch_rc<64, true, true>(p, s);
-    case 64 * 4 + 2: return launch_rc<64, true, false>(p, s);
-    case 64 * 4 + 0: return launch_rc<64, false, false>(p, s);
-    case 128 * 4 + 3: return launch_rc<128, true, true>(p, s);
-    case 128 * 4 + 2: return launch_rc<128, true, false>(p, s);
-    case 256 * 4 + 3: return launch_rc<256, true, true>(p, s);
-    case 256 * 4 + 2: return launch_rc<256, true, false>(p, s);
-    case 320 * 4 + 3: return launch_rc<320, true, true>(p, s);
-    case 320 * 4 + 2: return launch_rc<320, true, false>(p, s);
-    case 320 * 4 + 0: return launch_rc<320, false, false>(p, s);
+    case 64 * 8 + 5: return launch_rc<64, true, 1>(p, s);
+    case 64 * 8 + 6: return launch_rc<64, true, 2>(p, s);
+    case 64 * 8 + 4: return launch_rc<64, true, 0>(p, s);
+    case 64 * 8 + 0: return launch_rc<64, false, 0>(p, s);
+    case 128 * 8 + 5: return launch_rc<128, true, 1>(p, s);
+    case 128 * 8 + 4: return launch_rc<128, true, 0>(p, s);
+    case 256 * 8 + 5: return launch_rc<256, true, 1>(p, s);
+    case 256 * 8 + 4: return launch_rc<256, true, 0>(p, s);
+    case 320 * 8 + 5: return launch_rc<320, true, 1>(p, s);
+    case 320 * 8 + 6: return launch_rc<320, true, 2>(p, s);
+    case 320 * 8 + 4: return launch_rc<320, true, 0>(p, s);
+    case 320 * 8 + 0: return launch_rc<320, false, 0>(p, s);
     default: return mvd_fail("rowchain: this (width, to_out, proj_out) form is not instantiated");
   }
 }
 
 }  // namespace
 
-size_t rowhead_stream_halfs() { return (size_t)RH_NT_ALLOC * 512; }
+size_t rowhead_stream_halfs(int xp) { return (size_t)rh_nt_alloc(xp != 0) * 512; }
 
-int rowhead_pack(const RhWeights& w, float* tmp, half_t* stream, hipStream_t s) {
+int rowhead_pack(const RhWeights& w, int xp, float* tmp, half_t* stream, hipStream_t s) {
   hipLaunchKernelGGL(rowhead_bias_fold_kernel, dim3(cdiv(3 * RH_C, 128)), dim3(128), 0, s, w.w_q, w.w_k, w.w_v, w.ln_b, tmp);
-  const long n = (long)RH_NT_ALLOC * 64;
-  hipLaunchKernelGGL(rowhead_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, tmp, stream);
+  const long n = (long)rh_nt_alloc(xp != 0) * 64;
+  hipLaunchKernelGGL(rowhead_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, xp ? 1 : 0, tmp, stream);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int launch_rowhead(const RowHead& p, hipStream_t s) {
-  if (p.rows <= 0 || p.rows % 128 || (p.ld_n0 & 7) || (p.ld_t0 & 3) || (p.ld_qkv & 7)) return mvd_fail("rowhead: rows % 128 and 16-byte aligned row strides");
+template <bool XP>
+static int launch_rh(const RowHead& p, hipStream_t s) {
   static bool attr_done[MVD_MAX_DEVICES] = {false};
   bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)rowhead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RH_LDS_BYTES));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)rowhead_kernel<XP>, hipFuncAttributeMaxDynamicSharedMemorySize, RH_LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(rowhead_kernel, dim3(p.rows / 128), dim3(256), RH_LDS_BYTES, s, p);
+  hipLaunchKernelGGL(rowhead_kernel<XP>, dim3(p.rows / 128), dim3(256), RH_LDS_BYTES, s, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+
+int launch_rowhead(const RowHead& p, int xp, hipStream_t s) {
+  if (p.rows <= 0 || p.rows % 128 || (p.ld_n0 & 7) || (p.ld_t0 & 3) || (p.ld_qkv & 7) || (xp && p.ld_n0 < 3 * RH_C))
+    return mvd_fail("rowhead: rows % 128, 16-byte aligned row strides ([hi | lo | hi] input rows for the extended-precision form)");
+  return xp ? launch_rh<true>(p, s) : launch_rh<false>(p, s);
 }
 
 bool rowchain_takes(int C, int rows, int T) { return rc_supported_c(C) && rows > 0 && rows % 128 == 0 && T % 32 == 0; }
 
-size_t rowchain_stream_halfs(int C, int ao, int po) { return (size_t)rc_layout(C, ao != 0, po != 0).NT_ALLOC * 512; }
+size_t rowchain_stream_halfs(int C, int ao, int po) { return (size_t)rc_layout(C, ao != 0, po).NT_ALLOC * 512; }
 
 int rowchain_pack(const RcWeights& w, int C, int ao, int po, float* tmp, half_t* stream, hipStream_t s) {
   if (!rc_supported_c(C)) return mvd_fail("rowchain_pack: unsupported width");
-  const RcLayout L = rc_layout(C, ao != 0, po != 0);
+  const RcLayout L = rc_layout(C, ao != 0, po);
   hipLaunchKernelGGL(rowchain_bias_fold_kernel, dim3(cdiv(8 * C, 128)), dim3(128), 0, s, w.w1, w.b1, w.ln_b, 8 * C, C, tmp);
   const long n = (long)L.NT_ALLOC * 64;
   hipLaunchKernelGGL(rowchain_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, L, tmp, stream);

@@ -24,9 +24,10 @@ struct RcLayout {
 //   [0, PRO)              : PRO_PAD unused | to_out (AO_N = KC * F, order (k-step, row block)) | FF1 of unit 0 | FF1 of unit 1
 //   PRO + u * BODY, u < NU: FF1 of unit u + 2 (G1; zeros past the last unit) | FF2 of unit u (G2, order (half, row block)) | pad
 //                           (a three-stage pipeline: FF1 of unit u + 2 and FF2 of unit u run beside the GEGLU of unit u + 1)
-//   PRO + LOOP            : FF2 bias (F) | proj_out (KC * F) | pad to a half-body     -- TAIL
+//   PRO + LOOP            : FF2 bias (F) | proj_out (KC * F; extended precision: (hi, lo) per (k step, row block)) | pad to a half-body -- TAIL
 //   + 96 positions of slack: the ring runs three half-bodies ahead without a bounds test
-constexpr RcLayout rc_layout(int C, bool ao, bool po) {
+// po: 0 = no proj_out, 1 = proj_out, 2 = proj_out in extended precision (weights as hi and lo fragments, three products)
+constexpr RcLayout rc_layout(int C, bool ao, int po) {
   RcLayout L{};
   L.C = C; L.ao = ao; L.po = po;
   L.F = C / 32; L.KC = C / 16; L.K1 = L.KC + 1; L.NU = C / 8;
@@ -38,7 +39,7 @@ constexpr RcLayout rc_layout(int C, bool ao, bool po) {
   L.PRO = (L.PRO_REAL + 127) / 128 * 128;
   L.PRO_PAD = L.PRO - L.PRO_REAL;
   L.LOOP = L.NU * L.BODY;
-  L.TAIL_REAL = L.F + (po ? L.KC * L.F : 0);
+  L.TAIL_REAL = L.F + (po == 1 ? L.KC * L.F : (po == 2 ? 2 * L.KC * L.F : 0));
   L.TAIL = (L.TAIL_REAL + 31) / 32 * 32;
   L.NT = L.PRO + L.LOOP + L.TAIL;
   L.NT_ALLOC = L.NT + 96;
@@ -82,8 +83,14 @@ struct RowChain {
 // Stream (C = 320 only): 56 unused | proj_in (20 k steps x 10 row blocks, natural k: its B operand is the fp16 GroupNorm output read
 // from memory) | 10 groups of 64: (21 k steps x 3 row blocks of the stacked, LayerNorm-folded q|k|v matrix, the 21st step carrying
 // W beta as fp16 hi + lo) + one unused position | 96 of slack
-constexpr int RH_C = 320, RH_F = 10, RH_KC = 20, RH_K1 = 21, RH_PRO = 256, RH_PI = 200, RH_PAD = RH_PRO - RH_PI, RH_NG = 10, RH_BODY = 64,
-              RH_NT = RH_PRO + RH_NG * RH_BODY, RH_NT_ALLOC = RH_NT + 96;
+// With an extended-precision proj_in (xp) its section holds (hi, lo) weight fragments per (k step, row block) -- 400 fragments behind
+// 112 unused -- and the GroupNorm output arrives as [hi | lo | hi] rows of 3C halfs.
+constexpr int RH_C = 320, RH_F = 10, RH_KC = 20, RH_K1 = 21, RH_NG = 10, RH_BODY = 64;
+constexpr int rh_pi(bool xp) { return xp ? 400 : 200; }
+constexpr int rh_pro(bool xp) { return xp ? 512 : 256; }
+constexpr int rh_pad(bool xp) { return rh_pro(xp) - rh_pi(xp); }
+constexpr int rh_nt(bool xp) { return rh_pro(xp) + RH_NG * RH_BODY; }
+constexpr int rh_nt_alloc(bool xp) { return rh_nt(xp) + 96; }
 struct RhWeights {
   const float* w_pi;   // [C][C]   proj_in.weight (1x1 conv)
   const float* ln_g;   // [C]      norm1.weight
@@ -95,7 +102,7 @@ struct RhWeights {
 struct RowHead {
   const half_t* stream;
   int rows;
-  const half_t* n0;     // GroupNorm output fp16 [rows][ld_n0]
+  const half_t* n0;     // GroupNorm output fp16 [rows][ld_n0] ([hi | lo | hi], ld_n0 >= 3C, for the extended-precision form)
   int ld_n0;
   const float* b_pi;    // proj_in bias [C]
   float* t0;            // fp32 [rows][ld_t0]: the residual the to_out projection adds later
@@ -103,10 +110,10 @@ struct RowHead {
   half_t* qkv;          // fp16 [rows][ld_qkv], columns q | k | v
   int ld_qkv;
 };
-size_t rowhead_stream_halfs();
+size_t rowhead_stream_halfs(int xp);
 // tmp: 3C floats of scratch (the folded q|k|v bias)
-int rowhead_pack(const RhWeights& w, float* tmp, half_t* stream, hipStream_t s);
-int launch_rowhead(const RowHead& p, hipStream_t s);
+int rowhead_pack(const RhWeights& w, int xp, float* tmp, half_t* stream, hipStream_t s);
+int launch_rowhead(const RowHead& p, int xp, hipStream_t s);
 
 bool rowchain_takes(int C, int rows, int T);
 size_t rowchain_stream_halfs(int C, int ao, int po);

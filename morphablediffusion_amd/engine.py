@@ -650,7 +650,7 @@ class Engine:
         return out
 
     def op_st_tail(self, xin, ln_g, ln_b, w1, b1, w2, b2, ao=None, w_ao=None, b_ao=None, rowbias=None, T=None, w_po=None, b_po=None,
-                   resid=None, split=False, iters=0):
+                   resid=None, split=False, iters=0, xp_out=False):
         """Row-chain kernel (csrc/k_rowchain.hip) through the C ABI: [to_out + t0] -> LayerNorm3 -> FF -> + t2 [-> proj_out + x_in].
         Returns the fp32 result (and the mean milliseconds per launch when iters > 0)."""
         dev = self.device
@@ -658,7 +658,7 @@ class Engine:
         rows, Cc = xin.shape
         keep = [_f32(t, dev) if t is not None else None for t in (ao, rowbias, w_ao, b_ao, ln_g, ln_b, w1, b1, w2, b2, w_po, b_po, resid)]
         ao_, rb_, wao_, bao_, g_, b_, w1_, b1_, w2_, b2_, wpo_, bpo_, res_ = keep
-        flags = (1 if ao is not None else 0) | (2 if w_po is not None else 0) | (4 if split else 0)
+        flags = (1 if ao is not None else 0) | (2 if w_po is not None else 0) | (4 if split else 0) | (8 if xp_out else 0)
         out = torch.empty_like(xin)
         ms = C.c_float(0)
         L.check(self.lib.mvd_op_st_tail(self._ctx, Cc, rows, int(T or rows), L.ptr(ao_), L.ptr(xin), L.ptr(rb_), L.ptr(wao_), L.ptr(bao_),
@@ -666,7 +666,7 @@ class Engine:
                                         L.ptr(res_), L.ptr(out), flags, int(iters), C.byref(ms), _stream()))
         return (out, ms.value) if iters > 0 else out
 
-    def op_st_head(self, n0, w_pi, b_pi, ln_g, ln_b, w_q, w_k, w_v, iters=0):
+    def op_st_head(self, n0, w_pi, b_pi, ln_g, ln_b, w_q, w_k, w_v, iters=0, xp=False):
         """Row-head kernel (csrc/k_rowchain.hip) through the C ABI: proj_in -> t0, LayerNorm1, q | k | v.  Returns (t0, qkv[, ms])."""
         dev = self.device
         n0 = _f32(n0, dev)
@@ -675,7 +675,7 @@ class Engine:
         t0 = torch.empty(rows, Cc, device=dev)
         qkv = torch.empty(rows, 3 * Cc, device=dev)
         ms = C.c_float(0)
-        L.check(self.lib.mvd_op_st_head(self._ctx, rows, L.ptr(n0), *[L.ptr(t) for t in keep], L.ptr(t0), L.ptr(qkv), int(iters),
+        L.check(self.lib.mvd_op_st_head(self._ctx, rows, 1 if xp else 0, L.ptr(n0), *[L.ptr(t) for t in keep], L.ptr(t0), L.ptr(qkv), int(iters),
                                         C.byref(ms), _stream()))
         return (t0, qkv, ms.value) if iters > 0 else (t0, qkv)
 

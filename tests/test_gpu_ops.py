@@ -299,3 +299,22 @@ def test_st_head_rowhead_asymmetric(eng):
     l1 = F.layer_norm(t0_ref, (C,), ln_g.double(), ln_b.double(), 1e-5)
     close(t0, t0_ref.float(), "st_head asym t0", rel=1e-6, mx=1e-6)
     close(qkv, (l1 @ torch.cat([wq, wk, wv]).double().t()).float(), "st_head asym qkv")
+
+
+def test_rowchain_and_rowhead_extended_precision_forms(eng):
+    """The forms the last output block takes at the default precision level: proj_out / proj_in with both operands split into
+    fp16 hi + lo parts inside the kernels (three products).  Against fp64 the extended-precision projection must beat the fp16
+    floor of the plain form by a wide margin on t0 (one GEMM deep), and the whole tail must stay within the bound."""
+    C, rows, T = 320, 2048, 1024
+    d = _st_tail_case(C, rows, T, True, True, seed=9)
+    close(eng.op_st_tail(xp_out=True, **d), _st_tail_ref(d), "st_tail xp proj_out")
+    g = torch.Generator().manual_seed(91)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    n0, w_pi, b_pi = r(rows, C), r(C, C, sc=C ** -0.5), 0.3 * r(C)
+    ln_g, ln_b = 1.0 + 0.2 * r(C), 0.2 * r(C)
+    wq, wk, wv = (r(C, C, sc=C ** -0.5) for _ in range(3))
+    t0, qkv = eng.op_st_head(n0, w_pi, b_pi, ln_g, ln_b, wq, wk, wv, xp=True)
+    t0_ref = n0.double() @ w_pi.double().t() + b_pi.double()   # n0 is NOT rounded to fp16 in this form
+    l1 = F.layer_norm(t0_ref, (C,), ln_g.double(), ln_b.double(), 1e-5)
+    close(t0, t0_ref.float(), "st_head xp t0", rel=5e-6, mx=5e-5)
+    close(qkv, (l1 @ torch.cat([wq, wk, wv]).double().t()).float(), "st_head xp qkv")

@@ -22,10 +22,17 @@ for ao, po in ((False, False), (True, False), (True, True)):
     fl = 2.0 * rows * C * C * (12 + (1 if ao else 0) + (1 if po else 0))
     print(f"rowchain C={C} rows={rows} ao={int(ao)} po={int(po)}: {ms * 1e3:8.1f} us  {fl / ms * 1e-9:7.0f} TFLOP/s  "
           f"({fl / ms * 1e-9 / 2500:.3f} of peak)  relL2(first 4096 rows)={err:.2e}", flush=True)
+d = _st_tail_case(C, rows, T, True, True)
+got, ms = e.op_st_tail(iters=iters, xp_out=True, **d)
+print(f"rowchain C={C} rows={rows} ao=1 po=2 (extended-precision proj_out): {ms * 1e3:8.1f} us", flush=True)
 g = torch.Generator().manual_seed(3)
 r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
 t0, qkv, ms = e.op_st_head(r(rows, C), r(C, C, sc=C ** -0.5), r(C), 1 + 0.1 * r(C), 0.1 * r(C), r(C, C, sc=C ** -0.5), r(C, C, sc=C ** -0.5),
                            r(C, C, sc=C ** -0.5), iters=iters)
 fl = 2.0 * rows * C * C * 4
 print(f"rowhead  C={C} rows={rows} (proj_in, LayerNorm1, q|k|v): {ms * 1e3:8.1f} us  {fl / ms * 1e-9:7.0f} TFLOP/s", flush=True)
+g = torch.Generator().manual_seed(3)
+t0, qkv, ms = e.op_st_head(r(rows, C), r(C, C, sc=C ** -0.5), r(C), 1 + 0.1 * r(C), 0.1 * r(C), r(C, C, sc=C ** -0.5), r(C, C, sc=C ** -0.5),
+                           r(C, C, sc=C ** -0.5), iters=iters, xp=True)
+print(f"rowhead  C={C} rows={rows} extended-precision proj_in: {ms * 1e3:8.1f} us", flush=True)
 e.close()
