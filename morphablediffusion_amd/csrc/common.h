@@ -34,6 +34,23 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 // A is a channels-last activation tensor [B, PZ, PY, PX, lda] (fp16 or fp32) gathered through a
 // tap table; W is fp16 [ntaps][N][Cin] (k-contiguous per output channel).
 // ------------------------------------------------------------------------------------------------
+// Which operand the workgroups of one XCD (one L2) should share.  Workgroup ids are dealt round-robin to the 8 XCDs and the kernels
+// remap them so that an XCD owns a CONTIGUOUS range of tiles; walking that range row-tile-major makes an XCD re-use the activations
+// of a few row tiles against every column group (all 8 L2s fill with all the weights), column-major the other way round.  Returns
+// true when the column-major walk fills the L2s with clearly fewer bytes (deep levels: weights >> activations).
+inline bool xcd_prefers_cols(int tiles_m, int groups_n, double a_bytes, double w_bytes) {
+  const int nwg = tiles_m * groups_n, q = (nwg + 7) / 8;
+  if (nwg < 16) return false;
+  auto span = [](int q_, int inner, int outer) {  // distinct outer indices under q_ consecutive ids (inner index fastest), on average
+    const double n = q_ % inner == 0 ? q_ / inner : (q_ - 1) / (double)inner + 1.0;
+    return n < outer ? n : (double)outer;
+  };
+  const double at = a_bytes / tiles_m, wt = w_bytes / groups_n;
+  const double row = at * span(q, groups_n, tiles_m) + wt * (q < groups_n ? q : groups_n);
+  const double col = wt * span(q, tiles_m, groups_n) + at * (q < tiles_m ? q : tiles_m);
+  return col < 0.8 * row;
+}
+
 struct IGemm {
   const void* a;        // activation base (channel offset already applied)
   int a_f32;            // 1: fp32 source (converted to fp16 while staging), 0: fp16 source
@@ -82,6 +99,7 @@ struct IGemm {
   int act;              // ACT_SILU applied last (non-GEGLU path)
   // split-K
   int nch;              // dense GEMM kernel: column tiles walked by one workgroup
+  int xcd_cols;         // set by the launchers (xcd_prefers_cols): an XCD's workgroups share COLUMN tiles (weights) instead of row tiles
   // parity-batched launch (LDS-DMA kernel only): blockIdx.z picks one of npar tap tables / output offsets, so the
   // 8 parity classes of a transposed conv (or the 4 of a folded upsample conv) are ONE launch
   int npar;

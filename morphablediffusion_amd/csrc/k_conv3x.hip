@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  if (g.xcd_cols) {  // deep levels (weights >> activations): an XCD keeps one column tile's stream against every pixel tile
+    tn = bid / tiles_m;
+    tm = bid - tn * tiles_m;
+  }
   const int n0 = tn * 32 * NF;
   // block gb of the tile -> sample, top-left pixel
   auto block_pos = [&](int gb, int& b, int& y0, int& x0) {
@@ -313,7 +317,11 @@ int launch_cx(const IGemm& g, const half_t* stream, hipStream_t s) {
   }
   constexpr int NI = CxGeo<IW>::NI;
   dim3 grid(cdiv(g.B * (g.Y / IW) * (g.X / IW), NI) * (g.N / (32 * NF)), g.splitk > 1 ? g.splitk : 1);
-  hipLaunchKernelGGL((conv3x_kernel<NF, IW>), grid, dim3(256), LDS, s, g, stream);
+  IGemm gl = g;
+  static const bool no_cols = getenv("MVD_NO_XCD_COLS") != nullptr;
+  const int tiles_m = cdiv(g.B * (g.Y / IW) * (g.X / IW), NI);
+  gl.xcd_cols = !no_cols && xcd_prefers_cols(tiles_m, g.N / (32 * NF), (double)tiles_m * CxGeo<IW>::ROWS * g.Cin * 2, 9.0 * g.N * g.Cin * 2);
+  hipLaunchKernelGGL((conv3x_kernel<NF, IW>), grid, dim3(256), LDS, s, gl, stream);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

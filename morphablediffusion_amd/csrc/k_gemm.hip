@@ -91,7 +91,11 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
   // MODE 0: fixed row tile tm, column tiles [tn_beg, tn_end).  WALK: linear tile ids [tn_beg, tn_end), id = tm*tiles_n + tn
-  const int tm = WALK ? 0 : bid / groups_n, gn = WALK ? 0 : bid - tm * groups_n;
+  int tm = WALK ? 0 : bid / groups_n, gn = WALK ? 0 : bid - tm * groups_n;
+  if (!WALK && g.xcd_cols) {  // column-group-major walk: an XCD keeps a few column groups' weights against every row tile
+    gn = bid / tiles_m;
+    tm = bid - gn * tiles_m;
+  }
   int m0 = tm * GBM;
   const int tn_beg = WALK ? bid * nch : gn * nch;
   const int tn_end = WALK ? min(tiles_m * tiles_n, tn_beg + nch) : min(tiles_n, tn_beg + nch);
@@ -493,7 +497,15 @@ int launch_gd(const IGemm& g, int M, hipStream_t s) {
   const int nch = g.nch > 0 ? g.nch : 1;
   const int gx = MODE ? cdiv(cdiv(M, GBM) * cdiv(g.N, BN), nch) : cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch);
   dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
-  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE, PLAIN>), grid, dim3(GNT), LDS, s, g);
+  IGemm gl = g;
+  gl.xcd_cols = 0;
+  if (MODE == 0) {
+    static const bool no_cols = getenv("MVD_NO_XCD_COLS") != nullptr;
+    const int ntaps = g.npar > 0 ? g.par_ntaps[0] : g.ntaps;
+    gl.xcd_cols = !no_cols && xcd_prefers_cols(cdiv(M, GBM), cdiv(cdiv(g.N, BN), nch),
+                                               (double)g.B * g.PZ * g.PY * g.PX * g.Cin * (g.a_f32 ? 4 : 2), (double)ntaps * g.N * g.Cin * 2);
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE, PLAIN>), grid, dim3(GNT), LDS, s, gl);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

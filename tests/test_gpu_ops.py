@@ -54,6 +54,8 @@ def test_linear_asymmetric_identity(eng):
     (1024, 64, 384, False, 0, False), (700, 328, 200, True, 0, False), (4096, 320, 320, True, 0, False),
     (2048, 1280, 1280, False, 0, False), (2048, 1280, 640, True, 3, False), (513, 72, 964, False, 0, False),
     (8192, 320, 2560, False, 0, True), (1000, 128, 512, False, 0, True), (16384, 64, 2048, True, 0, False),
+    # weights >> activations: the launcher walks these column-group-major (xcd_prefers_cols, common.h) -- ragged M, GEGLU, split-K
+    (2048, 1280, 3840, True, 0, False), (1300, 1280, 5120, False, 0, True), (512, 2560, 2560, True, 4, False),
 ])
 def test_linear_dense(eng, M, K, N, res, sk, geglu):
     a, w, b = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
@@ -245,6 +247,8 @@ def test_st_tail_rowchain_identity_weights(eng):
     (1, 960, 32, 32, 320, False, 0), (2, 64, 48, 16, 256, True, 0), (1, 256, 16, 16, 160, False, 4),
     # 8 x 8 images: four per workgroup tile (a partial last tile at B = 6), split over the channel chunks
     (8, 128, 8, 8, 160, True, 0), (6, 192, 8, 8, 320, True, 0), (4, 1280, 8, 8, 1280, True, 4), (1, 64, 8, 8, 128, False, 0),
+    # 8 pixel tiles x 8 column tiles of 3.7 MB of weights each: walked column-tile-major (xcd_prefers_cols)
+    (32, 1280, 8, 8, 1280, True, 0), (30, 640, 8, 8, 1280, False, 2),
 ])
 def test_conv3x(eng, B, Cin, H, W, Cout, res, sk):
     x = rnd(B, Cin, H, W)
