@@ -19,7 +19,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
                                                    const half_t* __restrict__ v, int ldv,
                                                    half_t* __restrict__ out, int ldo, int T, int heads, float scale,
-                                                   int Tstride) {
+                                                   int Tstride, int xcd_remap) {
   constexpr int KS = (D + 15) / 16;        // k-steps of the QK^T product
   constexpr int DK = KS * 16;
   constexpr int DVF = (D + 31) / 32;       // 32-row fragments of O^T
@@ -31,9 +31,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, lq = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // One-dimensional grid [sample][head][query tile], query tile fastest.  The hardware deals consecutive workgroups to the 8 XCDs
+  // round-robin: with T = 1024 (8 query tiles) every tile of a (sample, head) pair landed on a different XCD and each of the 8
+  // L2s fetched that head's K and V for itself (counter traffic 3.2 x the algorithmic bytes).  The bijective remap below gives
+  // an XCD a contiguous range of the linear index, so the query tiles of one head share one L2 (same arithmetic per workgroup:
+  // bit-identical results).
+  int bid = blockIdx.x;
+  if (xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int nqt = (T + 127) >> 7;
+  const int bh = bid / nqt, qt = bid - bh * nqt;
+  const int b = bh / heads, head = bh - b * heads;
   const int C = heads * D;
-  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
+  const int q_row = qt * 128 + wave * 32 + lq;
   const long tok0 = (long)b * Tstride;  // samples are Tstride rows apart (Tstride > T: padded token axis)
 
   // Q fragment (B operand): lane (q, hh) holds d = ks*16 + hh*8 .. +8
@@ -293,10 +305,12 @@ int launch_attention(const half_t* qk, int ldqk, const half_t* v, int ldv, half_
   if (Tstride <= 0) Tstride = T;
   if (Tstride < T || ldqk % 8 || ldv % 8 || ldo % 4 || d % 8 || ((uintptr_t)qk & 15) || ((uintptr_t)v & 15))
     return mvd_fail("attention: alignment (row strides and d multiples of 8, 16-byte aligned operands)");
-  dim3 grid(cdiv(T, 128), heads, B);
+  if ((long)cdiv(T, 128) * heads * B > 0x7FFFFFFFL) return mvd_fail("attention: grid too large");
+  dim3 grid((unsigned)(cdiv(T, 128) * heads * B));
+  static const int xcd_remap = getenv("MVD_ATTN_NO_XCD") == nullptr;  // A/B switch: the pre-remap workgroup order
   const float scale = 1.4426950408889634f / sqrtf((float)d);  // softmax scale * log2(e): the kernel uses exp2
 #define MVD_ATTN(DD) \
-  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, v, ldv, out, ldo, T, heads, scale, Tstride); break;
+  case DD: hipLaunchKernelGGL(attn_kernel<DD>, grid, dim3(256), 0, s, qk, ldqk, v, ldv, out, ldo, T, heads, scale, Tstride, xcd_remap); break;
   switch (d) {
     MVD_ATTN(8)
     MVD_ATTN(16)

@@ -164,7 +164,10 @@ def test_layer_norm(eng, rows, C):
 
 
 @pytest.mark.parametrize("B,T,heads,d", [(2, 256, 8, 40), (1, 1024, 8, 40), (2, 64, 8, 80), (3, 16, 8, 160), (1, 1024, 8, 8),
-                                         (2, 256, 8, 16), (1, 64, 8, 32), (1, 1024, 2, 160)])
+                                         (2, 256, 8, 16), (1, 64, 8, 32), (1, 1024, 2, 160),
+                                         # workgroup counts that are not multiples of the 8 XCDs (30 and 6: the bijective
+                                         # XCD remap's remainder branch) with a ragged last key / query tile
+                                         (3, 200, 5, 40), (1, 130, 3, 80)])
 def test_attention(eng, B, T, heads, d):
     C = heads * d
     q, k, v = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2), rnd(B, T, C, seed=3)

@@ -502,9 +502,27 @@ def gold_variants(ns):
               radii=(0.18, 0.45, 0.12))
 
 
+def gold_variants_full(ns, which=("n8", "lat64_n1", "smplx_n32")):
+    """The same three BASELINE.json configurations at the FULL UNet width (916.9 M parameters) -- the width their parity was
+    only property-tested at before: configs[1] (N=8, 256^2, 8 views per pass), configs[0] (one view, 64^2 latent, first DDIM
+    step) and configs[4] (SMPL-X-sized mesh, N=32, 512^2 -> 64^2 latents, orthographic, 4 views per pass).  Minutes of fp32 eager
+    PyTorch each on a few cores; the fixtures hold strided samples + checksums (tests/golden_inputs.pack)."""
+    import dataclasses
+    full64 = dataclasses.replace(gi.FULL_UNET, image_size=64)
+    if "n8" in which:
+        gold_step(ns, "step_full_n8.npz", gi.FULL_UNET, 8, "perspective", 10, True, 5023, 8)
+    if "lat64_n1" in which:
+        gold_step(ns, "step_full_lat64_n1.npz", full64, 1, "perspective", 0, False, 5023, 1, image_size=512)
+    if "smplx_n32" in which:
+        gold_step(ns, "step_full_smplx_n32.npz", full64, 32, "orthographic", 30, True, 10475, 4, image_size=512,
+                  radii=(0.18, 0.45, 0.12))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-variants-full", default=None,
+                    help="only the FULL-WIDTH BASELINE config 0/1/4 variants; comma list of n8,lat64_n1,smplx_n32 (or 'all')")
     ap.add_argument("--only-variants", action="store_true", help="only the BASELINE config 0/1/4 variants")
     ap.add_argument("--only-vae", action="store_true", help="only the first-stage decoder goldens")
     ap.add_argument("--only-train", action="store_true", help="only the training-step golden (loss + gradients)")
@@ -525,6 +543,10 @@ def main():
     ns = ref_import.import_reference_full()
     if args.only_variants:
         gold_variants(ns)
+        return
+    if args.only_variants_full:
+        w = args.only_variants_full
+        gold_variants_full(ns, ("n8", "lat64_n1", "smplx_n32") if w == "all" else tuple(w.split(",")))
         return
     if args.only_vae:
         gold_vae(ns)
@@ -553,6 +575,8 @@ def main():
     gold_train(ns)
     gold_cameras()
     gold_variants(ns)
+    if not args.skip_full:
+        gold_variants_full(ns)
     gold_trained(ns, not args.skip_full)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump({k: list(v) for k, v in sorted(hot.items())}, f)
