@@ -16,7 +16,7 @@
 namespace {
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
+__global__ __launch_bounds__(256, (D <= 40 ? 4 : D <= 80 ? 3 : 2)) void attn_kernel(const half_t* __restrict__ qk, int ldqk,
                                                    const half_t* __restrict__ v, int ldv,
                                                    half_t* __restrict__ out, int ldo, int T, int heads, float scale,
                                                    int Tstride, int xcd_remap) {
@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
   constexpr int DVP = DVF * 32;
   constexpr int KLD = DK + 8;              // halfs per K row in LDS
   constexpr int VLD = 64 + 8;              // halfs per V^T row in LDS
+  // d = 8, 16, 40, 80: the last 32-row fragment of O^T has padding rows.  Row D of the V^T image is then all ONES, so row D of
+  // O^T accumulates sum_k P[q][k] -- the softmax denominator comes out of the second MFMA (over exactly the fp16 P the numerator
+  // uses, rescaled with O^T for free) instead of 32 adds + a cross-half exchange per key tile of this VALU-bound kernel.
+  constexpr bool ROWSUM = DVP > D;
+  constexpr int RS_F = D / 32, RS_ROW = D - 32 * RS_F;                                  // fragment and row of the sum
+  constexpr int RS_HH = (RS_ROW >> 2) & 1, RS_R = (RS_ROW & 3) + 4 * (RS_ROW >> 3);    // half-wave and register holding it
   __shared__ __attribute__((aligned(16))) half_t sK[64 * KLD];
   __shared__ __attribute__((aligned(16))) half_t sV[DVP * VLD];
 
@@ -86,15 +92,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
     gv[i] = v + (tok0 + key) * ldv + head * D + ch * 8;
   }
   auto load_tiles = [&](int k0) {
-    const bool full = k0 + 64 <= T;  // wave-uniform
+    if (k0 + 64 <= T) {  // wave-uniform.  Full tile: every live slot is loaded (dead slots are never stored), nothing to clear
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i)
+        if (skey[i] >= 0) {
+          kreg[i] = *(const h8*)gk[i];
+          vreg[i] = *(const h8*)gv[i];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        kreg[i] = (h8)(half_t)0;
+        vreg[i] = (h8)(half_t)0;  // keys >= T must be zeros: their P is 0, but 0 x garbage could be NaN
+        if (skey[i] >= 0 && k0 + skey[i] < T) {
+          kreg[i] = *(const h8*)gk[i];
+          vreg[i] = *(const h8*)gv[i];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      kreg[i] = (h8)(half_t)0;
-      vreg[i] = (h8)(half_t)0;  // keys >= T must be zeros: their P is 0, but 0 x garbage could be NaN
-      if (skey[i] >= 0 && (full || k0 + skey[i] < T)) {
-        kreg[i] = *(const h8*)gk[i];
-        vreg[i] = *(const h8*)gv[i];
-      }
       gk[i] += 64 * (long)ldqk;
       gv[i] += 64 * (long)ldv;
     }
@@ -111,10 +128,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
   };
   // rows D..DVP-1 of the V^T image are padding of the last 32-row fragment, columns D..DK-1 of the K image padding of the last
   // k-step: zeroed once, never rewritten
-  for (int idx = tid; idx < (DVP - D) * 64; idx += 256) sV[(D + idx / 64) * VLD + (idx & 63)] = (half_t)0;
+  for (int idx = tid; idx < (DVP - D) * 64; idx += 256)
+    sV[(D + idx / 64) * VLD + (idx & 63)] = (ROWSUM && idx < 64) ? (half_t)1 : (half_t)0;
   if constexpr (DK > D)
     for (int idx = tid; idx < 64 * (DK - D); idx += 256) sK[(idx / (DK - D)) * KLD + D + idx % (DK - D)] = (half_t)0;
   load_tiles(0);
+  // The Q fragments came from global loads issued before the loop.  Without a use in front of the loop their first use is the
+  // first MFMA INSIDE it, and the compiler's wait-count pass (which merges the loop's entry and back edge) then puts an
+  // `s_waitcnt vmcnt(0)` in front of that MFMA in EVERY iteration -- right behind the loads of the next K / V tile, whose latency
+  // the one-tile-ahead staging exists to hide.  The empty asm consumes the fragments here: the wait lands in front of the loop.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   for (int k0 = 0; k0 < T; k0 += 64) {
     __syncthreads();  // every wave is done reading the previous tile
     store_tiles();
@@ -157,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], scale, -m_new));  // scores carry log2(e)
         s[f][r] = p;
-        psum += p;
+        if constexpr (!ROWSUM) psum += p;
       }
-    psum += __shfl_xor(psum, 32);
+    if constexpr (!ROWSUM) psum += __shfl_xor(psum, 32);
     if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {  // wave-uniform: once the maxima settle nothing is rescaled
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -189,6 +213,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const half_t* __restrict__
     }
   }
 
+  if constexpr (ROWSUM) {  // the denominator sits in register RS_R of fragment RS_F, in the RS_HH half of the wave
+    const float mine = o[RS_F][RS_R], other = __shfl_xor(mine, 32);
+    l_run = hh == RS_HH ? mine : other;
+  }
   if (q_row < T) {
     const float inv = 1.0f / l_run;
     half_t* orow = out + (tok0 + q_row) * ldo + head * D;
