@@ -1,4 +1,4 @@
-# One script regenerates every number DESIGN §5 quotes:  gpurun --timeout 3000 -- 'bash tools/gpu_batch.sh <tag> [tests] [pmc] [train]'
+# One script regenerates every number DESIGN §5 quotes:  gpurun --timeout 3000 -- 'bash tools/gpu_batch.sh <tag> [tests] [pmc] [train] [nocpu]'
 # -> gpurun_out/<tag>/{pytest.log, smoke.log, bench.json, bench_sim8.json, kernel_stats.csv, family_table.txt, layers_step.txt,
 #    pmc_mfma_busy.txt, pmc_hbm_traffic.txt, pmc_traffic.json, bench_train_b8.json, train_kernel_stats.txt}; copy what is to be
 #    judged into profiles/<round>_<tag>_* (pmc_traffic.json -> profiles/pmc_traffic.json is what bench.py's roofline.traffic reads).
@@ -10,7 +10,8 @@ if want tests; then
   (timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "parity|property|precision|passed|failed|Error|error|assert|FAILED|^E " | tail -400) > $O/pytest.log 2>&1
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-timeout 700 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+NC=""; if want nocpu; then NC="--no-cpu-baseline"; fi  # (the CPU-baseline leg is ~6 minutes of host time on the GPU box)
+timeout 700 python bench.py --steps 20 --warmup 3 $NC > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --simulate-gpus 8 > $O/bench_sim8.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof.err
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats.csv; rm -rf $O/prof

@@ -22,16 +22,21 @@ def main():
     for fn, ls in lines.items():
         if flt not in fn:
             continue
-        # innermost loops: label lines tagged "Inner Loop Header"; the loop ends at the last branch back to that label
-        for i, ln in enumerate(ls):
-            m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", ln)
-            if not m:
+        # innermost loops: the header block is tagged "Inner Loop Header", its other blocks "in Loop: Header=<label>"; blocks
+        # the loop rotation placed in front of the header are appended behind it (execution order)
+        blocks, cur = [], None
+        for ln in ls:
+            m = re.match(r"^\.L(BB\d+_\d+):(.*)$", ln)
+            if m:
+                cur = [m.group(1), m.group(2), []]
+                blocks.append(cur)
+            elif cur is not None:
+                cur[2].append(ln)
+        for bi, (lab, tag, _) in enumerate(blocks):
+            if "Inner Loop Header" not in tag:
                 continue
-            lab = m.group(1)
-            end = max((j for j in range(i, len(ls)) if re.search(r"s_cbranch\w*\s+" + re.escape(lab) + r"\b|s_branch\s+" + re.escape(lab) + r"\b", ls[j])), default=None)
-            if end is None:
-                continue
-            body = ls[i:end + 1]
+            mine = lambda b: b[0] == lab or re.search(r"Header=" + lab + r"\b", b[1])
+            body = [l for b in blocks[bi:] if mine(b) for l in b[2]] + [l for b in blocks[:bi] if mine(b) for l in b[2]]
             if not any("v_mfma" in b for b in body):
                 continue
             ev, run = [], 0
