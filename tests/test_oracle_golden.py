@@ -134,14 +134,16 @@ def test_step_and_stages_small(name, projection):
     check(eps, g, "eps")
 
 
-@pytest.mark.parametrize("name,projection", [("step_small_n8.npz", "perspective"), ("step_small_lat64_n1.npz", "perspective")])
+@pytest.mark.parametrize("name,projection", [("step_small_n8.npz", "perspective"), ("step_small_lat64_n1.npz", "perspective"),
+                                             ("step_full_lat64_n1.npz", "perspective")])
 def test_step_config_variants(name, projection):
-    """BASELINE configs 1 and 0 at reduced width (N=8 at 256^2; one view at a 64^2 latent, first DDIM step).
-    The N=32 / SMPL-X-sized variant (config 4) is checked on the GPU only: the oracle needs minutes for it."""
+    """BASELINE configs 1 and 0 at reduced width (N=8 at 256^2; one view at a 64^2 latent, first DDIM step), and config 0 at the
+    FULL UNet width (the reference's own CPU-runnable case).  The full-width N=8 and the N=32 / SMPL-X-sized variants are
+    checked on the GPU only: the oracle needs minutes for them."""
     import dataclasses
     g = load(name)
     N, index, bvn, size = int(g["N"]), int(g["index"]), int(g["bvn"]), int(g["image_size"])
-    ucfg = dataclasses.replace(gi.SMALL_UNET, image_size=size // 8)
+    ucfg = dataclasses.replace(gi.FULL_UNET if name.startswith("step_full") else gi.SMALL_UNET, image_size=size // 8)
     vcfg = VolumeConfig(num_views=N, projection=projection, input_image_size=size)
     W = gi.full_weights(ucfg, vcfg)
     batch = synthetic.make_batch(N, projection, int(g["nverts_in"]), mesh_seed=1, image_size=size,
