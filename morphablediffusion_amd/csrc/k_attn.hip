@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : D <= 80 ? 3 : 2)) void attn_ker
   constexpr int DVF = (D + 31) / 32;       // 32-row fragments of O^T
   constexpr int DVP = DVF * 32;
   constexpr int KLD = DK + 8;              // halfs per K row in LDS
-  constexpr int VLD = 64 + 8;              // halfs per V^T row in LDS
+  // halfs per V^T row in LDS: 68 = 136 B puts the 16 lanes of a ds_read2_b64 group on 16 distinct bank pairs (row pitch 34 dwords
+  // = 2 mod 32) and halves the conflicts of the transposing 2-byte stores (72 = 36 dwords: rows 8 apart shared a bank;
+  // tools/lds_bank_model.py: 912 -> 496 LDS cycles per workgroup and key tile at d = 40)
+  constexpr int VLD = 64 + 4;
   // d = 8, 16, 40, 80: the last 32-row fragment of O^T has padding rows.  Row D of the V^T image is then all ONES, so row D of
   // O^T accumulates sum_k P[q][k] -- the softmax denominator comes out of the second MFMA (over exactly the fp16 P the numerator
   // uses, rescaled with O^T for free) instead of 32 adds + a cross-half exchange per key tile of this VALU-bound kernel.
