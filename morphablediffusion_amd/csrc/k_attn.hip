@@ -25,18 +25,22 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : D <= 80 ? 3 : 2)) void attn_ker
   constexpr int DVF = (D + 31) / 32;       // 32-row fragments of O^T
   constexpr int DVP = DVF * 32;
   constexpr int KLD = DK + 8;              // halfs per K row in LDS
-  // halfs per V^T row in LDS: 68 = 136 B puts the 16 lanes of a ds_read2_b64 group on 16 distinct bank pairs (row pitch 34 dwords
-  // = 2 mod 32) and halves the conflicts of the transposing 2-byte stores (72 = 36 dwords: rows 8 apart shared a bank;
-  // tools/lds_bank_model.py: 912 -> 496 LDS cycles per workgroup and key tile at d = 40)
-  constexpr int VLD = 64 + 4;
-  // d = 8, 16, 40, 80: the last 32-row fragment of O^T has padding rows.  Row D of the V^T image is then all ONES, so row D of
+  // V stays ROW-MAJOR in LDS ([key][d], one 16-byte store per staged chunk) and the V^T fragments of the second MFMA come out of
+  // gfx950's transposing LDS read: in a 16-lane group lane i supplies the 8-byte address of row i / 4, columns 4 (i % 4) .. of a
+  // [4 keys][16 columns] block and receives column i, keys 0 .. 3 (tools/tr_b16_probe.hip) -- two reads give a lane the 8 keys of
+  // its d-column in exactly the order the P^T fragment uses.  Rounds 1-5 built a transposed image with eight 2-byte stores per
+  // chunk instead: bank-conflicted stores (5-way at a 72-half pitch, 3-way at 68) on top of 16 store instructions per thread and
+  // key tile.  Row pitch VLD: half of it = 16 or 48 (mod 64) dwords puts the 4 key rows of a 32-lane group on 4 disjoint
+  // 16-bank ranges (tools/lds_bank_model.py).
+  constexpr int VLD = DVP <= 32 ? 32 : (DVP <= 96 ? 96 : 160);
+  // d = 8, 16, 40, 80: the last 32-row fragment of O^T has padding rows.  Column D of the V image is then all ONES, so row D of
   // O^T accumulates sum_k P[q][k] -- the softmax denominator comes out of the second MFMA (over exactly the fp16 P the numerator
   // uses, rescaled with O^T for free) instead of 32 adds + a cross-half exchange per key tile of this VALU-bound kernel.
   constexpr bool ROWSUM = DVP > D;
   constexpr int RS_F = D / 32, RS_ROW = D - 32 * RS_F;                                  // fragment and row of the sum
   constexpr int RS_HH = (RS_ROW >> 2) & 1, RS_R = (RS_ROW & 3) + 4 * (RS_ROW >> 3);    // half-wave and register holding it
   __shared__ __attribute__((aligned(16))) half_t sK[64 * KLD];
-  __shared__ __attribute__((aligned(16))) half_t sV[DVP * VLD];
+  __shared__ __attribute__((aligned(16))) half_t sV[64 * VLD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, lq = lane & 31;
@@ -124,17 +128,28 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : D <= 80 ? 3 : 2)) void attn_ker
     for (int i = 0; i < NSLOT; ++i) {
       if (skey[i] >= 0) {
         *(h8*)(sK + skey[i] * KLD + sch[i] * 8) = kreg[i];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sV[(sch[i] * 8 + e) * VLD + skey[i]] = vreg[i][e];
+        *(h8*)(sV + skey[i] * VLD + sch[i] * 8) = vreg[i];
       }
     }
   };
-  // rows D..DVP-1 of the V^T image are padding of the last 32-row fragment, columns D..DK-1 of the K image padding of the last
-  // k-step: zeroed once, never rewritten
-  for (int idx = tid; idx < (DVP - D) * 64; idx += 256)
-    sV[(D + idx / 64) * VLD + (idx & 63)] = (ROWSUM && idx < 64) ? (half_t)1 : (half_t)0;
+  // columns D..DVP-1 of the V image are padding of the last 32-row fragment of O^T, columns D..DK-1 of the K image padding of the
+  // last k-step: written once, never rewritten
+  if constexpr (DVP > D) {
+    for (int idx = tid; idx < (DVP - D) * 64; idx += 256) {
+      const int key = idx / (DVP - D), col = D + idx - key * (DVP - D);
+      sV[key * VLD + col] = col == D ? (half_t)1 : (half_t)0;  // (ROWSUM == DVP > D)
+    }
+  }
   if constexpr (DK > D)
     for (int idx = tid; idx < 64 * (DK - D); idx += 256) sK[(idx / (DK - D)) * KLD + D + idx % (DK - D)] = (half_t)0;
+  // this lane's address inside a [4 keys][16 columns] block of the transposing read: lane i of a 16-lane group -> key row i / 4,
+  // columns 4 (i % 4) ..; the group's block: keys 4 hh .., columns 16 ((lane >> 4) & 1) ..
+  const half_t* vbase = sV + (4 * hh + ((lane & 15) >> 2)) * VLD + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+  auto tr_read = [](const half_t* p) -> h4 {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p));
+    return __builtin_bit_cast(h4, r);
+  };
   load_tiles(0);
   // The Q fragments came from global loads issued before the loop.  Without a use in front of the loop their first use is the
   // first MFMA INSIDE it, and the compiler's wait-count pass (which merges the loop's entry and back edge) then puts an
@@ -205,9 +220,9 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : D <= 80 ? 3 : 2)) void attn_ker
       for (int j = 0; j < 8; ++j) pb[j] = (half_t)s[kk >> 1][8 * (kk & 1) + j];
 #pragma unroll
       for (int f = 0; f < DVF; ++f) {
-        const half_t* vrow = sV + (f * 32 + lq) * VLD + kk * 16 + 4 * hh;
-        const h4 v0 = *(const h4*)(vrow);
-        const h4 v1 = *(const h4*)(vrow + 8);
+        const half_t* vblk = vbase + (kk * 16) * VLD + f * 32;
+        const h4 v0 = tr_read(vblk);            // keys 16 kk + 4 hh + 0..3 of d-column f * 32 + lq
+        const h4 v1 = tr_read(vblk + 8 * VLD);  // keys 16 kk + 8 + 4 hh + 0..3
         h8 va;
         va[0] = v0[0]; va[1] = v0[1]; va[2] = v0[2]; va[3] = v0[3];
         va[4] = v1[0]; va[5] = v1[1]; va[6] = v1[2]; va[7] = v1[3];
