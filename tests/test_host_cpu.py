@@ -534,3 +534,31 @@ def test_bench_reads_roofline_traffic_from_the_pmc_summary(tmp_path, monkeypatch
     assert bench.pmc_traffic("gemm_dma_kernel<128,0>", "headline") is None
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert committed["config"] == "headline" and "FETCH_SIZE" in committed["source"]
+
+
+def test_lds_layouts_of_the_attention_and_conv3x_kernels_are_conflict_free_in_the_bank_model():
+    """The two LDS layouts round 5 changed, pinned in the bank model of tools/lds_bank_model.py (the banking
+    rules of the microarchitecture guide): the attention kernel's row-major V image at the row pitches k_attn.hip selects serves
+    every transposing read in one cycle per 32-lane group, conv3x's position-based XOR key every activation fragment read in one
+    cycle per 16-lane group -- and the layouts they replaced do not (a change of either constant has to re-run the model)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(root, "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = open(os.path.join(root, "morphablediffusion_amd", "csrc", "k_attn.hip")).read()
+    assert "constexpr int VLD = DVP <= 32 ? 32 : (DVP <= 96 ? 96 : 160);" in src, "k_attn.hip: V row pitch changed -- re-run the model"
+    for D in (8, 16, 32, 40, 64, 80, 160):
+        dvp = (D + 31) // 32 * 32
+        vld = 32 if dvp <= 32 else (96 if dvp <= 96 else 160)
+        reads = 4 * (dvp // 32) * 2            # 16-key steps x fragments x two reads
+        assert m.attn_tr_read_cycles(D, vld) == 2 * reads, (D, vld)   # two 32-lane groups, one cycle each
+    assert m.attn_tr_read_cycles(40, 72) > m.attn_tr_read_cycles(40, 96)
+    # the transposed image of rounds 1-5: 72 -> 68 halfs halved its LDS cycles
+    assert m.attn_vt_write_cycles(40, 72) + 4 * m.attn_vt_read_cycles(40, 72) == 912
+    assert m.attn_vt_write_cycles(40, 68) + 4 * m.attn_vt_read_cycles(40, 68) == 496
+    csrc = open(os.path.join(root, "morphablediffusion_amd", "csrc", "k_conv3x.hip")).read()
+    assert "if constexpr (IW == 16) return (hx >> 1) & 7;" in csrc and "return ((hx >> 1) + 4 * (hy & 1)) & 7;" in csrc
+    for iw in (16, 8):
+        assert m.conv3x_halo_read_cycles(m.conv3x_key_position(iw), iw) == 1.0
+        assert m.conv3x_halo_read_cycles(m.conv3x_key_linear(iw), iw) >= 2.0
