@@ -443,7 +443,7 @@ def main():
     def one_step(i, xx):
         index = nsteps - 1 - (i % nsteps)
         step = int(sampler.ddim_timesteps[index])
-        ts = torch.full((1,), step, device=dev, dtype=torch.long)
+        ts = sampler._time_steps(1, step, dev)  # as SyncDDIMSampler.sample does: one resident tensor per DDIM step value
         return sampler.denoise_apply(xx, info, clip, ts, index, 2.0, batch_view_num=bvn, is_step0=index == 0,
                                      batch=batch, noise=noise, host_steps=[step])
 

@@ -178,6 +178,10 @@ int mvd_comm_unique_id(mvd_rccl_id* id_out);
 int mvd_comm_init(mvd_ctx* ctx, const mvd_rccl_id* id, int rank, int world);
 int mvd_comm_destroy(mvd_ctx* ctx);
 int mvd_exchange_view_features(mvd_ctx* ctx, const float* local, float* all, int n_local, void* stream);
+/* In-place sum all-reduce of `count` device floats over the context's communicator on `stream` (ncclAllReduce): the
+ * "all_reduce" form of the step's exchange (321 KB of per-vertex sums) and the building block of the gradient
+ * averaging below. */
+int mvd_comm_all_reduce(mvd_ctx* ctx, float* buf, size_t count, void* stream);
 /* Cross-stream hand-over of the volume.  The exchange + mvd_fuse_vertex_features + mvd_volume_from_fused may run on a
  * communication stream of the caller while `stream` of mvd_denoise_views already executes the UNet's input blocks (which
  * need none of it): record a hipEvent_t after mvd_volume_from_fused on that stream and register it here; every later reader
@@ -295,6 +299,13 @@ int mvd_train_grad_bucket_count(mvd_ctx* ctx);
 int mvd_train_grad_bucket(mvd_ctx* ctx, int k, int max_ranges, int64_t* offs, int64_t* lens, int* n_ranges);
 int mvd_train_grad_bucket_wait(mvd_ctx* ctx, int k, void* stream);
 int mvd_train_set_bucket_snapshot(mvd_ctx* ctx, float* arena);
+/* The whole reducer behind the C ABI, on the communicator of mvd_comm_init (replaces DistributedDataParallel's reducer,
+ * train_morphable_diffusion.py:302-303; no Python and no torch.distributed per bucket).  phase 0, called once right after
+ * mvd_train_unet_step: every bucket's ranges are all-reduced (sum, in place in the gradient arena) on `comm_stream`, each bucket
+ * behind its event.  phase 1, after the conditioner's backward was enqueued on `stream`: `comm_stream` waits for `stream`,
+ * every arena range outside the buckets is reduced, `stream` waits for `comm_stream` and the arena is scaled by 1 / world on
+ * `stream`.  phase 1 without a phase 0 reduces the whole arena (the flat all-reduce). */
+int mvd_train_sync_gradients(mvd_ctx* ctx, int phase, void* comm_stream, void* stream);
 /* Puts a volume [64,V,V,V] (reference layout, e.g. one sample of construct_spatial_volume's [B,64,V,V,V] result) back into
  * the context for mvd_frustum_volumes / mvd_denoise_views: with B > 1 samples per step (training_step) the per-sample
  * volumes are built first and the frustum stage runs afterwards (morphable_diffusion.py:531-533). */

@@ -4,7 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "engine.h"
 #include "rowchain.h"
@@ -169,6 +172,8 @@ void mvd_destroy(mvd_ctx* c) {
     if (c->bevents[i]) hipEventDestroy(c->bevents[i]);
   }
   if (c->bev_after) hipEventDestroy(c->bev_after);
+  for (hipEvent_t ev : c->ev_grad_sync)
+    if (ev) hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
@@ -851,28 +856,35 @@ struct RcclApi {
   int (*comm_init_rank)(void**, int, mvd_rccl_id, int) = nullptr;
   int (*comm_destroy)(void*) = nullptr;
   int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
   const char* (*get_error_string)(int) = nullptr;
 };
 RcclApi* rccl_api() {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // C++11 magic static: initialised exactly once, by one thread, before any caller sees it (a one-thread-per-GPU host may call
+  // mvd_comm_init for several contexts at the same time)
+  static const RcclApi api = [] {
+    RcclApi a;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-      api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (api.h) break;
+      a.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (a.h) break;
     }
-    if (api.h) {
-      api.get_unique_id = (int (*)(void*))dlsym(api.h, "ncclGetUniqueId");
-      api.comm_init_rank = (int (*)(void**, int, mvd_rccl_id, int))dlsym(api.h, "ncclCommInitRank");
-      api.comm_destroy = (int (*)(void*))dlsym(api.h, "ncclCommDestroy");
-      api.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.h, "ncclAllGather");
-      api.get_error_string = (const char* (*)(int))dlsym(api.h, "ncclGetErrorString");
-      if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) api.h = nullptr;
+    if (a.h) {
+      a.get_unique_id = (int (*)(void*))dlsym(a.h, "ncclGetUniqueId");
+      a.comm_init_rank = (int (*)(void**, int, mvd_rccl_id, int))dlsym(a.h, "ncclCommInitRank");
+      a.comm_destroy = (int (*)(void*))dlsym(a.h, "ncclCommDestroy");
+      a.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(a.h, "ncclAllGather");
+      a.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(a.h, "ncclAllReduce");
+      a.group_start = (int (*)())dlsym(a.h, "ncclGroupStart");
+      a.group_end = (int (*)())dlsym(a.h, "ncclGroupEnd");
+      a.get_error_string = (const char* (*)(int))dlsym(a.h, "ncclGetErrorString");
+      if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.all_reduce) a.h = nullptr;
     }
-  }
-  return api.h ? &api : nullptr;
+    return a;
+  }();
+  return api.h ? const_cast<RcclApi*>(&api) : nullptr;
 }
 int rccl_fail(RcclApi* a, const char* what, int rc) {
   static thread_local std::string msg;
@@ -922,9 +934,74 @@ int mvd_exchange_view_features(mvd_ctx* c, const float* local, float* all, int n
   if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!local || !all || n_local <= 0 || c->mesh.Nv <= 0) return mvd_fail("mvd_exchange_view_features: bad arguments / no mesh is set");
   RcclApi* a = rccl_api();
+  if (!a) return mvd_fail("mvd_exchange_view_features: librccl.so could not be opened");
+  // `all` holds comm_world * n_local views: the step's partition is even (SyncDDIMSampler.view_range), so a rank count that does
+  // not divide the configured view count, or a slice of another size, is a caller error and not a gather of some other shape
+  if (c->v.num_views > 0 && (long)c->comm_world * n_local != c->v.num_views)
+    return mvd_fail("mvd_exchange_view_features: comm_world * n_local does not equal the configured view count");
   const size_t count = (size_t)n_local * c->mesh.Nv * 16;  // fp32 elements this rank contributes: [n_local][Nv][16]
   const int rc = a->all_gather(local, all, count, /* ncclFloat32 */ 7, c->comm, S(stream));
   return rc ? rccl_fail(a, "ncclAllGather", rc) : 0;
+}
+
+int mvd_comm_all_reduce(mvd_ctx* c, float* buf, size_t count, void* stream) {
+  if (!c || !c->comm) return mvd_fail("mvd_comm_all_reduce: no communicator (mvd_comm_init)");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!buf || count == 0) return mvd_fail("mvd_comm_all_reduce: bad arguments");
+  RcclApi* a = rccl_api();
+  if (!a) return mvd_fail("mvd_comm_all_reduce: librccl.so could not be opened");
+  const int rc = a->all_reduce(buf, buf, count, /* ncclFloat32 */ 7, /* ncclSum */ 0, c->comm, S(stream));
+  return rc ? rccl_fail(a, "ncclAllReduce", rc) : 0;
+}
+
+// DDP's reducer on the gradient arena, entirely behind the C ABI (train_morphable_diffusion.py:302-303).  phase 0, right after
+// mvd_train_unet_step: every bucket's ranges are all-reduced (sum, in place) on `comm_stream`, each bucket behind its own event
+// -- one host call for all 26 buckets, no Python and no torch.distributed per bucket.  phase 1, after the conditioner's backward:
+// `comm_stream` waits for `stream`, reduces every arena range no bucket covered, `stream` waits for `comm_stream`, and the arena is
+// scaled by 1 / world on `stream`.  The arithmetic per element is the flat all-reduce's: sum over ranks, then the scale.
+int mvd_train_sync_gradients(mvd_ctx* c, int phase, void* comm_stream, void* stream) {
+  if (!c || !c->comm) return mvd_fail("mvd_train_sync_gradients: no communicator (mvd_comm_init)");
+  if (hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
+  if (!c->arena_g || c->arena_n == 0) return mvd_fail("mvd_train_sync_gradients: no gradient arena (mvd_train_enable)");
+  if (phase != 0 && phase != 1) return mvd_fail("mvd_train_sync_gradients: phase is 0 (start) or 1 (finish)");
+  RcclApi* a = rccl_api();
+  if (!a) return mvd_fail("mvd_train_sync_gradients: librccl.so could not be opened");
+  hipStream_t cs = S(comm_stream), ms = S(stream);
+  auto reduce = [&](size_t off, size_t n) -> int {
+    const int rc = a->all_reduce(c->arena_g + off, c->arena_g + off, n, 7, 0, c->comm, cs);
+    return rc ? rccl_fail(a, "ncclAllReduce", rc) : 0;
+  };
+  if (phase == 0) {
+    for (int k = 0; k < c->n_buckets; ++k) {
+      const mvd_ctx::GradBucket& b = c->buckets[k];
+      if (b.ev) HIP_CHECK_RET(hipStreamWaitEvent(cs, b.ev, 0));
+      for (size_t r = 0; r < b.off.size(); ++r) RET_IF(reduce(b.off[r], b.len[r]));
+    }
+    c->grad_sync_started = true;
+    return 0;
+  }
+  if (!c->ev_grad_sync[0]) {
+    HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_grad_sync[0], hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_grad_sync[1], hipEventDisableTiming));
+  }
+  HIP_CHECK_RET(hipEventRecord(c->ev_grad_sync[0], ms));  // the conditioner's backward wrote the rest of the arena on `stream`
+  HIP_CHECK_RET(hipStreamWaitEvent(cs, c->ev_grad_sync[0], 0));
+  std::vector<std::pair<size_t, size_t>> spans;
+  if (c->grad_sync_started)
+    for (int k = 0; k < c->n_buckets; ++k)
+      for (size_t r = 0; r < c->buckets[k].off.size(); ++r) spans.push_back({c->buckets[k].off[r], c->buckets[k].off[r] + c->buckets[k].len[r]});
+  std::sort(spans.begin(), spans.end());
+  size_t pos = 0;
+  for (auto& sp : spans) {
+    if (sp.first < pos) return mvd_fail("mvd_train_sync_gradients: gradient buckets overlap");
+    if (sp.first > pos) RET_IF(reduce(pos, sp.first - pos));
+    pos = sp.second;
+  }
+  if (pos < c->arena_n) RET_IF(reduce(pos, c->arena_n - pos));
+  c->grad_sync_started = false;
+  HIP_CHECK_RET(hipEventRecord(c->ev_grad_sync[1], cs));
+  HIP_CHECK_RET(hipStreamWaitEvent(ms, c->ev_grad_sync[1], 0));
+  return launch_scale_copy(c->arena_g, c->arena_n, 1.0f / (float)c->comm_world, c->arena_g, ms);
 }
 
 // ------------------------------------------------------------------------------------------ test hooks

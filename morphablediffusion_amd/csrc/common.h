@@ -108,7 +108,8 @@ struct IGemm {
   int par_oz[8], par_oy[8], par_ox[8];
   const half_t* wx;     // the same weights as a conv3x fragment stream (k_conv3x.hip) packed for column tiles of wx_bn, or null
   int wx_bn;
-  int bn;               // column-tile width (64 / 128 / 160); 0 = pick from N
+  int bn;               // column-tile width (64 / 96 / 128 / 160); 0 = pick from N
+  int bm;               // LDS-DMA GEMM only: row-tile height, 256 (0 = 256: eight waves) or 128 (four waves; plain GEMMs)
   int splitk;
   float* partial;       // [splitk][M][N] fp32 when splitk > 1
 };
@@ -148,10 +149,12 @@ size_t conv3x_stream_halfs(int N, int Cin, int bn);
 int conv3x_pack(const half_t* w, int N, int Cin, int bn, half_t* stream, hipStream_t s);
 int launch_conv3x(const IGemm& g, const half_t* stream, int bn, hipStream_t s);
 bool gemm_dma_eligible(const IGemm& g);
+bool gemm_dma_is_plain(const IGemm& g);
 void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, int* splitk_out);
 int launch_target_encoder(const float* x, const float* pre, int n_views, const half_t* const* w, const float* const* bias,
                           const int* cin, const float* const* gamma, const float* const* beta, float* feats, hipStream_t s);
-void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out);
+void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out,
+                      int* bm_out = nullptr);
 int launch_gemm_dma(const IGemm& g, hipStream_t s);
 
 int launch_gn_stats(const float* x, int ld, int B, int rows_per_sample, int C, int G, const float* preadd, int pld,

@@ -57,6 +57,7 @@ struct ResW {
   ConvW c1, c2, skip;
   bool has_skip = false;
   int cin = 0, cout = 0, emb_off = 0;
+  int res = 0;      // resolution (pixels per side) the block runs at: decides which kernel forms its weights are packed for
   std::string key;  // state_dict prefix (for the extended-precision re-pack)
 };
 struct STW {
@@ -75,6 +76,7 @@ struct CondW {
   NormW gn_in, gn_ctx, gn_o1, gn_o2;
   half_t* relu_beta = nullptr;  // [4*Cc] z row for an all-zero context (CFG uncond half); [hi | lo | hi] when wov.xp
   int dim = 0, Cc = 0, I = 0;
+  int res = 0;  // resolution the block runs at (a conditioner behind an Upsample runs at the new resolution)
   std::string key;
 };
 // first-stage decoder (AutoencoderKL.decode): ResnetBlock / AttnBlock / Upsample of
@@ -213,6 +215,8 @@ struct mvd_ctx {
   // RCCL communicator of the view-sharded step's one exchange (mvd_comm_init; librccl.so is opened on demand, c_api.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
+  hipEvent_t ev_grad_sync[2] = {nullptr, nullptr};  // mvd_train_sync_gradients: main -> comm, comm -> main
+  bool grad_sync_started = false;                   // phase 0 ran for the current step (its buckets are already reduced)
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
   bool vae_exact = false;   // first-stage encoder / decoder with every conv and the attention in extended precision (mvd_set_vae_precision)

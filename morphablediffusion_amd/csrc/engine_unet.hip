@@ -171,10 +171,12 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     static const bool old_plan = getenv("MVD_OLD_PLAN") != nullptr;
     const bool plain_gemm = !g.gn_partial && !g.rowscale && g.ntaps == 1;
     if (plain_gemm && !old_plan) {
-      int bn = 0;
+      int bn = 0, bm = 256;
+      // (128-row tiles exist for the PLAIN instantiation only: one centre tap, linear rows)
       gemm_dma_plan_us(M, g.N, ksteps, g.geglu, g.out_f32 ? 4 : (g.out_split ? 6 : 2), g.resid ? (g.resid_f32 ? 4 : 2) : 0, &bn,
-                       &nch, &sk2);
+                       &nch, &sk2, gemm_dma_is_plain(g) ? &bm : nullptr);
       g.bn = bn;
+      g.bm = bm;
     } else {
       gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
     }
@@ -189,9 +191,15 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     {  // sweeps (tools/gemm_plan_sweep.py): column-tile width and split of the next dense launches
       static const int tune_bn = getenv("MVD_DENSE_BN") ? atoi(getenv("MVD_DENSE_BN")) : 0;
       static const int tune_sk = getenv("MVD_DENSE_SK") ? atoi(getenv("MVD_DENSE_SK")) : 0;
+      static const int tune_bm = getenv("MVD_DENSE_BM") ? atoi(getenv("MVD_DENSE_BM")) : 0;
       if (tune_bn && !g.geglu && !g.gn_partial && !g.rowscale) {
         g.bn = tune_bn;
+        g.bm = (tune_bm == 128 && gemm_dma_is_plain(g)) ? 128 : 256;
         gemm_dma_plan(M, g.N, ksteps, g.bn, g.geglu, &nch, &sk2);
+        if (g.bm == 128) {  // no column walk with the swept 128-row tiles: one tile per workgroup
+          nch = 1;
+          sk2 = 1;
+        }
         if (force_splitk <= 0) sk = sk2;
       }
       if (tune_sk && !g.geglu && force_splitk <= 0) sk = tune_sk;
@@ -200,7 +208,7 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     if (sk > 1) sk = cdiv(ksteps, cdiv(ksteps, sk));  // no empty split
     g.nch = sk > 1 ? 1 : nch;
     static const bool plan_debug = getenv("MVD_PLAN_DEBUG") != nullptr;
-    if (plan_debug) fprintf(stderr, "[plan] M=%d N=%d ksteps=%d -> bn=%d nch=%d sk=%d\n", M, g.N, ksteps, g.bn, g.nch, sk);
+    if (plan_debug) fprintf(stderr, "[plan] M=%d N=%d ksteps=%d -> bm=%d bn=%d nch=%d sk=%d\n", M, g.N, ksteps, g.bm ? g.bm : 256, g.bn, g.nch, sk);
   } else {
     const int ksteps = g.ntaps * cdiv(g.Cin, 64);
     sk = force_splitk > 0 ? force_splitk : igemm_pick_splitk(M, g.N, ksteps, g.bn);
@@ -251,7 +259,8 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
       r = launch_conv3_halo(g, s);
     }
   } else if (dense) {
-    snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d>", g.bn, g.gn_partial ? 1 : (g.rowscale ? 2 : 0));
+    if (g.bm == 128) snprintf(fam, sizeof fam, "gemm_dma_kernel<128x%d>", g.bn);  // four-wave row tiles (round 6)
+    else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d>", g.bn, g.gn_partial ? 1 : (g.rowscale ? 2 : 0));
     ProbeScope ps(c, s, fam, flops, bytes);
     r = launch_gemm_dma(g, s);
   } else {
@@ -567,7 +576,9 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   static const int rc_min_rows = getenv("MVD_ROWCHAIN_MIN_ROWS") ? atoi(getenv("MVD_ROWCHAIN_MIN_ROWS")) : 16384;
   const bool rc = !no_rc && !f.train && !sv && t.rc_stream && rows >= rc_min_rows && rowchain_takes(C, rows, T) && !(in.ld & 3) && !(out.ld & 3);
   static const bool no_xpf = getenv("MVD_NO_XP_FUSE") != nullptr;  // A/B: extended-precision proj_in / proj_out as separate GEMMs
-  const bool rc_po = rc && t.rc_po == (t.proj_out.xp ? 2 : 1) && !(no_xpf && t.proj_out.xp);  // the stream was packed for this precision form of proj_out
+  // the stream was packed for this precision form of proj_out (rc_po 0: that form of the kernel does not exist at this width)
+  const bool rc_po = rc && t.rc_po != 0 && t.rc_po == (t.proj_out.xp ? 2 : 1) && !(no_xpf && t.proj_out.xp) &&
+                     rowchain_form_instantiated(C, 1, t.rc_po);
   half_t* n0 = ws_alloc<half_t>(c, (size_t)rows * C * wi);
   float* t0 = ws_alloc<float>(c, (size_t)rows * C);
   half_t* l1 = ws_alloc<half_t>(c, (size_t)rows * C);

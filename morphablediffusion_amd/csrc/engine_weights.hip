@@ -565,34 +565,30 @@ int xp_ops(mvd_ctx* c, const std::vector<UOp>& ops, bool convs3) {
 int build_conv3x_streams(mvd_ctx* c) {
   static const bool off = getenv("MVD_NO_CONV3X") != nullptr;
   if (off || !c->has_unet) return 0;
-  int l16 = -1;
-  for (int l = 0; l < 4; ++l) {  // conv3x takes resolutions divisible by 16 and 8 x 8 images
-    const int res = c->u.image_size >> l;
-    if ((res % 16 == 0 && res >= 16) || res == 8) l16 = l;
-    else break;
-  }
-  if (l16 < 0) return 0;
-  int nmax = 0;
-  for (int l = 0; l <= l16; ++l) nmax = std::max(nmax, c->u.model_channels * c->u.channel_mult[l]);
+  // conv3x takes resolutions divisible by 16 and 8 x 8 images (conv3x_eligible): only convolutions that RUN at such a resolution
+  // get a stream (the plan records it in ResW::res / CondW::res) -- with channel_mult (1, 2, 4, 4) the 4 x 4 level's 1280-wide
+  // ResBlocks share their width with the 8 x 8 level's, and a stream for them would be ~29 MB each, packed (and re-packed every
+  // training step) for a kernel that never takes them
+  auto takes = [](int res) { return (res % 16 == 0 && res >= 16) || res == 8; };
   std::vector<ConvW*> cs;
   for (ResW& r : c->res) {
+    if (!takes(r.res)) continue;
     cs.push_back(&r.c1);
     cs.push_back(&r.c2);
   }
   for (CondW& d : c->conds) {  // the DepthTransformers' 3x3 output convolutions (attention.py:66-73)
+    if (!takes(d.res)) continue;
     cs.push_back(&d.conv1);
     cs.push_back(&d.conv2);
   }
-  {
-    for (ConvW* w : cs) {
-      if (w->taps != 9 || w->Cin % 64 || w->N > nmax) continue;
-      const int bn = w->N % 160 == 0 ? 160 : (w->N % 128 == 0 ? 128 : 0);
-      if (!bn) continue;
-      engine_build_rotate(c);
-      RET_IF(dmalloc(c, (void**)&w->wx, conv3x_stream_halfs(w->N, w->Cin, bn) * sizeof(half_t)));
-      RET_IF(conv3x_pack(w->w, w->N, w->Cin, bn, w->wx, c->bs));
-      w->wx_bn = bn;
-    }
+  for (ConvW* w : cs) {
+    if (w->taps != 9 || w->Cin % 64) continue;
+    const int bn = w->N % 160 == 0 ? 160 : (w->N % 128 == 0 ? 128 : 0);
+    if (!bn) continue;
+    engine_build_rotate(c);
+    RET_IF(dmalloc(c, (void**)&w->wx, conv3x_stream_halfs(w->N, w->Cin, bn) * sizeof(half_t)));
+    RET_IF(conv3x_pack(w->w, w->N, w->Cin, bn, w->wx, c->bs));
+    w->wx_bn = bn;
   }
   return engine_build_join(c);
 }
@@ -621,6 +617,9 @@ int build_rowchain_streams(mvd_ctx* c) {
     if (wao->numel != (size_t)C * C || w1->numel != (size_t)8 * C * C || w2->numel != (size_t)4 * C * C || wpo->numel != (size_t)C * C)
       return mvd_fail("build_rowchain_streams: transformer block weights do not have the row-chain kernel's shapes");
     st.rc_po = st.proj_out.xp ? 2 : 1;
+    // a width without the extended-precision form (C = 128 / 256): the stream carries no proj_out section, the block runs the
+    // (1, 0) form + the separate extended-precision proj_out GEMM (unet_do_st: rc_po false)
+    if (!rowchain_form_instantiated(C, 1, st.rc_po)) st.rc_po = 0;
     float* tmp = nullptr;
     RET_IF(dmalloc(c, (void**)&tmp, (size_t)8 * C * sizeof(float)));
     RET_IF(dmalloc(c, (void**)&st.rc_stream, rowchain_stream_halfs(C, 1, st.rc_po) * sizeof(half_t)));
@@ -736,6 +735,7 @@ int build_unet_section(mvd_ctx* c) {
       std::vector<UOp> ops;
       const std::string b = "input_blocks." + std::to_string(bi);
       RET_IF(add_res(b + ".0", ch, mult * mc, ops));
+      c->res.back().res = u.image_size / ds;
       ch = mult * mc;
       if (u.attention_levels & ds) RET_IF(add_st(b + ".1", ch, ops));
       c->in_blocks.push_back(ops);
@@ -752,8 +752,10 @@ int build_unet_section(mvd_ctx* c) {
     }
   }
   RET_IF(add_res("middle_block.0", ch, ch, c->mid_block));
+  c->res.back().res = u.image_size / ds;
   RET_IF(add_st("middle_block.1", ch, c->mid_block));
   RET_IF(add_res("middle_block.2", ch, ch, c->mid_block));
+  c->res.back().res = u.image_size / ds;
   bi = 0;
   for (int level = 3; level >= 0; --level) {
     const int mult = u.channel_mult[level];
@@ -763,6 +765,7 @@ int build_unet_section(mvd_ctx* c) {
       std::vector<UOp> ops;
       const std::string b = "output_blocks." + std::to_string(bi);
       RET_IF(add_res(b + ".0", ch + ich, mc * mult, ops));
+      c->res.back().res = u.image_size / ds;
       ch = mc * mult;
       int j = 1;
       if (u.attention_levels & ds) {
@@ -821,10 +824,12 @@ int build_unet_section(mvd_ctx* c) {
     const int* d = u.volume_dims;
     const int dims[10] = {c2, c2, c2, c2, c1, c1, c1, c0, c0, c0};
     const int ccs[10] = {d[3], d[2], d[2], d[1], d[1], d[1], d[0], d[0], d[0], d[0]};
+    const int lvl[10] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0};  // the volume level each block attends to = the resolution it runs at
     c->conds.resize(10);
     RET_IF(build_cond(c, U + "middle_conditions", dims[0], ccs[0], &c->conds[0]));
     for (int k = 0; k < 9; ++k)
       RET_IF(build_cond(c, U + "output_conditions." + std::to_string(k), dims[k + 1], ccs[k + 1], &c->conds[k + 1]));
+    for (int k = 0; k < 10; ++k) c->conds[k].res = u.image_size >> lvl[k];
   }
   return 0;
 }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
       float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!part) {
         if (g.bias) bsum = *(const float4*)(g.bias + n);
-        if (g.rowbias) {
+        if (g.rowbias && live) {  // (a dead wave of the last 8 x 8 tile has b >= B: no read past the per-sample rows)
           const float4 r = *(const float4*)(g.rowbias + (long)b * g.rb_ld + n);
           bsum.x += r.x; bsum.y += r.y; bsum.z += r.z; bsum.w += r.w;
         }

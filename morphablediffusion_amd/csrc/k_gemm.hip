@@ -22,12 +22,18 @@
 //     instantiation without integer divisions, biases enter as the accumulators' initial value, fp16 results leave as
 //     16-byte stores (measured phase by phase with tools/gemm_timeline.py).
 // LDS rows are 128 B (64 halfs) with the 16-byte chunk XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128.
+// Round 6: the row-tile height is a template parameter.  BM = 256 (eight waves) is the form above; BM = 128 (four waves, one per
+// SIMD, 32 rows x BN columns each) was built for the shapes whose 256-row tile grid cannot fill the chip: 8192 x 640 is 160 tiles of
+// 256 x 128 on 256 CUs (0.625 of a round, every layer of the 16 x 16 transformer blocks) but exactly 256 tiles of 128 x 160;
+// 2048 x 1280 is 160 tiles of 256 x 64 but 224 of 128 x 96.  Same ring, same epilogues, same bits per output element (the
+// reduction order over k does not depend on the tile shape).  Measured: it LOSES on every shape of the step (gemm_dma_plan_us) --
+// kept as a tested form behind MVD_BM128=1 / MVD_DENSE_BM=128, not planned by default.
 #include "common.h"
 #include "igemm_epilogue.h"
 
 namespace {
 
-constexpr int GBM = 256, GNT = 512, GST = 3;
+constexpr int GBM = 256, GST = 3;
 
 #ifdef MVD_TIMELINE
 // investigation build only (make EXTRA=-DMVD_TIMELINE): per-workgroup phase timestamps of the last launch
@@ -60,14 +66,16 @@ __device__ __forceinline__ void wait_vmg() {
 // A offsets are m * lda, so the set-up has no integer division and the first loads go out a few hundred cycles after the
 // workgroup starts (a kernel's first pass over its code runs at instruction-fetch speed, ~0.7 us per KiB: measured
 // with tools/gemm_timeline.py, the general set-up cost 1.8 us per workgroup before the first load was issued).
-template <int BN, int MODE = 0, bool PLAIN = false>
-__global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
+template <int BM, int BN, int MODE = 0, bool PLAIN = false>
+__global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  [[maybe_unused]] constexpr int GBM = BM, GNT = BM * 2;
+  constexpr int NWV = BM / 32;  // waves: each owns 32 rows x BN columns
   constexpr int FN = BN / 32;
   constexpr int A_BYTES = GBM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
   constexpr int WGR = BN / 8;                       // 8-row weight groups per stage (one DMA instruction each)
-  constexpr int NA = GBM / 64;                      // A instructions per wave and stage (4)
-  constexpr int NW = (WGR + 7) / 8, NW_MIN = WGR / 8;
+  constexpr int NA = GBM / (8 * NWV);               // A instructions per wave and stage (4)
+  constexpr int NW = (WGR + NWV - 1) / NWV, NW_MIN = WGR / NWV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   int ab[NA], az[NA], ay[NA], ax[NA];  // output pixel of each A row, pre-multiplied by the stride
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    const int row = (wave + NWV * i) * 8 + (lane >> 3);
     a_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
     if constexpr (PLAIN) {
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
   }
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    const int row = (wave + NWV * i) * 8 + (lane >> 3);
     w_ch[i] = (lane & 7) ^ ((row >> 1) & 7);
     w_row[i] = row;
     w_off[i] = ((unsigned)row * (unsigned)Cin + w_ch[i] * 8) * 2;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
       if (tmw != set_for) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          const int m = tmw * GBM + (wave + 8 * i) * 8 + (lane >> 3);
+          const int m = tmw * GBM + (wave + NWV * i) * 8 + (lane >> 3);
           a_off[i] = (((unsigned)m * (unsigned)g.lda + a_ch[i] * 8) * 2) | (0u - (unsigned)(m >= M));
         }
         set_for = tmw;
@@ -205,13 +213,13 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
     for (int i = 0; i < NA; ++i)
       if (p == i) {
         const unsigned inval = (0u - (unsigned)(a_off[i] == 0xFFFFFFFFu)) | (0u - (unsigned)(d_kb + a_ch[i] * 8 >= Cin));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sA + (wave + 8 * i) * 1024), 16, (a_off[i] + d_kb * 2) | inval,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(sA + (wave + NWV * i) * 1024), 16, (a_off[i] + d_kb * 2) | inval,
                                                  0, 0, 0);
       }
 #pragma unroll
     for (int i = 0; i < NW; ++i)
       if (p == NA + i) {
-        const int grp = wave + 8 * i;
+        const int grp = wave + NWV * i;
         if (grp < WGR) {
           const unsigned inval = (0u - (unsigned)(d_n0 + w_row[i] >= N)) | (0u - (unsigned)(d_kb + w_ch[i] * 8 >= Cin));
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr)(sW + grp * 1024), 16, (w_off[i] + d_wbase) | inval, 0, 0, 0);
@@ -483,29 +491,30 @@ __global__ __launch_bounds__(GNT, 1) void gemm_dma_kernel(const IGemm g) {
 #endif
 }
 
-template <int BN, int MODE = 0, bool PLAIN = false>
+template <int BM, int BN, int MODE = 0, bool PLAIN = false>
 int launch_gd(const IGemm& g, int M, hipStream_t s) {
-  constexpr int LDS = GST * (GBM * 128 + BN * 128);
+  constexpr int LDS = GST * (BM * 128 + BN * 128);
   static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(BM == 256 || (BM == 128 && MODE == 0), "the 128-row form exists for the general / plain GEMM only");
   static bool attr_done[MVD_MAX_DEVICES] = {false};  // the attribute is per device
   bool& attr_set = attr_done[mvd_current_device()];
   if (!attr_set) {
     HIP_CHECK_RET(
-        hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, MODE, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        hipFuncSetAttribute((const void*)gemm_dma_kernel<BM, BN, MODE, PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int nch = g.nch > 0 ? g.nch : 1;
-  const int gx = MODE ? cdiv(cdiv(M, GBM) * cdiv(g.N, BN), nch) : cdiv(M, GBM) * cdiv(cdiv(g.N, BN), nch);
+  const int gx = MODE ? cdiv(cdiv(M, BM) * cdiv(g.N, BN), nch) : cdiv(M, BM) * cdiv(cdiv(g.N, BN), nch);
   dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
   IGemm gl = g;
   gl.xcd_cols = 0;
   if (MODE == 0) {
     static const bool no_cols = getenv("MVD_NO_XCD_COLS") != nullptr;
     const int ntaps = g.npar > 0 ? g.par_ntaps[0] : g.ntaps;
-    gl.xcd_cols = !no_cols && xcd_prefers_cols(cdiv(M, GBM), cdiv(cdiv(g.N, BN), nch),
+    gl.xcd_cols = !no_cols && xcd_prefers_cols(cdiv(M, BM), cdiv(cdiv(g.N, BN), nch),
                                                (double)g.B * g.PZ * g.PY * g.PX * g.Cin * (g.a_f32 ? 4 : 2), (double)ntaps * g.N * g.Cin * 2);
   }
-  hipLaunchKernelGGL((gemm_dma_kernel<BN, MODE, PLAIN>), grid, dim3(GNT), LDS, s, gl);
+  hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, MODE, PLAIN>), grid, dim3(BM * 2), LDS, s, gl);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -570,27 +579,41 @@ void gemm_dma_plan(int M, int N, int ksteps, int bn, int geglu, int* nch_out, in
 //   split-K   = fp32 slabs written by the GEMM and read back by the reduce launch (its own ~5 us of launch and latency).
 // The k-step model above undervalued the slab traffic: e.g. 8192 x 2560 x 640 ran 63 us as 3 splits and 49 us unsplit.
 // out_b / res_b: bytes per result element stored and per residual element read (GEGLU: per paired column).
-void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out) {
+// bm_out (optional): also consider 128-row tiles (four waves) with 96 / 128 / 160 columns -- for the shapes whose 256-row tile grid
+// leaves CUs idle.  k-step times of the 128-row forms fitted to tools/gemm_plan_sweep.py on the same box (round 6).
+void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b, int* bn_io, int* nch_out, int* splitk_out, int* bm_out) {
   const int CUS = 256;
-  const int tiles_m = cdiv(M, GBM);
   double best = 1e30;
-  int best_bn = *bn_io, best_nch = 1, best_sk = 1;
-  const int cand[3] = {64, 128, 160};
-  for (int ci = 0; ci < 3; ++ci) {
-    const int bn = cand[ci];
-    if (geglu ? bn != 128 : (*bn_io < 0 && bn != -*bn_io)) continue;  // bn_io < 0: the caller fixes the width
-    const double t_step = bn == 64 ? 0.70 : (bn == 128 ? 1.05 : 1.25);
-    const int tiles_n = cdiv(N, bn);
+  int best_bn = *bn_io, best_nch = 1, best_sk = 1, best_bm = 256;
+  // MEASURED, and it lost (tools/gemm_bm_sweep.py, profiles/r06_b_bm_sweep.txt): a k-step of the four-wave tile takes 0.70 / 0.79 /
+  // 1.03 us at 96 / 128 / 160 columns -- as long as the eight-wave tile of twice the rows (0.70 / 1.05 / 1.25 at 64 / 128 / 160): one
+  // wave per SIMD pays every DMA issue, LDS wait and barrier of the step itself, so what a k-step costs is its dependent chain, not
+  // its MFMAs.  8192 x 640 x 640: 27.0 us as 256 tiles of 128 x 160 against 24.0 as 160 tiles of 256 x 128; no shape of the step won.
+  // The planner therefore only offers these tiles when MVD_BM128=1 (A/B reproduction); with the measured step times it would not pick them.
+  static const bool no_bm128 = getenv("MVD_BM128") == nullptr || getenv("MVD_NO_BM128") != nullptr;
+  struct Cand {
+    int bm, bn;
+    double t_step;
+  };
+  const Cand cand[6] = {{256, 64, 0.70}, {256, 128, 1.05}, {256, 160, 1.25}, {128, 96, 0.70}, {128, 128, 0.79}, {128, 160, 1.03}};
+  for (int ci = 0; ci < 6; ++ci) {
+    const int bm = cand[ci].bm, bn = cand[ci].bn;
+    if (bm == 128 && (!bm_out || no_bm128 || geglu)) continue;
+    if (bm == 256 && (geglu ? bn != 128 : (*bn_io < 0 && bn != -*bn_io))) continue;  // bn_io < 0: the caller fixes the width
+    if (bm == 128 && *bn_io < 0) continue;
+    const double t_step = cand[ci].t_step;
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const double tile_cols = geglu ? bn / 2 : bn;
     for (int nch = 1; nch <= tiles_n; ++nch) {
       const int wgs = tiles_m * cdiv(tiles_n, nch), rounds = cdiv(wgs, CUS);
       const int in_round = wgs < CUS ? wgs : CUS;
-      double t_epi = in_round * 256.0 * tile_cols * (out_b + res_b) / 6e6;
+      double t_epi = in_round * (double)bm * tile_cols * (out_b + res_b) / 6e6;
       if (t_epi < 2.5) t_epi = 2.5;
       const double t = rounds * (2.8 + (double)nch * ksteps * t_step + nch * t_epi) + 2.0;
       if (t < best) {
         best = t;
         best_bn = bn;
+        best_bm = bm;
         best_nch = nch;
         best_sk = 1;
       }
@@ -604,13 +627,14 @@ void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b,
       if (sk_eff != sk && sk <= 16) continue;
       const int wgs = tiles_m * tiles_n * sk_eff, rounds = cdiv(wgs, CUS);
       const int in_round = wgs < CUS ? wgs : CUS;
-      double t_epi = in_round * 256.0 * bn * 4.0 / 6e6;
+      double t_epi = in_round * (double)bm * bn * 4.0 / 6e6;
       if (t_epi < 2.5) t_epi = 2.5;
       const double mn = (double)M * N;
       const double t = rounds * (2.8 + per * t_step + t_epi) + 2.0 + 5.0 + (sk_eff * mn * 4.0 + mn * (out_b + res_b)) / 6e6;
       if (t < best) {
         best = t;
         best_bn = bn;
+        best_bm = bm;
         best_nch = 1;
         best_sk = sk_eff;
       }
@@ -619,6 +643,16 @@ void gemm_dma_plan_us(int M, int N, int ksteps, int geglu, int out_b, int res_b,
   *bn_io = best_bn;
   *nch_out = best_nch;
   *splitk_out = best_sk;
+  if (bm_out) *bm_out = best_bm;
+}
+
+// one centre tap, unit strides, linear input and output rows: the PLAIN instantiations (every Linear layer and 1 x 1 conv)
+bool gemm_dma_is_plain(const IGemm& g) {
+  static const bool no_plain = getenv("MVD_NO_PLAIN") != nullptr;
+  const long M = (long)g.B * g.Z * g.Y * g.X;
+  return !no_plain && g.npar == 0 && g.ntaps == 1 && g.tap[0] == igemm_tap(0, 0, 0, 0) && g.out_linear && g.ups == 0 && g.sz == 1 &&
+         g.sy == 1 && g.sx == 1 && g.PZ == g.Z && g.PY == g.Y && g.PX == g.X && g.IZ == g.Z && g.IY == g.Y && g.IX == g.X &&
+         M < (1 << 22) && !g.gn_partial && !g.rowscale;
 }
 
 int launch_gemm_dma(const IGemm& g, hipStream_t s) {
@@ -639,15 +673,20 @@ int launch_gemm_dma(const IGemm& g, hipStream_t s) {
   if (g.gn_partial || g.rowscale) {  // folded-GroupNorm passes: plain GEMM, 64 / 128 wide tiles
     if (g.ntaps != 1 || g.splitk > 1 || g.npar > 0 || g.geglu || !g.out_linear || (g.bn != 64 && g.bn != 128))
       return mvd_fail("gemm_dma: the folded-GroupNorm passes need a plain GEMM");
-    if (g.gn_partial) return g.bn == 64 ? launch_gd<64, 1>(g, M, s) : launch_gd<128, 1>(g, M, s);
+    if (g.bm == 128) return mvd_fail("gemm_dma: the folded-GroupNorm passes use 256-row tiles");
+    if (g.gn_partial) return g.bn == 64 ? launch_gd<256, 64, 1>(g, M, s) : launch_gd<256, 128, 1>(g, M, s);
     if (!g.rowbias || g.out_f32) return mvd_fail("gemm_dma: the apply pass needs scale, shift and an fp16 output");
-    return g.bn == 64 ? launch_gd<64, 2>(g, M, s) : launch_gd<128, 2>(g, M, s);
+    return g.bn == 64 ? launch_gd<256, 64, 2>(g, M, s) : launch_gd<256, 128, 2>(g, M, s);
   }
   // split-K: the caller (igemm_go) runs launch_splitk_reduce
-  static const bool no_plain = getenv("MVD_NO_PLAIN") != nullptr;
-  const bool plain = !no_plain && g.npar == 0 && g.ntaps == 1 && g.tap[0] == igemm_tap(0, 0, 0, 0) && g.out_linear && g.ups == 0 &&
-                     g.sz == 1 && g.sy == 1 && g.sx == 1 && g.PZ == g.Z && g.PY == g.Y && g.PX == g.X && g.IZ == g.Z &&
-                     g.IY == g.Y && g.IX == g.X && M < (1 << 22);
-  if (plain) return g.bn == 160 ? launch_gd<160, 0, true>(g, M, s) : (g.bn == 64 ? launch_gd<64, 0, true>(g, M, s) : launch_gd<128, 0, true>(g, M, s));
-  return g.bn == 160 ? launch_gd<160>(g, M, s) : (g.bn == 64 ? launch_gd<64>(g, M, s) : launch_gd<128>(g, M, s));
+  const bool plain = gemm_dma_is_plain(g);
+  if (g.bm == 128) {  // four-wave row tiles (the plan picks them for plain dense layers only)
+    if (!plain || g.geglu) return mvd_fail("gemm_dma: 128-row tiles are for plain (one tap, linear rows, no GEGLU) GEMMs");
+    if (g.bn == 96) return launch_gd<128, 96, 0, true>(g, M, s);
+    if (g.bn == 128) return launch_gd<128, 128, 0, true>(g, M, s);
+    if (g.bn == 160) return launch_gd<128, 160, 0, true>(g, M, s);
+    return mvd_fail("gemm_dma: 128-row tiles come 96, 128 or 160 columns wide");
+  }
+  if (plain) return g.bn == 160 ? launch_gd<256, 160, 0, true>(g, M, s) : (g.bn == 64 ? launch_gd<256, 64, 0, true>(g, M, s) : launch_gd<256, 128, 0, true>(g, M, s));
+  return g.bn == 160 ? launch_gd<256, 160>(g, M, s) : (g.bn == 64 ? launch_gd<256, 64>(g, M, s) : launch_gd<256, 128>(g, M, s));
 }

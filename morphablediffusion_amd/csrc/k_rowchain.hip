@@ -735,7 +735,12 @@ int launch_rc(const RowChain& p, hipStream_t s) {
 }
 
 // instantiated forms: the engine uses (to_out, proj_out) = (1, 1) and (1, 2) (extended-precision proj_out); (1, 0) writes x + ff(x);
-// (0, 0) is the feed-forward part alone (tests, tools/rowchain_bench.py)
+// (0, 0) is the feed-forward part alone (tests, tools/rowchain_bench.py).  rc_form_instantiated() below lists the same keys: the
+// engine packs and plans against it, so a width without the (1, 2) form runs (1, 0) + the separate extended-precision proj_out GEMM.
+constexpr bool rc_form_key_ok(int key) {
+  return key == 64 * 8 + 5 || key == 64 * 8 + 6 || key == 64 * 8 + 4 || key == 64 * 8 + 0 || key == 128 * 8 + 5 || key == 128 * 8 + 4 ||
+         key == 256 * 8 + 5 || key == 256 * 8 + 4 || key == 320 * 8 + 5 || key == 320 * 8 + 6 || key == 320 * 8 + 4 || key == 320 * 8 + 0;
+}
 int launch_rc_any(const RowChain& p, int C, int ao, int po, hipStream_t s) {
   const int key = C * 8 + (ao ? 4 : 0) + po;
   switch (key) {
@@ -785,6 +790,8 @@ int launch_rowhead(const RowHead& p, int xp, hipStream_t s) {
     return mvd_fail("rowhead: rows % 128, 16-byte aligned row strides ([hi | lo | hi] input rows for the extended-precision form)");
   return xp ? launch_rh<true>(p, s) : launch_rh<false>(p, s);
 }
+
+bool rowchain_form_instantiated(int C, int ao, int po) { return rc_form_key_ok(C * 8 + (ao ? 4 : 0) + po); }
 
 bool rowchain_takes(int C, int rows, int T) { return rc_supported_c(C) && rows > 0 && rows % 128 == 0 && T % 32 == 0; }
 

@@ -116,6 +116,9 @@ int rowhead_pack(const RhWeights& w, int xp, float* tmp, half_t* stream, hipStre
 int launch_rowhead(const RowHead& p, int xp, hipStream_t s);
 
 bool rowchain_takes(int C, int rows, int T);
+// which (width, to_out, proj_out) forms of the kernel exist (launch_rc_any): every supported width has (1, 0) and (1, 1); the
+// extended-precision proj_out (1, 2) only C = 64 and C = 320
+bool rowchain_form_instantiated(int C, int ao, int po);
 size_t rowchain_stream_halfs(int C, int ao, int po);
 // tmp: 8C floats of scratch (the folded FF1 bias)
 int rowchain_pack(const RcWeights& w, int C, int ao, int po, float* tmp, half_t* stream, hipStream_t s);

@@ -303,7 +303,8 @@ class Engine:
         import torch.distributed as dist
         if world is None:
             world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-            rank = dist.get_rank() if world > 1 else 0
+        if rank is None:  # derived independently of `world`: comm_init(world=W) alone must not leave rank 0 without the id
+            rank = dist.get_rank() if (world > 1 and dist.is_available() and dist.is_initialized()) else 0
         ident = (C.c_char * 128)()
         if rank == 0:
             L.check(self.lib.mvd_comm_unique_id(C.byref(ident)))
@@ -323,6 +324,17 @@ class Engine:
         assert vf_local.is_contiguous() and vf_all.is_contiguous() and vf_local.dtype == vf_all.dtype == torch.float32
         L.check(self.lib.mvd_exchange_view_features(self._ctx, L.ptr(vf_local), L.ptr(vf_all), vf_local.shape[0], _stream()))
         return vf_all
+
+    def comm_all_reduce(self, buf):
+        """In-place sum all-reduce of a contiguous float32 device tensor on the library's communicator (mvd_comm_all_reduce)."""
+        assert buf.is_contiguous() and buf.dtype == torch.float32
+        L.check(self.lib.mvd_comm_all_reduce(self._ctx, L.ptr(buf), C.c_size_t(buf.numel()), _stream()))
+        return buf
+
+    def sync_gradients(self, phase, comm_stream):
+        """mvd_train_sync_gradients: phase 0 = all buckets of the last train_unet_step on ``comm_stream`` (a torch.cuda.Stream),
+        phase 1 = the rest of the arena, the join with the current stream and the 1 / world scale."""
+        L.check(self.lib.mvd_train_sync_gradients(self._ctx, int(phase), C.c_void_p(comm_stream.cuda_stream), _stream()))
 
     def stage_target_encoder(self, x_noisy, t_embed, v_embed):
         """NoisyTargetViewEncoder alone (network.py:181-207): x_noisy [n,4,s,s], t_embed [time_dim], v_embed [n,view_dim] ->
@@ -549,14 +561,19 @@ class Engine:
         return outs
 
     def denoise_views(self, x_noisy, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg_scale, noise, coef,
-                      want_eps=False):
-        """coef = (sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma) python floats."""
+                      want_eps=False, out=None, eps_out=None):
+        """coef = (sqrt_one_minus_at, sqrt_at, sqrt_aprev, dir_coef, sigma) python floats.  ``out`` / ``eps_out``: contiguous
+        float32 device tensors shaped like x_noisy that receive x_prev / the guided eps directly (no copy afterwards)."""
         dev = self.device
         x = _f32(x_noisy, dev)
         vi = view_idx.to(device=dev, dtype=torch.int32).contiguous()
         TN = vi.shape[0]
-        x_prev = torch.empty_like(x)
-        eps = torch.empty_like(x) if want_eps else None
+
+        def direct(t):
+            return t is not None and t.is_contiguous() and t.dtype == torch.float32 and t.device == x.device and t.shape == x.shape
+
+        x_prev = out if direct(out) else torch.empty_like(x)
+        eps = (eps_out if direct(eps_out) else torch.empty_like(x)) if want_eps else None
         nz = None if noise is None else _f32(noise, dev)
         xi, cl, te, ve = _f32(x_input, dev), _f32(clip, dev), _f32(t_embed, dev), _f32(v_embed, dev)
         L.check(self.lib.mvd_denoise_views(
@@ -564,6 +581,10 @@ class Engine:
             L.ptr(te), L.ptr(ve), L.ptr(vi), TN, C.c_float(cfg_scale), L.ptr(nz),
             C.c_float(coef[0]), C.c_float(coef[1]), C.c_float(coef[2]), C.c_float(coef[3]), C.c_float(coef[4]),
             L.ptr(eps), L.ptr(x_prev), _stream()))
+        if out is not None and x_prev is not out:
+            out.copy_(x_prev)
+        if want_eps and eps_out is not None and eps is not eps_out:
+            eps_out.copy_(eps)
         return (x_prev, eps) if want_eps else x_prev
 
     def denoise_views_batch(self, slots, x_noisy, x_input, clip, timesteps, t_embed, v_embed, view_idx, cfg_scale, noise, coef,

@@ -589,8 +589,10 @@ class SyncMultiviewDiffusion(nn.Module):
         if dev.type == "cuda":
             if getattr(self, "_grad_comm", None) is None:
                 self._grad_comm = torch.cuda.Stream(device=dev)
+            lib_comm = ensure_library_comm(eng, dev)
             self._grad_sync = BucketedGradSync(eng.flat_grads, eng.grad_buckets(), comm=self._grad_comm,
-                                               wait=lambda k: eng.grad_bucket_wait(k, self._grad_comm))
+                                               wait=lambda k: eng.grad_bucket_wait(k, self._grad_comm),
+                                               engine=eng if lib_comm else None)
         else:  # CPU stand-ins of the engine (tests): no streams, the buckets are reduced in order
             self._grad_sync = BucketedGradSync(eng.flat_grads, eng.grad_buckets())
         self._grad_sync.start()
@@ -664,6 +666,42 @@ def _dist_world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def ensure_library_comm(eng, dev):
+    """Under a launcher with one device per rank (process group on the nccl = RCCL backend) the collectives of the step -- the
+    view exchange of the sharded sampler, the gradient reducer of the training step -- run on the LIBRARY's communicator
+    (mvd_comm_init) instead of through Python's c10d: created here on first use, collectively (every rank gets here at the same
+    point of its first step).  Falls back to torch.distributed -- on ALL ranks, agreed by a MIN all-reduce of the outcome --
+    when librccl cannot be opened or the communicator cannot be created; MVD_NO_LIB_COMM=1 keeps c10d.  Returns True when the
+    library communicator spans the process group."""
+    import os
+    import warnings
+    import torch.distributed as dist
+    world = _dist_world()
+    if world <= 1 or getattr(dev, "type", str(dev).split(":")[0]) != "cuda":
+        return False
+    if getattr(eng, "comm_world", 0) == world:
+        return True
+    if getattr(eng, "_lib_comm_tried", False):
+        return False
+    eng._lib_comm_tried = True
+    if os.environ.get("MVD_NO_LIB_COMM") or dist.get_backend() != "nccl":  # gloo stand-ins share one device: no RCCL there
+        return False
+    ok = 1
+    try:
+        eng.comm_init(dist.get_rank(), world)
+    except Exception as exc:  # MvdError: librccl.so missing, ncclCommInitRank failed
+        ok = 0
+        warnings.warn(f"mvd_comm_init failed ({exc}); the step's collectives stay on torch.distributed")
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if ok:
+            eng.comm_destroy()
+        eng.comm_world = 0
+        return False
+    return True
+
+
 class BucketedGradSync:
     """DDP's reducer on the flat gradient arena: ``buckets`` = lists of (offset, length) ranges in the order their gradients
     become final; ``start()`` enqueues one all-reduce per range on the communication stream ``comm``, each bucket behind
@@ -671,8 +709,11 @@ class BucketedGradSync:
     covered (the conditioner's parameters, written after the UNet's backward), makes the caller's stream wait for ``comm`` and
     scales by 1 / world_size.  The arithmetic per element is the flat all-reduce's: sum over ranks, then the scale."""
 
-    def __init__(self, flat, buckets, comm=None, wait=None):
+    def __init__(self, flat, buckets, comm=None, wait=None, engine=None):
         self.flat, self.buckets, self.comm, self.wait = flat, buckets, comm, wait
+        # engine: its library communicator spans the process group -> the whole reducer is two C calls (mvd_train_sync_gradients:
+        # ncclAllReduce per range on `comm`, no Python per bucket); None: one dist.all_reduce per range (c10d)
+        self.engine = engine if comm is not None else None
         self.done = False
 
     def _ctx(self):
@@ -681,6 +722,9 @@ class BucketedGradSync:
 
     def start(self):
         import torch.distributed as dist
+        if self.engine is not None:
+            self.engine.sync_gradients(0, self.comm)
+            return
         with self._ctx():
             for k, ranges in enumerate(self.buckets):
                 if self.wait is not None:
@@ -705,6 +749,10 @@ class BucketedGradSync:
     def finish(self):
         import torch.distributed as dist
         if self.done:
+            return True
+        if self.engine is not None:
+            self.engine.sync_gradients(1, self.comm)  # rest of the arena, join, 1 / world -- all in the library
+            self.done = True
             return True
         if self.comm is not None:
             self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))  # the conditioner's backward wrote the rest
@@ -961,13 +1009,13 @@ class SyncDDIMSampler:
         lo = rank * NL if world > 1 else 0
         if world == 1 and NL != N:
             raise ValueError("x_target_noisy must hold all views when the sampler is not sharded")
-        v_embed = m.get_viewpoint_embedding(batch).to(x_target_noisy.device)
+        v_embed = self._v_embed(batch, x_target_noisy.device)
         t_embed = m.embed_time(time_steps)
         coef = self.schedule.coefficients(index)
         if noise is None and not is_step0:
             noise = torch.randn_like(x_target_noisy)
-        out = torch.empty_like(x_target_noisy)
-        eps_out = torch.empty_like(x_target_noisy) if return_eps else None
+        out = torch.empty_like(x_target_noisy, memory_format=torch.contiguous_format)
+        eps_out = torch.empty_like(out) if return_eps else None
         # view indices of this rank, resident on the device (a host tensor here would be a pageable host-to-device copy per
         # engine call: a host synchronisation on the step path, and not capturable in a hipGraph)
         key = (lo, NL, str(x_target_noisy.device))
@@ -999,14 +1047,18 @@ class SyncDDIMSampler:
             for ni in range(0, NL, batch_view_num):
                 sl = slice(ni, min(NL, ni + batch_view_num))
                 idx = local_idx[sl]
+                # x_prev / eps land in the caller-visible tensors straight from the C call (contiguous slices of `out`), and the
+                # view embeddings are a slice, not a gather: no torch kernel on the step path
+                o_v, e_v = out[bi, sl], (eps_out[bi, sl] if return_eps else None)
                 r = eng.denoise_views(
                     x_target_noisy[bi, sl], x_input[bi], clip_embed[bi].reshape(-1), host_steps[bi], t_embed[bi],
-                    v_embed[bi, idx], idx, float(unconditional_scale),
-                    None if is_step0 else noise[bi, sl], coef, want_eps=return_eps)
-                if return_eps:
-                    out[bi, sl], eps_out[bi, sl] = r
-                else:
-                    out[bi, sl] = r
+                    v_embed[bi, lo + sl.start:lo + sl.stop], idx, float(unconditional_scale),
+                    None if is_step0 else noise[bi, sl], coef, want_eps=return_eps, out=o_v, eps_out=e_v)
+                xp, ep = r if return_eps else (r, None)
+                if xp.data_ptr() != o_v.data_ptr():  # an engine that returned its own tensors (CPU stand-ins)
+                    o_v.copy_(xp)
+                if return_eps and ep.data_ptr() != e_v.data_ptr():
+                    e_v.copy_(ep)
         return (out, eps_out) if return_eps else out
 
     def _denoise_apply_batched(self, x_target_noisy, x_input, clip_embed, host_steps, t_embed, v_embed, local_idx, lo, NL, rank, world,
@@ -1034,6 +1086,18 @@ class SyncDDIMSampler:
                 out[:, sl] = r
         return (out, eps_out) if return_eps else out
 
+    def _v_embed(self, batch, device):
+        """get_viewpoint_embedding(batch) on `device`, cached on the CONTENT identity of the four angle tensors (storage address,
+        shape, in-place version counter; references held so an address cannot be recycled under a live key): the embedding is
+        constant over the 50 steps of a trajectory, and its ~12 torch kernels were on every step."""
+        ts = tuple(batch[k] for k in ("target_elevation", "input_elevation", "target_azimuth", "input_azimuth"))
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device)) for t in ts) + (str(device),)
+        c = getattr(self, "_ve_cache", None)
+        if c is None or c[0] != key:
+            c = (key, self.model.get_viewpoint_embedding(batch).to(device).contiguous(), ts)
+            self._ve_cache = c
+        return c[1]
+
     def _buf(self, name, shape, device):
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
@@ -1050,6 +1114,8 @@ class SyncDDIMSampler:
         eng = self.model.engine
         dev = x_local.device
         real = world > 1 and not self.simulate_world
+        if real:  # under a launcher the designed path is the library's communicator (falls back to c10d, logged)
+            ensure_library_comm(eng, dev)
         side = self.overlap and dev.type == "cuda"
         # nn.Module semantics, as in the reference: in train mode the sparse CNN's BatchNorm layers use batch statistics
         # (construct_spatial_volume, morphable_diffusion.py:253-254); callers that sample call .eval() (generate_face.py:77)
@@ -1135,7 +1201,7 @@ class SyncDDIMSampler:
         with torch.no_grad():
             for i, step in enumerate(time_range):
                 index = total_steps - i - 1
-                time_steps = torch.full((B,), int(step), device=device, dtype=torch.long)
+                time_steps = self._time_steps(B, int(step), device)
                 noise = draw() if index != 0 else None
                 x = self.denoise_apply(x, input_info, clip_embed, time_steps, index, unconditional_scale,
                                        batch_view_num=batch_view_num, is_step0=index == 0, batch=batch, noise=noise,
@@ -1146,6 +1212,14 @@ class SyncDDIMSampler:
                 if index % log_every_t == 0 or index == total_steps - 1:
                     intermediates["x_inter"].append(self._gather(x, world))
         return self._gather(x, world), intermediates
+
+    def _time_steps(self, B, step, device):
+        """[B] int64 tensor of one DDIM time step, kept per step value (50 small tensors per sampler): no fill kernel per step."""
+        c = self.__dict__.setdefault("_ts_cache", {})
+        key = (B, step, str(device))
+        if key not in c:
+            c[key] = torch.full((B,), step, device=device, dtype=torch.long)
+        return c[key]
 
     def _gather(self, x, world):
         if world == 1:

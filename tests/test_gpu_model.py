@@ -140,6 +140,81 @@ def test_unet_blocks_small_vs_golden_through_the_rowchain_kernel():
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:]
 
 
+def _small_emb(W, cfg, t):
+    from oracle import mvd_oracle as O
+    P = "model.diffusion_model."
+    emb = O.timestep_embedding(t, cfg.model_channels)
+    emb = torch.nn.functional.linear(emb, W[P + "time_embed.0.weight"], W[P + "time_embed.0.bias"])
+    return torch.nn.functional.linear(O.silu(emb), W[P + "time_embed.2.weight"], W[P + "time_embed.2.bias"])
+
+
+def test_resblock_8x8_partial_tile_with_timestep_bias_vs_oracle():
+    """conv3x's 8 x 8 form packs four images per tile; with B % 4 != 0 the dead waves of the last tile must not read the
+    per-sample (timestep-embedding) bias rows past the batch.  B = 3 and B = 6 through the production ResBlock (conv1 carries the
+    emb row bias) against the oracle's ResBlock (openaimodel.py:256-276)."""
+    from morphablediffusion_amd.model import DepthWiseAttention
+    from oracle import mvd_oracle as O
+    cfg = gi.SMALL_UNET
+    W = gi.unet_weights(cfg)
+    net = DepthWiseAttention(volume_dims=cfg.volume_dims, image_size=32, in_channels=8, out_channels=4,
+                             model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                             channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                             transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+    net.load_state_dict({k[len("model.diffusion_model."):]: v for k, v in W.items()})
+    for B in (3, 6):
+        x = torch.randn(B, 256, 8, 8, generator=torch.Generator().manual_seed(40 + B))
+        t = torch.tensor([981, 481, 1, 21, 701, 333][:B])
+        got = net._engine.unet_block("input_blocks.8.0", x, timesteps=t).cpu()
+        want = O.res_block(W, "model.diffusion_model.input_blocks.8.0", x, _small_emb(W, cfg, t))
+        rl2 = ((got - want).norm() / want.norm()).item()
+        print(f"[parity] res 8x8 B={B} (partial conv3x tile, row bias): relL2={rl2:.2e}")
+        assert rl2 <= REL_L2
+
+
+_XP_ROWCHAIN_WORKER = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tests import golden_inputs as gi
+from morphablediffusion_amd.model import DepthWiseAttention
+from morphablediffusion_amd.spec import UNetConfig
+from oracle import mvd_oracle as O
+import dataclasses
+for mc in (128, 256):
+    cfg = dataclasses.replace(gi.SMALL_UNET, model_channels=mc)
+    W = gi.unet_weights(cfg)
+    net = DepthWiseAttention(volume_dims=cfg.volume_dims, image_size=32, in_channels=8, out_channels=4, model_channels=mc,
+                             attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
+                             use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+    net.load_state_dict({k[len("model.diffusion_model."):]: v for k, v in W.items()})
+    g = torch.Generator().manual_seed(9 + mc)
+    x, ctx = torch.randn(2, mc, 32, 32, generator=g), torch.randn(2, 1, 768, generator=g)
+    # output_blocks.11.1: the last output block's transformer -- proj_out in extended precision at the default precision level
+    got = net._engine.unet_block("output_blocks.11.1", x, context=ctx).cpu()
+    want = O.spatial_transformer(W, "model.diffusion_model.output_blocks.11.1", x, ctx, 8)
+    rl2 = ((got - want).norm() / want.norm()).item()
+    print(f"[parity] st C={mc} rowchain forced, xp proj_out: relL2={rl2:.2e}")
+    assert rl2 <= 1e-3, rl2
+print("XP_ROWCHAIN_OK")
+"""
+
+
+def test_rowchain_forced_with_extended_precision_proj_out_at_c128_c256(tmp_path):
+    """rowchain_kernel<C, 1, 2> (proj_out in extended precision) exists for C = 64 and 320 only; a UNet with
+    model_channels 128 / 256 whose last output block takes the row chain (here forced: MVD_ROWCHAIN_MIN_ROWS=0) must run the
+    (1, 0) form + the separate extended-precision proj_out GEMM instead of failing with 'form is not instantiated'."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "xp_rowchain.py"
+    script.write_text(_XP_ROWCHAIN_WORKER % {"root": root})
+    r = subprocess.run([sys.executable, str(script)], cwd=root, env=dict(os.environ, MVD_ROWCHAIN_MIN_ROWS="0"),
+                       capture_output=True, text=True, timeout=900)
+    for line in r.stdout.splitlines():
+        if "[parity]" in line:
+            print(line)
+    assert r.returncode == 0 and "XP_ROWCHAIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_unet_full_vs_golden():
     from morphablediffusion_amd.model import DepthWiseAttention
     cfg = gi.FULL_UNET

@@ -76,6 +76,24 @@ def test_linear_dense_identity(eng):
     close(eng.op_linear(torch.eye(K), w, a_half=True), w.t().contiguous(), "dense linear identity", rel=1e-6, mx=1e-6)
 
 
+@pytest.mark.parametrize("bn", [96, 128, 160])
+def test_linear_dense_through_the_four_wave_tiles(bn):
+    """Round 6: gemm_dma_kernel<128, BN> (128-row tiles, four waves) forced for every plain dense launch (MVD_DENSE_BM / MVD_DENSE_BN,
+    read once per process, hence the subprocess): the dense-linear cases above -- ragged M / N / K tails, residual, forced split-K,
+    the identity check -- must hold on the new tile shapes too (GEGLU launches keep the 256-row form)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-k",
+                        "test_linear_dense and not four_wave"], cwd=root,
+                       env=dict(os.environ, MVD_DENSE_BM="128", MVD_DENSE_BN=str(bn), MVD_PLAN_DEBUG="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
+    assert f"bm=128 bn={bn}" in r.stderr, "the forced 128-row tiles were not used"  # [plan] lines of igemm_go
+    worst = max(float(l.split("relL2=")[1].split()[0]) for l in r.stdout.splitlines() if "[parity] dense linear" in l and "relL2=" in l)
+    print(f"[parity] dense linear through gemm_dma_kernel<128,{bn}>: worst relL2={worst:.2e}")
+
+
 def test_linear_geglu(eng):
     M, K, N = 200, 64, 512
     a, w, b = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)

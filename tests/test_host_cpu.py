@@ -150,7 +150,8 @@ class FakeEngine:
         for v in range(vf_all.shape[0]): acc = acc + vf_all[v]  # fixed view order
         return acc / self.N + 0.5
     def volume_from_fused(self, fused, want_output=True, train=False): self.fused = fused.clone()
-    def denoise_views(self, x, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg, noise, coef, want_eps=False):
+    def denoise_views(self, x, x_input, clip, timestep, t_embed, v_embed, view_idx, cfg, noise, coef, want_eps=False, out=None,
+                      eps_out=None):  # (returns its own tensor: the sampler copies it into its `out` slice)
         s = self.fused.sum()
         out = x * coef[2] + s * 1e-3 + view_idx.float().view(-1, 1, 1, 1) * 1e-2
         return out + (0 if noise is None else coef[4] * noise)

@@ -35,7 +35,11 @@ def family(name):
         if m.group(1) == "igemm_kernel":
             return f"igemm_kernel<{1 if a[0] == 'true' else 0},{a[1]}>"
         if m.group(1) == "gemm_dma_kernel":
-            a = a[:2]  # <BN, MODE, PLAIN>: the engine books the plain and the general instance under one family
+            # <BM, BN, MODE, PLAIN>: the engine books the plain and the general instance under one family, the four-wave
+            # 128-row tiles as gemm_dma_kernel<128xBN>
+            if len(a) >= 4:
+                return f"gemm_dma_kernel<128x{a[1]}>" if a[0] == "128" else f"gemm_dma_kernel<{a[1]},{a[2]}>"
+            a = a[:2]
         return f"{m.group(1)}<{','.join(a)}>"
     m = re.search(r"conv3x_kernelILi(\d+)E", name) or re.search(r"conv3x_kernel<\s*(\d+)", name)
     if m:  # mangled or demangled; the engine books conv3x_kernel<NF> for both tile geometries
