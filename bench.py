@@ -45,6 +45,25 @@ def pmc_traffic(family, config):
         return None
 
 
+KERNEL_DURATIONS_FILE = os.environ.get("MVD_KERNEL_DURATIONS", os.path.join("profiles", "kernel_durations.json"))
+
+
+def rocprof_us_per_launch(family, config):
+    """rocprofv3's average duration (us) of ``family`` from the stamped summary tools/prof_summary.py writes (same build, same
+    workload), or None."""
+    try:
+        with open(os.path.join(ROOT, KERNEL_DURATIONS_FILE) if not os.path.isabs(KERNEL_DURATIONS_FILE) else KERNEL_DURATIONS_FILE) as f:
+            d = json.load(f)
+        if d.get("config") != config:
+            return None
+        from morphablediffusion_amd.lib import csrc_sha16
+        if d.get("csrc_sha16") != csrc_sha16():
+            return None
+        return d["us_per_launch"].get(family)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def unet_kwargs(cfg):
     return dict(volume_dims=list(cfg.volume_dims), image_size=cfg.image_size, in_channels=8, out_channels=4,
                 model_channels=cfg.model_channels, attention_resolutions=[4, 2, 1], num_res_blocks=2,
@@ -462,9 +481,15 @@ def main():
         # what an event bracket adds to a launch's own duration: pairs of events with nothing between them, recorded by the
         # survey pass on the same stream after every 8th launch; subtracted per bracketed launch below (rocprofv3's kernel
         # durations, which the roofline must agree with, do not contain it)
+        # ... measured two ways: an EMPTY bracket (event overhead alone) and a bracket around a NULL kernel (event overhead +
+        # the dispatch latency between the first event and the kernel's first wave).  The second is what separates an event
+        # bracket from rocprofv3's begin-to-end kernel duration (round 5 subtracted the first: 16 % high on a 45 us kernel)
         empty = [f for f in families if f["family"] == "(empty bracket)"]
-        families = [f for f in families if f["family"] != "(empty bracket)"]
-        bracket_ms = (empty[0]["ms"] / empty[0]["sampled"]) if empty and empty[0]["sampled"] else 0.0
+        nullk = [f for f in families if f["family"] == "(null-kernel bracket)"]
+        families = [f for f in families if not f["family"].startswith("(")]
+        empty_ms = (empty[0]["ms"] / empty[0]["sampled"]) if empty and empty[0]["sampled"] else 0.0
+        null_ms = (nullk[0]["ms"] / nullk[0]["sampled"]) if nullk and nullk[0]["sampled"] else 0.0
+        bracket_ms = null_ms if null_ms > 0 else empty_ms
         for f in families:
             f["ms_raw"] = f["ms"]
             f["ms"] = max(f["ms"] - f["sampled"] * bracket_ms, 0.5 * f["ms"])
@@ -545,6 +570,9 @@ def main():
     dom = roof(timed[dominant]) if dominant and dominant in timed else None
     if dom is None and families:  # nothing bracketed in the timed region (stride too large for the step count)
         dom = roof(max(families, key=lambda f: f["ms"]))
+    us_rp = rocprof_us_per_launch(dominant, args.config) if (dominant and world == 1 and not args.simulate_gpus) else None
+    if dom is not None:  # algorithmic work per launch in units of the bounding roof's peak-seconds: frac = this / launch duration
+        dom["frac_alg_per_launch"] = dom["achieved"] / dom["peak"] * dom["us_per_launch"] * 1e-6
     if rank == 0:
         out = {
             "metric": "multi-view denoising steps/sec (N=16 views, 256x256, CFG 2.0, DDIM-50 step)" if args.config == "headline"
@@ -572,11 +600,17 @@ def main():
                 "how": f"HIP events on the launch stream around a deterministic 1-in-{args.probe_stride} sample of this "
                        f"family's launches INSIDE the timed region ({dom['launches_bracketed']} of {dom['launches']} launches, "
                        f"{dom['us_per_launch_raw']:.1f} us per bracket, {dom['us_per_launch']:.1f} us after subtracting the "
-                       f"{1e3 * bracket_ms:.1f} us an EMPTY bracket measures on the same stream in the survey pass); achieved = "
-                       f"summed algorithmic {'FLOPs' if dom['bound'] == 'mfma' else 'bytes'} / summed (event time - empty bracket); "
+                       f"{1e3 * bracket_ms:.1f} us a bracket around a NULL kernel measures on the same stream in the survey pass: event "
+                       f"overhead + dispatch latency; an empty bracket alone measures {1e3 * empty_ms:.1f} us); achieved = "
+                       f"summed algorithmic {'FLOPs' if dom['bound'] == 'mfma' else 'bytes'} / summed (event time - null-kernel bracket); "
                        f"the family was picked as the one with the largest summed time in a 2-step survey pass that brackets "
                        f"every launch of every family",
-                "event_bracket_overhead_us": 1e3 * bracket_ms, "us_per_launch": dom["us_per_launch"],
+                "event_bracket_overhead_us": 1e3 * bracket_ms, "empty_bracket_us": 1e3 * empty_ms, "null_kernel_bracket_us": 1e3 * null_ms,
+                "us_per_launch": dom["us_per_launch"],
+                # the same family under rocprofv3 (profiles/kernel_durations.json, written by tools/prof_summary.py for THIS build
+                # and workload; null when absent or stale): its average kernel duration and the roofline fraction that follows
+                "us_per_launch_rocprof": us_rp,
+                "frac_rocprof": (dom["frac_alg_per_launch"] / (us_rp * 1e-6)) if us_rp else None,
                 "us_per_launch_uncorrected": dom["us_per_launch_raw"],
                 "tflops": dom["tflops"], "gbs": dom["gbs"],
                 "mfma_frac": dom["tflops"] / PEAK_F16_TFLOPS, "hbm_frac": dom["gbs"] / PEAK_HBM_GBS},

@@ -1305,6 +1305,7 @@ int mvd_probe_config(mvd_ctx* c, int mode, const char* family, int stride) {
     c->probe_counter = 0;
     c->probe_fam.clear();
     c->probe_empty.clear();
+    c->probe_null.clear();
   }
   return 0;
 }
@@ -1344,6 +1345,21 @@ int mvd_probe_report(mvd_ctx* c, char* buf, size_t cap) {
              "%s{\"family\": \"(empty bracket)\", \"launches\": %zu, \"sampled\": %zu, \"ms\": %.6f, \"flops\": 0, \"bytes\": 0, "
              "\"all_flops\": 0, \"all_bytes\": 0}",
              first ? "" : ", ", c->probe_empty.size(), c->probe_empty.size(), ms);
+    out += line;
+  }
+  if (!c->probe_null.empty()) {  // event overhead + dispatch latency of a launch (survey mode), as a pseudo-family
+    double ms = 0.0;
+    for (size_t e : c->probe_null) {
+      HIP_CHECK_RET(hipEventSynchronize(c->probe_ev[e + 1]));
+      float t = 0.f;
+      HIP_CHECK_RET(hipEventElapsedTime(&t, c->probe_ev[e], c->probe_ev[e + 1]));
+      ms += t;
+    }
+    char line[256];
+    snprintf(line, sizeof line,
+             "%s{\"family\": \"(null-kernel bracket)\", \"launches\": %zu, \"sampled\": %zu, \"ms\": %.6f, \"flops\": 0, \"bytes\": 0, "
+             "\"all_flops\": 0, \"all_bytes\": 0}",
+             out.size() > 1 ? ", " : "", c->probe_null.size(), c->probe_null.size(), ms);
     out += line;
   }
   out += "]";
@@ -1430,11 +1446,22 @@ int mvd_bench_group_norm(mvd_ctx* c, int B, int C, int HW, int groups, int flags
   NormW nw;
   nw.g = gb; nw.b = gb + C; nw.C = C;
   RET_IF(run_group_norm(c, x, C, B, HW, nw, groups, 1e-5f, ACT_SILU, nullptr, y, C * wo, s, 0, split));  // warm-up
+  // flags & 2: the APPLY pass alone (statistics given): what a GroupNorm costs once its statistics come out of the producer's epilogue
+  float* partial = nullptr;
+  int nslabs = 0;
+  if (flags & 2) {
+    partial = ws_alloc<float>(c, (size_t)B * gn_max_slabs() * groups * 2);
+    WS_CHECK(partial);
+    RET_IF(launch_gn_stats(x, C, B, HW, C, groups, nullptr, 0, partial, &nslabs, s));
+  }
   hipEvent_t e0, e1;
   HIP_CHECK_RET(hipEventCreate(&e0));
   HIP_CHECK_RET(hipEventCreate(&e1));
   HIP_CHECK_RET(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) RET_IF(run_group_norm(c, x, C, B, HW, nw, groups, 1e-5f, ACT_SILU, nullptr, y, C * wo, s, 0, split));
+  for (int i = 0; i < iters; ++i) {
+    if (flags & 2) RET_IF(launch_gn_apply(x, C, B, HW, C, groups, nullptr, 0, partial, nslabs, nw.g, nw.b, 1e-5f, ACT_SILU, y, C * wo, s, split));
+    else RET_IF(run_group_norm(c, x, C, B, HW, nw, groups, 1e-5f, ACT_SILU, nullptr, y, C * wo, s, 0, split));
+  }
   HIP_CHECK_RET(hipEventRecord(e1, s));
   HIP_CHECK_RET(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -242,3 +242,4 @@ int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view
                           float vol_len, int persp, half_t* out, hipStream_t s);
 int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);
 int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s);
+int launch_probe_null(hipStream_t s);  // one wave that does nothing: the launch path's own cost (ProbeScope calibration)

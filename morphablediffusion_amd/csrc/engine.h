@@ -243,6 +243,7 @@ struct mvd_ctx {
   std::map<std::string, ProbeFam> probe_fam;
   std::vector<hipEvent_t> probe_ev;   // pool, two events per bracketed launch
   size_t probe_used = 0;
+  std::vector<size_t> probe_null;     // survey mode: brackets around a null kernel (event overhead + dispatch latency)
   std::vector<size_t> probe_empty;    // survey mode: brackets with NOTHING between the two events (what a bracket itself costs)
   std::map<std::string, RawTensor> raw;
   std::vector<void*> owned;  // packed device allocations
@@ -642,6 +643,24 @@ struct ProbeScope {
       c->probe_used += 2;
       c->probe_empty.push_back(e);
       hipEventRecord(c->probe_ev[e], s);
+      hipEventRecord(c->probe_ev[e + 1], s);
+    }
+    // ... and, offset by four brackets, one around a NULL kernel (one wave, no memory access): event overhead PLUS the dispatch
+    // latency every bracketed launch pays between the first event's completion and its own first wave -- which rocprofv3's kernel
+    // durations (begin to end of the kernel itself) do not contain.  Round 5 subtracted the empty bracket only and its
+    // dominant-kernel time sat 16 % above rocprofv3's; pseudo-family "(null-kernel bracket)".
+    if (c->probe_mode == 1 && (slot & 14) == 8) {
+      if (c->probe_used + 2 > c->probe_ev.size())
+        for (int i = 0; i < 2; ++i) {
+          hipEvent_t ev;
+          if (hipEventCreate(&ev) != hipSuccess) return;
+          c->probe_ev.push_back(ev);
+        }
+      const size_t e = c->probe_used;
+      c->probe_used += 2;
+      c->probe_null.push_back(e);
+      hipEventRecord(c->probe_ev[e], s);
+      launch_probe_null(s);
       hipEventRecord(c->probe_ev[e + 1], s);
     }
   }

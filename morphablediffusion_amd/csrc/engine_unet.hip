@@ -731,10 +731,31 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
   float* o = ws_alloc<float>(c, (size_t)rows * I);
   float* o2 = ws_alloc<float>(c, (size_t)rows * I);
   WS_CHECK(p && pn && z && o && o2);
+  // The three GEMMs of this block whose result only feeds a GroupNorm (proj_in -> gn_in, the folded output projection -> gn_o1,
+  // conv1 -> gn_o2) leave their split-K slabs to that norm when the plan splits K (GemmArgs::slabs, as ResBlock conv1 does): the
+  // reduce pass -- a launch, a write and a read of the tensor -- disappears (round 6: 24 of the headline step's 46 reduce launches
+  // sat in front of a GroupNorm here; MVD_NO_COND_DEFER=1 restores them).  Inference only: the backward pass reads p / o / o2.
+  static const bool no_cdefer = getenv("MVD_NO_COND_DEFER") != nullptr || getenv("MVD_NO_DEFER_REDUCE") != nullptr ||
+                                getenv("MVD_GN_TWO_PASS") != nullptr;
+  const size_t slab_elems = (size_t)rows * I;
+  auto offer_slabs = [&](GemmArgs& ga, int* sk, int ldo) {
+    *sk = 1;
+    if (no_cdefer || f.train || !gn_group_eligible(I, HW, I, 8, 0, ldo)) return;
+    const size_t nsl = rows > 8192 ? 4 : 16;
+    ga.slabs = ws_alloc<float>(c, nsl * slab_elems);
+    ga.slabs_cap = ga.slabs ? nsl * slab_elems : 0;
+    ga.sk_used = sk;
+  };
   GemmArgs g;
+  int skd = 1;
   g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &d.proj_in; g.out = p; g.ldc = I;
+  offer_slabs(g, &skd, xq ? 3 * I : I);
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq));
+  if (skd > 1)
+    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq, skd, slab_elems,
+                          d.proj_in.bias));
+  else
+    RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq));
   if (f.n_ctx > 0) {
     float* qk = ws_alloc<float>(c, (size_t)crow * 4 * Cc);
     half_t* cn = cond_idx >= 0 && f.cn_pre[cond_idx] ? nullptr : ws_alloc<half_t>(c, (size_t)crow * D * Cc);
@@ -770,12 +791,20 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
   }
   g = GemmArgs();
   g.a = z; g.lda = 4 * Cc * wz; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
+  offer_slabs(g, &skd, x1 ? 3 * I : I);
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
-  RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1));
+  if (skd > 1)
+    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1, skd, slab_elems));
+  else
+    RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1));
   g = GemmArgs();
   g.a = pn; g.lda = x1 ? 3 * I : I; g.w = &d.conv1; g.out = o2; g.ldc = I; g.use_bias = false;
+  offer_slabs(g, &skd, x2 ? 3 * I : I);
   RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
-  RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2));
+  if (skd > 1)
+    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2, skd, slab_elems));
+  else
+    RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2));
   g = GemmArgs();
   g.a = pn; g.lda = x2 ? 3 * I : I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
   RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));

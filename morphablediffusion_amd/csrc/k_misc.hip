@@ -574,3 +574,11 @@ int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStr
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+namespace {
+__global__ void probe_null_kernel() {}
+}  // namespace
+int launch_probe_null(hipStream_t s) {
+  hipLaunchKernelGGL(probe_null_kernel, dim3(1), dim3(64), 0, s);
+  return hipGetLastError() == hipSuccess ? 0 : mvd_fail("probe_null launch failed");
+}

@@ -749,9 +749,10 @@ class Engine:
         L.check(self.lib.mvd_bench_linear(self._ctx, M, K, N, flags, iters, C.byref(ms), _stream()))
         return ms.value
 
-    def bench_group_norm(self, B, Cc, HW, groups=32, split=False, iters=20):
+    def bench_group_norm(self, B, Cc, HW, groups=32, split=False, iters=20, apply_only=False):
         ms = C.c_float(0)
-        L.check(self.lib.mvd_bench_group_norm(self._ctx, B, Cc, HW, groups, 1 if split else 0, iters, C.byref(ms), _stream()))
+        L.check(self.lib.mvd_bench_group_norm(self._ctx, B, Cc, HW, groups, (1 if split else 0) | (2 if apply_only else 0), iters, C.byref(ms),
+                                              _stream()))
         return ms.value
 
     def probe_config(self, mode, family=None, stride=1):

@@ -15,7 +15,7 @@ timeout 700 python bench.py --steps 20 --warmup 3 $NC > $O/bench.json 2> $O/benc
 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --simulate-gpus 8 > $O/bench_sim8.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof.err
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats.csv; rm -rf $O/prof
-python tools/prof_summary.py $O/kernel_stats.csv $O/bench_prof.json > $O/family_table.txt
+python tools/prof_summary.py $O/kernel_stats.csv $O/bench_prof.json $O/kernel_durations.json > $O/family_table.txt
 MVD_LAYER_TIMING=1 timeout 300 python tools/layer_step.py 2> $O/layers.log > /dev/null; python tools/layer_agg.py $O/layers.log 40 > $O/layers_step.txt 2>/dev/null
 if want pmc; then
   CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"

@@ -1,6 +1,6 @@
 """Per-kernel-family table of one bench.py run under rocprofv3, regenerated from files under profiles/:
 
-  python tools/prof_summary.py <kernel_stats.csv | results.db> <bench.json> [total_steps]
+  python tools/prof_summary.py <kernel_stats.csv | results.db> <bench.json> [total_steps] [out.json]
 
 * kernel time, launches, average duration per family come from rocprofv3 (--kernel-trace --stats; CSV or the SQLite db);
 * algorithmic FLOPs / bytes per step and family come from the bench line's "families" (booked by the engine's probe at each
@@ -14,7 +14,10 @@ import sys
 
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 path, bench = sys.argv[1], json.load(open(sys.argv[2]))
-steps = float(sys.argv[3]) if len(sys.argv) > 3 else bench["steps"] + bench["warmup"] + 2
+extra = sys.argv[3:]
+json_out = next((a for a in extra if a.endswith(".json")), None)  # optional: stamped per-family durations for bench.py's frac_rocprof
+nums = [a for a in extra if not a.endswith(".json")]
+steps = float(nums[0]) if nums else bench["steps"] + bench["warmup"] + 2
 
 
 def rows_from(path):
@@ -85,3 +88,15 @@ for f, t in sorted(fam_t.items(), key=lambda kv: -kv[1]):
     print(line)
 for t, n, name in sorted(other, reverse=True)[:10]:
     print(f"{name[:60]:60s} {t / steps / 1e6:8.3f} ms/step {n / steps:7.1f} launches/step")
+
+# machine-readable: rocprofv3's average duration per family, stamped with the hash of the library sources and the workload --
+# bench.py prints roofline.frac_rocprof from it (profiles/kernel_durations.json) next to its own event-bracket figure
+if json_out:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from morphablediffusion_amd.lib import csrc_sha16
+    json.dump({"source": "rocprofv3 --kernel-trace --stats over bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras: TotalDurationNs / Calls "
+                         "per kernel family (kernel begin to end, no launch path)",
+               "config": bench.get("config", {}).get("name"), "csrc_sha16": csrc_sha16(),
+               "us_per_launch": {f: fam_t[f] / fam_n[f] / 1e3 for f in fam_t}, "launches_per_step": {f: fam_n[f] / steps for f in fam_t},
+               "kernel_ms_per_step": tot / steps / 1e6}, open(json_out, "w"), indent=1)
