@@ -264,7 +264,7 @@ def train_main(args):
     model = SyncMultiviewDiffusion(
         unet_config={"target": "ldm.models.diffusion.attention.DepthWiseAttention", "params": unet_kwargs(ucfg)},
         scheduler_config=sched_cfg, finetune_unet=True, view_num=N, image_size=256, cfg_scale=2.0, device=dev, workspace_gb=96.0,
-        train_mode=True, recompute=not args.keep_activations,
+        train_mode=True, recompute=not args.keep_activations, precision_level=2,  # (the training tests' level; inference default: 3)
         loss_scale=1.0 if args.dtype == "bf16" else 65536.0)  # bf16 has fp32's exponent range: no loss scaling
     model.load_state_dict(W)
     from morphablediffusion_amd import lib as mvd_lib

@@ -68,10 +68,12 @@ int mvd_upload_weight(mvd_ctx* ctx, const char* name, const float* data, const i
 /* Numerical policy, to be set before mvd_finalize_weights.  MFMA operands are fp16 (11 significand bits: ~4e-4 relative
  * error per GEMM output); the layers whose error reaches the UNet output almost undamped run in EXTENDED precision: both
  * operands split into fp16 hi + lo parts, three products accumulated in fp32 (a_hi w_hi + a_lo w_hi + a_hi w_lo).
- * level 0: none.  1: output conv + conv_in.  2 (default): + the cheap layers of the last output block.  3: + its ResBlock 3x3
- * convs.  4: + the cheap layers of the block before.  5: all such layers of every full-resolution output block.  6: + of the
- * full-resolution input blocks.  Measured error of the UNet's eps against the fp32 reference: 9.3e-4
- * at level 0, 5.8e-4 at level 2, 4.4e-4 at level 4, for +2.2 % / +5.1 % step time. */
+ * level 0: none.  1: output conv + conv_in.  2: + the cheap layers (skip conv, transformer proj_in / proj_out, DepthTransformer)
+ * of the last output block.  3 (default since round 6): + the same layers of the block before it.  4: + the last block's ResBlock
+ * 3x3 convs.  5: all such layers of every full-resolution output block.  6: + of the full-resolution input blocks.  The ladder is
+ * ordered by error removed per unit of time (until round 5 levels 3 and 4 added these two steps in the other order and the
+ * default was 2).  Measured guided-eps error of the full step against the fp32 reference and step time (DESIGN.md section 2,
+ * profiles/r06_k_xp_levels.txt): level 2 7.3-8.4e-4, level 4 6.0-7.1e-4 at +3.6 %; level 3 sits between at +1.2 %. */
 int mvd_set_precision_level(mvd_ctx* ctx, int level);
 /* First-stage model (mvd_vae_decode / mvd_vae_encode), to be set before mvd_finalize_weights.  0 (default): fp16 MFMA operands
  * like the UNet -- ~30 convolutions in series leave 1.8-2.0e-3 relative L2 in the decoded image (at most 0.8 of an 8-bit step).

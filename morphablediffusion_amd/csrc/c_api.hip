@@ -174,6 +174,8 @@ void mvd_destroy(mvd_ctx* c) {
   if (c->bev_after) hipEventDestroy(c->bev_after);
   for (hipEvent_t ev : c->ev_grad_sync)
     if (ev) hipEventDestroy(ev);
+  for (auto& cc : c->cond_const)
+    if (cc.k) hipFree(cc.k);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);

@@ -174,6 +174,12 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
                     float* mat = nullptr, int ldm = 0);
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
                      half_t* out, hipStream_t s);
+bool layernorm_slabs_takes(int C);
+// x = nslab split-K slabs [rows][C] (slab_stride floats apart): their sum + bias + rowbias[row / T] + resid is written to mat (fp32)
+// and normalised into out (fp16): the producing GEMM's reduce pass and the LayerNorm in one launch
+int launch_layernorm_slabs(const float* slabs, int nslab, size_t slab_stride, int rows, int C, const float* bias, const float* rowbias,
+                           int rb_ld, int T, const float* resid, int ldr, float* mat, const float* gamma, const float* beta, float eps,
+                           half_t* out, hipStream_t s);
 int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
                          float* out, hipStream_t s);
 // q | k rows at `qk` (k at column offset heads*d), V row-major at `v` (row strides ldqk / ldv: all three normally live
@@ -242,4 +248,6 @@ int launch_frustum_gather(const float* vol, const ViewCam* cams, const int* view
                           float vol_len, int persp, half_t* out, hipStream_t s);
 int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);
 int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s);
+// out[(b * HW + p) * ldo + c] = in[(b * HW + p) * ldi + c] + img[p * C + c] for b < nb (C, ldi, ldo multiples of 4)
+int launch_add_image_rows(const float* in, int ldi, const float* img, int C, int nb, int HW, float* out, int ldo, hipStream_t s);
 int launch_probe_null(hipStream_t s);  // one wave that does nothing: the launch path's own cost (ProbeScope calibration)

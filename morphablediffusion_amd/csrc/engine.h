@@ -220,13 +220,24 @@ struct mvd_ctx {
   bool finalized = false;
   bool has_unet = false, has_cond = false, has_step = false;
   bool vae_exact = false;   // first-stage encoder / decoder with every conv and the attention in extended precision (mvd_set_vae_precision)
-  int precision_level = 2;  // extended-precision policy (engine_weights.hip: apply_xp_policy), mvd_set_precision_level
+  int precision_level = 3;  // extended-precision policy (engine_weights.hip: apply_xp_policy), mvd_set_precision_level
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
   // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr, ev_emb0 = nullptr, ev_emb = nullptr;
   std::vector<hipEvent_t> ev_cond;
+  // DepthTransformer on a sample WITHOUT context (the unconditional half of classifier-free guidance: all-zero frustum volumes):
+  // GroupNorm(proj_context(0)) = beta, k is constant along the depth axis, the softmax uniform, so depth_attn's output -- and with
+  // it everything proj_out computes -- does not depend on x: the block is x + K with an image K [H*W][dim] that depends on the
+  // weights and the resolution only (reference ldm/models/diffusion/attention.py:26-47, 78-84).  K is computed once per context
+  // (first use, by running the block on one context-free sample) and the step runs the block on the samples WITH context only.
+  struct CondConst {
+    float* k = nullptr;
+    int H = 0, W = 0;
+    bool valid = false;
+  };
+  std::vector<CondConst> cond_const;
   // in-situ per-kernel-family timing (bench.py's roofline object): HIP events on the launch stream around launches, keyed
   // by the kernel's template instance.  mode 0 off; 1 every launch of every family; 2 only family `probe_only`, a
   // pseudo-random 1-in-`probe_stride` sample of its launches (keeps the timed region undisturbed)

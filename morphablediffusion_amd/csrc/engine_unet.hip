@@ -595,6 +595,24 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   else
     RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp));
   GemmArgs g;
+  // A GEMM whose fp32 result is read by a LayerNorm first (proj_in -> LayerNorm1, to_out -> LayerNorm3) leaves its split-K slabs to
+  // that LayerNorm when the plan splits K: launch_layernorm_slabs sums them, adds what the reduce pass would have added, writes the
+  // finished fp32 row (t0 / t2: the later residuals) and the normalised fp16 row -- no reduce launch (the low-resolution blocks and
+  // the few-views-per-rank step, where K is split).  Inference only.
+  // MEASURED (profiles/r06_g_ab_ln_defer.txt): 2 launches fewer at the headline, 12 fewer at 2 views per rank, and no time gained
+  // (13.20 vs 13.17 ms, 6.49 vs 6.45 ms): a dependent 5 us reduce launch with a warm L2 costs what the wider LayerNorm costs.  Kept
+  // as a tested form behind MVD_LN_DEFER=1, off by default.
+  static const bool no_ln_defer = getenv("MVD_LN_DEFER") == nullptr || getenv("MVD_NO_DEFER_REDUCE") != nullptr;
+  const size_t ln_slab_elems = (size_t)rows * C;
+  int sk_ln = 1;
+  auto offer_ln_slabs = [&](GemmArgs& ga, int* sk) {
+    *sk = 1;
+    if (no_ln_defer || f.train || sv || !layernorm_slabs_takes(C) || (c->a2_total & 3) || (t.a2_off & 3)) return;
+    const size_t nsl = rows > 8192 ? 4 : 16;
+    ga.slabs = ws_alloc<float>(c, nsl * ln_slab_elems);
+    ga.slabs_cap = ga.slabs ? nsl * ln_slab_elems : 0;
+    ga.sk_used = sk;
+  };
   static const bool no_rh = getenv("MVD_NO_ROWHEAD") != nullptr;
   if (rc && !no_rh && t.rh_stream && t.rh_xp == (t.proj_in.xp ? 1 : 0) && !(no_xpf && t.proj_in.xp)) {
     // row-head kernel: proj_in -> t0, LayerNorm1 and the q | k | v projection in one launch (k_rowchain.hip)
@@ -606,10 +624,15 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
     RET_IF(launch_rowhead(hp, t.rh_xp, f.s));
   } else {
   g.a = n0; g.lda = C * wi; g.w = &t.proj_in; g.out = t0; g.ldc = C;
+  offer_ln_slabs(g, &sk_ln);
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
-    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
-    RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
+    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * (6.0 + (sk_ln > 1 ? 4.0 * sk_ln : 0.0)));
+    if (sk_ln > 1)  // proj_in split K: LayerNorm1 sums the slabs, adds the bias, writes t0 (the later residual) and l1
+      RET_IF(launch_layernorm_slabs(g.slabs, sk_ln, ln_slab_elems, rows, C, t.proj_in.bias, nullptr, 0, T, nullptr, 0, t0, t.ln1.g, t.ln1.b,
+                                    1e-5f, l1, f.s));
+    else
+      RET_IF(launch_layernorm(t0, rows, C, t.ln1.g, t.ln1.b, 1e-5f, l1, f.s));
   }
   // q | k | v projection in one GEMM; the attention kernel transposes V while staging it
   g = GemmArgs();
@@ -653,10 +676,16 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   g = GemmArgs();
   g.a = ao; g.lda = C; g.w = &t.attn_out; g.out = t2; g.ldc = C; g.resid = t0; g.ldr = C;
   g.rowbias = f.a2_all + t.a2_off; g.rb_ld = c->a2_total;
+  offer_ln_slabs(g, &sk_ln);
+  g.defer_epilogue = g.slabs != nullptr;  // bias, attn2's per-sample row and the residual t0 are then LayerNorm3's to add
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
-    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * 6.0);
-    RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l3, f.s));
+    ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * (6.0 + (sk_ln > 1 ? 4.0 * (sk_ln + 1) : 0.0)));
+    if (sk_ln > 1)
+      RET_IF(launch_layernorm_slabs(g.slabs, sk_ln, ln_slab_elems, rows, C, t.attn_out.bias, g.rowbias, g.rb_ld, T, t0, C, t2, t.ln3.g,
+                                    t.ln3.b, 1e-5f, l3, f.s));
+    else
+      RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l3, f.s));
   }
   g = GemmArgs();
   g.a = l3; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
@@ -720,8 +749,40 @@ int ctx_fold(Fwd& f, const CondW& d, int HW, int D, int level, half_t* cn, hipSt
 int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int level, int cond_idx) {
   mvd_ctx* c = f.c;
   WsScope ws_scope(c, WS_BLOCK);
-  const int HW = H * W, rows = f.Bv * HW, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
+  const int HW = H * W, I = d.I, Cc = d.Cc, D = f.depth0 >> level;
   const int crow = f.n_ctx * HW;
+  // Samples without context (CFG's unconditional half) get x + K (mvd_ctx::CondConst): the block below then runs on the Bx = n_ctx
+  // samples WITH context only -- half the rows of proj_in, the three GroupNorms, the output projection and both 3x3 convolutions.
+  // MVD_NO_COND_CONST=1: the round-5 form (every layer over all samples, the context-free rows' z filled with relu(beta)).
+  static const bool no_const = getenv("MVD_NO_COND_CONST") != nullptr;
+  const int n_free = f.Bv - f.n_ctx;
+  const bool use_const = !no_const && !f.train && !c->train_mode && cond_idx >= 0 && n_free > 0 && f.n_ctx > 0 && !(d.dim & 3) &&
+                         !(in.ld & 3) && !(out.ld & 3);
+  if (use_const) {
+    if (c->cond_const.size() < c->conds.size()) c->cond_const.resize(c->conds.size());
+    mvd_ctx::CondConst& cc = c->cond_const[cond_idx];
+    if (!cc.valid || cc.H != H || cc.W != W) {
+      if (cc.k && (cc.H != H || cc.W != W)) {
+        HIP_CHECK_RET(hipFree(cc.k));
+        cc.k = nullptr;
+      }
+      if (!cc.k) HIP_CHECK_RET(hipMalloc((void**)&cc.k, (size_t)HW * d.dim * sizeof(float)));
+      float* zero = ws_alloc<float>(c, (size_t)HW * d.dim);
+      WS_CHECK(zero);
+      HIP_CHECK_RET(hipMemsetAsync(zero, 0, (size_t)HW * d.dim * sizeof(float), f.s));
+      Fwd f0 = f;  // one context-free sample: the block's residual branch on its own (the input is zero, so out = K)
+      f0.Bv = 1;
+      f0.n_ctx = 0;
+      View in0, out0;
+      in0.p = zero; in0.ld = d.dim; in0.C = d.dim;
+      out0.p = cc.k; out0.ld = d.dim; out0.C = d.dim;
+      RET_IF(unet_do_cond(f0, d, in0, out0, H, W, level, -1));
+      cc.H = H;
+      cc.W = W;
+      cc.valid = true;
+    }
+  }
+  const int Bx = use_const ? f.n_ctx : f.Bv, rows = Bx * HW;
   // extended precision (ConvW::xp): operands are [hi | lo | hi]
   const int xq = d.wqk.xp, xo = d.wov.xp, x1 = d.conv1.xp, x2 = d.conv2.xp;
   const int wpn = (xq || x1 || x2) ? 3 : 1, wz = xo ? 3 : 1;
@@ -750,12 +811,12 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
   int skd = 1;
   g.a = in.p; g.a_f32 = 1; g.lda = in.ld; g.w = &d.proj_in; g.out = p; g.ldc = I;
   offer_slabs(g, &skd, xq ? 3 * I : I);
-  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(run_linear(c, g, Bx, rows, f.s));
   if (skd > 1)
-    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq, skd, slab_elems,
+    RET_IF(run_group_norm(c, g.slabs, I, Bx, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq, skd, slab_elems,
                           d.proj_in.bias));
   else
-    RET_IF(run_group_norm(c, p, I, f.Bv, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq));
+    RET_IF(run_group_norm(c, p, I, Bx, HW, d.gn_in, 8, 1e-5f, ACT_SILU, nullptr, pn, xq ? 3 * I : I, f.s, 0, xq));
   if (f.n_ctx > 0) {
     float* qk = ws_alloc<float>(c, (size_t)crow * 4 * Cc);
     half_t* cn = cond_idx >= 0 && f.cn_pre[cond_idx] ? nullptr : ws_alloc<half_t>(c, (size_t)crow * D * Cc);
@@ -786,28 +847,33 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
       // head) are filled by the same launch
       RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo, rows - crow, d.relu_beta));
     }
-  } else if (f.Bv > f.n_ctx) {
+  } else if (Bx > f.n_ctx) {
     RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc * wz, 4 * Cc * wz, rows - crow, d.relu_beta, 4 * Cc * wz, f.s));
   }
   g = GemmArgs();
   g.a = z; g.lda = 4 * Cc * wz; g.w = &d.wov; g.out = o; g.ldc = I; g.use_bias = false;
   offer_slabs(g, &skd, x1 ? 3 * I : I);
-  RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  RET_IF(run_linear(c, g, Bx, rows, f.s));
   if (skd > 1)
-    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1, skd, slab_elems));
+    RET_IF(run_group_norm(c, g.slabs, I, Bx, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1, skd, slab_elems));
   else
-    RET_IF(run_group_norm(c, o, I, f.Bv, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1));
+    RET_IF(run_group_norm(c, o, I, Bx, HW, d.gn_o1, 8, 1e-5f, ACT_RELU, nullptr, pn, x1 ? 3 * I : I, f.s, 0, x1));
   g = GemmArgs();
   g.a = pn; g.lda = x1 ? 3 * I : I; g.w = &d.conv1; g.out = o2; g.ldc = I; g.use_bias = false;
   offer_slabs(g, &skd, x2 ? 3 * I : I);
-  RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
+  RET_IF(run_conv2d(c, g, Bx, H, W, 1, 0, f.s));
   if (skd > 1)
-    RET_IF(run_group_norm(c, g.slabs, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2, skd, slab_elems));
+    RET_IF(run_group_norm(c, g.slabs, I, Bx, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2, skd, slab_elems));
   else
-    RET_IF(run_group_norm(c, o2, I, f.Bv, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2));
+    RET_IF(run_group_norm(c, o2, I, Bx, HW, d.gn_o2, 8, 1e-5f, ACT_RELU, nullptr, pn, x2 ? 3 * I : I, f.s, 0, x2));
   g = GemmArgs();
   g.a = pn; g.lda = x2 ? 3 * I : I; g.w = &d.conv2; g.out = out.p; g.ldc = out.ld; g.use_bias = false; g.resid = in.p; g.ldr = in.ld;
-  RET_IF(run_conv2d(c, g, f.Bv, H, W, 1, 0, f.s));
+  RET_IF(run_conv2d(c, g, Bx, H, W, 1, 0, f.s));
+  if (use_const) {  // the context-free samples (behind the others in the batch): x + K
+    ProbeScope ps(c, f.s, "cond_const_add", 0.0, (double)n_free * HW * d.dim * 8.0);
+    RET_IF(launch_add_image_rows(in.p + (size_t)crow * in.ld, in.ld, c->cond_const[cond_idx].k, d.dim, n_free, HW,
+                                 out.p + (size_t)crow * out.ld, out.ld, f.s));
+  }
   return 0;
 }
 

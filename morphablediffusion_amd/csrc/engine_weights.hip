@@ -652,11 +652,16 @@ int apply_xp_policy(mvd_ctx* c) {
   RET_IF(repack_xp(c, U + "out.2.weight", &c->out_conv));
   RET_IF(repack_xp(c, U + "input_blocks.0.0.weight", &c->convs[c->in_blocks[0][0].idx], 8));
   if (lvl < 2) return 0;
+  // Ladder (round 6: ordered by error removed per unit of time, profiles/r06_k_xp_levels.txt): 2 = the last output block's cheap
+  // layers (skip conv, transformer proj_in / proj_out) and its DepthTransformer; 3 = the same for the block before it (guided eps
+  // -12 % for +1.2 % of the step: the default); 4 = + the last block's 3x3 ResBlock convolutions (-7 % more for +2.4 %);
+  // 5 = three blocks with their 3x3 convolutions; 6 = + the full-resolution input blocks.
+  // (Until round 5 level 3 was "level 2 + the last block's 3x3 convolutions": the costlier step came first.)
   const int nb = (int)c->out_blocks.size();
-  const int nblk = lvl >= 5 ? 3 : (lvl >= 4 ? 2 : 1);
+  const int nblk = lvl >= 5 ? 3 : (lvl >= 3 ? 2 : 1);
   for (int k = 0; k < nblk && k < nb; ++k) {
     const int bi = nb - 1 - k;
-    RET_IF(xp_ops(c, c->out_blocks[bi], lvl >= 5 || (lvl >= 3 && k == 0)));
+    RET_IF(xp_ops(c, c->out_blocks[bi], lvl >= 5 || (lvl >= 4 && k == 0)));
     if (bi >= 3 && 1 + (bi - 3) < (int)c->conds.size()) RET_IF(xp_cond(c, c->conds[1 + (bi - 3)]));  // attention.py:100
   }
   if (lvl >= 6)
@@ -955,6 +960,7 @@ int engine_finalize(mvd_ctx* c) {
   c->has_step = has_step;
   c->has_cond = has_cond;
   if (c->train_mode) RET_IF(engine_train_setup(c));  // masters into the arena first: the packs below read them from there
+  for (auto& cc : c->cond_const) cc.valid = false;  // the DepthTransformers' context-free images depend on the weights
   c->sec_begin = c->owned.size();
   RET_IF(build_hot_sections(c));
   c->sec_end = c->owned.size();

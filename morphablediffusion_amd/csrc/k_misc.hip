@@ -582,3 +582,26 @@ int launch_probe_null(hipStream_t s) {
   hipLaunchKernelGGL(probe_null_kernel, dim3(1), dim3(64), 0, s);
   return hipGetLastError() == hipSuccess ? 0 : mvd_fail("probe_null launch failed");
 }
+
+namespace {
+__global__ __launch_bounds__(256) void add_image_rows_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ img, int C4,
+                                                             long total4, int HW, float* __restrict__ out, int ldo) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C4;
+    const int q = (int)(i - row * C4), p = (int)(row % HW);
+    const float4 a = *(const float4*)(in + row * ldi + q * 4), k = *(const float4*)(img + ((long)p * C4 + q) * 4);
+    *(float4*)(out + row * ldo + q * 4) = make_float4(a.x + k.x, a.y + k.y, a.z + k.z, a.w + k.w);
+  }
+}
+}  // namespace
+int launch_add_image_rows(const float* in, int ldi, const float* img, int C, int nb, int HW, float* out, int ldo, hipStream_t s) {
+  if ((C & 3) || (ldi & 3) || (ldo & 3) || (((uintptr_t)in | (uintptr_t)img | (uintptr_t)out) & 15))
+    return mvd_fail("add_image_rows: 16-byte aligned rows");
+  const long total4 = (long)nb * HW * (C / 4);
+  if (total4 <= 0) return 0;
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_image_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, ldi, img, C / 4, total4, HW, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -491,10 +491,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // holding NO octets (32-byte loads, 16-byte fp16 stores; the scalar form above moves 4 bytes per lane and instruction and
 // reaches ~2.5 TB/s); a wave normalises 64 / L rows at a time.  Mean, then the centred second moment, both reduced with
 // xor shuffles inside the L-lane group.
-template <int L, int NO>
+// SLABS: x is `nslab` split-K slabs (slab_stride floats apart) of the producing GEMM; their sum + bias[c] + the per-sample bias
+// rowbias[row / T][c] + the residual is the row to normalise, and that finished row is also written to `mat` in fp32 (the later
+// residual adds read it) -- the GEMM's reduce pass and the LayerNorm in one launch (as gn_group_kernel does for GroupNorm).
+struct LnSlabs {
+  int nslab;
+  long slab_stride;
+  const float* bias;
+  const float* rowbias;  // [B][rb_ld] or null
+  int rb_ld, T;
+  const float* resid;    // [rows][ldr] or null
+  int ldr;
+  float* mat;            // [rows][C]
+};
+template <int L, int NO, bool SLABS = false>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int rows, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float eps, half_t* __restrict__ out) {
+                                                            float eps, half_t* __restrict__ out, const LnSlabs sl = LnSlabs()) {
   constexpr int RPW = 64 / L;  // rows per wave
   // gain and bias through LDS (loaded once per workgroup while the rows are in flight): as global loads inside the store
   // loop every iteration waited on its own
@@ -513,6 +526,36 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     const int c = (sub + L * i) * 8;
     const float4 a = *(const float4*)(xr + c), b = *(const float4*)(xr + c + 4);
     v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+  }
+  if constexpr (SLABS) {
+    const long r0 = ok ? row : 0;
+    for (int sb = 1; sb < sl.nslab; ++sb) {  // slab order: the sum is the reduce pass's
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const float* p = x + (long)sb * sl.slab_stride + r0 * C + (sub + L * i) * 8;
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w; v[i][4] += b.x; v[i][5] += b.y; v[i][6] += b.z; v[i][7] += b.w;
+      }
+    }
+    const int smp = (int)(r0 / sl.T);
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int c = (sub + L * i) * 8;
+      auto add8 = [&](const float* p) {
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w; v[i][4] += b.x; v[i][5] += b.y; v[i][6] += b.z; v[i][7] += b.w;
+      };
+      // the order of the reduce pass's epilogue (igemm_epilogue.h epilogue_vec4): ((sum + bias) + per-sample bias) + residual --
+      // the finished row has the bits the reduce pass would have written
+      if (sl.bias) add8(sl.bias + c);
+      if (sl.rowbias) add8(sl.rowbias + (long)smp * sl.rb_ld + c);
+      if (sl.resid) add8(sl.resid + r0 * sl.ldr + c);
+      if (ok) {
+        float* m = sl.mat + r0 * C + c;
+        *(float4*)m = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        *(float4*)(m + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+      }
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -655,6 +698,30 @@ int launch_layernorm(const float* x, int rows, int C, const float* gamma, const 
 #undef MVD_LNV
   }
   hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (long)C, rows, C, gamma, beta, eps, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// The split-K form: x = nslab slabs of [rows][C]; see LnSlabs.  C = 8 * L * 5 (the UNet's widths), 16-byte aligned operands.
+bool layernorm_slabs_takes(int C) { return C % 40 == 0 && (C / 40 == 8 || C / 40 == 16 || C / 40 == 32 || C / 40 == 64); }
+int launch_layernorm_slabs(const float* slabs, int nslab, size_t slab_stride, int rows, int C, const float* bias, const float* rowbias,
+                           int rb_ld, int T, const float* resid, int ldr, float* mat, const float* gamma, const float* beta, float eps,
+                           half_t* out, hipStream_t s) {
+  if (!layernorm_slabs_takes(C) || nslab < 1 || T < 1 || !mat) return mvd_fail("layernorm_slabs: unsupported width / arguments");
+  if ((((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mat | (uintptr_t)bias | (uintptr_t)rowbias |
+        (uintptr_t)resid) & 15) || (slab_stride & 3) || (rb_ld & 3) || (ldr & 3))
+    return mvd_fail("layernorm_slabs: operands must be 16-byte aligned");
+  LnSlabs sl;
+  sl.nslab = nslab; sl.slab_stride = (long)slab_stride; sl.bias = bias; sl.rowbias = rowbias; sl.rb_ld = rb_ld; sl.T = T;
+  sl.resid = resid; sl.ldr = ldr; sl.mat = mat;
+  const int L = C / 40;
+#define MVD_LNS(L_) \
+  hipLaunchKernelGGL((layernorm_vec_kernel<L_, 5, true>), dim3(cdiv(rows, 4 * (64 / L_))), dim3(256), 0, s, slabs, rows, C, gamma, beta, eps, out, sl)
+  if (L == 8) MVD_LNS(8);
+  else if (L == 16) MVD_LNS(16);
+  else if (L == 32) MVD_LNS(32);
+  else MVD_LNS(64);
+#undef MVD_LNS
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

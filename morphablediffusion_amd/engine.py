@@ -35,9 +35,9 @@ def _level_dims(d, s):
 
 class Engine:
     def __init__(self, ucfg: UNetConfig, vcfg: VolumeConfig, device="cuda:0", workspace_gb: float = 16.0,
-                 precision_level: int = 2, train: bool = False, vae_exact: bool = False):
+                 precision_level: int = 3, train: bool = False, vae_exact: bool = False):
         """precision_level: mvd_set_precision_level (0..6): how many of the output-side layers run with split fp16 operands
-        (extended precision); 2 is the default the parity bounds are stated for."""
+        (extended precision); 3 is the default the parity bounds are stated for (include/mvd.h: the ladder)."""
         self.precision_level = int(precision_level)
         self.vae_exact = bool(vae_exact)  # mvd_set_vae_precision: first-stage model in extended precision (~3x its cost)
         self.train_mode = bool(train)  # mvd_train_enable: master parameters / gradients kept in flat arenas (training step)

@@ -46,7 +46,7 @@ class DepthWiseAttention(nn.Module):
     """Drop-in for ldm.models.diffusion.attention.DepthWiseAttention (YAML unet_config.target,
     configs/facescape.yaml:26-42).  forward(x, timesteps, context, source_dict) -> [Bv,4,h,w]."""
 
-    def __init__(self, volume_dims=(5, 16, 32, 64), *args, precision_level=2, train_mode=False, **kwargs):
+    def __init__(self, volume_dims=(5, 16, 32, 64), *args, precision_level=3, train_mode=False, **kwargs):
         super().__init__()
         if args:
             raise TypeError("pass UNet arguments by keyword, as the reference config does")
@@ -317,7 +317,7 @@ class SyncMultiviewDiffusion(nn.Module):
                  projection="perspective", use_spatial_volume=False, view_num=16, image_size=256, cfg_scale=3.0,
                  output_num=8, batch_view_num=4, drop_conditions=False, drop_scheme="default",
                  clip_image_encoder_path=None, sample_type="ddim", sample_steps=50, target_elevation=30,
-                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=2,
+                 first_stage_model=None, clip_image_encoder=None, device="cuda:0", workspace_gb=16.0, precision_level=3,
                  train_mode=False, loss_scale=65536.0, recompute=True, first_stage_precision="exact"):
         """train_mode / loss_scale / recompute are not reference kwargs: train_mode keeps fp32 master parameters, gradients and
         Adam moments in the engine (training_step runs the backward pass); loss_scale multiplies dL/dpred so that the fp16 MFMA

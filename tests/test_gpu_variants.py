@@ -28,6 +28,9 @@ VARIANTS = {
     # together with the halo kernel of rounds 1-4 in place of conv3x (k_conv3x.hip) for the 3x3 convolutions
     # (the row-head kernel -- proj_in, LayerNorm1, q|k|v in one launch -- rides on the same switch)
     "rowchain_at_every_batch_halo_conv": {"MVD_ROWCHAIN_MIN_ROWS": "0", "MVD_NO_CONV3X": "1"},
+    # round 6: LayerNorm1 / LayerNorm3 sum the split-K slabs of proj_in / to_out themselves (launch_layernorm_slabs; off by default:
+    # measured neutral), and the DepthTransformer's GroupNorms do NOT (their default since round 6 is to sum them)
+    "layernorm_sums_splitk_slabs_cond_reduces": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1"},
 }
 
 
