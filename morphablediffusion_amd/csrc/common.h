@@ -172,14 +172,15 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split = 0,
                     int nslab = 1, size_t slab_stride = 0, const float* bias2 = nullptr, const float* resid = nullptr, int ldr = 0,
                     float* mat = nullptr, int ldm = 0);
+// raw (optional): x itself as fp16, rows ld_raw halfs apart (widths 320 / 640 / 1280 / 2560, 16-byte aligned)
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps,
-                     half_t* out, hipStream_t s);
+                     half_t* out, hipStream_t s, half_t* raw = nullptr, int ld_raw = 0);
 bool layernorm_slabs_takes(int C);
 // x = nslab split-K slabs [rows][C] (slab_stride floats apart): their sum + bias + rowbias[row / T] + resid is written to mat (fp32)
 // and normalised into out (fp16): the producing GEMM's reduce pass and the LayerNorm in one launch
 int launch_layernorm_slabs(const float* slabs, int nslab, size_t slab_stride, int rows, int C, const float* bias, const float* rowbias,
                            int rb_ld, int T, const float* resid, int ldr, float* mat, const float* gamma, const float* beta, float eps,
-                           half_t* out, hipStream_t s);
+                           half_t* out, hipStream_t s, half_t* raw = nullptr, int ld_raw = 0);
 int launch_layernorm_f32(const float* x, long ldx, int rows, int C, const float* gamma, const float* beta, float eps,
                          float* out, hipStream_t s);
 // q | k rows at `qk` (k at column offset heads*d), V row-major at `v` (row strides ldqk / ldv: all three normally live
@@ -192,8 +193,9 @@ int launch_clip_tokens(const float* pe, const float* cls, const float* pos, int 
                        hipStream_t s);
 int launch_scale_copy(const float* src, size_t n, float k, float* dst, hipStream_t s);
 int launch_softmax_rows(const float* s, long rows, int cols, half_t* p, hipStream_t st);
+// ldx (0 = Cc): halfs between consecutive rows of ctxn (the block's column slice of a context fold shared by one level)
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s, int split = 0, int nfill = 0, const half_t* fill_row = nullptr);
+                      hipStream_t s, int split = 0, int nfill = 0, const half_t* fill_row = nullptr, int ldx = 0);
 int launch_small_linear(const float* a, int lda, int rows, int K, const half_t* w, const float* bias, int N,
                         int act_in, float* out, int ldo, int accumulate, hipStream_t s);
 int launch_timestep_embedding(const int64_t* t, int B, int dim, float* out, hipStream_t s);
@@ -213,6 +215,10 @@ int launch_fold_qk(const float* wq, const float* wk, int heads, int hd, int Cc, 
                    hipStream_t s, float* out32 = nullptr);
 int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, int I, half_t* out, hipStream_t s,
                    float* out32 = nullptr);
+// C[m][n] = sum_k A[m][k] B[k][n] in fp64 (row-major fp32 operands, row strides lda / ldb), written as fp16 (out16, row stride ldc)
+// or fp32 (out32, row stride ldc): weight folds at finalize time
+int launch_fold_mm(const float* a, int lda, const float* b, int ldb, int M, int N, int K, half_t* out16, int ldc, float* out32,
+                   hipStream_t s);
 int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s, int split = 0);
 int launch_cfg_ddim(const float* eps_c, const float* eps_u, float scale, const float* x, const float* noise,
                     float sqrt_one_minus_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma,

@@ -70,6 +70,11 @@ struct STW {
   half_t* rc_stream = nullptr;
   half_t* rh_stream = nullptr;  // ... and proj_in | LayerNorm1-folded q|k|v for the row-head kernel (C = 320)
   int rc_po = 1, rh_xp = 0;     // forms the streams were packed for: proj_out plain (1) / extended precision (2); proj_in likewise
+  // FF2 and proj_out as ONE GEMM (inference, plain-precision proj_out, layered path): both are linear and nothing sits between
+  // them, so  proj_out(t2 + FF2(g) + b2) + b_po = [g | t2] [W_po W_2 | W_po]^T + (W_po b2 + b_po)  -- K = 5C instead of two
+  // launches with K = 4C and K = C and the [rows][C] intermediate in between.  ffp: [C][5C] fp16 (W_po W_2 folded in fp64 at
+  // finalize), ffp.bias the folded bias; null weights = not built (training contexts, extended-precision proj_out).
+  ConvW ffp;
 };
 struct CondW {
   ConvW proj_in, proj_ctx, wqk, wov, conv1, conv2;
@@ -232,6 +237,18 @@ struct mvd_ctx {
   // it everything proj_out computes -- does not depend on x: the block is x + K with an image K [H*W][dim] that depends on the
   // weights and the resolution only (reference ldm/models/diffusion/attention.py:26-47, 78-84).  K is computed once per context
   // (first use, by running the block on one context-free sample) and the step runs the block on the samples WITH context only.
+  // The DepthTransformers that attend to the SAME context level (4 at level 0, 3 at level 1, 2 at level 2 with the reference's
+  // volume_dims) each normalise their own 1x1x1 projection of that volume: stacked along N the projections are ONE GEMM over the
+  // volume (the statistics pass and the apply pass read it once per LEVEL instead of once per block: 100 MB at level 0 and 16
+  // views), the GroupNorms one finalize over nblk * 8 groups.  Built with the weights (engine_weights.hip), used by the side-stream
+  // context fold of the inference forward (engine_unet.hip: fork_ctx).
+  struct CtxGroup {
+    int level = 0, Cc = 0, nblk = 0;
+    int cond[4] = {0, 0, 0, 0};
+    ConvW w;      // stacked proj_context weights [nblk * Cc][Cc]
+    NormW gn;     // stacked GroupNorm gain / bias [nblk * Cc]
+  };
+  std::vector<CtxGroup> ctx_groups;
   struct CondConst {
     float* k = nullptr;
     int H = 0, W = 0;
@@ -438,6 +455,7 @@ struct Fwd {
   const half_t* src16[4];  // fp16 view of each context level (the source itself or a copy made once per forward)
   // relu(GroupNorm(proj_context(volume))) of every DepthTransformer, produced on the side stream (nullptr: inline)
   const half_t* cn_pre[16] = {nullptr};
+  int cn_ld[16] = {0};     // row stride (halfs) of cn_pre[k]: Cc, or the stacked width when the blocks of one level were folded together
   bool ctx_side = false;  // the volumes were produced / converted on the side stream: inline readers wait for ev_ctx
   bool train = false;     // training forward: no deferred split-K slabs, LN1 / LN3 outputs in separate buffers
 };

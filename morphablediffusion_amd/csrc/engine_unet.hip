@@ -585,10 +585,15 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   half_t* qkv = ws_alloc<half_t>(c, (size_t)rows * 3 * C);
   half_t* ao = ws_alloc<half_t>(c, (size_t)rows * C);
   float* t2 = rc ? nullptr : ws_alloc<float>(c, (size_t)rows * C);
-  half_t* gg = rc ? nullptr : ws_alloc<half_t>(c, (size_t)rows * 4 * C);
-  half_t* t3 = rc_po ? nullptr : ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
+  // Layered path, plain-precision proj_out, inference: FF2 and proj_out are ONE GEMM over [gg | t2] with K = 5C (STW::ffp); LayerNorm3
+  // leaves the fp16 copy of t2 behind the 4C columns of gg, t3 does not exist (MVD_NO_FFP=1: the two layers)
+  static const bool ln_scalar = getenv("MVD_LN_SCALAR") != nullptr;
+  const bool ffp = !rc && t.ffp.w && !f.train && !sv && !t.proj_out.xp && !ln_scalar && layernorm_slabs_takes(C);
+  const int ldg = ffp ? 5 * C : 4 * C;
+  half_t* gg = rc ? nullptr : ws_alloc<half_t>(c, (size_t)rows * ldg);
+  half_t* t3 = (rc_po || ffp) ? nullptr : ws_alloc<half_t>(c, (size_t)rows * C * wo);  // x + ff(x): only ever the proj_out operand -> fp16
   half_t* l3 = f.train ? ws_alloc<half_t>(c, (size_t)rows * C) : l1;  // the backward pass needs both LayerNorm outputs
-  WS_CHECK(n0 && t0 && l1 && qkv && ao && (rc || (t2 && gg)) && (rc_po || t3) && l3);
+  WS_CHECK(n0 && t0 && l1 && qkv && ao && (rc || (t2 && gg)) && (rc_po || ffp || t3) && l3);
   if (in_carry && in_carry->sk > 1)
     RET_IF(run_group_norm(c, in_carry->slabs, C, f.Bv, T, t.norm, 32, 1e-6f, ACT_NONE, nullptr, n0, C * wi, f.s, 0, t.proj_in.xp,
                           in_carry->sk, in_carry->stride, in_carry->bias, in_carry->resid, in_carry->ldr, in.p, in.ld));
@@ -681,22 +686,28 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   {
     ProbeScope ps(c, f.s, "layernorm", 0.0, (double)rows * C * (6.0 + (sk_ln > 1 ? 4.0 * (sk_ln + 1) : 0.0)));
+    half_t* t2h = ffp ? gg + 4 * C : nullptr;  // fp16 t2 as columns [4C, 5C) of the folded GEMM's operand
     if (sk_ln > 1)
       RET_IF(launch_layernorm_slabs(g.slabs, sk_ln, ln_slab_elems, rows, C, t.attn_out.bias, g.rowbias, g.rb_ld, T, t0, C, t2, t.ln3.g,
-                                    t.ln3.b, 1e-5f, l3, f.s));
+                                    t.ln3.b, 1e-5f, l3, f.s, t2h, ldg));
     else
-      RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l3, f.s));
+      RET_IF(launch_layernorm(t2, rows, C, t.ln3.g, t.ln3.b, 1e-5f, l3, f.s, t2h, ldg));
   }
   g = GemmArgs();
-  g.a = l3; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = 4 * C; g.geglu = 1;
+  g.a = l3; g.lda = C; g.w = &t.ff1; g.out = gg; g.out_f32 = 0; g.ldc = ldg; g.geglu = 1;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
+  if (!ffp) {
   g = GemmArgs();
   g.a = gg; g.lda = 4 * C; g.w = &t.ff2; g.out = t3; g.out_f32 = 0; g.ldc = C * wo; g.resid = t2; g.ldr = C;
   g.out_split = t.proj_out.xp ? C : 0;
   RET_IF(run_linear(c, g, f.Bv, rows, f.s));
   }
+  }
   g = GemmArgs();
   g.a = t3; g.lda = C * wo; g.w = &t.proj_out; g.out = out.p; g.ldc = out.ld; g.resid = in.p; g.ldr = in.ld;
+  if (ffp) {  // [gg | t2] [W_po W_2 | W_po]^T + (W_po b2 + b_po) + x
+    g.a = gg; g.lda = 5 * C; g.w = &t.ffp;
+  }
   int skp = 1;
   if (out_carry && out_carry->slabs) {
     g.slabs = out_carry->slabs; g.slabs_cap = out_carry->cap; g.sk_used = &skp; g.defer_epilogue = true;
@@ -705,7 +716,7 @@ int unet_do_st(Fwd& f, const STW& t, View in, View out, int H, int W, STSaved* s
   if (out_carry) {
     out_carry->sk = skp;
     out_carry->stride = (size_t)rows * C;
-    out_carry->bias = t.proj_out.bias;
+    out_carry->bias = ffp ? t.ffp.bias : t.proj_out.bias;
     out_carry->resid = in.p;
     out_carry->ldr = in.ld;
   }
@@ -727,6 +738,24 @@ bool ctx_fold_ok(const Fwd& f, const CondW& d, int HW, int D, int level) {
   return !fold_off && f.n_ctx > 0 && f.src16[level] && rps % 256 == 0 && (cpg == 8 || cpg == 16 || cpg == 32) &&
          (long)f.n_ctx * HW * D >= 512;
 }
+// the same for every DepthTransformer of one context level at once (mvd_ctx::CtxGroup): cn_all [n_ctx * HW * D][nblk * Cc]
+int ctx_fold_group(Fwd& f, const mvd_ctx::CtxGroup& gp, int HW, int D, half_t* cn_all, hipStream_t s) {
+  mvd_ctx* c = f.c;
+  const int Cc = gp.Cc, N = gp.nblk * Cc, crow = f.n_ctx * HW, rps = D * HW, cpg = Cc / 8, ntile = rps / 256, G = gp.nblk * 8;
+  float* part = ws_alloc<float>(c, (size_t)f.n_ctx * ntile * G * 2);
+  float* sc = ws_alloc<float>(c, (size_t)f.n_ctx * N);
+  float* sh = ws_alloc<float>(c, (size_t)f.n_ctx * N);
+  WS_CHECK(part && sc && sh);
+  GemmArgs g;
+  g.a = f.src16[gp.level]; g.lda = Cc; g.w = &gp.w; g.use_bias = false; g.gn_partial = part; g.gn_cpg = cpg; g.force_splitk = 1;
+  RET_IF(run_linear(c, g, f.n_ctx, crow * D, s));
+  RET_IF(launch_gn_finalize(part, f.n_ctx, ntile, rps, N, G, gp.gn.g, gp.gn.b, 1e-5f, sc, sh, N, s));
+  g = GemmArgs();
+  g.a = f.src16[gp.level]; g.lda = Cc; g.w = &gp.w; g.use_bias = false; g.out = cn_all; g.out_f32 = 0; g.ldc = N;
+  g.rowscale = sc; g.rs_ld = N; g.rowbias = sh; g.rb_ld = N; g.act = ACT_RELU; g.force_splitk = 1;
+  return run_linear(c, g, f.n_ctx, crow * D, s);
+}
+
 int ctx_fold(Fwd& f, const CondW& d, int HW, int D, int level, half_t* cn, hipStream_t s) {
   mvd_ctx* c = f.c;
   const int Cc = d.Cc, crow = f.n_ctx * HW, rps = D * HW, cpg = Cc / 8, ntile = rps / 256;
@@ -845,7 +874,7 @@ int unet_do_cond(Fwd& f, const CondW& d, View in, View out, int H, int W, int le
                     (double)crow * D * Cc * 2.0 + (double)crow * 4 * Cc * 6.0);
       // the rows of the unconditional samples (all-zero context: GN(0) = beta, uniform softmax -> z = relu(beta) for every
       // head) are filled by the same launch
-      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo, rows - crow, d.relu_beta));
+      RET_IF(launch_depth_attn(qk, cn, z, f.n_ctx, HW, D, Cc, 4, f.s, xo, rows - crow, d.relu_beta, cnp ? f.cn_ld[cond_idx] : Cc));
     }
   } else if (Bx > f.n_ctx) {
     RET_IF(launch_fill_rows_f16(z + (size_t)crow * 4 * Cc * wz, 4 * Cc * wz, rows - crow, d.relu_beta, 4 * Cc * wz, f.s));
@@ -1068,8 +1097,34 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       Hc = out_res_of(c->out_blocks[i], Hc);
       if (i >= 3 && 1 + (i - 3) < cH.size()) cH[1 + (i - 3)] = Hc;
     }
+    // the blocks of one level together (mvd_ctx::CtxGroup: the volume is read once per pass and level); MVD_NO_CTX_GROUP=1: one by one
+    static const bool no_group = getenv("MVD_NO_CTX_GROUP") != nullptr;
+    std::vector<char> grouped(c->conds.size(), 0);
+    for (const mvd_ctx::CtxGroup& gp : c->ctx_groups) {
+      if (no_group) break;
+      bool ok = gp.nblk >= 2;
+      int Hk = 0;
+      for (int j = 0; j < gp.nblk && ok; ++j) {
+        const int k = gp.cond[j];
+        ok = k < (int)cH.size() && cH[k] > 0 && level_of(cH[k]) == gp.level && (Hk == 0 || cH[k] == Hk) && c->conds[k].Cc == gp.Cc;
+        if (ok) Hk = cH[k];
+      }
+      if (!ok) continue;
+      const int HW = Hk * Hk, D = depth0 >> gp.level, N = gp.nblk * gp.Cc;
+      if (!ctx_fold_ok(f, c->conds[gp.cond[0]], HW, D, gp.level) || gp.nblk * 8 > 32) continue;
+      half_t* cn_all = ws_alloc<half_t>(c, (size_t)n_ctx * HW * D * N);
+      WS_CHECK(cn_all);
+      RET_IF(ctx_fold_group(f, gp, HW, D, cn_all, c->side));
+      for (int j = 0; j < gp.nblk; ++j) {
+        const int k = gp.cond[j];
+        HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
+        f.cn_pre[k] = cn_all + (size_t)j * gp.Cc;
+        f.cn_ld[k] = N;
+        grouped[k] = 1;
+      }
+    }
     for (size_t k = 0; k < c->conds.size(); ++k) {
-      if (cH[k] <= 0) continue;
+      if (cH[k] <= 0 || grouped[k]) continue;
       const CondW& d = c->conds[k];
       const int lv = level_of(cH[k]), HW = cH[k] * cH[k], D = depth0 >> lv;
       if (lv > 3 || !ctx_fold_ok(f, d, HW, D, lv)) continue;
@@ -1078,6 +1133,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
       RET_IF(ctx_fold(f, d, HW, D, lv, cn, c->side));
       HIP_CHECK_RET(hipEventRecord(c->ev_cond[k], c->side));
       f.cn_pre[k] = cn;
+      f.cn_ld[k] = d.Cc;
     }
     return 0;
   };

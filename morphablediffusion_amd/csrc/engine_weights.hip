@@ -645,6 +645,44 @@ int build_rowchain_streams(mvd_ctx* c) {
   return engine_build_join(c);
 }
 
+// FF2 + proj_out folded into one GEMM per transformer block (STW::ffp).  After the extended-precision policy: a block whose proj_out
+// runs in extended precision keeps the two layers.  Inference contexts only (a training context re-packs every step and its
+// backward pass needs both layers).
+int build_ffp(mvd_ctx* c) {
+  static const bool off = getenv("MVD_NO_FFP") != nullptr;
+  if (off || !c->has_unet || c->train_mode) return 0;
+  for (STW& st : c->st) {
+    if (st.proj_out.xp || (st.C & 7)) continue;
+    const int C = st.C;
+    const std::string t = st.key + ".transformer_blocks.0";
+    RawTensor *w2, *b2, *wpo, *bpo;
+    RET_IF(get_raw(c, t + ".ff.net.2.weight", &w2));
+    RET_IF(get_raw(c, t + ".ff.net.2.bias", &b2));
+    RET_IF(get_raw(c, st.key + ".proj_out.weight", &wpo));
+    RET_IF(get_raw(c, st.key + ".proj_out.bias", &bpo));
+    if (w2->numel != (size_t)4 * C * C || wpo->numel != (size_t)C * C || b2->numel != (size_t)C || bpo->numel != (size_t)C) continue;
+    engine_build_rotate(c);
+    ConvW& f = st.ffp;
+    f.N = C; f.Cin = 5 * C; f.cin_l = 5 * C; f.taps = 1;
+    half_t* tmp16 = nullptr;
+    float* tmp32 = nullptr;
+    RET_IF(dmalloc(c, (void**)&f.w, (size_t)C * 5 * C * sizeof(half_t)));
+    RET_IF(dmalloc(c, (void**)&f.bias, (size_t)C * sizeof(float)));
+    RET_IF(dmalloc(c, (void**)&tmp16, (size_t)C * C * sizeof(half_t)));
+    RET_IF(dmalloc(c, (void**)&tmp32, (size_t)C * sizeof(float)));
+    // columns [0, 4C): W_po W_2  (M = C rows of W_po, K = C, N = 4C columns of W_2), fp64 accumulation, rows 5C halfs apart
+    RET_IF(launch_fold_mm(wpo->d, C, w2->d, 4 * C, C, 4 * C, C, f.w, 5 * C, nullptr, c->bs));
+    // columns [4C, 5C): W_po itself
+    RET_IF(launch_f32_to_f16(wpo->d, tmp16, (size_t)C * C, c->bs));
+    HIP_CHECK_RET(hipMemcpy2DAsync(f.w + 4 * C, (size_t)5 * C * sizeof(half_t), tmp16, (size_t)C * sizeof(half_t), (size_t)C * sizeof(half_t), C,
+                                   hipMemcpyDeviceToDevice, c->bs));
+    // bias: W_po b2 + b_po
+    RET_IF(launch_fold_mm(wpo->d, C, b2->d, 1, C, 1, C, nullptr, 1, tmp32, c->bs));
+    RET_IF(launch_add_rows(f.bias, tmp32, bpo->d, (size_t)C, c->bs));
+  }
+  return engine_build_join(c);
+}
+
 int apply_xp_policy(mvd_ctx* c) {
   const int lvl = getenv("MVD_XP") ? atoi(getenv("MVD_XP")) : c->precision_level;
   if (lvl <= 0 || !c->has_unet) return 0;
@@ -835,6 +873,33 @@ int build_unet_section(mvd_ctx* c) {
     for (int k = 0; k < 9; ++k)
       RET_IF(build_cond(c, U + "output_conditions." + std::to_string(k), dims[k + 1], ccs[k + 1], &c->conds[k + 1]));
     for (int k = 0; k < 10; ++k) c->conds[k].res = u.image_size >> lvl[k];
+    // stacked context projections per level (mvd_ctx::CtxGroup): [nblk * Cc][Cc] fp16 rows copied from the blocks' own packs,
+    // gain / bias concatenated.  Plain (not extended-precision) projections only -- proj_context never is.
+    c->ctx_groups.clear();
+    for (int L = 0; L < 4; ++L) {
+      mvd_ctx::CtxGroup gp;
+      gp.level = L;
+      for (int k = 0; k < 10; ++k)
+        if (lvl[k] == L && gp.nblk < 4 && !c->conds[k].proj_ctx.xp && (gp.nblk == 0 || c->conds[k].Cc == gp.Cc)) {
+          gp.Cc = c->conds[k].Cc;
+          gp.cond[gp.nblk++] = k;
+        }
+      if (gp.nblk < 2) continue;
+      const int Cc = gp.Cc, N = gp.nblk * Cc;
+      gp.w.N = N; gp.w.Cin = Cc; gp.w.taps = 1;
+      gp.gn.C = N;
+      RET_IF(dmalloc(c, (void**)&gp.w.w, (size_t)N * Cc * sizeof(half_t)));
+      RET_IF(dmalloc(c, (void**)&gp.gn.g, (size_t)N * sizeof(float)));
+      RET_IF(dmalloc(c, (void**)&gp.gn.b, (size_t)N * sizeof(float)));
+      for (int j = 0; j < gp.nblk; ++j) {
+        const CondW& d = c->conds[gp.cond[j]];
+        if (d.proj_ctx.N != Cc || d.proj_ctx.Cin != Cc) return mvd_fail("build_unet_section: unexpected proj_context shape");
+        HIP_CHECK_RET(hipMemcpyAsync(gp.w.w + (size_t)j * Cc * Cc, d.proj_ctx.w, (size_t)Cc * Cc * sizeof(half_t), hipMemcpyDeviceToDevice, c->bs));
+        HIP_CHECK_RET(hipMemcpyAsync(gp.gn.g + (size_t)j * Cc, d.gn_ctx.g, (size_t)Cc * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
+        HIP_CHECK_RET(hipMemcpyAsync(gp.gn.b + (size_t)j * Cc, d.gn_ctx.b, (size_t)Cc * sizeof(float), hipMemcpyDeviceToDevice, c->bs));
+      }
+      c->ctx_groups.push_back(gp);
+    }
   }
   return 0;
 }
@@ -928,6 +993,7 @@ int build_hot_sections(mvd_ctx* c) {
     RET_IF(engine_build_join(c));  // the adjoint packs and the conv3x streams read the forward packs
     RET_IF(build_conv3x_streams(c));
     RET_IF(build_rowchain_streams(c));
+    RET_IF(build_ffp(c));
     if (c->train_mode) RET_IF(engine_build_dgrad(c));
   }
   if (c->has_step) RET_IF(build_step_section(c));

@@ -15,7 +15,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict__ qk, const half_t* __restrict__ ctxn,
                                                          half_t* __restrict__ z, int npix, int HW, int D, int Cc, int split,
-                                                         int nfill, const half_t* __restrict__ fill_row) {
+                                                         int nfill, const half_t* __restrict__ fill_row, int ldx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
     const int cpr = Cc / 8;
     for (int idx = lane; idx < D * cpr; idx += 64) {
       const int d = idx / cpr, ch = idx - d * cpr;
-      *(h8*)(sX + d * xld + ch * 8) = *(const h8*)(ctxn + (((long)b * D + d) * HW + p) * Cc + ch * 8);
+      *(h8*)(sX + d * xld + ch * 8) = *(const h8*)(ctxn + (((long)b * D + d) * HW + p) * ldx + ch * 8);
     }
     const float4* q4 = (const float4*)(qk + (long)pix * H * Cc);
     for (int idx = lane; idx < H * Cc / 4; idx += 64) ((float4*)sQ)[idx] = q4[idx];
@@ -125,10 +125,12 @@ __global__ __launch_bounds__(256) void depth_attn_kernel(const float* __restrict
 }  // namespace
 
 int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond, int HW, int D, int Cc, int heads,
-                      hipStream_t s, int split, int nfill, const half_t* fill_row) {
+                      hipStream_t s, int split, int nfill, const half_t* fill_row, int ldx) {
   if (heads != 4) return mvd_fail("depth_attn: the reference always uses 4 heads (attention.py:97-115)");
   if (Cc % 8 || D > 64) return mvd_fail("depth_attn: Cc must be a multiple of 8 and D <= 64");
   if (((uintptr_t)z & 15)) return mvd_fail("depth_attn: output must be 16-byte aligned");
+  if (ldx == 0) ldx = Cc;
+  if (ldx < Cc || (ldx & 7) || ((uintptr_t)ctxn & 15)) return mvd_fail("depth_attn: context rows must be 16-byte aligned and at least Cc wide");
   const int npix = n_cond * HW;
   if (nfill < 0 || (nfill > 0 && (!fill_row || ((uintptr_t)fill_row & 15)))) return mvd_fail("depth_attn: bad fill row");
   if (npix + nfill == 0) return 0;
@@ -143,7 +145,7 @@ int launch_depth_attn(const float* qk, const half_t* ctxn, half_t* z, int n_cond
     attr_set = true;
   }
   hipLaunchKernelGGL(depth_attn_kernel, dim3(cdiv(npix + nfill, 4)), dim3(256), lds, s, qk, ctxn, z, npix, HW, D, Cc, split,
-                     nfill, fill_row);
+                     nfill, fill_row, ldx);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

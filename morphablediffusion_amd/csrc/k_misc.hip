@@ -540,6 +540,14 @@ int launch_fold_ov(const float* wo, const float* wv, int heads, int hd, int Cc, 
   return 0;
 }
 
+int launch_fold_mm(const float* a, int lda, const float* b, int ldb, int M, int N, int K, half_t* out16, int ldc, float* out32,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(fold_gemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64), 1), dim3(256), 0, s, a, 0L, (long)lda, 1L, b, 0L, (long)ldb, 1L, M, N, K,
+                     1.0f, 0L, (long)ldc, 1L, out16, out32);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 int launch_relu_beta_tile(const float* beta, int Cc, int heads, half_t* out, hipStream_t s, int split) {
   hipLaunchKernelGGL(relu_beta_tile_kernel, dim3(cdiv(heads * Cc, 256)), dim3(256), 0, s, beta, Cc, heads, out, split);
   HIP_CHECK_RET(hipGetLastError());

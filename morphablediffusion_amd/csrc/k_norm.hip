@@ -503,6 +503,8 @@ struct LnSlabs {
   const float* resid;    // [rows][ldr] or null
   int ldr;
   float* mat;            // [rows][C]
+  half_t* raw;           // optional: the row to normalise (before the norm) also as fp16, rows ld_raw halfs apart -- the second
+  int ld_raw;            // operand block of a GEMM that takes [f(LN(x)) | x] (engine_unet.hip: the folded FF2 + proj_out)
 };
 template <int L, int NO, bool SLABS = false>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int rows, int C,
@@ -555,6 +557,15 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         *(float4*)m = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
         *(float4*)(m + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
       }
+    }
+  }
+  if (sl.raw && ok) {
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      h8 r;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = (half_t)v[i][k];
+      *(h8*)(sl.raw + (long)row * sl.ld_raw + (sub + L * i) * 8) = r;
     }
   }
   float s = 0.f;
@@ -679,14 +690,19 @@ int launch_gn_finalize(const float* partial, int B, int nslabs, int rows_per_sam
 }
 
 int launch_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, float eps, half_t* out,
-                     hipStream_t s) {
+                     hipStream_t s, half_t* raw, int ld_raw) {
   if (C > 64 * 24) return mvd_fail("layernorm: C too large");
+  if (raw && (!layernorm_slabs_takes(C) || (ld_raw & 7) || ((uintptr_t)raw & 15) || (((uintptr_t)x | (uintptr_t)out) & 15)))
+    return mvd_fail("layernorm: the fp16 copy of the input needs a width of 8 * L * 5 and 16-byte aligned rows");
+  LnSlabs sl = LnSlabs();
+  sl.raw = raw;
+  sl.ld_raw = ld_raw;
   static const bool no_vec = getenv("MVD_LN_SCALAR") != nullptr;
   const bool aligned = !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15);
   if (!no_vec && aligned && C % 40 == 0) {  // C = 8 * L * 5: the UNet's 320 / 640 / 1280 / 2560-wide rows
     const int L = C / 40;
 #define MVD_LNV(L_) \
-  hipLaunchKernelGGL((layernorm_vec_kernel<L_, 5>), dim3(cdiv(rows, 4 * (64 / L_))), dim3(256), 0, s, x, rows, C, gamma, beta, eps, out)
+  hipLaunchKernelGGL((layernorm_vec_kernel<L_, 5>), dim3(cdiv(rows, 4 * (64 / L_))), dim3(256), 0, s, x, rows, C, gamma, beta, eps, out, sl)
     if (L == 8 || L == 16 || L == 32 || L == 64) {
       if (L == 8) MVD_LNV(8);
       else if (L == 16) MVD_LNV(16);
@@ -697,6 +713,7 @@ int launch_layernorm(const float* x, int rows, int C, const float* gamma, const 
     }
 #undef MVD_LNV
   }
+  if (raw) return mvd_fail("layernorm: the fp16 copy of the input is written by the vector form only (MVD_LN_SCALAR / alignment)");
   hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (long)C, rows, C, gamma, beta, eps, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -706,14 +723,15 @@ int launch_layernorm(const float* x, int rows, int C, const float* gamma, const 
 bool layernorm_slabs_takes(int C) { return C % 40 == 0 && (C / 40 == 8 || C / 40 == 16 || C / 40 == 32 || C / 40 == 64); }
 int launch_layernorm_slabs(const float* slabs, int nslab, size_t slab_stride, int rows, int C, const float* bias, const float* rowbias,
                            int rb_ld, int T, const float* resid, int ldr, float* mat, const float* gamma, const float* beta, float eps,
-                           half_t* out, hipStream_t s) {
+                           half_t* out, hipStream_t s, half_t* raw, int ld_raw) {
+  if (raw && ((ld_raw & 7) || ((uintptr_t)raw & 15))) return mvd_fail("layernorm_slabs: the fp16 copy needs 16-byte aligned rows");
   if (!layernorm_slabs_takes(C) || nslab < 1 || T < 1 || !mat) return mvd_fail("layernorm_slabs: unsupported width / arguments");
   if ((((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mat | (uintptr_t)bias | (uintptr_t)rowbias |
         (uintptr_t)resid) & 15) || (slab_stride & 3) || (rb_ld & 3) || (ldr & 3))
     return mvd_fail("layernorm_slabs: operands must be 16-byte aligned");
   LnSlabs sl;
   sl.nslab = nslab; sl.slab_stride = (long)slab_stride; sl.bias = bias; sl.rowbias = rowbias; sl.rb_ld = rb_ld; sl.T = T;
-  sl.resid = resid; sl.ldr = ldr; sl.mat = mat;
+  sl.resid = resid; sl.ldr = ldr; sl.mat = mat; sl.raw = raw; sl.ld_raw = ld_raw;
   const int L = C / 40;
 #define MVD_LNS(L_) \
   hipLaunchKernelGGL((layernorm_vec_kernel<L_, 5, true>), dim3(cdiv(rows, 4 * (64 / L_))), dim3(256), 0, s, slabs, rows, C, gamma, beta, eps, out, sl)

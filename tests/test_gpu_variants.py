@@ -31,6 +31,11 @@ VARIANTS = {
     # round 6: LayerNorm1 / LayerNorm3 sum the split-K slabs of proj_in / to_out themselves (launch_layernorm_slabs; off by default:
     # measured neutral), and the DepthTransformer's GroupNorms do NOT (their default since round 6 is to sum them)
     "layernorm_sums_splitk_slabs_cond_reduces": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1"},
+    # round 6: every DepthTransformer folds its own context projection (no per-level stacked GEMM) and runs over ALL samples, the
+    # context-free ones through relu(beta) rows instead of the precomputed constant image (mvd_ctx::CtxGroup / CondConst off)
+    "depth_transformer_block_by_block_all_samples": {"MVD_NO_CTX_GROUP": "1", "MVD_NO_COND_CONST": "1"},
+    # round 6: FF2 and proj_out as two GEMMs with the fp16 intermediate between them (default: one GEMM over [gg | t2], STW::ffp)
+    "ff2_and_proj_out_as_two_gemms": {"MVD_NO_FFP": "1"},
 }
 
 
