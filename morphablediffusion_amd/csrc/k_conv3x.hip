@@ -246,22 +246,40 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
   const int M = g.B * H * W;
   float* part = g.splitk > 1 ? g.partial + (long)blockIdx.y * M * N : nullptr;
   const int cq = (lane & 7) * 4;
+  // output rows of this lane: fragment p, row (lane >> 3) + 8 i
+  long row4[2][4];
+  int b = 0;
+  bool live = true;
+  {
+    int y0, x0;
+    block_pos(tm * NI + (IW == 16 ? 0 : wave), b, y0, x0);
+    live = tm * NI + (IW == 16 ? 0 : wave) < nblocks;  // a tile of 8 x 8 images may end past the batch
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    long row4[4];
-    int b = 0;
-    bool live = true;
-    {
-      int y0, x0;
-      block_pos(tm * NI + (IW == 16 ? 0 : wave), b, y0, x0);
-      live = tm * NI + (IW == 16 ? 0 : wave) < nblocks;  // a tile of 8 x 8 images may end past the batch
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int fr = (lane >> 3) + 8 * i;  // pixel of the fragment
         const int yy = IW == 16 ? 4 * wave + 2 * p + (fr >> 4) : 4 * p + (fr >> 3), xx = IW == 16 ? (fr & 15) : (fr & 7);
-        row4[i] = (long)(b * H + y0 + yy) * W + x0 + xx;
+        row4[p][i] = (long)(b * H + y0 + yy) * W + x0 + xx;
       }
-    }
+  }
+#ifndef CX_NO_RESID_PREFETCH
+  // Every residual value of the tile is requested BEFORE the first transpose (2 x NF x 4 loads of 16 bytes per lane, in flight
+  // together: one wave per SIMD has the registers): fragment by fragment behind each LDS round trip the epilogue kept four loads
+  // in flight per lane and ran at ~4 TB/s with the matrix pipe idle (round 6; CX_NO_RESID_PREFETCH restores that form)
+  float4 rpre[2][NF][4];
+  const bool has_res = g.resid && !part && live;
+  if (has_res) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rpre[p][f][i] = *(const float4*)((const float*)g.resid + row4[p][i] * g.ldr + n0 + 32 * f + cq);
+  }
+#endif
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -284,15 +302,19 @@ __global__ __launch_bounds__(256) void conv3x_kernel(const IGemm g, const half_t
         float4 v = *(const float4*)(sc + fr * EPI_LD + cq);
         if (!live) continue;
         if (part) {
-          *(float4*)(part + row4[i] * N + n) = v;
+          *(float4*)(part + row4[p][i] * N + n) = v;
           continue;
         }
         v.x += bsum.x; v.y += bsum.y; v.z += bsum.z; v.w += bsum.w;
         if (g.resid) {
-          const float4 r = *(const float4*)((const float*)g.resid + row4[i] * g.ldr + n);
+#ifndef CX_NO_RESID_PREFETCH
+          const float4 r = rpre[p][f][i];
+#else
+          const float4 r = *(const float4*)((const float*)g.resid + row4[p][i] * g.ldr + n);
+#endif
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
-        *(float4*)((float*)g.out + row4[i] * g.ldc + n) = v;
+        *(float4*)((float*)g.out + row4[p][i] * g.ldc + n) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is rewritten by the next block
     }
