@@ -348,6 +348,18 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
 
   // ---- store: each 32 x 32 block through a wave-private LDS scratch -> full 128-byte row segments
   float* sc = (float*)(smem + RC_RING_BYTES + wave * EPI_WAVE_BYTES);
+#ifndef RC_NO_RESID_PREFETCH
+  // the block input (the residual of proj_out) for the whole 32 x C tile, requested before the first transpose: F x 4 loads of 16
+  // bytes in flight per lane instead of four behind each LDS round trip (as conv3x does since round 6)
+  [[maybe_unused]] float4 rres[PO != 0 ? F : 1][4];
+  if constexpr (PO != 0) {
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rres[f][i] = *(const float4*)(p.resid + (long)(m0 + (lane >> 3) + 8 * i) * p.ld_r + 32 * f + (lane & 7) * 4);
+  }
+#endif
 #pragma unroll
   for (int f = 0; f < F; ++f) {
 #pragma unroll
@@ -362,7 +374,11 @@ __global__ __launch_bounds__(256) void rowchain_kernel(const RowChain p) {
         const int fr = (lane >> 3) + 8 * i;
         const long row = m0 + fr;
         float4 v = *(const float4*)(sc + fr * EPI_LD + cq);
+#ifndef RC_NO_RESID_PREFETCH
+        const float4 r = rres[f][i];
+#else
         const float4 r = *(const float4*)(p.resid + row * p.ld_r + n);
+#endif
         v.x += bp.x + r.x; v.y += bp.y + r.y; v.z += bp.z + r.z; v.w += bp.w + r.w;
         *(float4*)((float*)p.out + row * p.ld_o + n) = v;
       }
