@@ -156,6 +156,11 @@ int mvd_vertex_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed
 int mvd_vertex_view_features(mvd_ctx* ctx, const float* x_noisy, const float* t_embed, const float* v_embed,
                              const int32_t* view_idx, int n_local, float* vf_out, void* stream);
 int mvd_fuse_vertex_features(mvd_ctx* ctx, const float* vf_all, int n_views, float* fused_out, void* stream);
+/* 1 when mvd_vertex_view_features touches no memory of the context's shared workspace (the 2-D encoder runs as its one-launch
+ * form out of a scratch of its own): the call may then be enqueued on the caller's communication stream WHILE mvd_denoise_views of
+ * the same context runs on another stream -- the sampler moves the step's head (encoder, vertex gather, exchange, sparse CNN) off
+ * the UNet's stream entirely.  0: keep it on the stream the UNet is launched on (64 x 64 latents, MVD_NO_FUSED_ENC). */
+int mvd_vertex_features_stream_safe(mvd_ctx* ctx);
 /* Stage probes for the parity tests (each stage of the conditioner on its own, in the reference's layouts):
  *   mvd_stage_target_encoder   NoisyTargetViewEncoder.forward (ldm/models/diffusion/network.py:181-207) for n_local views of one
  *                              sample: x_noisy [n_local,4,s,s], t_embed [time_dim], v_embed [n_local,view_dim] -> feats [n_local,16,s,s];

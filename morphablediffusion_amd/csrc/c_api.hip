@@ -176,6 +176,7 @@ void mvd_destroy(mvd_ctx* c) {
     if (ev) hipEventDestroy(ev);
   for (auto& cc : c->cond_const)
     if (cc.k) hipFree(cc.k);
+  if (c->enc_scratch) hipFree(c->enc_scratch);
   for (hipEvent_t ev : c->ev_cond) hipEventDestroy(ev);
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
@@ -378,6 +379,10 @@ int mvd_vertex_view_features(mvd_ctx* c, const float* x_noisy, const float* t_em
   if (c && hipSetDevice(c->device) != hipSuccess) return mvd_fail("hipSetDevice failed");
   if (!c || !vf_out) return mvd_fail("mvd_vertex_view_features: null argument");
   return engine_vertex_features(c, x_noisy, t_embed, v_embed, view_idx, n_local, 0, nullptr, S(stream), vf_out);
+}
+
+int mvd_vertex_features_stream_safe(mvd_ctx* c) {
+  return (c && c->finalized && c->has_cond && engine_encoder_is_fused(c)) ? 1 : 0;
 }
 
 int mvd_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, void* stream) {

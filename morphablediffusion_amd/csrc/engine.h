@@ -249,6 +249,8 @@ struct mvd_ctx {
     NormW gn;     // stacked GroupNorm gain / bias [nblk * Cc]
   };
   std::vector<CtxGroup> ctx_groups;
+  float* enc_scratch = nullptr;  // 2-D encoder output + FiLM rows of mvd_vertex_view_features (engine_cond.hip: stream-safe form)
+  size_t enc_scratch_cap = 0;    // floats
   struct CondConst {
     float* k = nullptr;
     int H = 0, W = 0;
@@ -508,7 +510,8 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
                            float* vf_out = nullptr);
 // NoisyTargetViewEncoder alone: x_noisy [n_local,4,S,S] -> feats channels-last [n_local*S*S][16]
 int engine_target_encoder(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local, float* feats,
-                          hipStream_t s);
+                          hipStream_t s, float* pre_own = nullptr);
+bool engine_encoder_is_fused(const mvd_ctx* c);
 // the sparse voxel CNN alone: *rows_out = feature rows [n_sites[2]][64] of the coarsest level (mesh ping-pong buffer)
 int engine_sparse_net(mvd_ctx* c, const float* fused, hipStream_t s, bool bn_batch_stats, const float** rows_out);
 int engine_fuse_vertex_features(mvd_ctx* c, const float* vf_all, int n_views, float* fused_out, hipStream_t s);

@@ -486,28 +486,42 @@ int engine_select_sample(mvd_ctx* c, int slot) {
 // ----------------------------------------------------------------------------------------------------
 // NoisyTargetViewEncoder (network.py:181-207) for n_local views + fused unprojection/vertex gather + this
 // rank's share of the view mean (morphable_diffusion.py:203-231).
+// the whole 2-D encoder as one launch (k_enc.hip) applies: 32 x 32 latents, the reference's 8 -> 16 -> ... -> 16 channel plan
+bool engine_encoder_is_fused(const mvd_ctx* c) {
+  static const bool no_fused_enc = getenv("MVD_NO_FUSED_ENC") != nullptr;
+  bool fused_enc = !no_fused_enc && c->has_cond && c->u.image_size == 32 && c->enc_init.Cin == 8 && c->enc_init.N == 16 &&
+                   c->enc_init.taps == 9 && !c->enc_init.xp && c->enc_final.N == 16 && c->enc_final.Cin == 16 && !c->enc_final.xp;
+  for (int i = 0; i < 3 && fused_enc; ++i)
+    fused_enc = c->enc_blocks[i].c1.Cin == 16 && c->enc_blocks[i].c1.N == 16 && !c->enc_blocks[i].c1.xp &&
+                c->enc_blocks[i].c2.Cin == 16 && c->enc_blocks[i].c2.N == 16 && !c->enc_blocks[i].c2.xp;
+  return fused_enc;
+}
+
+// pre_own (optional, n_local * 48 floats): the FiLM rows in storage of the caller's instead of the shared workspace -- with it
+// (and the fused encoder) the call touches no workspace memory, i.e. it may run on a stream beside a UNet pass of the same context
 int engine_target_encoder(mvd_ctx* c, const float* x_noisy, const float* t_embed, const float* v_embed, int n_local, float* feats,
-                          hipStream_t s) {
+                          hipStream_t s, float* pre_own) {
   if (!c->finalized || !c->has_cond) return mvd_fail("spatial_volume weights not uploaded / finalized");
   WsScope ws_scope(c);
   const int S = c->u.image_size, HW = S * S, rows = n_local * HW, td = c->v.time_dim, vd = c->v.view_dim;
-  float* x8 = ws_alloc<float>(c, (size_t)rows * 8);
-  float* h = ws_alloc<float>(c, (size_t)rows * 16);
-  float* h2 = ws_alloc<float>(c, (size_t)rows * 16);
-  float* r1 = ws_alloc<float>(c, (size_t)rows * 16);
-  half_t* a = ws_alloc<half_t>(c, (size_t)rows * 16);
-  float* pre = ws_alloc<float>(c, (size_t)n_local * 48);
-  WS_CHECK(x8 && h && h2 && r1 && a && pre);
+  const bool fused_enc = engine_encoder_is_fused(c);
+  if (pre_own && !fused_enc) return mvd_fail("engine_target_encoder: caller-owned scratch needs the one-launch encoder");
+  float *x8 = nullptr, *h = nullptr, *h2 = nullptr, *r1 = nullptr, *pre = pre_own;
+  half_t* a = nullptr;
+  if (!fused_enc) {
+    x8 = ws_alloc<float>(c, (size_t)rows * 8);
+    h = ws_alloc<float>(c, (size_t)rows * 16);
+    h2 = ws_alloc<float>(c, (size_t)rows * 16);
+    r1 = ws_alloc<float>(c, (size_t)rows * 16);
+    a = ws_alloc<half_t>(c, (size_t)rows * 16);
+    WS_CHECK(x8 && h && h2 && r1 && a);
+  }
+  if (!pre) pre = ws_alloc<float>(c, (size_t)n_local * 48);
+  WS_CHECK(pre);
   // x + time_embed(t) + view_embed(v) of all three blocks in two launches (the step embedding is shared by
   // all views of the sample): pre[v][16*i + c]
   RET_IF(launch_small_linear(t_embed, td, -n_local, td, c->enc_t.w, c->enc_t.bias, 48, ACT_NONE, pre, 48, 0, s));
   RET_IF(launch_small_linear(v_embed, vd, n_local, vd, c->enc_v.w, c->enc_v.bias, 48, ACT_NONE, pre, 48, 1, s));
-  static const bool no_fused_enc = getenv("MVD_NO_FUSED_ENC") != nullptr;
-  bool fused_enc = !no_fused_enc && S == 32 && c->enc_init.Cin == 8 && c->enc_init.N == 16 && c->enc_init.taps == 9 &&
-                   !c->enc_init.xp && c->enc_final.N == 16 && c->enc_final.Cin == 16 && !c->enc_final.xp;
-  for (int i = 0; i < 3 && fused_enc; ++i)
-    fused_enc = c->enc_blocks[i].c1.Cin == 16 && c->enc_blocks[i].c1.N == 16 && !c->enc_blocks[i].c1.xp &&
-                c->enc_blocks[i].c2.Cin == 16 && c->enc_blocks[i].c2.N == 16 && !c->enc_blocks[i].c2.xp;
   if (fused_enc) {  // the whole encoder in one launch, one workgroup per view (k_enc.hip)
     const half_t* w[8];
     const float *bias[8], *gamma[7], *beta[7];
@@ -560,11 +574,28 @@ int engine_vertex_features(mvd_ctx* c, const float* x_noisy, const float* t_embe
   if (!c->mesh.Nv || !c->cams) return mvd_fail("mvd_set_mesh / mvd_set_cameras must be called first");
   WsScope ws_scope(c);
   const int S = c->u.image_size, rows = n_local * S * S;
-  float* feats = ws_alloc<float>(c, (size_t)rows * 16);
+  // With the one-launch encoder and a caller-provided vf_out the stage runs out of a scratch of the context's own (grown on
+  // demand, never shrunk) instead of the shared workspace: it may then be enqueued on the communication stream while the UNet of
+  // the same context runs on the caller's (mvd_vertex_features_stream_safe; the step's head leaves the critical path)
+  float *feats = nullptr, *pre_own = nullptr;
+  if (vf_out && engine_encoder_is_fused(c)) {
+    const size_t need = (size_t)rows * 16 + (size_t)n_local * 48;
+    if (c->enc_scratch_cap < need) {
+      if (c->enc_scratch) HIP_CHECK_RET(hipFree(c->enc_scratch));
+      c->enc_scratch = nullptr;
+      c->enc_scratch_cap = 0;
+      HIP_CHECK_RET(hipMalloc((void**)&c->enc_scratch, need * sizeof(float)));
+      c->enc_scratch_cap = need;
+    }
+    feats = c->enc_scratch;
+    pre_own = c->enc_scratch + (size_t)rows * 16;
+  } else {
+    feats = ws_alloc<float>(c, (size_t)rows * 16);
+  }
   // vf_out: the per-view vertex features themselves [n_local][Nv][16] (the all-gather variant of the view exchange)
   float* vf = vf_out ? vf_out : ws_alloc<float>(c, (size_t)n_local * c->mesh.Nv * 16);
   WS_CHECK(feats && vf);
-  RET_IF(engine_target_encoder(c, x_noisy, t_embed, v_embed, n_local, feats, s));
+  RET_IF(engine_target_encoder(c, x_noisy, t_embed, v_embed, n_local, feats, s, pre_own));
   RET_IF(launch_vertex_gather(feats, c->cams, view_idx_dev, n_local, c->mesh.verts, c->mesh.Nv, c->v.spatial_volume_size,
                               c->v.spatial_volume_length, S, c->v.projection == 0, vf, s));
   if (fused_out)

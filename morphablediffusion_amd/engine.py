@@ -288,6 +288,10 @@ class Engine:
                                                   L.ptr(out), _stream()))
         return out
 
+    def vertex_features_stream_safe(self):
+        """mvd_vertex_features_stream_safe: vertex_view_features may run on a side stream beside denoise_views of this engine."""
+        return bool(self.lib.mvd_vertex_features_stream_safe(self._ctx))
+
     def fuse_vertex_features(self, vf_all, out=None):
         """SMPLFeatureExtractor over all views in index order: [num_views,Nv,16] -> [Nv,16]."""
         vf = _f32(vf_all, self.device)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MVD_LIB_PATH", os.path.join(_HERE, "libmvd_hip.so" if
 
 SYMBOLS = [
     "mvd_create", "mvd_destroy", "mvd_last_error", "mvd_compute_dtype", "mvd_upload_weight", "mvd_set_precision_level", "mvd_set_vae_precision", "mvd_finalize_weights", "mvd_unet_forward", "mvd_unet_block",
-    "mvd_embed_time", "mvd_select_sample", "mvd_set_mesh", "mvd_set_cameras", "mvd_set_mesh_async", "mvd_set_cameras_async", "mvd_set_samples_async", "mvd_rulebook_build", "mvd_rulebook_table", "mvd_vertex_features", "mvd_vertex_view_features", "mvd_fuse_vertex_features",
+    "mvd_embed_time", "mvd_select_sample", "mvd_set_mesh", "mvd_set_cameras", "mvd_set_mesh_async", "mvd_set_cameras_async", "mvd_set_samples_async", "mvd_rulebook_build", "mvd_rulebook_table", "mvd_vertex_features", "mvd_vertex_view_features", "mvd_vertex_features_stream_safe", "mvd_fuse_vertex_features",
     "mvd_comm_unique_id", "mvd_comm_init", "mvd_comm_destroy", "mvd_exchange_view_features", "mvd_comm_all_reduce", "mvd_train_sync_gradients",
     "mvd_stage_target_encoder", "mvd_stage_sparse_dense", "mvd_set_volume_ready_event", "mvd_volume_from_fused", "mvd_volume_from_fused_train", "mvd_mse_loss", "mvd_set_volume", "mvd_train_enable", "mvd_train_param_count", "mvd_train_param_info", "mvd_train_arena_size", "mvd_train_adopt_arena", "mvd_train_zero_grad", "mvd_train_unet_step", "mvd_train_get_grad", "mvd_train_get_tensor", "mvd_train_bn_calls", "mvd_train_cond_backward", "mvd_train_conditioner_backward", "mvd_train_conditioner_backward_batch", "mvd_train_adamw_step", "mvd_train_repack", "mvd_train_repack_async", "mvd_train_grad_bucket_count", "mvd_train_grad_bucket", "mvd_train_grad_bucket_wait", "mvd_train_set_bucket_snapshot",
     "mvd_frustum_volumes", "mvd_frustum_volumes_batch", "mvd_denoise_views", "mvd_denoise_views_batch", "mvd_op_conv", "mvd_op_linear", "mvd_op_group_norm",

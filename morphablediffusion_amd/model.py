@@ -1125,17 +1125,29 @@ class SyncDDIMSampler:
         NL = x_local.shape[0]
         if self.exchange == "all_gather":
             Nv = eng.num_vertices
+            # The whole head of the step -- 2-D encoder + vertex gather too -- goes to the communication stream when the engine's
+            # vertex-feature stage touches no shared workspace (mvd_vertex_features_stream_safe): the UNet's input blocks need none
+            # of it, so the caller's stream starts the UNet at once (round 6: ~0.1 ms of small kernels per step left the
+            # critical path).  MVD_HEAD_ON_MAIN=1: the round-5 placement.
+            import os
+            head_side = (side and dev.type == "cuda" and not os.environ.get("MVD_HEAD_ON_MAIN")
+                         and getattr(eng, "vertex_features_stream_safe", lambda: False)())
             if dev.type == "cuda":
                 vf_all = self._buf("vf_all" + tag, (N, Nv, 16), dev)
                 lo = rank * NL if world > 1 else 0
                 vf_loc = vf_all[lo:lo + NL] if not real else self._buf("vf_loc" + tag, (NL, Nv, 16), dev)
-                eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx, out=vf_loc)
+                if not head_side:
+                    eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx, out=vf_loc)
             else:  # CPU stand-ins of the engine (tests)
                 vf_loc = eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx)
                 vf_all = vf_loc if world == 1 else torch.empty((N,) + tuple(vf_loc.shape[1:]), dtype=vf_loc.dtype)
             fused_buf = self._buf("fused" + tag, (Nv, 16), dev) if dev.type == "cuda" else None
 
             def tail():
+                if head_side:  # on the communication stream, behind ev_in (x_local and t_embed are final there)
+                    for t_ in (x_local, t_embed, v_embed_local):  # allocated on the caller's stream, read on this one
+                        t_.record_stream(torch.cuda.current_stream(dev))
+                    eng.vertex_view_features(x_local, t_embed, v_embed_local, local_idx, out=vf_loc)
                 if real and getattr(eng, "comm_world", 0) == world:
                     # the library's own communicator (mvd_comm_init): ncclAllGather enqueued by the C ABI on this stream, no
                     # torch.distributed on the step path (SyncDDIMSampler.use_library_exchange)
