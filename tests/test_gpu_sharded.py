@@ -184,3 +184,48 @@ def test_library_owned_rccl_exchange_one_rank():
             eng.exchange_view_features(loc, out)  # no communicator any more: loud
     finally:
         m.engine.close()
+
+
+def test_library_owned_rccl_all_reduce_and_gradient_reducer_one_rank():
+    """Round 6: the rest of the collectives behind the C ABI on the world-1 communicator -- mvd_comm_all_reduce (sum, in place) and
+    mvd_train_sync_gradients (phase 0: every bucket of the last training step on the communication stream behind its event;
+    phase 1: the ranges no bucket covers, the join, the 1 / world scale).  With one rank the sum is the identity and the scale is 1,
+    so the gradient arena must come back bit for bit -- what the test pins is the call sequence, the event / stream plumbing and
+    the bucket coverage (a range reduced twice or never would still be invisible here; the 2-rank gloo test covers the arithmetic
+    through the same bucket ranges)."""
+    import numpy as np
+    from tests.test_gpu_train import make_train_model
+    from tests import golden_inputs as gi
+    from morphablediffusion_amd.spec import VolumeConfig
+    from morphablediffusion_amd import synthetic
+    N = 4
+    m = make_train_model(gi.SMALL_UNET, VolumeConfig(num_views=N), N, workspace_gb=4.0)
+    try:
+        eng = m.engine
+        eng.comm_init(rank=0, world=1)
+        buf = torch.randn(1 << 16, device="cuda")
+        ref = buf.clone()
+        eng.comm_all_reduce(buf)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, ref)
+        batch = {k: v.cuda() for k, v in synthetic.make_batch(N, "perspective", 300, mesh_seed=3).items()}
+        g = torch.Generator().manual_seed(4)
+        prepared = ((torch.randn(1, N, 4, 32, 32, generator=g) * 0.8).cuda(), torch.randn(1, 1, 768, generator=g).cuda(),
+                    {"x": (torch.randn(1, 4, 32, 32, generator=g) * 0.18215).cuda()})
+        m.overlap_grad_sync = False  # no process group here: drive the reducer by hand
+        m.training_step(batch, prepared=prepared, time_steps=torch.tensor([500]), noise=torch.randn(1, N, 4, 32, 32, generator=g),
+                        target_index=torch.tensor([[1]]), drop_random=torch.tensor([0.9]))
+        torch.cuda.synchronize()
+        want = eng.flat_grads.clone()
+        assert len(eng.grad_buckets()) > 1 and float(want.abs().sum()) > 0
+        comm = torch.cuda.Stream()
+        eng.sync_gradients(0, comm)
+        eng.sync_gradients(1, comm)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.flat_grads, want)
+        eng.sync_gradients(1, comm)  # phase 1 alone: the flat all-reduce
+        torch.cuda.synchronize()
+        assert torch.equal(eng.flat_grads, want)
+        print("[property] library reducer, world 1: arena unchanged through phase 0 + 1 and through the flat form")
+    finally:
+        m.engine.close()
