@@ -5,8 +5,8 @@ parameter (856 tensors, of which the 170 of get_trainable_parameters(), attentio
 frustum volumes.  Then the optimiser: ArenaAdamW against torch.optim.AdamW, the in-place re-pack against a fresh load.
 Tolerances: the engine computes on fp16 MFMA operands with fp32 accumulation (forward AND backward); the configuration's own
 dtype, bf16 (BASELINE.json config 4), carries 4e-3 per operation.  Loss 1e-3, prediction 2e-3.  Gradients, relative L2 per
-tensor: the 686 tensors of the UNet trunk <= 1e-2 (measured: worst 4.6e-3, median 2.4e-3 = sqrt(#layers) x the fp16 operand
-rounding).  The 170 DepthTransformer tensors <= 5e-2 (measured: worst 3.7e-2, median 1.0e-2): their backward pass goes through
+tensor: the 686 tensors of the UNet trunk <= 7e-3 (round 6: 1.5 x the measured worst 4.7e-3, median 2.4e-3 = sqrt(#layers) x the
+fp16 operand rounding; was 1e-2).  The 170 DepthTransformer tensors <= 5e-2 (measured: worst 3.7e-2, median 1.0e-2): their backward pass goes through
 three ReLU masks and a softmax over nearly uniform depth weights that are re-derived from the block's input, which carries the
 forward pass's fp16 rounding (5e-4 .. 1e-3) -- a relative input perturbation eps flips ~eps of the mask bits and moves these
 gradients by ~sqrt(eps): tests/test_host_cpu.py::test_depth_transformer_gradient_sensitivity shows the reference arithmetic
@@ -128,9 +128,9 @@ def test_training_step_every_unet_gradient_vs_reference():
           f"{sorted(r[0] for r in cond)[len(cond) // 2]:.2e}; {len(rest)} other UNet tensors worst {max(r[0] for r in rest):.2e} "
           f"median {sorted(r[0] for r in rest)[len(rest) // 2]:.2e}")
     assert len(cond) == 170
-    assert max(r[0] for r in cond) <= 5e-2, cond[0]
+    assert max(r[0] for r in cond) <= 5e-2, cond[0]  # measured 3.65e-2 (insensitive to the precision policy: ReLU-mask flips)
     assert sorted(r[0] for r in cond)[len(cond) // 2] <= 1.5e-2
-    assert max(r[0] for r in rest) <= 1e-2, rest[0]
+    assert max(r[0] for r in rest) <= 7e-3, rest[0]  # measured 4.69e-3 (profiles/r05_z_train_grad_vs_precision_level.txt) x 1.5
     # gradient w.r.t. the frustum volumes (before the dropout): the entry point of the conditioner's backward
     for res_, d in m.last_dsrc.items():
         a, b, _ = gi.unpack_compare(d.cpu() / m.loss_scale, g, f"dsrc.{res_}")
@@ -151,8 +151,8 @@ def test_training_step_every_unet_gradient_vs_reference():
 def test_training_step_full_width_gradients_vs_reference():
     """The FULL-WIDTH training step (916.9 M-parameter UNet, B = 2) against the reference's own training_step + loss.backward()
     run on the CPU (tools/make_goldens.py --only-train-full -> tests/golden/train_full.npz): loss, prediction and a sample of 26
-    gradient tensors -- every block kind, every resolution level, both ends of the network, six DepthTransformer tensors.  Same
-    bounds as at reduced width (until round 4 the full-width step was only property-tested)."""
+    gradient tensors -- every block kind, every resolution level, both ends of the network, six DepthTransformer tensors.  Bounds
+    from what the full-width step measures (tighter than at reduced width: wider reductions average the operand rounding)."""
     path = os.path.join(G, "train_full.npz")
     g = np.load(path)
     batch, x0, x_in, clip, ts, noise, ti, dr = _train_inputs(g)
@@ -174,8 +174,9 @@ def test_training_step_full_width_gradients_vs_reference():
     cond = [r for r in rows if r[2].startswith(("middle_conditions.", "output_conditions."))]
     rest = [r for r in rows if not r[2].startswith(("middle_conditions.", "output_conditions."))]
     assert len(cond) == 6 and len(rest) == 20
-    assert max(r[0] for r in cond) <= 5e-2, cond[0]
-    assert max(r[0] for r in rest) <= 1e-2, rest[0]
+    # round 6: 1.5 x the measured worst (profiles/r05_z_pytest_full.log: DepthTransformer 1.63e-2, trunk 2.60e-3); was 5e-2 / 1e-2
+    assert max(r[0] for r in cond) <= 2.5e-2, cond[0]
+    assert max(r[0] for r in rest) <= 4e-3, rest[0]
     m.engine.close()
 
 

@@ -44,12 +44,14 @@ def test_training_step_bf16_vs_reference_and_fp16_control():
     assert b["dtype"] == "bf16" and f["dtype"] == "f16" and b["loss_scale"] == 1.0
     assert b["finite"] and b["bit_reproducible"] and b["steps_skipped"] == 0
     assert b["loss_rel_err"] <= 2e-3 and b["pred_rel_l2"] <= 1.2e-2
-    assert b["grad_trunk_worst"] <= 8e-2 and b["grad_trunk_median"] <= 4e-2
-    assert b["grad_dt_worst"] <= 0.3 and b["grad_dt_median"] <= 0.1
+    # round 6: 1.5 x what this step measures (profiles/r05_z_pytest_full.log: trunk worst 3.59e-2 median 1.73e-2, DepthTransformer
+    # worst 1.16e-1 median 3.38e-2); until round 5 the bounds were 8e-2 / 4e-2 and 0.3 / 0.1
+    assert b["grad_trunk_worst"] <= 5.5e-2 and b["grad_trunk_median"] <= 2.6e-2
+    assert b["grad_dt_worst"] <= 0.18 and b["grad_dt_median"] <= 5.1e-2
     assert b["grad_cosine"] >= 0.9995 and f["grad_cosine"] >= 0.9999
     assert b["losses"][-1] < 0.9 * b["losses"][0], b["losses"]
     # the control keeps the fp16 bounds of tests/test_gpu_train.py
-    assert f["loss_rel_err"] <= 1e-3 and f["pred_rel_l2"] <= 2e-3 and f["grad_trunk_worst"] <= 1e-2
+    assert f["loss_rel_err"] <= 1e-3 and f["pred_rel_l2"] <= 2e-3 and f["grad_trunk_worst"] <= 7e-3
     # both dtypes descend alike on the same batch (same optimiser, fp32 masters)
     assert abs(b["losses"][-1] - f["losses"][-1]) <= 0.1 * f["losses"][0]
 
