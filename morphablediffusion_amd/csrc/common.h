@@ -256,4 +256,6 @@ int launch_bits_checksum(const void* p, size_t bytes, unsigned long long* out, h
 int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStream_t s);
 // out[(b * HW + p) * ldo + c] = in[(b * HW + p) * ldi + c] + img[p * C + c] for b < nb (C, ldi, ldo multiples of 4)
 int launch_add_image_rows(const float* in, int ldi, const float* img, int C, int nb, int HW, float* out, int ldo, hipStream_t s);
+// nearest x2 upsample + fp16 cast: in fp32 [B][H][W][ldi] -> out fp16 [B][2H][2W][C]
+int launch_upsample2_f16(const float* in, int ldi, int B, int H, int W, int C, half_t* out, hipStream_t s);
 int launch_probe_null(hipStream_t s);  // one wave that does nothing: the launch path's own cost (ProbeScope calibration)

@@ -30,6 +30,7 @@ struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
   half_t* wx = nullptr;    // 3x3 ResBlock convs at 16-divisible resolutions: the weights as a conv3x fragment stream (k_conv3x.hip)
   int wx_bn = 0;           // ... packed for column tiles of this width
   half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
+  int res_out = 0;         // upsample convs only: the resolution they produce (decides whether they get a conv3x stream)
   float* bias = nullptr;
   int N = 0, Cin = 0, taps = 1;
   // training mode only (engine_train.hip: build_dgrad): the adjoint's weights, fp16 [taps, flipped][cin_l][Np] with Np = N padded

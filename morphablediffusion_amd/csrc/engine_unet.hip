@@ -934,8 +934,22 @@ int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRe
         g.a = as; g.a_f32 = 0; g.lda = 3 * Cl;
       }
       // weight-streaming regime (few pixels): the 9-tap form moves 9 slabs instead of 16
-      if (ups && c->convs[op.idx].w_up && f.Bv * H * W >= 2048) RET_IF(run_upconv2d(c, g, f.Bv, H, W, f.s));
-      else RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
+      static const bool no_up3x = getenv("MVD_NO_UP_CONV3X") != nullptr;
+      const ConvW& cw = c->convs[op.idx];
+      if (ups && cw.w_up && f.Bv * H * W >= 2048) {
+        RET_IF(run_upconv2d(c, g, f.Bv, H, W, f.s));
+      } else if (ups && !no_up3x && !f.train && cw.wx && !cw.xp && 2 * H == cw.res_out && 2 * W == cw.res_out && c->use_halo && !(in.ld & 3) &&
+                 !(op.cin & 3)) {
+        // 4 x 4 -> 8 x 8: the nearest-upsampled image as fp16 (one small launch), then conv3x over whole 8 x 8 images (round 6: the
+        // register-staged 9-tap GEMM on the fp32 source ran this layer at 476 TFLOP/s, 127 us of the step)
+        half_t* up = ws_alloc<half_t>(c, (size_t)f.Bv * 4 * H * W * op.cin);
+        WS_CHECK(up);
+        RET_IF(launch_upsample2_f16(in.p, in.ld, f.Bv, H, W, op.cin, up, f.s));
+        g.a = up; g.a_f32 = 0; g.lda = op.cin;
+        RET_IF(run_conv2d(c, g, f.Bv, 2 * H, 2 * W, 1, 0, f.s));
+      } else {
+        RET_IF(run_conv2d(c, g, f.Bv, H, W, stride, ups, f.s));
+      }
       if (op.kind == OP_DOWN) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
       if (out_carry) {
         out_carry->sk = skc;

@@ -581,6 +581,10 @@ int build_conv3x_streams(mvd_ctx* c) {
     cs.push_back(&d.conv1);
     cs.push_back(&d.conv2);
   }
+  // the Upsample convolution that produces 8 x 8 images (openaimodel.py:112-117): few pixels, so instead of the parity-folded form
+  // it runs as nearest-upsample + cast (one small launch) and conv3x over the 8 x 8 images (unet_do_op)
+  for (ConvW& w : c->convs)
+    if (w.res_out == 8 && !w.xp) cs.push_back(&w);
   for (ConvW* w : cs) {
     if (w->taps != 9 || w->Cin % 64) continue;
     const int bn = w->N % 160 == 0 ? 160 : (w->N % 128 == 0 ? 128 : 0);
@@ -818,6 +822,7 @@ int build_unet_section(mvd_ctx* c) {
       if (level && i == u.num_res_blocks) {
         RET_IF(add_conv(b + "." + std::to_string(j) + ".conv", OP_UP, ch, ch, ops));
         ds /= 2;
+        c->convs.back().res_out = u.image_size / ds;
       }
       c->out_blocks.push_back(ops);
       ++bi;

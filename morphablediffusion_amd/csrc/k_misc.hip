@@ -613,3 +613,32 @@ int launch_add_image_rows(const float* in, int ldi, const float* img, int C, int
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+namespace {
+// nearest x2 upsample + fp16 cast of a channels-last image batch: out[b][y][x][c] = (half) in[b][y >> 1][x >> 1][c]
+__global__ __launch_bounds__(256) void upsample2_f16_kernel(const float* __restrict__ in, int ldi, int B, int H, int W, int C4,
+                                                            half_t* __restrict__ out) {
+  const long total = (long)B * 4 * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int x = (int)(p % (2 * W));
+    p /= 2 * W;
+    const int y = (int)(p % (2 * H)), b = (int)(p / (2 * H));
+    const float4 v = *(const float4*)(in + (((long)b * H + (y >> 1)) * W + (x >> 1)) * ldi + q * 4);
+    h4 o;
+    o[0] = (half_t)v.x; o[1] = (half_t)v.y; o[2] = (half_t)v.z; o[3] = (half_t)v.w;
+    *(h4*)(out + i * 4) = o;
+  }
+}
+}  // namespace
+int launch_upsample2_f16(const float* in, int ldi, int B, int H, int W, int C, half_t* out, hipStream_t s) {
+  if ((C & 3) || (ldi & 3) || (((uintptr_t)in | (uintptr_t)out) & 15)) return mvd_fail("upsample2_f16: 16-byte aligned rows");
+  const long total = (long)B * 4 * H * W * (C / 4);
+  if (total <= 0) return 0;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(upsample2_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, ldi, B, H, W, C / 4, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -215,6 +215,28 @@ def test_rowchain_forced_with_extended_precision_proj_out_at_c128_c256(tmp_path)
     assert r.returncode == 0 and "XP_ROWCHAIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_upsample_4_to_8_through_conv3x_vs_torch():
+    """Round 6: the Upsample block that produces 8 x 8 images (output_blocks.2.1: nearest x2 + 3x3 conv, openaimodel.py:112-117) runs
+    as one upsample-and-cast launch + conv3x over the 8 x 8 images; B = 3 leaves a partial conv3x tile (four images per tile)."""
+    import torch.nn.functional as F
+    from morphablediffusion_amd.model import DepthWiseAttention
+    cfg = gi.SMALL_UNET
+    W = gi.unet_weights(cfg)
+    net = DepthWiseAttention(volume_dims=cfg.volume_dims, image_size=32, in_channels=8, out_channels=4,
+                             model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                             channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                             transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+    net.load_state_dict({k[len("model.diffusion_model."):]: v for k, v in W.items()})
+    for B in (3, 8):
+        x = torch.randn(B, 256, 4, 4, generator=torch.Generator().manual_seed(70 + B))
+        got = net._engine.unet_block("output_blocks.2.1", x).cpu()
+        want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), W["model.diffusion_model.output_blocks.2.1.conv.weight"],
+                        W["model.diffusion_model.output_blocks.2.1.conv.bias"], padding=1)
+        rl2 = ((got - want).norm() / want.norm()).item()
+        print(f"[parity] upsample 4 -> 8 (B={B}): relL2={rl2:.2e}")
+        assert got.shape == want.shape and rl2 <= REL_L2
+
+
 def test_full_width_transformer_blocks_low_resolution_vs_oracle():
     """Round 6: at few rows per GEMM (8 x 8 and 4 x 4 images, a few samples) proj_in and to_out split K and leave their slabs to
     LayerNorm1 / LayerNorm3 (launch_layernorm_slabs: slab sum + bias + attn2's per-sample row + residual, the finished fp32 row
