@@ -28,14 +28,15 @@ VARIANTS = {
     # together with the halo kernel of rounds 1-4 in place of conv3x (k_conv3x.hip) for the 3x3 convolutions
     # (the row-head kernel -- proj_in, LayerNorm1, q|k|v in one launch -- rides on the same switch)
     "rowchain_at_every_batch_halo_conv": {"MVD_ROWCHAIN_MIN_ROWS": "0", "MVD_NO_CONV3X": "1"},
-    # round 6: LayerNorm1 / LayerNorm3 sum the split-K slabs of proj_in / to_out themselves (launch_layernorm_slabs; off by default:
-    # measured neutral), and the DepthTransformer's GroupNorms do NOT (their default since round 6 is to sum them)
-    "layernorm_sums_splitk_slabs_cond_reduces": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1"},
-    # round 6: every DepthTransformer folds its own context projection (no per-level stacked GEMM) and runs over ALL samples, the
-    # context-free ones through relu(beta) rows instead of the precomputed constant image (mvd_ctx::CtxGroup / CondConst off)
-    "depth_transformer_block_by_block_all_samples": {"MVD_NO_CTX_GROUP": "1", "MVD_NO_COND_CONST": "1"},
-    # round 6: FF2 and proj_out as two GEMMs with the fp16 intermediate between them (default: one GEMM over [gg | t2], STW::ffp)
-    "ff2_and_proj_out_as_two_gemms": {"MVD_NO_FFP": "1"},
+    # round 6, the restructured paths against their round-5 forms (two processes instead of one per switch: each is a full-width
+    # model load).  (a) LayerNorm1 / LayerNorm3 sum the split-K slabs of proj_in / to_out (off by default: measured neutral), the
+    # DepthTransformer's GroupNorms do NOT sum theirs (the folded FF2 + proj_out GEMM then takes its fp16 t2 from the slab form);
+    "ln_sums_slabs_cond_reduces": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1"},
+    # (b) every DepthTransformer folds its own context projection and runs over ALL samples (no per-level stacked GEMM, no cached
+    # constant image for the context-free half), FF2 and proj_out as two GEMMs with the fp16 intermediate between them, the 4 -> 8
+    # Upsample as the 9-tap GEMM on the fp32 source, the step's head on the UNet's stream
+    "round5_forms_of_the_round6_restructurings": {"MVD_NO_CTX_GROUP": "1", "MVD_NO_COND_CONST": "1", "MVD_NO_FFP": "1",
+                                                  "MVD_NO_UP_CONV3X": "1", "MVD_HEAD_ON_MAIN": "1"},
 }
 
 
