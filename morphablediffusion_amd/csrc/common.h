@@ -106,6 +106,7 @@ struct IGemm {
   int par_ntaps[8];
   int par_tap[8][8];
   int par_oz[8], par_oy[8], par_ox[8];
+  int par_walk;         // LDS-DMA kernel: one workgroup walks the npar classes of its tile (grid.z = 1) instead of one per class
   const half_t* wx;     // the same weights as a conv3x fragment stream (k_conv3x.hip) packed for column tiles of wx_bn, or null
   int wx_bn;
   int bn;               // column-tile width (64 / 96 / 128 / 160); 0 = pick from N

@@ -126,6 +126,16 @@ int igemm_go(mvd_ctx* c, IGemm& g, int force_splitk, hipStream_t s, const GemmAr
     g.nch = nch;
     g.splitk = 1;
     g.partial = nullptr;
+    // Parity walk (k_gemm.hip PWALK): every workgroup walks the parity classes of its tile instead of one workgroup per class --
+    // meant for the frustum network's level-0 ConvTranspose3d (384 tiles x 8 classes of 2 ... 16 k-steps each: 282 us at 154
+    // TFLOP/s).  MEASURED (profiles/r06_y_ab_pwalk.txt, threshold 192 tiles): 12.828 vs 12.811 ms per step, 6.169 vs 6.169 at 2
+    // views per rank -- nothing: the launch sits on the side stream beside the trunk.  Tested form, off unless
+    // MVD_PAR_WALK_MIN=<tiles> is set.
+    static const int pwalk_min = getenv("MVD_PAR_WALK_MIN") ? atoi(getenv("MVD_PAR_WALK_MIN")) : 0;
+    if (pwalk_min > 0 && cdiv(M, 256) * cdiv(g.N, g.bn) >= pwalk_min) {
+      g.par_walk = 1;
+      g.nch = 1;
+    }
     double fl = 0.0;
     for (int p = 0; p < g.npar; ++p) fl += 2.0 * M * g.N * (double)(g.cin_alg ? g.cin_alg : g.Cin) * g.par_ntaps[p];
     const double by = (double)g.B * g.PZ * g.PY * g.PX * g.Cin * 2 + (double)g.npar * kmax * g.N * g.Cin * 2 +

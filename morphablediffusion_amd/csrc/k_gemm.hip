@@ -105,15 +105,21 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
     tm = bid - gn * tiles_m;
   }
   int m0 = tm * GBM;
-  const int tn_beg = WALK ? bid * nch : gn * nch;
-  const int tn_end = WALK ? min(tiles_m * tiles_n, tn_beg + nch) : min(tiles_n, tn_beg + nch);
+  // PARITY WALK (g.par_walk, general MODE 0 kernel only; round 6): the workgroup owns ONE column tile and walks the npar parity
+  // classes of a transposed / upsample convolution one after the other -- the "tile" index of the step stream below is then the
+  // parity class, its k range par_ntaps[class] * cpt -- instead of one workgroup per class (blockIdx.z).  The level-0 ConvTranspose3d
+  // of the frustum network is 3072 workgroups of 2 ... 16 k-steps that way (282 us at 154 TFLOP/s: fill, drain and a 64 KiB
+  // epilogue per handful of steps); walked, the ring never drains between classes.
+  const bool PWALK = MODE == 0 && !PLAIN && g.npar > 0 && g.par_walk != 0;
+  const int col_tile = gn * nch;  // PWALK: the one column tile of this workgroup
+  const int tn_beg = PWALK ? 0 : (WALK ? bid * nch : gn * nch);
+  const int tn_end = PWALK ? g.npar : (WALK ? min(tiles_m * tiles_n, tn_beg + nch) : min(tiles_n, tn_beg + nch));
 
-  // parity-batched launch: this workgroup's tap table and output offsets
-  const int par = g.npar > 0 ? (int)blockIdx.z : 0;
+  // parity-batched launch: this workgroup's tap table and output offsets (PWALK: of the class being consumed, see par_of)
+  const int par = (g.npar > 0 && !PWALK) ? (int)blockIdx.z : 0;
   const int ntaps = g.npar > 0 ? g.par_ntaps[par] : g.ntaps;
-  const int ozo = g.npar > 0 ? g.par_oz[par] : g.ozo, oyo = g.npar > 0 ? g.par_oy[par] : g.oyo,
-            oxo = g.npar > 0 ? g.par_ox[par] : g.oxo;
-  const int ksteps_all = ntaps * ((Cin + 63) / 64);
+  const int cpt0 = (Cin + 63) / 64;
+  const int ksteps_all = ntaps * cpt0;
   int kbeg = 0, kend = ksteps_all;
   if (g.splitk > 1) {
     const int per = (ksteps_all + g.splitk - 1) / g.splitk;
@@ -121,7 +127,13 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
     kend = min(ksteps_all, kbeg + per);
   }
   const int ksteps = kend - kbeg;
-  const int nsteps = ksteps > 0 ? ksteps * (tn_end - tn_beg) : 0;
+  // k range end of stream tile `t` (PWALK: of class t)
+  auto kend_of = [&](int t) { return PWALK ? g.par_ntaps[t] * cpt0 : kend; };
+  int nsteps = ksteps > 0 ? ksteps * (tn_end - tn_beg) : 0;
+  if (PWALK) {
+    nsteps = 0;
+    for (int t = 0; t < g.npar; ++t) nsteps += g.par_ntaps[t] * cpt0;
+  }
 
   const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a), (short)0, 0xFFFFFFFEu, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(g.w), (short)0, 0xFFFFFFFEu, 0x00020000);
@@ -162,9 +174,9 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
   const int cpt = (Cin + 63) / 64;  // k-steps per tap
   [[maybe_unused]] const float inv_rps = 1.0f / (float)(g.Z * g.Y * g.X);
   unsigned w_slab = 0;              // byte offset of the current tap's weight slab
-  auto set_tap = [&](int tap) {
-    const int tu = __builtin_amdgcn_readfirstlane(tap);
-    const int ti = g.npar > 0 ? g.par_tap[par][tu] : g.tap[tu];  // one packed dword per tap, scalar load
+  auto set_tap = [&](int tap, int pr) {
+    const int tu = __builtin_amdgcn_readfirstlane(tap), pu = __builtin_amdgcn_readfirstlane(pr);
+    const int ti = g.npar > 0 ? g.par_tap[pu][tu] : g.tap[tu];  // one packed dword per tap, scalar load
     const int dz = (ti & 3) - 1, dy = ((ti >> 2) & 3) - 1, dx = ((ti >> 4) & 3) - 1;
     w_slab = (unsigned)(ti >> 8) * (unsigned)N * (unsigned)Cin * 2;
 #pragma unroll
@@ -196,9 +208,11 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
     } else if constexpr (!PLAIN) {
       tap = ks / cpt;
       cc = ks - tap * cpt;
-      if (tap != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
-        set_tap(tap);
-        set_for = tap;
+      const int pr = PWALK ? tile : par, key = pr * 64 + tap;
+      if (PWALK) tn = col_tile;
+      if (key != set_for) {  // nothing of this step is in flight yet: the scalar-load wait cannot drain a tile load
+        set_tap(tap, pr);
+        set_for = key;
       }
     }
     d_kb = cc * 64;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
   // prologue: steps 0 and 1 in flight, step 0 landed
   int p_tn = tn_beg, p_ks = kbeg;  // (tile, k) of the next step to prefetch
   auto advance = [&](int& tn, int& ks) {
-    if (++ks == kend) {
+    if (++ks == kend_of(tn)) {
       ks = kbeg;
       ++tn;
     }
@@ -357,13 +371,17 @@ __global__ __launch_bounds__(BM * 2, 1) void gemm_dma_kernel(const IGemm g) {
     if (s == 1) TL(15);
     __builtin_amdgcn_s_barrier();
 
-    const bool tile_done = ks + 1 == kend;
+    const bool tile_done = ks + 1 == kend_of(tn);
     if (s == 0) TL(2);
     if (s == 1) TL(3);
     if (tile_done) {
       TL(4);
       // ---- epilogue of column tile tn; scratch = the ring slot just consumed (free until the next prefetch) ----
-      int n0 = tn * BN;
+      int n0 = (PWALK ? col_tile : tn) * BN;
+      // output offsets of the class this tile belongs to (PWALK: the class just finished)
+      const int opar = PWALK ? tn : par;
+      const int ozo = g.npar > 0 ? g.par_oz[opar] : g.ozo, oyo = g.npar > 0 ? g.par_oy[opar] : g.oyo,
+                oxo = g.npar > 0 ? g.par_ox[opar] : g.oxo;
       if constexpr (WALK) {
         const int tmw = tn / tiles_n;
         m0 = tmw * GBM;
@@ -505,7 +523,8 @@ int launch_gd(const IGemm& g, int M, hipStream_t s) {
   }
   const int nch = g.nch > 0 ? g.nch : 1;
   const int gx = MODE ? cdiv(cdiv(M, BM) * cdiv(g.N, BN), nch) : cdiv(M, BM) * cdiv(cdiv(g.N, BN), nch);
-  dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, g.npar > 0 ? g.npar : 1);
+  const bool pwalk = MODE == 0 && !PLAIN && g.npar > 0 && g.par_walk != 0;
+  dim3 grid(gx, g.splitk > 1 ? g.splitk : 1, (g.npar > 0 && !pwalk) ? g.npar : 1);
   IGemm gl = g;
   gl.xcd_cols = 0;
   if (MODE == 0) {

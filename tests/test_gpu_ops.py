@@ -162,6 +162,23 @@ def test_conv3d(eng, stride, transposed, res, Cin):
           f"conv3d s={stride} T={transposed} res={res}")
 
 
+def test_transposed_and_upsample_convs_through_the_parity_walk():
+    """Round 6: one workgroup walks the parity classes of its tile (k_gemm.hip PWALK; the planner takes it when the tile grid fills the
+    chip by itself: the frustum network's level-0 ConvTranspose3d).  Forced for every parity-batched launch (MVD_PAR_WALK_MIN=1,
+    read once per process, hence the subprocess): the ConvTranspose3d cases (8 classes of 1 ... 8 taps, with and without residual)
+    and the parity-folded upsample convolutions (4 classes of 4 taps) of this file."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-k",
+                        "(test_conv3d or test_conv2d or test_upconv) and not parity_walk"], cwd=root,
+                       env=dict(os.environ, MVD_PAR_WALK_MIN="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
+    worst = max(float(l.split("relL2=")[1].split()[0]) for l in r.stdout.splitlines() if "[parity] conv" in l and "relL2=" in l)
+    print(f"[parity] parity-batched convolutions through the parity walk: worst relL2={worst:.2e}")
+
+
 @pytest.mark.parametrize("B,C,HW,G,eps,act", [(2, 64, 1024, 32, 1e-5, 1), (2, 320, 256, 32, 1e-6, 0), (3, 16, 1024, 8, 1e-5, 1),
                                               (1, 512, 96, 8, 1e-5, 2), (2, 1920, 64, 32, 1e-5, 1), (1, 64, 49152, 8, 1e-5, 1),
                                               (2, 640, 1024, 32, 1e-5, 1), (3, 960, 1024, 32, 1e-5, 1), (2, 1280, 16, 32, 1e-5, 1),
