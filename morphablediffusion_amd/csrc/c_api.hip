@@ -181,6 +181,9 @@ void mvd_destroy(mvd_ctx* c) {
   for (hipEvent_t ev : {c->ev_fork, c->ev_join, c->ev_join2, c->ev_ctx, c->ev_emb0, c->ev_emb})
     if (ev) hipEventDestroy(ev);
   if (c->side) hipStreamDestroy(c->side);
+  if (c->side2) hipStreamDestroy(c->side2);
+  for (hipEvent_t ev : {c->ev_s2_fork, c->ev_s2_join})
+    if (ev) hipEventDestroy(ev);
   delete c;
 }
 

@@ -230,6 +230,10 @@ struct mvd_ctx {
   bool use_halo = true;  // route eligible 3x3 convs through the LDS-halo kernel (MVD_NO_HALO=1 disables)
   // side stream: the context halves of the DepthTransformers (GroupNorm(proj_context(volume)), ready as soon as the frustum
   // volumes are) run beside the UNet trunk instead of inside it (engine_unet.hip)
+  // second helper stream: a ResBlock's 1x1 skip convolution reads only the block input, so it runs beside GroupNorm1 -> conv1 ->
+  // GroupNorm2 instead of in front of conv2 (unet_do_res); forked and joined inside the block
+  hipStream_t side2 = nullptr;
+  hipEvent_t ev_s2_fork = nullptr, ev_s2_join = nullptr;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ctx = nullptr, ev_emb0 = nullptr, ev_emb = nullptr;
   std::vector<hipEvent_t> ev_cond;

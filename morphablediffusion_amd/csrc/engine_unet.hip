@@ -503,11 +503,52 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
   float* h1 = ws_alloc<float>(c, (size_t)rows * r.cout);
   half_t* a2 = ws_alloc<half_t>(c, (size_t)rows * r.cout * w2);
   WS_CHECK(a1 && h1 && a2);
-  if (in_carry && in_carry->sk > 1)  // the previous block's last GEMM left its split-K slabs: sum + bias + residual -> in, then normalise
+  // The 1x1 skip convolution (openaimodel.py:273: skip_connection(x)) reads the block input only: on a helper stream it can run
+  // beside GroupNorm1 -> conv1 -> GroupNorm2 instead of in front of conv2.  MEASURED (profiles/r06_z_ab_skip_side.txt): 12.24 vs
+  // 12.245 ms per step, 6.11 vs 6.01 ms at 2 views per rank -- the chip gives two dependent-free kernels of one process no more
+  // than their sum (the same answer as the two half-batch chains).  Tested form, on with MVD_SKIP_SIDE=1 only.
+  // Its result buffer is allocated here (block scope, or the carry's storage); it takes no split-K scratch on the helper stream
+  // (the workspace scopes are released in host order).
+  static const bool no_skip_side = getenv("MVD_SKIP_SIDE") == nullptr;
+  const bool skip_side = r.has_skip && !no_skip_side && !f.train && !sv;
+  const bool sk_in_carry = r.has_skip && out_carry && out_carry->aux && out_carry->aux_cap >= (size_t)rows * r.cout;
+  float* skbuf = nullptr;
+  auto launch_skip = [&](hipStream_t ss, bool no_split) -> int {
+    GemmArgs gs;
+    gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = skbuf; gs.ldc = r.cout;
+    if (no_split) gs.force_splitk = 1;
+    if (r.skip.xp) {  // fp32 source -> [hi | lo | hi] copy
+      half_t* as = ws_alloc<half_t>(c, (size_t)rows * 3 * r.cin);
+      WS_CHECK(as);
+      RET_IF(launch_rows_f32_to_f16_split(in.p, in.ld, rows, r.cin, as, ss));
+      gs.a = as; gs.a_f32 = 0; gs.lda = 3 * r.cin;
+    }
+    return run_linear(c, gs, f.Bv, rows, ss);
+  };
+  auto fork_skip = [&]() -> int {
+    if (!c->side2) {
+      HIP_CHECK_RET(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_s2_fork, hipEventDisableTiming));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&c->ev_s2_join, hipEventDisableTiming));
+    }
+    HIP_CHECK_RET(hipEventRecord(c->ev_s2_fork, f.s));  // the block input is final on the caller's stream here
+    HIP_CHECK_RET(hipStreamWaitEvent(c->side2, c->ev_s2_fork, 0));
+    RET_IF(launch_skip(c->side2, true));
+    HIP_CHECK_RET(hipEventRecord(c->ev_s2_join, c->side2));
+    return 0;
+  };
+  if (r.has_skip) {
+    skbuf = sk_in_carry ? out_carry->aux : ws_alloc<float>(c, (size_t)rows * r.cout);
+    WS_CHECK(skbuf);
+  }
+  const bool in_slabs = in_carry && in_carry->sk > 1;
+  if (skip_side && !in_slabs) RET_IF(fork_skip());
+  if (in_slabs)  // the previous block's last GEMM left its split-K slabs: sum + bias + residual -> in, then normalise
     RET_IF(run_group_norm(c, in_carry->slabs, r.cin, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp,
                           in_carry->sk, in_carry->stride, in_carry->bias, in_carry->resid, in_carry->ldr, in.p, in.ld));
   else
     RET_IF(run_group_norm(c, in.p, in.ld, f.Bv, H * W, r.n1, 32, 1e-5f, ACT_SILU, nullptr, a1, r.cin * w1, f.s, 0, r.c1.xp));
+  if (skip_side && in_slabs) RET_IF(fork_skip());  // (that GroupNorm materialised the block input: the skip conv reads it)
   GemmArgs g1;
   g1.a = a1; g1.lda = r.cin * w1; g1.w = &r.c1; g1.out = h1; g1.ldc = r.cout;
   g1.rowbias = f.emb_all + r.emb_off; g1.rb_ld = c->emb_total;
@@ -536,20 +577,10 @@ int unet_do_res(Fwd& f, const ResW& r, View in, View out, int H, int W, ResSaved
     // A deferred conv2 hands `resid` to the NEXT block's GroupNorm, i.e. beyond this function's workspace scope: the skip conv's
     // result may then only live in the carry's own storage.  Without that storage (carry_storage could not get the second
     // buffer) conv2 must not defer.
-    const bool sk_in_carry = out_carry && out_carry->aux && out_carry->aux_cap >= (size_t)rows * r.cout;
     skip_outlives_scope = sk_in_carry;
-    float* sk = sk_in_carry ? out_carry->aux : ws_alloc<float>(c, (size_t)rows * r.cout);
-    WS_CHECK(sk);
-    GemmArgs gs;
-    gs.a = in.p; gs.a_f32 = 1; gs.lda = in.ld; gs.w = &r.skip; gs.out = sk; gs.ldc = r.cout;
-    if (r.skip.xp) {  // fp32 source -> [hi | lo | hi] copy
-      half_t* as = ws_alloc<half_t>(c, (size_t)rows * 3 * r.cin);
-      WS_CHECK(as);
-      RET_IF(launch_rows_f32_to_f16_split(in.p, in.ld, rows, r.cin, as, f.s));
-      gs.a = as; gs.a_f32 = 0; gs.lda = 3 * r.cin;
-    }
-    RET_IF(run_linear(c, gs, f.Bv, rows, f.s));
-    resid = sk;
+    if (skip_side) HIP_CHECK_RET(hipStreamWaitEvent(f.s, c->ev_s2_join, 0));  // conv2 (or the next block's GroupNorm) reads it
+    else RET_IF(launch_skip(f.s, false));
+    resid = skbuf;
     ldr = r.cout;
   }
   GemmArgs g2;

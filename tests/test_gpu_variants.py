@@ -31,7 +31,8 @@ VARIANTS = {
     # round 6, the restructured paths against their round-5 forms (two processes instead of one per switch: each is a full-width
     # model load).  (a) LayerNorm1 / LayerNorm3 sum the split-K slabs of proj_in / to_out (off by default: measured neutral), the
     # DepthTransformer's GroupNorms do NOT sum theirs (the folded FF2 + proj_out GEMM then takes its fp16 t2 from the slab form);
-    "ln_sums_slabs_cond_reduces": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1"},
+    # and the ResBlocks' skip convolutions on a helper stream beside GroupNorm1 -> conv1 -> GroupNorm2 (opt-in: measured neutral)
+    "ln_sums_slabs_cond_reduces_skip_conv_on_helper_stream": {"MVD_LN_DEFER": "1", "MVD_NO_COND_DEFER": "1", "MVD_SKIP_SIDE": "1"},
     # (b) every DepthTransformer folds its own context projection and runs over ALL samples (no per-level stacked GEMM, no cached
     # constant image for the context-free half), FF2 and proj_out as two GEMMs with the fp16 intermediate between them, the 4 -> 8
     # Upsample as the 9-tap GEMM on the fp32 source, the step's head on the UNet's stream
