@@ -259,4 +259,8 @@ int launch_add_rows(float* dst, const float* a, const float* b, size_t n, hipStr
 int launch_add_image_rows(const float* in, int ldi, const float* img, int C, int nb, int HW, float* out, int ldo, hipStream_t s);
 // nearest x2 upsample + fp16 cast: in fp32 [B][H][W][ldi] -> out fp16 [B][2H][2W][C]
 int launch_upsample2_f16(const float* in, int ldi, int B, int H, int W, int C, half_t* out, hipStream_t s);
+// 3 x 3, pad 1, stride 1 convolution of a channels-last fp32 image batch with 4 or 8 input channels, in exact fp32 on the vector ALU:
+// x [B][H][W][ldx], w [N][cin_src][3][3] (the checkpoint's layout), out [B][H][W][ldo] (+ bias)
+int launch_conv_in_f32(const float* x, int ldx, const float* w, int cin_src, const float* bias, int N, int B, int H, int W, float* out,
+                       int ldo, hipStream_t s);
 int launch_probe_null(hipStream_t s);  // one wave that does nothing: the launch path's own cost (ProbeScope calibration)

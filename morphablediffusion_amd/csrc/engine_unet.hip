@@ -965,6 +965,22 @@ int unet_do_op(Fwd& f, const UOp& op, View in, View out, int& H, int& W, StageRe
       if (can_defer) {
         g.slabs = out_carry->slabs; g.slabs_cap = out_carry->cap; g.sk_used = &skc; g.defer_epilogue = true;
       }
+      static const bool no_in32 = getenv("MVD_NO_CONV_IN_F32") != nullptr;
+      if (op.kind == OP_CONV_IN && !f.train && !no_in32 && c->convs[op.idx].w32) {
+        // inference: the first convolution in exact fp32 on the vector ALU (K = 72 is all staging for the MFMA forms)
+        const ConvW& cw = c->convs[op.idx];
+        ProbeScope ps(c, f.s, "conv_in_f32_kernel", 2.0 * f.Bv * H * W * 72.0 * cw.N,
+                      (double)f.Bv * H * W * (cw.N + 8) * 4.0);
+        RET_IF(launch_conv_in_f32(in.p, in.ld, cw.w32, cw.cin_src, cw.bias, cw.N, f.Bv, H, W, out.p, out.ld, f.s));
+        if (out_carry) {
+          out_carry->sk = 1;
+          out_carry->stride = (size_t)f.Bv * H * W * op.cout;
+          out_carry->bias = cw.bias;
+          out_carry->resid = nullptr;
+          out_carry->ldr = 0;
+        }
+        return 0;
+      }
       const int stride = op.kind == OP_DOWN ? 2 : 1, ups = op.kind == OP_UP ? 1 : 0;
       WsScope ws_scope(c, WS_BLOCK);
       if (c->convs[op.idx].xp) {  // extended precision (conv_in): fp32 source -> [hi | lo | hi] copy

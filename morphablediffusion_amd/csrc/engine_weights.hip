@@ -765,6 +765,10 @@ int build_unet_section(mvd_ctx* c) {
       RET_IF(dmalloc(c, (void**)&w.w_up, (size_t)16 * w.N * w.Cin * sizeof(half_t)));
       RET_IF(launch_pack_upconv_weight(r->d, w.N, w.Cin, w.w_up, c->bs));
     }
+    if (kind == OP_CONV_IN && w.taps == 9 && (cin == 4 || cin == 8) && cout <= 512) {
+      RET_IF(copy_f32(c, U + wkey + ".weight", &w.w32));  // training mode: a view of the master arena, always current
+      w.cin_src = cin;
+    }
     c->convs.push_back(w);
     ops.push_back({kind, (int)c->convs.size() - 1, cin, cout});
     return 0;

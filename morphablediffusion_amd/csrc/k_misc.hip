@@ -642,3 +642,83 @@ int launch_upsample2_f16(const float* in, int ldi, int B, int H, int W, int C, h
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+namespace {
+// The UNet's first convolution in exact fp32 (round 6).  8 (padded) input channels make K = 72: as an MFMA implicit GEMM the layer
+// is all operand staging (extended-precision form: a 35 us split cast + a 61 us GEMM for 3 GFLOP).  Here one thread owns one output
+// channel and keeps its 72 weights in registers; the image row and its two neighbours (+ the zero halo) sit in LDS and every lane
+// reads the same address, so the only vector-memory traffic is the coalesced output rows.  LDS returns 128 B per clock whether or
+// not the lanes agree, so the reads are what has to be rationed: four adjacent output pixels share each input column (9 b128 reads
+// per pixel instead of 18), which puts the LDS time at the multiply-adds' own.  One workgroup per image row: 1024 groups of 5 waves
+// keep the four SIMDs evenly loaded.  Exact fp32 multiply-adds in a fixed order (row-major, column, channel).
+// MEASURED (tools/conv_in_prof.py under rocprofv3, 32 samples of 32 x 32, 8 -> 320): 31.8 us per launch, the same as the plain
+// fp16 MFMA form (32.2 us) and in front of the extended-precision form it replaces (split cast + 3x-K GEMM); in the step that is
+// 0.01-0.04 ms (profiles/r06_zb_ab_conv_in_f32.txt).  Forms that lost: inputs through the scalar cache as SGPR operands (no gain
+// in the step at all); 18 reads per pixel with 4 rows per group (LDS-bound).
+template <int CIN, int P>  // 4 or 8 input channels (the checkpoint's [N][CIN][3][3] rows); P adjacent pixels per pass (divides W)
+__global__ __launch_bounds__(512, 4) void conv_in_f32_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int N, int H, int W,
+                                                           float* __restrict__ out, int ldo) {
+  extern __shared__ float xs[];  // [3][W + 2][CIN]
+  const int b = blockIdx.x / H, y = blockIdx.x % H;
+  const int Wp = W + 2;
+  for (int i = threadIdx.x; i < 3 * Wp * CIN; i += blockDim.x) {
+    const int ch = i % CIN, px = (i / CIN) % Wp - 1, py = y + i / (CIN * Wp) - 1;
+    xs[i] = (px >= 0 && px < W && py >= 0 && py < H) ? x[(((long)b * H + py) * W + px) * ldx + ch] : 0.f;
+  }
+  const int n = threadIdx.x < N ? threadIdx.x : N - 1;
+  float wr[9][CIN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ch = 0; ch < CIN; ++ch) wr[t][ch] = w[(long)n * CIN * 9 + ch * 9 + t];
+  const float bn = bias ? bias[n] : 0.f;
+  __syncthreads();
+  if (threadIdx.x >= N) return;
+  float* orow = out + (((long)b * H + y) * W) * ldo + n;
+  for (int px0 = 0; px0 < W; px0 += P) {
+    float acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int col = 0; col < P + 2; ++col) {  // input column px0 + col - 1 feeds output pixel px0 + col - dx
+        const float4* pv = (const float4*)(xs + (dy * Wp + px0 + col) * CIN);
+        float v[CIN];
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) *(float4*)(v + 4 * q) = pv[q];
+#pragma unroll
+        for (int dx = 2; dx >= 0; --dx) {
+          const int p = col - dx;
+          if (p < 0 || p >= P) continue;
+#pragma unroll
+          for (int ch = 0; ch < CIN; ++ch) acc[p] = fmaf(wr[dy * 3 + dx][ch], v[ch], acc[p]);
+        }
+        if (col & 1) __builtin_amdgcn_sched_barrier(0);  // at most two columns of reads in flight: 72 weights + 16 stay under 128 VGPRs
+      }
+#pragma unroll
+    for (int p = 0; p < P; ++p) orow[(long)(px0 + p) * ldo] = acc[p] + bn;
+  }
+}
+}  // namespace
+int launch_conv_in_f32(const float* x, int ldx, const float* w, int cin_src, const float* bias, int N, int B, int H, int W, float* out,
+                       int ldo, hipStream_t s) {
+  if ((cin_src != 4 && cin_src != 8) || N < 1 || N > 512) return mvd_fail("conv_in_f32: 4 or 8 input and at most 512 output channels");
+  if (((uintptr_t)w) & 15) return mvd_fail("conv_in_f32: 16-byte aligned weights");
+  if (B <= 0) return 0;
+  const int threads = (N + 63) / 64 * 64;
+  const size_t lds = (size_t)3 * (W + 2) * cin_src * sizeof(float);
+  if (lds > 64 * 1024) return mvd_fail("conv_in_f32: image row too wide for the LDS strip");
+  const dim3 grid((unsigned)(B * H)), block(threads);
+  if (cin_src == 8 && W % 4 == 0)
+    hipLaunchKernelGGL((conv_in_f32_kernel<8, 4>), grid, block, lds, s, x, ldx, w, bias, N, H, W, out, ldo);
+  else if (cin_src == 8)
+    hipLaunchKernelGGL((conv_in_f32_kernel<8, 1>), grid, block, lds, s, x, ldx, w, bias, N, H, W, out, ldo);
+  else if (W % 4 == 0)
+    hipLaunchKernelGGL((conv_in_f32_kernel<4, 4>), grid, block, lds, s, x, ldx, w, bias, N, H, W, out, ldo);
+  else
+    hipLaunchKernelGGL((conv_in_f32_kernel<4, 1>), grid, block, lds, s, x, ldx, w, bias, N, H, W, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -299,6 +299,17 @@ def test_conv3x(eng, B, Cin, H, W, Cout, res, sk):
     close(eng.op_conv(x, w, b, resid=r, force_splitk=sk), want, f"conv3x B={B} {Cin}->{Cout} {H}x{W} res={res} sk={sk}")
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(4, 8, 32, 32, 320), (3, 8, 16, 16, 64), (2, 4, 12, 20, 96), (1, 8, 6, 6, 40), (2, 4, 5, 10, 128)])
+def test_first_layer_conv_exact_fp32(eng, B, Cin, H, W, Cout):
+    """The UNet's first 3x3 convolution at inference (k_misc.hip: conv_in_f32_kernel): fp32 multiply-adds, so it matches torch's
+    fp32 convolution to summation order (reference: ldm/modules/diffusionmodules/openaimodel.py:606-610, conv_nd(dims, in_channels,
+    model_channels, 3, padding=1))."""
+    torch.manual_seed(5)
+    x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) * 0.2, torch.randn(Cout)
+    got = eng.op_conv(x, w, b, force_splitk=-2)
+    close(got, F.conv2d(x, w, b, padding=1), f"first-layer conv {Cin}->{Cout} {H}x{W}", rel=2e-6, mx=1e-5)
+
+
 def test_conv3x_impulse(eng):
     """A one-hot input pixel / channel reproduces the (flipped) kernel around it: catches a swapped tap, a transposed fragment or a
     mis-placed halo row exactly (products are exact in fp16 for these weights)."""
