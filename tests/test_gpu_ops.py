@@ -182,7 +182,8 @@ def test_transposed_and_upsample_convs_through_the_parity_walk():
 @pytest.mark.parametrize("B,C,HW,G,eps,act", [(2, 64, 1024, 32, 1e-5, 1), (2, 320, 256, 32, 1e-6, 0), (3, 16, 1024, 8, 1e-5, 1),
                                               (1, 512, 96, 8, 1e-5, 2), (2, 1920, 64, 32, 1e-5, 1), (1, 64, 49152, 8, 1e-5, 1),
                                               (2, 640, 1024, 32, 1e-5, 1), (3, 960, 1024, 32, 1e-5, 1), (2, 1280, 16, 32, 1e-5, 1),
-                                              (2, 2560, 64, 32, 1e-5, 1), (2, 1280, 1024, 32, 1e-5, 0)])
+                                              (2, 2560, 64, 32, 1e-5, 1), (2, 1280, 1024, 32, 1e-5, 0), (3, 320, 1024, 32, 1e-5, 1),
+                                              (2, 640, 64, 32, 1e-5, 1), (2, 320, 100, 32, 1e-5, 1)])
 def test_group_norm(eng, B, C, HW, G, eps, act):
     x = rnd(B, C, HW) * 2.0 + 0.7
     g, b = 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
