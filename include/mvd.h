@@ -354,7 +354,8 @@ int mvd_denoise_views_batch(mvd_ctx* ctx, int B, const int* slots, const float* 
 int mvd_op_conv(mvd_ctx* ctx, const float* x_nchw, int B, int Cin, int H, int W, const float* w, const float* bias,
                 int Cout, int ksize, int stride, int upsample, const float* resid_nchw, float* out_nchw, int force_splitk,
                 void* stream);
-/* (mvd_op_conv: force_splitk == -2 with Cin <= 8 runs the UNet's inference form of its first layer, exact fp32 on the vector ALU) */
+/* (mvd_op_conv: force_splitk == -2 with Cin <= 8 runs the UNet's inference form of its first layer, -3 with Cout <= 4 that of its
+ * last layer: exact fp32 on the vector ALU) */
 /* a_half != 0: A is rounded to fp16 in HBM first (the layout of operand-only activations) and, for M >= 512,
  * the dense LDS-DMA GEMM runs; resid [M][N] (or null) is added in the epilogue; force_splitk > 0 fixes the
  * split-K factor */

@@ -1032,6 +1032,12 @@ int mvd_op_conv(mvd_ctx* c, const float* x_nchw, int B, int Cin, int H, int W, c
   RET_IF(launch_nchw_to_nhwc(x_nchw, B, Cin, H * W, xn, cpad, cpad, s));
   RET_IF(launch_pack_weight(w, Cout, cpad, taps, 0, 0, wp, s, Cin));
   if (rn) RET_IF(launch_nchw_to_nhwc(resid_nchw, B, Cout, Ho * Wo, rn, Cout, Cout, s));
+  if (force_splitk == -3) {  // the UNet's last layer at inference: exact fp32 on the vector ALU (launch_out_conv_f32)
+    if (taps != 9 || stride != 1 || upsample || rn || cpad != Cin) return mvd_fail("op_conv: the fp32 output-head form is 3x3, stride 1, no residual");
+    RET_IF(launch_out_conv_f32(xn, Cin, w, bias, Cout, B, H, W, on, Cout, s));
+    RET_IF(launch_nhwc_to_nchw(on, Cout, B, Cout, Ho * Wo, out_nchw, s));
+    return 0;
+  }
   if (force_splitk == -2) {  // the UNet's first layer at inference: exact fp32 on the vector ALU (launch_conv_in_f32)
     if (taps != 9 || stride != 1 || upsample || rn) return mvd_fail("op_conv: the fp32 first-layer form is 3x3, stride 1, no residual");
     RET_IF(launch_conv_in_f32(xn, cpad, w, Cin, bias, Cout, B, H, W, on, Cout, s));

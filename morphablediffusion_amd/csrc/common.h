@@ -263,4 +263,8 @@ int launch_upsample2_f16(const float* in, int ldi, int B, int H, int W, int C, h
 // x [B][H][W][ldx], w [N][cin_src][3][3] (the checkpoint's layout), out [B][H][W][ldo] (+ bias)
 int launch_conv_in_f32(const float* x, int ldx, const float* w, int cin_src, const float* bias, int N, int B, int H, int W, float* out,
                        int ldo, hipStream_t s);
+// 3 x 3, pad 1, stride 1 convolution C -> N <= 4 of a channels-last fp32 image batch in exact fp32 on the vector ALU (the UNet's
+// output head): a [B][H][W][C], w [N][C][3][3] (the checkpoint's layout), out [B][H][W][ldo] (+ bias).  C % 32 == 0, W % 16 == 0.
+int launch_out_conv_f32(const float* a, int C, const float* w, const float* bias, int N, int B, int H, int W, float* out, int ldo,
+                        hipStream_t s);
 int launch_probe_null(hipStream_t s);  // one wave that does nothing: the launch path's own cost (ProbeScope calibration)

@@ -31,7 +31,7 @@ struct ConvW {  // packed for the implicit GEMM: fp16 [taps][N][Cin]
   int wx_bn = 0;           // ... packed for column tiles of this width
   half_t* w_up = nullptr;  // upsample convs only: the 16 parity-folded 2x2 slabs (k_misc.hip: pack_upconv_weight_kernel)
   int res_out = 0;         // upsample convs only: the resolution they produce (decides whether they get a conv3x stream)
-  float* w32 = nullptr;    // conv_in only: the fp32 weights [N][cin_src][3][3] for the exact vector-ALU form (launch_conv_in_f32)
+  float* w32 = nullptr;    // conv_in / the output conv: the fp32 weights [N][cin_src][3][3] for the exact vector-ALU forms (k_misc.hip)
   int cin_src = 0;         // ... their (unpadded) input width
   float* bias = nullptr;
   int N = 0, Cin = 0, taps = 1;

@@ -1414,6 +1414,15 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
   // out: GroupNorm32 + SiLU + zero-init conv (openaimodel.py:717-721)
   {
     const int rows = Bv * H * W;
+    static const bool no_head32 = getenv("MVD_NO_OUT_CONV_F32") != nullptr || getenv("MVD_GN_TWO_PASS") != nullptr;
+    if (!tape && !no_head32 && c->out_conv.w32 && !(W & 15) && gn_group_eligible(mc, H * W, mc, 32, 0, 2 * mc)) {
+      // inference: GroupNorm + SiLU written in fp32, the 3 x 3 convolution onto 4 channels in exact fp32 on the vector ALU
+      float* a32 = ws_alloc<float>(c, (size_t)rows * mc);
+      WS_CHECK(a32);
+      RET_IF(run_group_norm(c, final_h, mc, Bv, H * W, c->out_norm, 32, 1e-5f, ACT_SILU, nullptr, (half_t*)a32, 2 * mc, s, 0, 2));
+      ProbeScope ps(c, s, "out_conv_f32_kernel", 2.0 * rows * 9.0 * mc * c->out_conv.N, (double)rows * (mc + u.out_channels) * 4.0);
+      RET_IF(launch_out_conv_f32(a32, mc, c->out_conv.w32, c->out_conv.bias, c->out_conv.N, Bv, H, W, eps_nhwc, u.out_channels, s));
+    } else {
     const int wx = c->out_conv.xp ? 3 : 1;  // extended precision: [hi | lo | hi] operand
     half_t* a = ws_alloc<half_t>(c, (size_t)rows * mc * wx);
     WS_CHECK(a);
@@ -1425,6 +1434,7 @@ int engine_unet(mvd_ctx* c, const float* x_nhwc, int x_ld, const int64_t* t, con
     GemmArgs g;
     g.a = a; g.lda = mc * wx; g.w = &c->out_conv; g.out = eps_nhwc; g.ldc = u.out_channels;
     RET_IF(run_conv2d(c, g, Bv, H, W, 1, 0, s));
+    }
   }
   static const bool dbg_sum = getenv("MVD_DEBUG_SUM") != nullptr;  // investigation aid: which buffers differ between repeats?
   if (dbg_sum) {

@@ -834,6 +834,10 @@ int build_unet_section(mvd_ctx* c) {
   }
   RET_IF(load_norm(c, U + "out.0", &c->out_norm));
   RET_IF(pack_conv(c, U + "out.2.weight", U + "out.2.bias", false, false, &c->out_conv));
+  if (c->out_conv.taps == 9 && c->out_conv.N <= 4 && mc % 32 == 0 && mc <= 512) {  // inference: the exact fp32 head (launch_out_conv_f32)
+    RET_IF(copy_f32(c, U + "out.2.weight", &c->out_conv.w32));
+    c->out_conv.cin_src = mc;
+  }
   // all ResBlock emb projections as ONE [emb_total][temb] linear (openaimodel.py:219-225)
   c->emb_all.N = c->emb_total;
   c->emb_all.K = temb;

@@ -722,3 +722,93 @@ int launch_conv_in_f32(const float* x, int ldx, const float* w, int cin_src, con
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+namespace {
+// The UNet's LAST convolution (3 x 3, C -> 4) in exact fp32 (round 6; openaimodel.py:717-721).  Four output columns are 1 / 8 of the
+// narrowest MFMA tile and the layer carries a sixth of the end-to-end error variance in fp16, so it ran as an extended-precision
+// implicit GEMM: 66 us + a 3x-wide GroupNorm output for 0.75 GFLOP.  Here the activations arrive in fp32 (gn_group_kernel,
+// split == 2) and a wave owns 16 adjacent pixels of an image row: lane (p, k) = pixels p and p + 8, every eighth 16-byte channel
+// quad (so the eight k-lanes of a pixel read one 128-byte line), 4 outputs x 2 pixels of accumulators, weights [tap][quad][ch][out]
+// in LDS (padded so the eight quads of a read land on distinct banks), a 3-step butterfly over k at the end.  Persistent
+// workgroups (one per CU) stage the weights once.  Fixed summation order.
+__global__ __launch_bounds__(256) void out_conv_f32_kernel(const float* __restrict__ a, int C, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int N, int B, int H, int W,
+                                                           float* __restrict__ out, int ldo) {
+  extern __shared__ float4 s_w[];  // [9][C / 32][34]: quad 8 j + k, channel i of the quad at (tap * J + j) * 34 + 4 k + (k >> 2) + i
+  const int J = C >> 5, tid = threadIdx.x;
+  for (int e = tid; e < 9 * C; e += 256) {
+    const int t = e / C, c = e - t * C, q = c >> 2, i = c & 3, j = q >> 3, k = q & 7;
+    float4 v;
+    v.x = N > 0 ? w[((long)0 * C + c) * 9 + t] : 0.f;
+    v.y = N > 1 ? w[((long)1 * C + c) * 9 + t] : 0.f;
+    v.z = N > 2 ? w[((long)2 * C + c) * 9 + t] : 0.f;
+    v.w = N > 3 ? w[((long)3 * C + c) * 9 + t] : 0.f;
+    s_w[(t * J + j) * 34 + 4 * k + (k >> 2) + i] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, p = lane & 7, k = lane >> 3;
+  const int runs_per_row = W >> 4, total = B * H * runs_per_row;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    bv.x = N > 0 ? bias[0] : 0.f; bv.y = N > 1 ? bias[1] : 0.f; bv.z = N > 2 ? bias[2] : 0.f; bv.w = N > 3 ? bias[3] : 0.f;
+  }
+  for (int run = blockIdx.x * 4 + wave; run < total; run += gridDim.x * 4) {
+    const int xr = run % runs_per_row, y = (run / runs_per_row) % H, b = run / (runs_per_row * H);
+    const int x0 = xr * 16 + p, x1 = x0 + 8;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int py = y + dy - 1;
+      if (py < 0 || py >= H) continue;  // wave-uniform
+      const float* arow = a + (((long)b * H + py) * W) * C + 4 * k;
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int q0 = x0 + dx - 1, q1 = x1 + dx - 1;
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+          if (q0 >= 0 && q0 < W) v0 = *(const float4*)(arow + (long)q0 * C + 32 * j);
+          if (q1 >= 0 && q1 < W) v1 = *(const float4*)(arow + (long)q1 * C + 32 * j);
+          const float4* wp = s_w + ((dy * 3 + dx) * J + j) * 34 + 4 * k + (k >> 2);
+          const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+#define MVD_OH(acc, v)                                                                                            \
+  acc.x = fmaf(v.x, w0.x, acc.x); acc.y = fmaf(v.x, w0.y, acc.y); acc.z = fmaf(v.x, w0.z, acc.z); acc.w = fmaf(v.x, w0.w, acc.w); \
+  acc.x = fmaf(v.y, w1.x, acc.x); acc.y = fmaf(v.y, w1.y, acc.y); acc.z = fmaf(v.y, w1.z, acc.z); acc.w = fmaf(v.y, w1.w, acc.w); \
+  acc.x = fmaf(v.z, w2.x, acc.x); acc.y = fmaf(v.z, w2.y, acc.y); acc.z = fmaf(v.z, w2.z, acc.z); acc.w = fmaf(v.z, w2.w, acc.w); \
+  acc.x = fmaf(v.w, w3.x, acc.x); acc.y = fmaf(v.w, w3.y, acc.y); acc.z = fmaf(v.w, w3.z, acc.z); acc.w = fmaf(v.w, w3.w, acc.w)
+          MVD_OH(acc0, v0);
+          MVD_OH(acc1, v1);
+#undef MVD_OH
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {  // over the eight channel-quad lanes of a pixel
+      acc0.x += __shfl_xor(acc0.x, m); acc0.y += __shfl_xor(acc0.y, m); acc0.z += __shfl_xor(acc0.z, m); acc0.w += __shfl_xor(acc0.w, m);
+      acc1.x += __shfl_xor(acc1.x, m); acc1.y += __shfl_xor(acc1.y, m); acc1.z += __shfl_xor(acc1.z, m); acc1.w += __shfl_xor(acc1.w, m);
+    }
+    if (k == 0) {
+      float* o0 = out + (((long)b * H + y) * W + x0) * ldo;
+      float* o1 = out + (((long)b * H + y) * W + x1) * ldo;
+      const float r0[4] = {acc0.x + bv.x, acc0.y + bv.y, acc0.z + bv.z, acc0.w + bv.w};
+      const float r1[4] = {acc1.x + bv.x, acc1.y + bv.y, acc1.z + bv.z, acc1.w + bv.w};
+      for (int o = 0; o < N; ++o) {
+        o0[o] = r0[o];
+        o1[o] = r1[o];
+      }
+    }
+  }
+}
+}  // namespace
+int launch_out_conv_f32(const float* a, int C, const float* w, const float* bias, int N, int B, int H, int W, float* out, int ldo,
+                        hipStream_t s) {
+  if (N < 1 || N > 4 || (C & 31) || (W & 15) || C > 512) return mvd_fail("out_conv_f32: N <= 4, C % 32 == 0 (<= 512), W % 16 == 0");
+  if (((uintptr_t)a) & 15) return mvd_fail("out_conv_f32: 16-byte aligned activations");
+  if (B <= 0) return 0;
+  const long runs = (long)B * H * (W / 16);
+  long grid = (runs + 3) / 4;
+  if (grid > 256) grid = 256;
+  const size_t lds = (size_t)9 * (C / 32) * 34 * sizeof(float4);
+  hipLaunchKernelGGL(out_conv_f32_kernel, dim3((unsigned)grid), dim3(256), lds, s, a, C, w, bias, N, B, H, W, out, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -383,6 +383,10 @@ __global__ __launch_bounds__(NT, (MAXE <= 10 ? 8 : 4)) void gn_group_kernel(cons
       o[0] = (half_t)y0;
       o[1] = (half_t)y1;
       half_t* op = ob + (long)row * ldo + 2 * j;
+      if (split == 2) {  // fp32 output (the exact output head): `out` is a float buffer, ldo / 2 floats per row
+        *(float2*)((float*)out + ((long)b * rows + row) * (ldo >> 1) + g * cpg + 2 * j) = make_float2(y0, y1);
+        continue;
+      }
       *(h2*)op = o;
       if (split) {  // [hi | lo | hi]: the operand of an extended-precision consumer
         h2 lo;
@@ -628,6 +632,7 @@ int launch_gn_apply(const float* x, int ld, int B, int rows_per_sample, int C, i
                     const float* partial, int nslabs, const float* gamma, const float* beta, float eps, int act,
                     half_t* out, int ldo, hipStream_t s, int split) {
   if (C > GN_MAXC || C % 4 || ld % 4 || ldo % 4) return mvd_fail("gn_apply: channel counts must be multiples of 4");
+  if (split == 2) return mvd_fail("gn_apply: the fp32 output is written by the one-launch form only");
   if (split && ldo < 3 * C) return mvd_fail("gn_apply: a split output needs ldo >= 3C");
   int blocks = rows_per_sample / 8;
   if (blocks < 1) blocks = 1;
@@ -651,7 +656,8 @@ int launch_gn_group(const float* x, int ld, int B, int rows, int C, int G, const
                     const float* beta, float eps, int act, half_t* out, int ldo, hipStream_t s, int split, int nslab,
                     size_t slab_stride, const float* bias2, const float* resid, int ldr, float* mat, int ldm) {
   const int n2 = rows * (C / G) / 2;
-  if (split && ldo < 3 * C) return mvd_fail("gn_group: a split output needs ldo >= 3C");
+  if (split == 1 && ldo < 3 * C) return mvd_fail("gn_group: a split output needs ldo >= 3C");
+  if (split == 2 && (ldo < 2 * C || (ldo & 3) || ((uintptr_t)out & 7))) return mvd_fail("gn_group: an fp32 output needs ldo >= 2C halfs, 8-byte aligned rows");
   if (nslab < 1 || nslab > 64) return mvd_fail("gn_group: 1 to 64 slabs");
   if ((resid && (ldr & 1)) || (mat && (ldm & 1))) return mvd_fail("gn_group: residual / materialised rows must be 8-byte aligned");
   const dim3 grid(B * G);

@@ -311,6 +311,17 @@ def test_first_layer_conv_exact_fp32(eng, B, Cin, H, W, Cout):
     close(got, F.conv2d(x, w, b, padding=1), f"first-layer conv {Cin}->{Cout} {H}x{W}", rel=2e-6, mx=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(4, 320, 32, 32, 4), (2, 64, 16, 16, 4), (1, 96, 8, 48, 3), (3, 32, 5, 16, 1)])
+def test_output_head_conv_exact_fp32(eng, B, Cin, H, W, Cout):
+    """The UNet's last 3x3 convolution at inference (k_misc.hip: out_conv_f32_kernel; reference:
+    ldm/modules/diffusionmodules/openaimodel.py:717-721, zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1))):
+    fp32 multiply-adds in a fixed order."""
+    torch.manual_seed(6)
+    x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cout, Cin, 3, 3) * 0.05, torch.randn(Cout)
+    got = eng.op_conv(x, w, b, force_splitk=-3)
+    close(got, F.conv2d(x, w, b, padding=1), f"output-head conv {Cin}->{Cout} {H}x{W}", rel=3e-6, mx=1e-5)
+
+
 def test_conv3x_impulse(eng):
     """A one-hot input pixel / channel reproduces the (flipped) kernel around it: catches a swapped tap, a transposed fragment or a
     mis-placed halo row exactly (products are exact in fp16 for these weights)."""
